@@ -1,0 +1,207 @@
+// Host-side (fp64) construction of the shared basis block of the polynomial fit.
+//
+// A C^3 piecewise degree-7 polynomial with S segments is parameterised by its knot data
+// (pos, vel, acc, jerk at the S+1 knots) exactly as the reference builds trajectories:
+// CompositeTraj([MinSnapPoly(Y_j, Y_{j+1}, T)]) with PolynomialOne's closed form
+// (src/d2d/trajectory.py:47-72, :166-208).  (pos, vel) at the first and last knot are the
+// end conditions; the other 4S knot values per axis are the free unknowns, whitened by the
+// Cholesky factor of Nfree^T Mref Nfree.
+#include <cmath>
+#include <cstring>
+
+#include "fit_plan.h"
+
+namespace {
+
+double arr(int k, int n) {   // n!/(n-k)!   src/d2d/trajectory.py:41-45
+  double a = 1;
+  for (int i = n; i > n - k; --i) a *= i;
+  return a;
+}
+
+struct Dense {
+  int r, c;
+  std::vector<double> a;
+  Dense(int r_, int c_) : r(r_), c(c_), a((size_t)r_ * c_, 0.0) {}
+  double &operator()(int i, int j) { return a[(size_t)i * c + j]; }
+  double operator()(int i, int j) const { return a[(size_t)i * c + j]; }
+};
+
+Dense matmul(const Dense &A, const Dense &B, bool tA = false) {
+  const int m = tA ? A.c : A.r, k = tA ? A.r : A.c, n = B.c;
+  Dense C(m, n);
+  for (int i = 0; i < m; ++i)
+    for (int l = 0; l < k; ++l) {
+      const double v = tA ? A(l, i) : A(i, l);
+      if (v == 0.0) continue;
+      for (int j = 0; j < n; ++j) C(i, j) += v * B(l, j);
+    }
+  return C;
+}
+
+// in-place Cholesky (lower); returns false if not positive definite
+bool cholesky(Dense &A) {
+  const int n = A.r;
+  for (int j = 0; j < n; ++j) {
+    double d = A(j, j);
+    for (int k = 0; k < j; ++k) d -= A(j, k) * A(j, k);
+    if (!(d > 0.0)) return false;
+    d = std::sqrt(d);
+    A(j, j) = d;
+    for (int i = j + 1; i < n; ++i) {
+      double s = A(i, j);
+      for (int k = 0; k < j; ++k) s -= A(i, k) * A(j, k);
+      A(i, j) = s / d;
+    }
+    for (int i = 0; i < j; ++i) A(i, j) = 0.0;
+  }
+  return true;
+}
+
+// general inverse by Gauss-Jordan with partial pivoting (4x4 only here)
+bool invert(Dense &A) {
+  const int n = A.r;
+  Dense I(n, n);
+  for (int i = 0; i < n; ++i) I(i, i) = 1.0;
+  for (int c = 0; c < n; ++c) {
+    int piv = c;
+    for (int r = c + 1; r < n; ++r)
+      if (std::fabs(A(r, c)) > std::fabs(A(piv, c))) piv = r;
+    if (A(piv, c) == 0.0) return false;
+    for (int j = 0; j < n; ++j) {
+      std::swap(A(c, j), A(piv, j));
+      std::swap(I(c, j), I(piv, j));
+    }
+    const double ip = 1.0 / A(c, c);
+    for (int j = 0; j < n; ++j) { A(c, j) *= ip; I(c, j) *= ip; }
+    for (int r = 0; r < n; ++r) {
+      if (r == c) continue;
+      const double f = A(r, c);
+      for (int j = 0; j < n; ++j) { A(r, j) -= f * A(c, j); I(r, j) -= f * I(c, j); }
+    }
+  }
+  A = I;
+  return true;
+}
+
+}  // namespace
+
+int fit_basis_build(d2d_fit_plan *pl) {
+  const int S = pl->S, K = pl->K, nz = 8 * S, nk = 4 * (S + 1), nq = 4 * S;
+  const double T = pl->duration / S;
+  pl->T = T;
+  pl->nq = nq;
+  // --- segment lookup of the K samples (CompositeTraj.get, src/d2d/trajectory.py:202-208)
+  std::vector<int> seg(K);
+  std::vector<double> tau(K);
+  {
+    std::vector<double> ends(S);
+    double acc = 0;
+    for (int s = 0; s < S; ++s) { acc += T; ends[s] = acc; }
+    for (int k = 0; k < K; ++k) {
+      // numpy.linspace(0, duration, K): start + k*step, last sample forced to `duration`
+      const double step = pl->duration / (K - 1);
+      const double t = (k == K - 1) ? pl->duration : k * step;
+      int s = S - 1;
+      for (int j = 0; j < S; ++j)
+        if (ends[j] > t) { s = j; break; }
+      seg[k] = s;
+      tau[k] = t - s * T;
+    }
+  }
+  // --- Phi_d (K x 8S), d = 0..2
+  std::vector<Dense> Phi;
+  for (int d = 0; d < 3; ++d) {
+    Dense P(K, nz);
+    for (int k = 0; k < K; ++k)
+      for (int p = d; p < 8; ++p) P(k, 8 * seg[k] + p) = arr(d, p) * std::pow(tau[k], p - d);
+    Phi.push_back(P);
+  }
+  // --- Hermite map of one segment (PolynomialOne.__init__, src/d2d/trajectory.py:54-66)
+  Dense M3(4, 4), M4(4, 4);
+  for (int i = 0; i < 4; ++i) {
+    for (int j = i; j < 4; ++j) M3(i, j) = arr(i, j) * std::pow(T, j - i);
+    for (int j = 0; j < 4; ++j) M4(i, j) = arr(i, j + 4) * std::pow(T, j - i + 4);
+  }
+  if (!invert(M4)) { d2d_set_error("fit_basis_build: singular Hermite block"); return D2D_EINVAL; }
+  Dense H(8, 8);
+  for (int i = 0; i < 4; ++i) H(i, i) = 1.0 / arr(i, i);
+  {
+    Dense M1i(4, 4);
+    for (int i = 0; i < 4; ++i) M1i(i, i) = 1.0 / arr(i, i);
+    Dense t = matmul(matmul(M4, M3), M1i);
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) { H(4 + i, j) = -t(i, j); H(4 + i, 4 + j) = M4(i, j); }
+  }
+  // --- knot map N (8S x 4(S+1)), split into fixed / free columns
+  Dense N(nz, nk);
+  for (int s = 0; s < S; ++s)
+    for (int i = 0; i < 8; ++i)
+      for (int j = 0; j < 8; ++j) N(8 * s + i, 4 * s + j) = H(i, j);
+  const int fixed[4] = {0, 1, 4 * S, 4 * S + 1};
+  std::vector<int> freec;
+  for (int i = 0; i < nk; ++i)
+    if (i != fixed[0] && i != fixed[1] && i != fixed[2] && i != fixed[3]) freec.push_back(i);
+  Dense Nf(nz, nq), Nx(nz, 4);
+  for (int i = 0; i < nz; ++i) {
+    for (int j = 0; j < nq; ++j) Nf(i, j) = N(i, freec[j]);
+    for (int j = 0; j < 4; ++j) Nx(i, j) = N(i, fixed[j]);
+  }
+  // --- whitening metric and its Cholesky factor
+  Dense M(nz, nz);
+  for (int d = 0; d < 3; ++d) {
+    Dense PtP = matmul(Phi[d], Phi[d], true);
+    for (size_t i = 0; i < M.a.size(); ++i) M.a[i] += pl->wref[d] * PtP.a[i];
+  }
+  Dense MNf = matmul(M, Nf);
+  Dense Gram = matmul(Nf, MNf, true);
+  for (int i = 0; i < nq; ++i)
+    for (int j = i + 1; j < nq; ++j) { const double s = 0.5 * (Gram(i, j) + Gram(j, i)); Gram(i, j) = s; Gram(j, i) = s; }
+  if (!cholesky(Gram)) { d2d_set_error("fit_basis_build: whitening metric not positive definite (wref, K, S?)"); return D2D_EINVAL; }
+  // Z = Nf L^-T  <=>  Z L^T = Nf : forward substitution over columns
+  Dense Z(nz, nq);
+  for (int i = 0; i < nz; ++i)
+    for (int j = 0; j < nq; ++j) {
+      double s = Nf(i, j);
+      for (int k = 0; k < j; ++k) s -= Z(i, k) * Gram(j, k);
+      Z(i, j) = s / Gram(j, j);
+    }
+  // Zp = Nx - Z (Z^T M Nx)
+  Dense ZtMNx = matmul(Z, matmul(M, Nx), true);
+  Dense Zp = Nx;
+  {
+    Dense c = matmul(Z, ZtMNx);
+    for (size_t i = 0; i < Zp.a.size(); ++i) Zp.a[i] -= c.a[i];
+  }
+  pl->Z = Z.a;
+  pl->Zp = Zp.a;
+  pl->G.assign((size_t)3 * K * nq, 0.0);
+  pl->Gp.assign((size_t)3 * K * 4, 0.0);
+  for (int d = 0; d < 3; ++d) {
+    Dense g = matmul(Phi[d], Z), gp = matmul(Phi[d], Zp);
+    std::memcpy(&pl->G[(size_t)d * K * nq], g.a.data(), sizeof(double) * K * nq);
+    std::memcpy(&pl->Gp[(size_t)d * K * 4], gp.a.data(), sizeof(double) * K * 4);
+  }
+  // Pinit = (G0^T G0)^-1 G0^T
+  Dense G0(K, nq);
+  std::memcpy(G0.a.data(), pl->G.data(), sizeof(double) * K * nq);
+  Dense A = matmul(G0, G0, true);
+  pl->G0tG0 = A.a;
+  Dense L = A;
+  if (!cholesky(L)) { d2d_set_error("fit_basis_build: G0^T G0 singular (K too small for S?)"); return D2D_EINVAL; }
+  pl->Pinit.assign((size_t)nq * K, 0.0);
+  std::vector<double> y(nq);
+  for (int k = 0; k < K; ++k) {
+    for (int i = 0; i < nq; ++i) {
+      double s = G0(k, i);
+      for (int j = 0; j < i; ++j) s -= L(i, j) * y[j];
+      y[i] = s / L(i, i);
+    }
+    for (int i = nq - 1; i >= 0; --i) {
+      double s = y[i];
+      for (int j = i + 1; j < nq; ++j) s -= L(j, i) * pl->Pinit[(size_t)j * K + k];
+      pl->Pinit[(size_t)i * K + k] = s / L(i, i);
+    }
+  }
+  return D2D_OK;
+}

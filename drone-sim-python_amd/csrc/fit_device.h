@@ -1,0 +1,199 @@
+// Device functions of the polynomial trajectory fit: one wavefront per trajectory,
+// lane = sample for the flat-output / residual phase, lane = unknown for J^T r and the
+// triangular solves, v_mfma_f32_16x16x4_f32 for J^T J.
+// Restates oracle/fit.py; reference lines are relative to the reference repository root.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/d2d.h"
+
+#define FIT_G 9.81        // src/d2d/guidance.py:39
+#define FIT_OBS_K 2.0     // src/d2d/opty_utils.py:103
+#define FIT_PHI_MAX 0.6981317007977318   // 40 deg  (src/multi_opt_planner.py:192)
+#define FIT_V_MIN 9.0
+#define FIT_V_MAX 15.0
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Compiler-level ordering of LDS traffic between the lanes of ONE wavefront (the LDS
+// itself executes a wave's DS instructions in order).
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Geometry of the shared LDS image of the basis block.
+struct FitGeom {
+  int K, nq, gstr;   // gstr = nq + 1: odd row stride -> conflict-free for lane=sample AND lane=unknown
+};
+
+// Scenario row in registers (wave-uniform values).
+struct Scen {
+  double x0, y0, psi0, x1, y1, psi1, vref, vsp, kv, kphi, kobs, s, wwp, wx, wy, goleft;
+  double o0x, o0y, o0r, o1x, o1y, o1r, wbnd;
+  double dx[4], dy[4];          // end data [pos0, vel0, pos1, vel1] per axis
+  double p2x, p2y;              // apex of the 'tri' dog-leg
+};
+
+__device__ __forceinline__ Scen load_scen(const double *__restrict__ sc, double duration) {
+  Scen s;
+  s.x0 = sc[D2D_SC_X0]; s.y0 = sc[D2D_SC_Y0]; s.psi0 = sc[D2D_SC_PSI0];
+  s.x1 = sc[D2D_SC_X1]; s.y1 = sc[D2D_SC_Y1]; s.psi1 = sc[D2D_SC_PSI1];
+  s.vref = sc[D2D_SC_VREF]; s.vsp = sc[D2D_SC_VSP]; s.kv = sc[D2D_SC_KV]; s.kphi = sc[D2D_SC_KPHI];
+  s.kobs = sc[D2D_SC_KOBS]; s.s = sc[D2D_SC_S]; s.wwp = sc[D2D_SC_WWP]; s.wx = sc[D2D_SC_WX];
+  s.wy = sc[D2D_SC_WY]; s.goleft = sc[D2D_SC_GOLEFT];
+  s.o0x = sc[D2D_SC_O0X]; s.o0y = sc[D2D_SC_O0Y]; s.o0r = sc[D2D_SC_O0R];
+  s.o1x = sc[D2D_SC_O1X]; s.o1y = sc[D2D_SC_O1Y]; s.o1r = sc[D2D_SC_O1R];
+  s.wbnd = sc[D2D_SC_WBND];
+  double s0, c0, s1, c1;
+  sincos(s.psi0, &s0, &c0);
+  sincos(s.psi1, &s1, &c1);
+  s.dx[0] = s.x0; s.dx[1] = s.vref * c0; s.dx[2] = s.x1; s.dx[3] = s.vref * c1;
+  s.dy[0] = s.y0; s.dy[1] = s.vref * s0; s.dy[2] = s.y1; s.dy[3] = s.vref * s1;
+  // triangle(), src/d2d/opty_utils.py:171-187
+  const double ex = s.x1 - s.x0, ey = s.y1 - s.y0;
+  const double d = sqrt(ex * ex + ey * ey);
+  const double ux = ex / d, uy = ey / d;
+  const double D = s.vref * duration;
+  s.p2x = s.x0 + ex / 2; s.p2y = s.y0 + ey / 2;
+  if (D > d) {
+    const double sg = (s.goleft > 0.0) ? 1.0 : ((s.goleft < 0.0) ? -1.0 : 0.0);
+    const double h = sg * sqrt(D * D - d * d) / 2;
+    s.p2x += h * (-uy); s.p2y += h * ux;
+  }
+  return s;
+}
+
+// numpy.linspace(a, b, n)[i]
+__device__ __forceinline__ double linspace_at(double a, double b, int n, int i) {
+  if (n == 1) return a;
+  if (i == n - 1) return b;
+  const double step = (b - a) / (n - 1);
+  return i * step + a;
+}
+
+__device__ __forceinline__ void waypoint_at(const Scen &s, int K, int k, double &wx, double &wy) {
+  const int n1 = K / 2, n2 = K - n1;
+  if (k < n1) { wx = linspace_at(s.x0, s.p2x, n1, k); wy = linspace_at(s.y0, s.p2y, n1, k); }
+  else { wx = linspace_at(s.p2x, s.x1, n2, k - n1); wy = linspace_at(s.p2y, s.y1, n2, k - n1); }
+}
+
+// Flat outputs at sample k:  Y = [x, y, xd, yd, xdd, ydd]  (oracle/fit.py flat_outputs)
+__device__ __forceinline__ void flat_outputs(const FitGeom &g, const double *__restrict__ G64,
+                                             const double *__restrict__ Gp64,
+                                             const double *__restrict__ q, const Scen &s, int k,
+                                             double Y[6]) {
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const double *gp = Gp64 + ((size_t)d * g.K + k) * 4;
+    double ax = 0.0, ay = 0.0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { ax = fma(gp[c], s.dx[c], ax); ay = fma(gp[c], s.dy[c], ay); }
+    Y[2 * d] = ax; Y[2 * d + 1] = ay;
+  }
+  const double *g0 = G64 + (size_t)k * g.gstr;
+  const double *g1 = g0 + (size_t)g.K * g.gstr;
+  const double *g2 = g1 + (size_t)g.K * g.gstr;
+  for (int j = 0; j < g.nq; ++j) {
+    const double qx = q[j], qy = q[g.nq + j];
+    const double a0 = g0[j], a1 = g1[j], a2 = g2[j];
+    Y[0] = fma(a0, qx, Y[0]); Y[1] = fma(a0, qy, Y[1]);
+    Y[2] = fma(a1, qx, Y[2]); Y[3] = fma(a1, qy, Y[3]);
+    Y[4] = fma(a2, qx, Y[4]); Y[5] = fma(a2, qy, Y[5]);
+  }
+}
+
+// Residual rows of one sample (oracle/fit.py residuals).  Returns sum r^2.
+// With WANT_JAC: u[6] = D^T r (for J^T r, fp64) and the fp32 row coefficients of the four
+// rows contracted by the MFMA -- v, phi (bound rows merged into their weights), obs0, obs1:
+//   coef[rho][0..2] = d row / d (x, xd, xdd),  coef[rho][3..5] = d row / d (y, yd, ydd)
+template <bool WANT_JAC>
+__device__ __forceinline__ double sample_terms(const Scen &s, const double Y[6], double wpx,
+                                               double wpy, double u[6], float coef[4][6]) {
+  const double x = Y[0], y = Y[1];
+  const double a = Y[2] - s.wx, b = Y[3] - s.wy, c = Y[4], d = Y[5];
+  const double va2 = a * a + b * b, va = sqrt(va2);
+  const double n = d * a - c * b;
+  const double ivg = 1.0 / (va * FIT_G);
+  const double w = n * ivg;
+  const double phi = atan(w);                       // src/d2d/guidance.py:40
+  const double cv2 = s.s * s.kv, cphi2 = s.s * s.kphi, cobs = sqrt(s.s * s.kobs);
+  const double cv = sqrt(cv2), cphi = sqrt(cphi2);
+  const double r0 = cv * (va - s.vsp);              // CostInput, src/d2d/opty_utils.py:85-97
+  const double r1 = cphi * phi;
+  const double r2 = s.wwp * (x - wpx), r3 = s.wwp * (y - wpy);
+  double h0 = 0.0, h1 = 0.0, e0x = 0.0, e0y = 0.0, e1x = 0.0, e1y = 0.0;
+  if (s.o0r > 0.0) {                                // CostObstacle kind 1, :99-134
+    e0x = (x - s.o0x) * (FIT_OBS_K / s.o0r); e0y = (y - s.o0y) * (FIT_OBS_K / s.o0r);
+    h0 = cobs * exp(-0.5 * (e0x * e0x + e0y * e0y));
+  }
+  if (s.o1r > 0.0) {
+    e1x = (x - s.o1x) * (FIT_OBS_K / s.o1r); e1y = (y - s.o1y) * (FIT_OBS_K / s.o1r);
+    h1 = cobs * exp(-0.5 * (e1x * e1x + e1y * e1y));
+  }
+  const double hphi = fmax(fabs(phi) - FIT_PHI_MAX, 0.0);
+  const double hv = fmax(va - FIT_V_MAX, 0.0) + fmin(va - FIT_V_MIN, 0.0);
+  const double r6 = s.wbnd * hphi, r7 = s.wbnd * hv;
+  const double cost = r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3 + h0 * h0 + h1 * h1 + r6 * r6 + r7 * r7;
+  if (WANT_JAC) {
+    const double dva_a = a / va, dva_b = b / va;
+    const double f = 1.0 / (1.0 + w * w);
+    const double nv3 = n / (va2 * va * FIT_G);
+    const double dp_a = (d * ivg - nv3 * a) * f, dp_b = (-c * ivg - nv3 * b) * f;
+    const double dp_c = -b * ivg * f, dp_d = a * ivg * f;
+    const double actp = (hphi > 0.0) ? ((phi > 0.0) ? 1.0 : -1.0) : 0.0;
+    const double actv = (va > FIT_V_MAX || va < FIT_V_MIN) ? 1.0 : 0.0;
+    const double k0 = FIT_OBS_K / (s.o0r > 0.0 ? s.o0r : 1.0), k1 = FIT_OBS_K / (s.o1r > 0.0 ? s.o1r : 1.0);
+    const double o0x = -h0 * e0x * k0, o0y = -h0 * e0y * k0;
+    const double o1x = -h1 * e1x * k1, o1y = -h1 * e1y * k1;
+    // u = D^T r over all eight rows
+    const double tv = cv * r0 + s.wbnd * actv * r7;                 // multiplies d va
+    const double tp = cphi * r1 + s.wbnd * actp * r6;               // multiplies d phi
+    u[0] = s.wwp * r2 + o0x * h0 + o1x * h1;
+    u[1] = s.wwp * r3 + o0y * h0 + o1y * h1;
+    u[2] = tv * dva_a + tp * dp_a;
+    u[3] = tv * dva_b + tp * dp_b;
+    u[4] = tp * dp_c;
+    u[5] = tp * dp_d;
+    // merged row weights for J^T J: (cv^2 + wb^2 actv) dva dva^T, (cphi^2 + wb^2 |actp|) dphi dphi^T
+    const double mv = sqrt(cv2 + s.wbnd * s.wbnd * actv);
+    const double mp = sqrt(cphi2 + s.wbnd * s.wbnd * actp * actp);
+    coef[0][0] = 0.f; coef[0][1] = (float)(mv * dva_a); coef[0][2] = 0.f;
+    coef[0][3] = 0.f; coef[0][4] = (float)(mv * dva_b); coef[0][5] = 0.f;
+    coef[1][0] = 0.f; coef[1][1] = (float)(mp * dp_a); coef[1][2] = (float)(mp * dp_c);
+    coef[1][3] = 0.f; coef[1][4] = (float)(mp * dp_b); coef[1][5] = (float)(mp * dp_d);
+    coef[2][0] = (float)o0x; coef[2][1] = 0.f; coef[2][2] = 0.f;
+    coef[2][3] = (float)o0y; coef[2][4] = 0.f; coef[2][5] = 0.f;
+    coef[3][0] = (float)o1x; coef[3][1] = 0.f; coef[3][2] = 0.f;
+    coef[3][3] = (float)o1y; coef[3][4] = 0.f; coef[3][5] = 0.f;
+  }
+  return cost;
+}
+
+// Cost at q (wave-cooperative): sum over samples of sum r^2.
+__device__ __forceinline__ double wave_cost(const FitGeom &g, const double *G64, const double *Gp64,
+                                            const double *q, const Scen &s, int lane) {
+  double acc = 0.0;
+  for (int k0 = 0; k0 < g.K; k0 += 64) {
+    const int k = k0 + lane;
+    if (k < g.K) {
+      double Y[6], wpx, wpy;
+      flat_outputs(g, G64, Gp64, q, s, k, Y);
+      waypoint_at(s, g.K, k, wpx, wpy);
+      acc += sample_terms<false>(s, Y, wpx, wpy, nullptr, nullptr);
+    }
+  }
+  return wave_sum(acc);
+}

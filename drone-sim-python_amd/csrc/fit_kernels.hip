@@ -1,0 +1,692 @@
+// Polynomial trajectory fit: kernels and C-ABI entry points (include/d2d.h).
+//
+//   fit_eval_kernel : flat outputs + residuals (fp64), J^T r (fp64), J^T J (fp32 MFMA)
+//   fit_step_kernel : damped Cholesky solve (fp32, registers + cross-lane broadcast),
+//                     trial cost (fp64), Nielsen gain-ratio update
+// One wavefront per trajectory; the basis block shared by the whole batch is staged in LDS
+// once per workgroup.  Restates oracle/fit.py (lm_solve, eval_normal).
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "fit_device.h"
+#include "fit_plan.h"
+
+#define FIT_WPB 8            // wavefronts (= trajectories) per workgroup
+#define FIT_THREADS (64 * FIT_WPB)
+
+// flags[b][4] = status, iters, need_eval, nevals ; lm[b][4] = lambda, nu, gmax, cost_prev
+enum { FL_STATUS = 0, FL_ITERS = 1, FL_NEED = 2, FL_NEVAL = 3 };
+
+struct FitLds {
+  // byte offsets into dynamic LDS
+  int G64, Gp64, G32, wave0, wave_stride;
+  int q, u, coef;     // offsets inside a wave's private block
+  int total;
+};
+
+static inline int align16(int v) { return (v + 15) & ~15; }
+
+static FitLds eval_lds_layout(int K, int nq) {
+  FitLds L;
+  const int gstr = nq + 1;
+  int o = 0;
+  L.G64 = o; o = align16(o + 3 * K * gstr * 8);
+  L.Gp64 = o; o = align16(o + 3 * K * 4 * 8);
+  L.G32 = o; o = align16(o + K * nq * 16);
+  L.wave0 = o;
+  int w = 0;
+  L.q = w; w = align16(w + 2 * nq * 8);
+  L.u = w; w = align16(w + K * 6 * 8);
+  L.coef = w; w = align16(w + K * 4 * 6 * 4);
+  L.wave_stride = w;
+  L.total = o + FIT_WPB * w;
+  return L;
+}
+
+// Cooperative copy global -> LDS (whole workgroup), 8-byte granules.
+__device__ __forceinline__ void stage(void *dst, const void *src, int bytes) {
+  double *d = reinterpret_cast<double *>(dst);
+  const double *s = reinterpret_cast<const double *>(src);
+  for (int i = threadIdx.x; i < bytes / 8; i += blockDim.x) d[i] = s[i];
+}
+
+// ------------------------------------------------------------------------------------
+// K1 + K2: cost, J^T r, J^T J.   H is written as the upper block triangle of 16x16 tiles
+// of a [n][n] row-major matrix (n = 2nq); symmetrize_kernel mirrors it for the public API.
+template <int NB>   // NB = ceil(2nq/16) column blocks of the MFMA tiling
+__global__ void __launch_bounds__(FIT_THREADS)
+fit_eval_kernel(int B, FitGeom g, FitLds L, double duration, const double *__restrict__ gG64,
+                const double *__restrict__ gGp64, const float *__restrict__ gG32,
+                const float *__restrict__ gW32, const double *__restrict__ scen,
+                const double *__restrict__ q_in, int32_t *__restrict__ flags,
+                double *__restrict__ cost_out, double *__restrict__ g_out, float *__restrict__ H_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  double *G64 = reinterpret_cast<double *>(lds + L.G64);
+  double *Gp64 = reinterpret_cast<double *>(lds + L.Gp64);
+  const f32x4 *G32 = reinterpret_cast<const f32x4 *>(lds + L.G32);
+  stage(G64, gG64, 3 * g.K * g.gstr * 8);
+  stage(Gp64, gGp64, 3 * g.K * 4 * 8);
+  stage(lds + L.G32, gG32, g.K * g.nq * 16);
+  __syncthreads();
+
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b = blockIdx.x * FIT_WPB + wave;
+  if (b >= B) return;
+  if (flags && (flags[4 * b + FL_STATUS] != D2D_ST_RUNNING || flags[4 * b + FL_NEED] == 0)) return;
+
+  unsigned char *wl = lds + L.wave0 + wave * L.wave_stride;
+  double *qs = reinterpret_cast<double *>(wl + L.q);
+  double *us = reinterpret_cast<double *>(wl + L.u);
+  float *cf = reinterpret_cast<float *>(wl + L.coef);
+  const int n = 2 * g.nq;
+  if (lane < n) qs[lane] = q_in[(size_t)b * n + lane];
+  const Scen s = load_scen(scen + (size_t)b * D2D_SCEN_STRIDE, duration);
+  wave_lds_sync();
+
+  // ---- phase 1: lane = sample ------------------------------------------------------
+  double cacc = 0.0;
+  for (int k0 = 0; k0 < g.K; k0 += 64) {
+    const int k = k0 + lane;
+    if (k < g.K) {
+      double Y[6], wpx, wpy, u[6];
+      float coef[4][6];
+      flat_outputs(g, G64, Gp64, qs, s, k, Y);
+      waypoint_at(s, g.K, k, wpx, wpy);
+      cacc += sample_terms<true>(s, Y, wpx, wpy, u, coef);
+#pragma unroll
+      for (int c = 0; c < 6; ++c) us[k * 6 + c] = u[c];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) cf[(k * 4 + r) * 6 + c] = coef[r][c];
+    }
+  }
+  const double cost = wave_sum(cacc);
+  wave_lds_sync();
+
+  // ---- phase 2: J^T r, lane = unknown (fp64) ----------------------------------------
+  if (lane < n) {
+    const int ax = lane >= g.nq ? 1 : 0, jj = lane - ax * g.nq;
+    const double *g0 = G64 + jj, *g1 = g0 + (size_t)g.K * g.gstr, *g2 = g1 + (size_t)g.K * g.gstr;
+    double acc = 0.0;
+    for (int k = 0; k < g.K; ++k) {
+      const double *uk = us + k * 6;
+      acc = fma(uk[ax], g0[k * g.gstr], acc);
+      acc = fma(uk[2 + ax], g1[k * g.gstr], acc);
+      acc = fma(uk[4 + ax], g2[k * g.gstr], acc);
+    }
+    if (g_out) g_out[(size_t)b * n + lane] = acc;
+  }
+  if (lane == 0) {
+    if (cost_out) cost_out[b] = cost;
+    if (flags) {
+      flags[4 * b + FL_NEED] = 0;
+      flags[4 * b + FL_NEVAL] += 1;
+      if (!(fabs(cost) <= 1.79e308)) flags[4 * b + FL_STATUS] = D2D_ST_NONFINITE;
+    }
+  }
+  if (!H_out) return;
+
+  // ---- phase 3: J^T J by v_mfma_f32_16x16x4_f32 --------------------------------------
+  // One MFMA k-step = the four contracted rows (v, phi, obs0, obs1) of one sample.
+  // Lane l supplies J[row rho = l>>4][col 16c + (l&15)] as A- and as B-operand alike.
+  const int rho = lane >> 4, ci = lane & 15;
+  int jcol[NB], jax[NB];
+  bool jok[NB];
+#pragma unroll
+  for (int c = 0; c < NB; ++c) {
+    const int col = 16 * c + ci;
+    jok[c] = col < n;
+    jax[c] = (col >= g.nq) ? 1 : 0;
+    jcol[c] = jok[c] ? col - jax[c] * g.nq : 0;
+  }
+  f32x4 acc[NB * (NB + 1) / 2];
+#pragma unroll
+  for (int t = 0; t < NB * (NB + 1) / 2; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < g.K; ++k) {
+    const float *cr = cf + (k * 4 + rho) * 6;
+    const float c0 = cr[0], c1 = cr[1], c2 = cr[2], c3 = cr[3], c4 = cr[4], c5 = cr[5];
+    float v[NB];
+#pragma unroll
+    for (int c = 0; c < NB; ++c) {
+      const f32x4 gk = G32[k * g.nq + jcol[c]];
+      const float vx = c0 * gk.x + c1 * gk.y + c2 * gk.z;
+      const float vy = c3 * gk.x + c4 * gk.y + c5 * gk.z;
+      v[c] = jok[c] ? (jax[c] ? vy : vx) : 0.f;
+    }
+    int t = 0;
+#pragma unroll
+    for (int I = 0; I < NB; ++I)
+#pragma unroll
+      for (int J = I; J < NB; ++J, ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[I], v[J], acc[t], 0, 0, 0);
+  }
+  // epilogue: + wwp^2 G0^T G0 on the xx / yy blocks; C/D layout row = (l>>4)*4 + reg, col = l&15
+  const float ww = (float)(s.wwp * s.wwp);
+  float *Hb = H_out + (size_t)b * n * n;
+  int t = 0;
+#pragma unroll
+  for (int I = 0; I < NB; ++I)
+#pragma unroll
+    for (int J = I; J < NB; ++J, ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * I + rho * 4 + r, col = 16 * J + ci;
+        if (row < n && col < n) {
+          float val = acc[t][r];
+          const int ra = row >= g.nq, ca = col >= g.nq;
+          if (ra == ca) val += ww * gW32[(row - ra * g.nq) * g.nq + (col - ca * g.nq)];
+          Hb[(size_t)row * n + col] = val;
+        }
+      }
+    }
+}
+
+// mirror the upper block triangle written by fit_eval_kernel into a full symmetric matrix
+__global__ void __launch_bounds__(256) symmetrize_kernel(int B, int n, float *__restrict__ H) {
+  const int b = blockIdx.x;
+  float *Hb = H + (size_t)b * n * n;
+  for (int i = threadIdx.x; i < n * n; i += blockDim.x) {
+    const int r = i / n, c = i - r * n;
+    if ((r >> 4) > (c >> 4)) Hb[i] = Hb[(size_t)c * n + r];
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// K3: one damped solve + trial + accept/reject.  N = padded system size (16*NB).
+struct StepLds {
+  int G64, Gp64, wave0, wave_stride, Lm, vec, qt, total;
+};
+static StepLds step_lds_layout(int K, int nq, int N) {
+  StepLds L;
+  const int gstr = nq + 1;
+  int o = 0;
+  L.G64 = o; o = align16(o + 3 * K * gstr * 8);
+  L.Gp64 = o; o = align16(o + 3 * K * 4 * 8);
+  L.wave0 = o;
+  int w = 0;
+  L.Lm = w; w = align16(w + N * (N + 1) * 4);
+  L.vec = w; w = align16(w + N * 4);
+  L.qt = w; w = align16(w + N * 8);
+  L.wave_stride = w;
+  L.total = o + FIT_WPB * w;
+  return L;
+}
+
+template <int N>
+__global__ void __launch_bounds__(FIT_THREADS)
+fit_step_kernel(int B, FitGeom g, StepLds L, double duration, d2d_fit_opts opts,
+                const double *__restrict__ gG64, const double *__restrict__ gGp64,
+                const double *__restrict__ scen, double *__restrict__ q_io,
+                const double *__restrict__ g_in, const float *__restrict__ H_in,
+                double *__restrict__ cost_io, double *__restrict__ lm, int32_t *__restrict__ flags) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  double *G64 = reinterpret_cast<double *>(lds + L.G64);
+  double *Gp64 = reinterpret_cast<double *>(lds + L.Gp64);
+  stage(G64, gG64, 3 * g.K * g.gstr * 8);
+  stage(Gp64, gGp64, 3 * g.K * 4 * 8);
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b = blockIdx.x * FIT_WPB + wave;
+  if (b >= B) return;
+  if (flags[4 * b + FL_STATUS] != D2D_ST_RUNNING) return;
+  unsigned char *wl = lds + L.wave0 + wave * L.wave_stride;
+  float *Lm = reinterpret_cast<float *>(wl + L.Lm);       // [N][N+1]
+  double *qt = reinterpret_cast<double *>(wl + L.qt);     // trial point
+  const int n = 2 * g.nq;
+  const int LS = N + 1;
+
+  const double lam = lm[4 * b + 0], nu = lm[4 * b + 1];
+  const double c = cost_io[b];
+  const int iters = flags[4 * b + FL_ITERS];
+  const bool act = lane < n;
+  const double gi = act ? g_in[(size_t)b * n + lane] : 0.0;
+  const double qi = act ? q_io[(size_t)b * n + lane] : 0.0;
+  const double gmax = wave_max(fabs(gi));
+  if (lane == 0) lm[4 * b + 2] = gmax;
+  if (gmax <= opts.gtol) {                                 // wave-uniform
+    if (lane == 0) flags[4 * b + FL_STATUS] = D2D_ST_CONVERGED;
+    return;
+  }
+  // ---- row `lane` of A = H + lam*diag(max(H_ii, floor)) into registers ---------------
+  const float *Hb = H_in + (size_t)b * n * n;
+  float row[N];
+  float dgi = 1.f;
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    float v = 0.f;
+    if (act && j < n) {
+      // upper block triangle is stored; mirror the rest
+      const bool up = (lane >> 4) <= (j >> 4);
+      v = up ? Hb[(size_t)lane * n + j] : Hb[(size_t)j * n + lane];
+    }
+    row[j] = v;
+  }
+  // diagonal
+  {
+    float d = 1.f;
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+      if (j == lane) d = row[j];
+    if (!act) d = 1.f;
+    dgi = fmaxf(d, (float)D2D_LM_DIAG_FLOOR);
+    const float add = (float)(lam * (double)dgi);
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+      if (j == lane) row[j] = act ? (d + add) : 1.f;
+  }
+  // ---- Cholesky, left-looking: lane = row, row j broadcast by v_readlane --------------
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    float sacc = row[j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) {
+      const float ljk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, row[k]), j));
+      sacc = fmaf(-row[k], ljk, sacc);
+    }
+    const float djj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sacc), j));
+    ok = ok && (djj > 0.f);
+    const float inv = rsqrtf(fmaxf(djj, 1e-30f));
+    row[j] = (lane >= j) ? sacc * inv : 0.f;   // L[lane][j]; diagonal = sqrt(djj)
+  }
+  // ---- forward substitution L y = -g (lane i keeps y_i) ------------------------------
+  float y = (float)(-gi);
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    float ljj = 1.f;
+#pragma unroll
+    for (int t = 0; t < N; ++t)
+      if (t == j) ljj = row[t];
+    const float yj_own = y / ljj;                                  // valid on lane j
+    const float yj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, yj_own), j));
+    if (lane == j) y = yj;
+    else if (lane > j) y = fmaf(-row[j], yj, y);
+  }
+  // ---- back substitution L^T delta = y: needs columns of L -> stage L in LDS ----------
+#pragma unroll
+  for (int j = 0; j < N; ++j)
+    if (lane < N) Lm[lane * LS + j] = row[j];
+  wave_lds_sync();
+  float dl = y;
+#pragma unroll
+  for (int i = N - 1; i >= 0; --i) {
+    float lii = 1.f;
+#pragma unroll
+    for (int t = 0; t < N; ++t)
+      if (t == i) lii = row[t];
+    const float di_own = dl / lii;                                 // valid on lane i
+    const float di = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, di_own), i));
+    if (lane == i) dl = di;
+    else if (lane < i) dl = fmaf(-Lm[i * LS + lane], di, dl);      // L[i][lane]
+  }
+  const double delta = act ? (double)dl : 0.0;
+  // ---- trial point, predicted and actual reduction ------------------------------------
+  if (lane < N) qt[lane] = qi + delta;
+  wave_lds_sync();
+  const Scen s = load_scen(scen + (size_t)b * D2D_SCEN_STRIDE, duration);
+  double ct = wave_cost(g, G64, Gp64, qt, s, lane);
+  const double pred = wave_sum(delta * (lam * (double)dgi * delta - gi));
+  const double dmax = wave_max(fabs(delta)), qmax = wave_max(fabs(qi));
+  const bool fin = ok && (fabs(ct) <= 1.79e308) && (pred > 0.0);
+  const double rho = fin ? (c - ct) / pred : -1.0;
+  int status = D2D_ST_RUNNING;
+  double lam_n = lam, nu_n = nu;
+  if (rho > 0.0) {
+    if (act) q_io[(size_t)b * n + lane] = qi + delta;
+    const double t = 2.0 * rho - 1.0;
+    lam_n = fmax(lam * fmax(1.0 / 3.0, 1.0 - t * t * t), D2D_LM_LAMBDA_MIN);
+    nu_n = 2.0;
+    const bool small_x = dmax <= opts.xtol * (qmax + opts.xtol);
+    const bool small_f = ((c - ct) <= opts.ftol * c) && (pred <= opts.ftol * c);
+    if (small_f || small_x) status = D2D_ST_CONVERGED;
+    if (lane == 0) {
+      cost_io[b] = ct;
+      flags[4 * b + FL_NEED] = 1;     // gradient / Hessian at the new point (also when converged)
+    }
+  } else {
+    lam_n = lam * nu;
+    nu_n = nu * 2.0;
+    if (lam_n > D2D_LM_LAMBDA_MAX) status = D2D_ST_STALLED;
+  }
+  if (lane == 0) {
+    lm[4 * b + 0] = lam_n;
+    lm[4 * b + 1] = nu_n;
+    flags[4 * b + FL_ITERS] = iters + 1;
+    if (status == D2D_ST_RUNNING && iters + 1 >= opts.max_iter) status = D2D_ST_MAXITER;
+    flags[4 * b + FL_STATUS] = status;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+fit_state_init_kernel(int B, double *__restrict__ lm, int32_t *__restrict__ flags) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  lm[4 * b + 0] = D2D_LM_LAMBDA0; lm[4 * b + 1] = 2.0; lm[4 * b + 2] = 0.0; lm[4 * b + 3] = 0.0;
+  flags[4 * b + FL_STATUS] = D2D_ST_RUNNING; flags[4 * b + FL_ITERS] = 0; flags[4 * b + FL_NEED] = 1;
+  flags[4 * b + FL_NEVAL] = 0;
+}
+
+// counts trajectories still running -> counter[0]
+__global__ void __launch_bounds__(256)
+fit_count_kernel(int B, const int32_t *__restrict__ flags, int32_t *__restrict__ counter) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int run = (b < B && flags[4 * b + FL_STATUS] == D2D_ST_RUNNING) ? 1 : 0;
+  const unsigned long long m = __ballot(run);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(counter, (int)__popcll(m));
+}
+
+// stats[0] += cost, stats[1] = max gmax, stats[2] += not converged, stats[3] += evaluations
+__global__ void __launch_bounds__(256)
+fit_stats_kernel(int B, int n, const double *__restrict__ cost, const double *__restrict__ g,
+                 const int32_t *__restrict__ flags, double *__restrict__ stats) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  double c = 0.0, gm = 0.0, nr = 0.0, ne = 0.0;
+  if (b < B) {
+    c = cost[b];
+    for (int j = 0; j < n; ++j) gm = fmax(gm, fabs(g[(size_t)b * n + j]));
+    const int st = flags[4 * b + FL_STATUS];
+    nr = (st == D2D_ST_CONVERGED || st == D2D_ST_STALLED) ? 0.0 : 1.0;
+    ne = flags[4 * b + FL_NEVAL];
+  }
+  c = wave_sum(c); gm = wave_max(gm); nr = wave_sum(nr); ne = wave_sum(ne);
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&stats[0], c);
+    atomicAdd(&stats[2], nr);
+    atomicAdd(&stats[3], ne);
+    // max of non-negative doubles == max of their bit patterns
+    atomicMax(reinterpret_cast<unsigned long long *>(&stats[1]), (unsigned long long)__double_as_longlong(gm));
+  }
+}
+
+__global__ void __launch_bounds__(256)
+fit_export_kernel(int B, const int32_t *__restrict__ flags, int32_t *__restrict__ iters,
+                  int32_t *__restrict__ status) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  if (iters) iters[b] = flags[4 * b + FL_ITERS];
+  if (status) status[b] = flags[4 * b + FL_STATUS];
+}
+
+// q0 = Pinit (wp - Gp0 d): one wavefront per trajectory, lane = unknown
+__global__ void __launch_bounds__(256)
+fit_init_kernel(int B, int K, int nq, double duration, const double *__restrict__ Gp,
+                const double *__restrict__ Pinit, const double *__restrict__ scen,
+                double *__restrict__ q) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + wave;
+  if (b >= B) return;
+  const Scen s = load_scen(scen + (size_t)b * D2D_SCEN_STRIDE, duration);
+  const int n = 2 * nq;
+  for (int l = lane; l < n; l += 64) {
+    const int ax = l >= nq, j = l - ax * nq;
+    double acc = 0.0;
+    for (int k = 0; k < K; ++k) {
+      double wx, wy;
+      waypoint_at(s, K, k, wx, wy);
+      const double *gp = Gp + (size_t)k * 4;
+      double base = 0.0;
+      for (int c = 0; c < 4; ++c) base += gp[c] * (ax ? s.dy[c] : s.dx[c]);
+      acc += Pinit[(size_t)j * K + k] * ((ax ? wy : wx) - base);
+    }
+    q[(size_t)b * n + l] = acc;
+  }
+}
+
+// z[b][axis][row] = Zp[row] . d_axis + Z[row] . q_axis
+__global__ void __launch_bounds__(256)
+fit_coeffs_kernel(int B, int S, int nq, double duration, const double *__restrict__ Z,
+                  const double *__restrict__ Zp, const double *__restrict__ scen,
+                  const double *__restrict__ q, double *__restrict__ z) {
+  const int nz = 8 * S;
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= (long)B * 2 * nz) return;
+  const int b = i / (2 * nz), r = i - (long)b * 2 * nz, ax = r / nz, row = r - ax * nz;
+  const Scen s = load_scen(scen + (size_t)b * D2D_SCEN_STRIDE, duration);
+  double acc = 0.0;
+  for (int c = 0; c < 4; ++c) acc += Zp[(size_t)row * 4 + c] * (ax ? s.dy[c] : s.dx[c]);
+  const double *qa = q + (size_t)b * 2 * nq + ax * nq;
+  for (int j = 0; j < nq; ++j) acc += Z[(size_t)row * nq + j] * qa[j];
+  z[i] = acc;
+}
+
+// flat outputs and flatness states at the K nodes
+__global__ void __launch_bounds__(256)
+fit_sample_kernel(int B, FitGeom g, double duration, const double *__restrict__ G64,
+                  const double *__restrict__ Gp64, const double *__restrict__ scen,
+                  const double *__restrict__ q, double *__restrict__ Yo, double *__restrict__ Xo) {
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= (long)B * g.K) return;
+  const int b = i / g.K, k = i - (long)b * g.K;
+  const Scen s = load_scen(scen + (size_t)b * D2D_SCEN_STRIDE, duration);
+  double Y[6];
+  flat_outputs(g, G64, Gp64, q + (size_t)b * 2 * g.nq, s, k, Y);
+  if (Yo)
+    for (int c = 0; c < 6; ++c) Yo[((size_t)b * 6 + c) * g.K + k] = Y[c];
+  if (Xo) {
+    // DiffFlatness.state_and_input_from_output, src/d2d/guidance.py:22-47
+    const double a = Y[2] - s.wx, bb = Y[3] - s.wy;
+    const double va = sqrt(a * a + bb * bb);
+    double *o = Xo + (size_t)b * 5 * g.K + k;
+    o[0] = Y[0]; o[g.K] = Y[1]; o[2 * g.K] = atan2(bb, a);
+    o[3 * g.K] = atan((Y[5] * a - Y[4] * bb) / va / FIT_G); o[4 * g.K] = va;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+template <typename T>
+static int upload(T **dst, const std::vector<T> &src) {
+  D2D_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(dst), src.size() * sizeof(T)));
+  D2D_CHECK_HIP(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+  return D2D_OK;
+}
+
+static FitGeom geom_of(const d2d_fit_plan *pl) { return FitGeom{pl->K, pl->nq, pl->nq + 1}; }
+
+static int ensure_scratch(d2d_fit_plan *pl, int B) {
+  if (B <= pl->cap_B) return D2D_OK;
+  const size_t n = 2 * pl->nq;
+  if (pl->d_g) { hipFree(pl->d_g); hipFree(pl->d_H); hipFree(pl->d_cost); hipFree(pl->d_lm); hipFree(pl->d_flags); }
+  D2D_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&pl->d_g), (size_t)B * n * sizeof(double)));
+  D2D_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&pl->d_H), (size_t)B * n * n * sizeof(float)));
+  D2D_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&pl->d_cost), (size_t)B * sizeof(double)));
+  D2D_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&pl->d_lm), (size_t)B * 4 * sizeof(double)));
+  D2D_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&pl->d_flags), (size_t)B * 4 * sizeof(int32_t)));
+  pl->cap_B = B;
+  return D2D_OK;
+}
+
+static int launch_eval(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, const double *scen, const double *q,
+                       int32_t *flags, double *cost, double *g, float *H) {
+  const FitGeom gm = geom_of(pl);
+  const FitLds L = eval_lds_layout(pl->K, pl->nq);
+  const int NB = (2 * pl->nq + 15) / 16;
+  const dim3 grid((B + FIT_WPB - 1) / FIT_WPB), block(FIT_THREADS);
+#define LAUNCH_EVAL(NBV)                                                                           \
+  hipLaunchKernelGGL(fit_eval_kernel<NBV>, grid, block, L.total, ctx->stream, B, gm, L, pl->duration, \
+                     pl->d_G, pl->d_Gp, pl->d_G32, pl->d_W32, scen, q, flags, cost, g, H)
+  if (NB == 1) LAUNCH_EVAL(1);
+  else if (NB == 2) LAUNCH_EVAL(2);
+  else LAUNCH_EVAL(3);
+#undef LAUNCH_EVAL
+  D2D_LAUNCH_CHECK();
+  return D2D_OK;
+}
+
+static int launch_step(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, const double *scen, double *q,
+                       const d2d_fit_opts &o) {
+  const FitGeom gm = geom_of(pl);
+  const int NB = (2 * pl->nq + 15) / 16;
+  const StepLds L = step_lds_layout(pl->K, pl->nq, 16 * NB);
+  const dim3 grid((B + FIT_WPB - 1) / FIT_WPB), block(FIT_THREADS);
+#define LAUNCH_STEP(NV)                                                                            \
+  hipLaunchKernelGGL(fit_step_kernel<NV>, grid, block, L.total, ctx->stream, B, gm, L, pl->duration, o, \
+                     pl->d_G, pl->d_Gp, scen, q, pl->d_g, pl->d_H, pl->d_cost, pl->d_lm, pl->d_flags)
+  if (NB == 1) LAUNCH_STEP(16);
+  else if (NB == 2) LAUNCH_STEP(32);
+  else LAUNCH_STEP(48);
+#undef LAUNCH_STEP
+  D2D_LAUNCH_CHECK();
+  return D2D_OK;
+}
+
+extern "C" {
+
+int d2d_fit_plan_create(d2d_ctx *ctx, int S, int K, double duration, const double *wref,
+                        d2d_fit_plan **out) {
+  D2D_REQUIRE(ctx && wref && out, "d2d_fit_plan_create: null argument");
+  D2D_REQUIRE(S >= 1 && S <= D2D_FIT_MAX_S, "d2d_fit_plan_create: S=%d not in 1..%d", S, D2D_FIT_MAX_S);
+  D2D_REQUIRE(K >= 8 * S / 3 + 2, "d2d_fit_plan_create: K=%d too small for S=%d", K, S);
+  D2D_REQUIRE(duration > 0, "d2d_fit_plan_create: duration must be > 0");
+  d2d_fit_plan *pl = new d2d_fit_plan();
+  pl->device = ctx->device;
+  pl->S = S; pl->K = K; pl->duration = duration;
+  for (int i = 0; i < 3; ++i) pl->wref[i] = wref[i];
+  if (int rc = fit_basis_build(pl)) { delete pl; return rc; }
+  const int nq = pl->nq, gstr = nq + 1;
+  const FitLds L = eval_lds_layout(K, nq);
+  const StepLds SL = step_lds_layout(K, nq, 16 * ((2 * nq + 15) / 16));
+  if (L.total > 160 * 1024 || SL.total > 160 * 1024) {
+    d2d_set_error("d2d_fit_plan_create: K=%d, S=%d needs %d B of LDS (> 160 KiB)", K, S, L.total > SL.total ? L.total : SL.total);
+    delete pl;
+    return D2D_EINVAL;
+  }
+  // device images: G64 with odd row stride, G32 interleaved (G0,G1,G2,0), W32 = G0^T G0
+  std::vector<double> g64((size_t)3 * K * gstr, 0.0);
+  for (int d = 0; d < 3; ++d)
+    for (int k = 0; k < K; ++k)
+      for (int j = 0; j < nq; ++j) g64[((size_t)d * K + k) * gstr + j] = pl->G[((size_t)d * K + k) * nq + j];
+  std::vector<float> g32((size_t)K * nq * 4, 0.f), w32((size_t)nq * nq);
+  for (int k = 0; k < K; ++k)
+    for (int j = 0; j < nq; ++j)
+      for (int d = 0; d < 3; ++d) g32[((size_t)k * nq + j) * 4 + d] = (float)pl->G[((size_t)d * K + k) * nq + j];
+  for (size_t i = 0; i < w32.size(); ++i) w32[i] = (float)pl->G0tG0[i];
+  D2D_CHECK_HIP(hipSetDevice(ctx->device));
+  int rc = upload(&pl->d_G, g64);
+  if (!rc) rc = upload(&pl->d_Gp, pl->Gp);
+  if (!rc) rc = upload(&pl->d_G32, g32);
+  if (!rc) rc = upload(&pl->d_W32, w32);
+  if (!rc) rc = upload(&pl->d_Z, pl->Z);
+  if (!rc) rc = upload(&pl->d_Zp, pl->Zp);
+  if (!rc) rc = upload(&pl->d_Pinit, pl->Pinit);
+  if (rc) { d2d_fit_plan_destroy(pl); return rc; }
+  // opt in to large dynamic LDS
+  hipFuncSetAttribute(reinterpret_cast<const void *>(&fit_eval_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipFuncSetAttribute(reinterpret_cast<const void *>(&fit_eval_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipFuncSetAttribute(reinterpret_cast<const void *>(&fit_eval_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipFuncSetAttribute(reinterpret_cast<const void *>(&fit_step_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipFuncSetAttribute(reinterpret_cast<const void *>(&fit_step_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipFuncSetAttribute(reinterpret_cast<const void *>(&fit_step_kernel<48>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipGetLastError();
+  *out = pl;
+  return D2D_OK;
+}
+
+int d2d_fit_plan_destroy(d2d_fit_plan *pl) {
+  if (!pl) return D2D_OK;
+  hipSetDevice(pl->device);
+  void *ptrs[] = {pl->d_G, pl->d_Gp, pl->d_G32, pl->d_W32, pl->d_Z, pl->d_Zp, pl->d_Pinit,
+                  pl->d_g, pl->d_H, pl->d_cost, pl->d_lm, pl->d_flags};
+  for (void *p : ptrs)
+    if (p) hipFree(p);
+  delete pl;
+  return D2D_OK;
+}
+
+int d2d_fit_plan_get(const d2d_fit_plan *pl, double *G, double *Gp, double *Z, double *Zp, double *Pinit) {
+  D2D_REQUIRE(pl != nullptr, "d2d_fit_plan_get: plan is NULL");
+  if (G) std::memcpy(G, pl->G.data(), pl->G.size() * sizeof(double));
+  if (Gp) std::memcpy(Gp, pl->Gp.data(), pl->Gp.size() * sizeof(double));
+  if (Z) std::memcpy(Z, pl->Z.data(), pl->Z.size() * sizeof(double));
+  if (Zp) std::memcpy(Zp, pl->Zp.data(), pl->Zp.size() * sizeof(double));
+  if (Pinit) std::memcpy(Pinit, pl->Pinit.data(), pl->Pinit.size() * sizeof(double));
+  return D2D_OK;
+}
+
+int d2d_fit_init(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, const double *scen, double *q) {
+  D2D_REQUIRE(ctx && pl && scen && q, "d2d_fit_init: null argument");
+  D2D_REQUIRE(B >= 1, "d2d_fit_init: B must be >= 1");
+  hipLaunchKernelGGL(fit_init_kernel, dim3((B + 3) / 4), dim3(256), 0, ctx->stream, B, pl->K, pl->nq, pl->duration,
+                     pl->d_Gp, pl->d_Pinit, scen, q);
+  D2D_LAUNCH_CHECK();
+  return D2D_OK;
+}
+
+int d2d_fit_eval(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, const double *scen, const double *q,
+                 double *cost, double *g, float *H) {
+  D2D_REQUIRE(ctx && pl && scen && q, "d2d_fit_eval: null argument");
+  D2D_REQUIRE(B >= 1, "d2d_fit_eval: B must be >= 1");
+  if (int rc = launch_eval(ctx, pl, B, scen, q, nullptr, cost, g, H)) return rc;
+  if (H) {
+    hipLaunchKernelGGL(symmetrize_kernel, dim3(B), dim3(256), 0, ctx->stream, B, 2 * pl->nq, H);
+    D2D_LAUNCH_CHECK();
+  }
+  return D2D_OK;
+}
+
+int d2d_fit_solve(d2d_ctx *ctx, const d2d_fit_plan *plc, int B, const double *scen, double *q,
+                  const d2d_fit_opts *opts, double *cost, int32_t *iters, int32_t *status, double *stats) {
+  D2D_REQUIRE(ctx && plc && scen && q, "d2d_fit_solve: null argument");
+  D2D_REQUIRE(B >= 1, "d2d_fit_solve: B must be >= 1");
+  d2d_fit_plan *pl = const_cast<d2d_fit_plan *>(plc);
+  d2d_fit_opts o = {200, 8, 1e-14, 1e-9, 1e-11};
+  if (opts) o = *opts;
+  D2D_REQUIRE(o.max_iter >= 1 && o.check_every >= 1, "d2d_fit_solve: max_iter and check_every must be >= 1");
+  if (int rc = ensure_scratch(pl, B)) return rc;
+  const dim3 g1((B + 255) / 256), b1(256);
+  hipLaunchKernelGGL(fit_state_init_kernel, g1, b1, 0, ctx->stream, B, pl->d_lm, pl->d_flags);
+  D2D_LAUNCH_CHECK();
+  int it = 0;
+  while (it < o.max_iter) {
+    if (int rc = launch_eval(ctx, pl, B, scen, q, pl->d_flags, pl->d_cost, pl->d_g, pl->d_H)) return rc;
+    if (int rc = launch_step(ctx, pl, B, scen, q, o)) return rc;
+    ++it;
+    if (it % o.check_every == 0 || it == o.max_iter) {
+      D2D_CHECK_HIP(hipMemsetAsync(ctx->counter_dev, 0, sizeof(int32_t), ctx->stream));
+      hipLaunchKernelGGL(fit_count_kernel, g1, b1, 0, ctx->stream, B, pl->d_flags, ctx->counter_dev);
+      D2D_LAUNCH_CHECK();
+      D2D_CHECK_HIP(hipMemcpyAsync(ctx->counter_host, ctx->counter_dev, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+      D2D_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+      if (ctx->counter_host[0] == 0) break;
+    }
+  }
+  // converged trajectories carry a pending evaluation at the accepted point: refresh cost/gmax
+  if (int rc = launch_eval(ctx, pl, B, scen, q, nullptr, pl->d_cost, pl->d_g, nullptr)) return rc;
+  if (cost) D2D_CHECK_HIP(hipMemcpyAsync(cost, pl->d_cost, (size_t)B * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  hipLaunchKernelGGL(fit_export_kernel, g1, b1, 0, ctx->stream, B, pl->d_flags, iters, status);
+  D2D_LAUNCH_CHECK();
+  if (stats) {
+    D2D_CHECK_HIP(hipMemsetAsync(ctx->stats_dev, 0, 4 * sizeof(double), ctx->stream));
+    hipLaunchKernelGGL(fit_stats_kernel, g1, b1, 0, ctx->stream, B, 2 * pl->nq, pl->d_cost, pl->d_g, pl->d_flags, ctx->stats_dev);
+    D2D_LAUNCH_CHECK();
+    D2D_CHECK_HIP(hipMemcpyAsync(ctx->stats_host, ctx->stats_dev, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  }
+  D2D_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  if (stats)
+    for (int i = 0; i < 4; ++i) stats[i] = ctx->stats_host[i];
+  return D2D_OK;
+}
+
+int d2d_fit_coeffs(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, const double *scen, const double *q, double *z) {
+  D2D_REQUIRE(ctx && pl && scen && q && z, "d2d_fit_coeffs: null argument");
+  D2D_REQUIRE(B >= 1, "d2d_fit_coeffs: B must be >= 1");
+  const long tot = (long)B * 16 * pl->S;
+  hipLaunchKernelGGL(fit_coeffs_kernel, dim3((tot + 255) / 256), dim3(256), 0, ctx->stream, B, pl->S, pl->nq,
+                     pl->duration, pl->d_Z, pl->d_Zp, scen, q, z);
+  D2D_LAUNCH_CHECK();
+  return D2D_OK;
+}
+
+int d2d_fit_sample(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, const double *scen, const double *q, double *Y, double *Xs) {
+  D2D_REQUIRE(ctx && pl && scen && q, "d2d_fit_sample: null argument");
+  D2D_REQUIRE(B >= 1, "d2d_fit_sample: B must be >= 1");
+  const long tot = (long)B * pl->K;
+  hipLaunchKernelGGL(fit_sample_kernel, dim3((tot + 255) / 256), dim3(256), 0, ctx->stream, B, geom_of(pl), pl->duration,
+                     pl->d_G, pl->d_Gp, scen, q, Y, Xs);
+  D2D_LAUNCH_CHECK();
+  return D2D_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,31 @@
+// Shared basis block of the polynomial fit (host build + device copies).
+#pragma once
+#include <vector>
+
+#include "common.h"
+
+struct d2d_fit_plan {
+  int device;
+  int S, K, nq;        // segments, samples, reduced unknowns per axis (4*S)
+  double duration, T;
+  double wref[3];
+  // host copies (fp64)
+  std::vector<double> G, Gp, Z, Zp, Pinit, G0tG0;
+  // device copies
+  double *d_G = nullptr;     // [3][K][GSTR]   GSTR = nq+1 (odd stride: conflict-free LDS image)
+  double *d_Gp = nullptr;    // [3][K][4]
+  float *d_G32 = nullptr;    // [K][nq][4] = (G0,G1,G2,0) for the MFMA operand generation
+  float *d_W32 = nullptr;    // [nq][nq]  G0^T G0 (waypoint rows' constant J^T J block)
+  double *d_Z = nullptr;     // [8S][nq]
+  double *d_Zp = nullptr;    // [8S][4]
+  double *d_Pinit = nullptr; // [nq][K]
+  // solver scratch, grown on demand (d2d_fit_solve)
+  int cap_B = 0;
+  double *d_g = nullptr;     // [B][2nq]
+  float *d_H = nullptr;      // [B][2nq][2nq]
+  double *d_cost = nullptr;  // [B]
+  double *d_lm = nullptr;    // [B][4] lambda, nu, gmax, pad
+  int32_t *d_flags = nullptr;  // [B][4] status, iters, need_eval, nevals
+};
+
+int fit_basis_build(d2d_fit_plan *pl);   // fills the host vectors

@@ -1,0 +1,330 @@
+// Plant / guidance / tracking kernels and their C-ABI entry points (include/d2d.h).
+// One drone per lane, state in registers across the whole time loop, fp64.
+#include <cmath>
+#include <vector>
+
+#include "common.h"
+#include "sim_device.h"
+
+static GlMesh make_mesh(double dt, double tau_phi, double tau_v) {
+  // oracle/sim.py gl_mesh: geometric panels resolve the phi boundary layer (tau_phi << dt)
+  static const double edges[D2D_GL_PANELS + 1] = {0.0, 1.0 / 16, 1.0 / 8, 1.0 / 4, 1.0 / 2, 1.0};
+  static const double c[4] = {0.06943184420297371, 0.33000947820757187, 0.6699905217924281,
+                              0.9305681557970262};
+  GlMesh m;
+  for (int p = 0; p < D2D_GL_PANELS; ++p) {
+    const double w = dt * (edges[p + 1] - edges[p]);
+    m.row[p][0] = w;
+    for (int i = 0; i < 4; ++i) {
+      m.row[p][1 + i] = std::exp(-c[i] * w / tau_phi);
+      m.row[p][5 + i] = std::exp(-c[i] * w / tau_v);
+    }
+    m.row[p][9] = std::exp(-w / tau_phi);
+    m.row[p][10] = std::exp(-w / tau_v);
+  }
+  return m;
+}
+
+// ------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) step_kernel(int n, const double *__restrict__ X,
+                                                   const double *__restrict__ U, double wx,
+                                                   double wy, GlMesh mesh,
+                                                   double *__restrict__ Xout) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  State5 s = {X[i], X[n + i], X[2 * n + i], X[3 * n + i], X[4 * n + i]};
+  s = plant_step(s, U[i], U[n + i], wx, wy, mesh);
+  Xout[i] = s.x; Xout[n + i] = s.y; Xout[2 * n + i] = s.psi; Xout[3 * n + i] = s.phi;
+  Xout[4 * n + i] = s.v;
+}
+
+// ------------------------------------------------------------------------------------
+// Circular formation: block = fpb formations of n_ac consecutive threads.
+// LDS: theta[256] | e[256] | ok[256 ints] | B[n_ac*(n_ac-1)] | zdes[n_ac-1]
+__global__ void __launch_bounds__(256)
+gvf_run_kernel(d2d_gvf_params p, GlMesh mesh, int fpb, const double *__restrict__ X0,
+               const double *__restrict__ centres, const double *__restrict__ radius,
+               const double *__restrict__ Bz, const double *__restrict__ X0f,
+               double *__restrict__ X_hist, double *__restrict__ U_hist,
+               double *__restrict__ Rr_hist, double *__restrict__ eth_hist,
+               double *__restrict__ X_final, int32_t *__restrict__ stop_row) {
+  extern __shared__ double lds[];
+  double *sh_theta = lds;
+  double *sh_e = lds + 256;
+  int *sh_ok = reinterpret_cast<int *>(lds + 512);
+  double *sh_B = lds + 512 + 128;
+  const int n_ac = p.n_ac, nm = n_ac - 1;
+  double *sh_z = sh_B + n_ac * nm;
+  for (int i = threadIdx.x; i < n_ac * nm + nm; i += blockDim.x) sh_B[i] = Bz[i];
+
+  const int t = threadIdx.x;
+  const int fl = t / n_ac, a = t - fl * n_ac;
+  const int f = blockIdx.x * fpb + fl;
+  const bool live = (fl < fpb) && (f < p.n_form);
+  const long N = (long)p.n_form * n_ac;
+  const long d = (long)f * n_ac + a;
+  const int base = live ? fl * n_ac : 0;
+
+  State5 s = {0, 0, 0, 0, 10};
+  double cx = 0, cy = 0, R = 1, fx = 0, fy = 0, fpsi = 0;
+  if (live) {
+    s = {X0[d], X0[N + d], X0[2 * N + d], X0[3 * N + d], X0[4 * N + d]};
+    cx = centres[d]; cy = centres[N + d]; R = radius[d];
+    if (X0f) { fx = X0f[d]; fy = X0f[N + d]; fpsi = X0f[2 * N + d]; }
+    if (X_hist) {
+      X_hist[d] = s.x; X_hist[N + d] = s.y; X_hist[2 * N + d] = s.psi; X_hist[3 * N + d] = s.phi;
+      X_hist[4 * N + d] = s.v;
+    }
+  }
+  __syncthreads();
+  const int rs = p.rec_stride;
+  int my_stop = p.n_rows;      // formation-uniform
+  bool prev_all_ok = false;    // result of the stop test at the end of the previous step
+  for (int i = 1; i < p.n_rows; ++i) {
+    // src/11_full_sim_case1.py:140 -- `if np.all(stop)==1 and t>0: break` at the top of step i
+    if (p.use_stop) {
+      if (prev_all_ok && (i - 1) > 0 && my_stop == p.n_rows) my_stop = i;
+      // every formation of this block has stopped: nothing left to integrate
+      if (__syncthreads_and((!live || my_stop != p.n_rows) ? 1 : 0)) break;
+    }
+    const bool run = live && (my_stop == p.n_rows);
+    // DCFController.get, src/d2d/guidance.py:103-126
+    sh_theta[t] = atan2(s.y - cy, s.x - cx);
+    __syncthreads();
+    double e = 0.0;
+    if (a < nm) {
+      double z = 0.0;
+      for (int k = 0; k < n_ac; ++k) z += sh_B[k * nm + a] * sh_theta[base + k];
+      e = z - sh_z[a];
+      if (e > D2D_PI) e -= D2D_TWO_PI;
+      if (e <= -D2D_PI) e += D2D_TWO_PI;
+    }
+    sh_e[t] = e;
+    __syncthreads();
+    double Ur = 0.0;
+    for (int m = 0; m < nm; ++m) Ur += sh_B[a * nm + m] * sh_e[base + m];
+    Ur *= -p.kr;
+    const double Rr = Ur + R;
+    const double phi_c = gvf_bank_cmd(s, cx, cy, Rr, p.ke, p.kd, nullptr, nullptr);
+    State5 sn = plant_step(s, phi_c, p.v_c, p.wx, p.wy, mesh);
+    if (run) {
+      if (U_hist && ((i - 1) % rs == 0)) {
+        const long r = (long)((i - 1) / rs) * 2 * N;
+        U_hist[r + d] = phi_c; U_hist[r + N + d] = p.v_c;
+      }
+      if (i % rs == 0) {
+        const long row = i / rs;
+        if (X_hist) {
+          const long r = row * 5 * N;
+          X_hist[r + d] = sn.x; X_hist[r + N + d] = sn.y; X_hist[r + 2 * N + d] = sn.psi;
+          X_hist[r + 3 * N + d] = sn.phi; X_hist[r + 4 * N + d] = sn.v;
+        }
+        if (Rr_hist) Rr_hist[row * N + d] = Rr;
+        if (eth_hist && a < nm) eth_hist[row * (long)p.n_form * nm + (long)f * nm + a] = e * (180.0 / D2D_PI);
+      }
+      s = sn;
+    }
+    if (p.use_stop) {
+      // :170-175 -- |X[0:3]-X0f[0:3]| <= tol for every aircraft of the formation
+      const bool ok = fabs(sn.x - fx) <= p.stop_tol[0] && fabs(sn.y - fy) <= p.stop_tol[1] &&
+                      fabs(sn.psi - fpsi) <= p.stop_tol[2];
+      sh_ok[t] = ok ? 1 : 0;
+      __syncthreads();
+      bool all_ok = true;
+      for (int k = 0; k < n_ac; ++k) all_ok = all_ok && (sh_ok[base + k] != 0);
+      prev_all_ok = all_ok;
+      // (the next iteration's first barrier orders these reads before sh_ok is rewritten)
+    }
+  }
+  if (live) {
+    X_final[d] = s.x; X_final[N + d] = s.y; X_final[2 * N + d] = s.psi; X_final[3 * N + d] = s.phi;
+    X_final[4 * N + d] = s.v;
+    if (a == 0 && stop_row) stop_row[f] = my_stop;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+ctrl_gain_kernel(d2d_track_params p, const double *__restrict__ X, const double *__restrict__ Yref,
+                 double *__restrict__ Xr, double *__restrict__ dX, double *__restrict__ U,
+                 double *__restrict__ Kg) {
+  const int n = p.n;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = i < n;
+  if (!live) i = n - 1;   // keep the whole wave converged in care_sda's __all()
+  State5 s = {X[i], X[n + i], X[2 * n + i], X[3 * n + i], X[4 * n + i]};
+  double Y[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) Y[c] = Yref[(long)c * n + i];
+  const GainOut o = compute_gain(s, Y, p);
+  if (!live) return;
+  if (Xr) { Xr[i] = o.Xr.x; Xr[n + i] = o.Xr.y; Xr[2 * n + i] = o.Xr.psi; Xr[3 * n + i] = o.Xr.phi; Xr[4 * n + i] = o.Xr.v; }
+  if (dX) {
+#pragma unroll
+    for (int c = 0; c < 5; ++c) dX[(long)c * n + i] = o.dX[c];
+  }
+  if (U) { U[i] = o.U[0]; U[n + i] = o.U[1]; }
+  if (Kg) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int c = 0; c < 5; ++c) Kg[(long)(r * 5 + c) * n + i] = o.K[r][c];
+  }
+}
+
+// numpy.gradient(f, edge_order=2) with unit spacing at row i of a [n_rows][n] plane
+__device__ __forceinline__ double grad2(const double *__restrict__ f, int i, int T, long n, long d) {
+  if (i == 0) return -1.5 * f[d] + 2.0 * f[n + d] - 0.5 * f[2 * n + d];
+  if (i == T - 1) return 1.5 * f[(long)(T - 1) * n + d] - 2.0 * f[(long)(T - 2) * n + d] + 0.5 * f[(long)(T - 3) * n + d];
+  return 0.5 * (f[(long)(i + 1) * n + d] - f[(long)(i - 1) * n + d]);
+}
+
+// ComputeDerivatives, src/11_full_sim_case1.py:197-204: first pass; the second pass reuses it.
+__global__ void __launch_bounds__(256)
+gradient_kernel(int T, int n, double inv_dt, const double *__restrict__ f, double *__restrict__ out) {
+  const long d = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  const int i = blockIdx.y;
+  if (d >= n) return;
+  out[(long)i * n + d] = grad2(f, i, T, n, d) * inv_dt;
+}
+
+// Tracking loop, src/11_full_sim_case1.py:272-290.
+__global__ void __launch_bounds__(64)
+track_run_kernel(d2d_track_params p, GlMesh mesh, const double *__restrict__ x_ref,
+                 const double *__restrict__ y_ref, const double *__restrict__ xd,
+                 const double *__restrict__ yd, const double *__restrict__ xdd,
+                 const double *__restrict__ ydd, const double *__restrict__ X0,
+                 double *__restrict__ X_hist, double *__restrict__ U_hist,
+                 double *__restrict__ Xr_hist, double *__restrict__ dX_hist,
+                 double *__restrict__ Yd_hist, double *__restrict__ Ydd_hist,
+                 double *__restrict__ X_final) {
+  const long n = p.n;
+  long d = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  const bool live = d < n;
+  if (!live) d = n - 1;
+  State5 s = {X0[d], X0[n + d], X0[2 * n + d], X0[3 * n + d], X0[4 * n + d]};
+  if (live && X_hist) {
+    X_hist[d] = s.x; X_hist[n + d] = s.y; X_hist[2 * n + d] = s.psi; X_hist[3 * n + d] = s.phi; X_hist[4 * n + d] = s.v;
+  }
+  for (int i = 1; i < p.n_rows; ++i) {
+    const long r = (long)i * n + d;
+    double Y[8] = {x_ref[r], y_ref[r], xd[r], yd[r], xdd[r], ydd[r], 0.0, 0.0};   // Yddd = [0,0] (:279)
+    const GainOut o = compute_gain(s, Y, p);
+    s = plant_step(s, o.U[0], o.U[1], p.wx, p.wy, mesh);
+    if (live) {
+      const long q = (long)(i - 1);
+      if (U_hist) { U_hist[q * 2 * n + d] = o.U[0]; U_hist[q * 2 * n + n + d] = o.U[1]; }
+      if (dX_hist) {
+#pragma unroll
+        for (int c = 0; c < 5; ++c) dX_hist[q * 5 * n + c * n + d] = o.dX[c];
+      }
+      if (Xr_hist) {
+        double *o5 = Xr_hist + q * 5 * n;
+        o5[d] = o.Xr.x; o5[n + d] = o.Xr.y; o5[2 * n + d] = o.Xr.psi; o5[3 * n + d] = o.Xr.phi; o5[4 * n + d] = o.Xr.v;
+      }
+      if (Yd_hist) { Yd_hist[q * 2 * n + d] = Y[2]; Yd_hist[q * 2 * n + n + d] = Y[3]; }
+      if (Ydd_hist) { Ydd_hist[q * 2 * n + d] = Y[4]; Ydd_hist[q * 2 * n + n + d] = Y[5]; }
+      if (X_hist) {
+        double *o5 = X_hist + (long)i * 5 * n;
+        o5[d] = s.x; o5[n + d] = s.y; o5[2 * n + d] = s.psi; o5[3 * n + d] = s.phi; o5[4 * n + d] = s.v;
+      }
+    }
+  }
+  if (live && X_final) {
+    X_final[d] = s.x; X_final[n + d] = s.y; X_final[2 * n + d] = s.psi; X_final[3 * n + d] = s.phi; X_final[4 * n + d] = s.v;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+extern "C" {
+
+int d2d_step(d2d_ctx *ctx, int n, const double *X, const double *U, double wx, double wy,
+             double tau_phi, double tau_v, double dt, double *Xout) {
+  D2D_REQUIRE(ctx && X && U && Xout, "d2d_step: null argument");
+  D2D_REQUIRE(n > 0 && tau_phi > 0 && tau_v > 0 && dt > 0, "d2d_step: n, tau_phi, tau_v, dt must be > 0");
+  const GlMesh mesh = make_mesh(dt, tau_phi, tau_v);
+  hipLaunchKernelGGL(step_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, X, U, wx, wy, mesh, Xout);
+  D2D_LAUNCH_CHECK();
+  return D2D_OK;
+}
+
+int d2d_sim_gvf_run(d2d_ctx *ctx, const d2d_gvf_params *p, const double *X0,
+                    const double *centres, const double *radius, const double *Bmat,
+                    const double *z_des, const double *X0f, double *X_hist, double *U_hist,
+                    double *Rr_hist, double *eth_hist, double *X_final, int32_t *stop_row) {
+  D2D_REQUIRE(ctx && p && X0 && centres && radius && X_final, "d2d_sim_gvf_run: null argument");
+  D2D_REQUIRE(p->n_ac >= 1 && p->n_ac <= 64, "d2d_sim_gvf_run: n_ac=%d not in 1..64", p->n_ac);
+  D2D_REQUIRE(p->n_form >= 1 && p->n_rows >= 1 && p->rec_stride >= 1, "d2d_sim_gvf_run: n_form, n_rows, rec_stride must be >= 1");
+  D2D_REQUIRE(p->n_ac == 1 || (Bmat && z_des), "d2d_sim_gvf_run: Bmat / z_des missing");
+  D2D_REQUIRE(!p->use_stop || X0f, "d2d_sim_gvf_run: use_stop needs X0f");
+  D2D_REQUIRE(p->dt > 0 && p->tau_phi > 0 && p->tau_v > 0, "d2d_sim_gvf_run: dt, tau_phi, tau_v must be > 0");
+  const int n_ac = p->n_ac, nm = n_ac - 1;
+  const size_t nb = (size_t)n_ac * nm + nm;
+  if (ctx->Bmat_cap < nb + 1) {
+    if (ctx->Bmat_dev) D2D_CHECK_HIP(hipFree(ctx->Bmat_dev));
+    D2D_CHECK_HIP(hipMalloc(&ctx->Bmat_dev, (nb + 1) * sizeof(double)));
+    ctx->Bmat_cap = nb + 1;
+  }
+  if (nb) {
+    std::vector<double> h(nb);
+    for (size_t i = 0; i < (size_t)n_ac * nm; ++i) h[i] = Bmat[i];
+    for (int i = 0; i < nm; ++i) h[(size_t)n_ac * nm + i] = z_des[i];
+    D2D_CHECK_HIP(hipMemcpyAsync(ctx->Bmat_dev, h.data(), nb * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    D2D_CHECK_HIP(hipStreamSynchronize(ctx->stream));   // h goes out of scope
+  }
+  // 64-thread blocks when that loses no lanes: more workgroups for the 256 CUs
+  const int threads = (64 % n_ac == 0) ? 64 : 256;
+  const int fpb = threads / n_ac;
+  const int blocks = (p->n_form + fpb - 1) / fpb;
+  const size_t lds = (512 + 128 + nb + 8) * sizeof(double);
+  const GlMesh mesh = make_mesh(p->dt, p->tau_phi, p->tau_v);
+  hipLaunchKernelGGL(gvf_run_kernel, dim3(blocks), dim3(threads), lds, ctx->stream, *p, mesh, fpb, X0, centres,
+                     radius, ctx->Bmat_dev, X0f, X_hist, U_hist, Rr_hist, eth_hist, X_final, stop_row);
+  D2D_LAUNCH_CHECK();
+  return D2D_OK;
+}
+
+static int check_track(const d2d_track_params *p, const char *who) {
+  D2D_REQUIRE(p->n >= 1, "%s: n must be >= 1", who);
+  D2D_REQUIRE(p->dt > 0 && p->tau_phi > 0 && p->tau_v > 0, "%s: dt, tau_phi, tau_v must be > 0", who);
+  D2D_REQUIRE(p->r_diag[0] > 0 && p->r_diag[1] > 0, "%s: R must be positive", who);
+  return D2D_OK;
+}
+
+int d2d_ctrl_gain(d2d_ctx *ctx, const d2d_track_params *p, const double *X, const double *Yref,
+                  double *Xr, double *dX, double *U, double *Kgain) {
+  D2D_REQUIRE(ctx && p && X && Yref, "d2d_ctrl_gain: null argument");
+  if (int rc = check_track(p, "d2d_ctrl_gain")) return rc;
+  hipLaunchKernelGGL(ctrl_gain_kernel, dim3((p->n + 63) / 64), dim3(64), 0, ctx->stream, *p, X, Yref, Xr, dX, U, Kgain);
+  D2D_LAUNCH_CHECK();
+  return D2D_OK;
+}
+
+int d2d_sim_track_run(d2d_ctx *ctx, const d2d_track_params *p, const double *x_ref,
+                      const double *y_ref, const double *X0, double *X_hist, double *U_hist,
+                      double *Xr_hist, double *dX_hist, double *Yd_hist, double *Ydd_hist,
+                      double *X_final) {
+  D2D_REQUIRE(ctx && p && x_ref && y_ref && X0, "d2d_sim_track_run: null argument");
+  if (int rc = check_track(p, "d2d_sim_track_run")) return rc;
+  D2D_REQUIRE(p->n_rows >= 3, "d2d_sim_track_run: n_rows must be >= 3 (second-order edge differences)");
+  const size_t plane = (size_t)p->n_rows * p->n * sizeof(double);
+  double *deriv = nullptr;
+  D2D_CHECK_HIP(hipMallocAsync(reinterpret_cast<void **>(&deriv), 4 * plane, ctx->stream));
+  double *xd = deriv, *yd = deriv + (size_t)p->n_rows * p->n, *xdd = yd + (size_t)p->n_rows * p->n,
+         *ydd = xdd + (size_t)p->n_rows * p->n;
+  const dim3 g((p->n + 255) / 256, p->n_rows), b(256);
+  const double inv_dt = 1.0 / p->dt;
+  hipLaunchKernelGGL(gradient_kernel, g, b, 0, ctx->stream, p->n_rows, p->n, inv_dt, x_ref, xd);
+  hipLaunchKernelGGL(gradient_kernel, g, b, 0, ctx->stream, p->n_rows, p->n, inv_dt, y_ref, yd);
+  hipLaunchKernelGGL(gradient_kernel, g, b, 0, ctx->stream, p->n_rows, p->n, inv_dt, xd, xdd);
+  hipLaunchKernelGGL(gradient_kernel, g, b, 0, ctx->stream, p->n_rows, p->n, inv_dt, yd, ydd);
+  D2D_LAUNCH_CHECK();
+  const GlMesh mesh = make_mesh(p->dt, p->tau_phi, p->tau_v);
+  hipLaunchKernelGGL(track_run_kernel, dim3((p->n + 63) / 64), dim3(64), 0, ctx->stream, *p, mesh, x_ref, y_ref, xd,
+                     yd, xdd, ydd, X0, X_hist, U_hist, Xr_hist, dX_hist, Yd_hist, Ydd_hist, X_final);
+  D2D_LAUNCH_CHECK();
+  D2D_CHECK_HIP(hipFreeAsync(deriv, ctx->stream));
+  return D2D_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,279 @@
+"""ctypes binding of libd2dhip.so (include/d2d.h) -- the only way host code reaches the
+HIP kernels.  PyTorch-ROCm tensors are used purely as device buffers (data_ptr()) and
+for the stream; no torch op takes part in the numerics.
+
+There is no CPU fallback: importing this module without the built library raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), 'lib', 'libd2dhip.so')
+
+SCEN_STRIDE = 24
+(SC_X0, SC_Y0, SC_PSI0, SC_X1, SC_Y1, SC_PSI1, SC_VREF, SC_VSP, SC_KV, SC_KPHI, SC_KOBS, SC_S,
+ SC_WWP, SC_WX, SC_WY, SC_GOLEFT, SC_O0X, SC_O0Y, SC_O0R, SC_O1X, SC_O1Y, SC_O1R, SC_WBND,
+ SC_PAD) = range(SCEN_STRIDE)
+ST_RUNNING, ST_CONVERGED, ST_MAXITER, ST_NONFINITE, ST_STALLED = range(5)
+
+
+class D2DError(RuntimeError):
+    pass
+
+
+class GvfParams(C.Structure):
+    _fields_ = [('n_form', C.c_int32), ('n_ac', C.c_int32), ('n_rows', C.c_int32), ('rec_stride', C.c_int32),
+                ('dt', C.c_double), ('tau_phi', C.c_double), ('tau_v', C.c_double),
+                ('ke', C.c_double), ('kd', C.c_double), ('kr', C.c_double), ('v_c', C.c_double),
+                ('wx', C.c_double), ('wy', C.c_double), ('use_stop', C.c_int32), ('pad_', C.c_int32),
+                ('stop_tol', C.c_double * 3)]
+
+
+class TrackParams(C.Structure):
+    _fields_ = [('n', C.c_int32), ('n_rows', C.c_int32), ('dt', C.c_double), ('tau_phi', C.c_double),
+                ('tau_v', C.c_double), ('wx', C.c_double), ('wy', C.c_double),
+                ('err_sats', C.c_double * 5), ('v_min', C.c_double), ('v_max', C.c_double),
+                ('phi_lim', C.c_double), ('q_diag', C.c_double * 5), ('r_diag', C.c_double * 2)]
+
+
+class FitOpts(C.Structure):
+    _fields_ = [('max_iter', C.c_int32), ('check_every', C.c_int32), ('ftol', C.c_double),
+                ('gtol', C.c_double), ('xtol', C.c_double)]
+
+
+_P = C.c_void_p
+_SIGS = {
+    'd2d_version': (C.c_int, []),
+    'd2d_last_error': (C.c_char_p, []),
+    'd2d_ctx_create': (C.c_int, [C.c_int, _P, C.POINTER(_P)]),
+    'd2d_ctx_destroy': (C.c_int, [_P]),
+    'd2d_ctx_sync': (C.c_int, [_P]),
+    'd2d_step': (C.c_int, [_P, C.c_int, _P, _P, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _P]),
+    'd2d_sim_gvf_run': (C.c_int, [_P, C.POINTER(GvfParams)] + [_P] * 12),
+    'd2d_ctrl_gain': (C.c_int, [_P, C.POINTER(TrackParams)] + [_P] * 6),
+    'd2d_sim_track_run': (C.c_int, [_P, C.POINTER(TrackParams)] + [_P] * 10),
+    'd2d_fit_plan_create': (C.c_int, [_P, C.c_int, C.c_int, C.c_double, _P, C.POINTER(_P)]),
+    'd2d_fit_plan_destroy': (C.c_int, [_P]),
+    'd2d_fit_plan_get': (C.c_int, [_P] * 6),
+    'd2d_fit_init': (C.c_int, [_P, _P, C.c_int, _P, _P]),
+    'd2d_fit_eval': (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P, _P]),
+    'd2d_fit_solve': (C.c_int, [_P, _P, C.c_int, _P, _P, C.POINTER(FitOpts), _P, _P, _P, _P]),
+    'd2d_fit_coeffs': (C.c_int, [_P, _P, C.c_int, _P, _P, _P]),
+    'd2d_fit_sample': (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P]),
+}
+EXPORTS = tuple(_SIGS)
+
+_lib = None
+
+
+def load():
+    """dlopen libd2dhip.so and declare every signature; fails loudly when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise D2DError(f'{LIB_PATH} not found: build it with __graft_entry__.build() '
+                       f'(make -C drone-sim-python_amd/csrc); there is no CPU fallback')
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise D2DError(f'libd2dhip error {rc}: {load().d2d_last_error().decode()}')
+
+
+def _torch():
+    import torch
+    if not torch.cuda.is_available():
+        raise D2DError('no HIP device visible to PyTorch-ROCm; the d2d engine has no CPU fallback')
+    return torch
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _hptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """d2d_ctx bound to the current torch stream of `device`."""
+
+    def __init__(self, device=0):
+        torch = _torch()
+        self.lib = load()
+        self.device = torch.device('cuda', device)
+        torch.cuda.set_device(self.device)
+        self.stream = torch.cuda.current_stream(self.device)
+        h = _P()
+        _check(self.lib.d2d_ctx_create(device, C.c_void_p(self.stream.cuda_stream), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.lib.d2d_ctx_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def sync(self):
+        _check(self.lib.d2d_ctx_sync(self.h))
+
+    # -- buffers --------------------------------------------------------------------
+    def dev(self, a, dtype=None):
+        """numpy array (or tensor) -> contiguous device tensor."""
+        torch = _torch()
+        if isinstance(a, torch.Tensor):
+            t = a.to(self.device)
+        else:
+            t = torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+        if dtype is not None:
+            t = t.to(dtype)
+        return t.contiguous()
+
+    def empty(self, *shape, dtype=None):
+        torch = _torch()
+        return torch.empty(*shape, dtype=dtype or torch.float64, device=self.device)
+
+    def zeros(self, *shape, dtype=None):
+        torch = _torch()
+        return torch.zeros(*shape, dtype=dtype or torch.float64, device=self.device)
+
+    # -- plant / guidance -----------------------------------------------------------
+    def step(self, X, U, W=(0.0, 0.0), tau_phi=0.01, tau_v=1.0, dt=0.05):
+        """X dev [5][n], U dev [2][n] -> Xnext dev [5][n]   (Aircraft.disc_dyn, batched)."""
+        n = X.shape[1]
+        out = self.empty(5, n)
+        _check(self.lib.d2d_step(self.h, n, _ptr(X), _ptr(U), W[0], W[1], tau_phi, tau_v, dt, _ptr(out)))
+        return out
+
+    def gvf_run(self, X0, centres, radius, n_ac, n_rows, dt, v_c, ke=4e-4, kd=25.0, kr=20.0,
+                B=None, z_des=None, tau_phi=0.01, tau_v=1.0, W=(0.0, 0.0), X0f=None,
+                stop_tol=(3.0, 3.0, np.deg2rad(0.5)), rec_stride=1, record=('X', 'U', 'Rr', 'eth')):
+        """Circular-formation phase for N = n_form*n_ac drones.  X0 dev [5][N], centres dev
+        [2][N], radius dev [N].  Returns dict of device tensors (plane-major)."""
+        torch = _torch()
+        N = X0.shape[1]
+        assert N % n_ac == 0
+        n_form = N // n_ac
+        if B is None:
+            B = np.zeros((n_ac, max(n_ac - 1, 0)))
+            for i in range(n_ac - 1):
+                B[i, i] = -1.0; B[i + 1, i] = 1.0
+        B = np.ascontiguousarray(B, dtype=np.float64)
+        z_des = np.zeros(max(n_ac - 1, 0)) if z_des is None else np.ascontiguousarray(z_des, dtype=np.float64).reshape(-1)
+        p = GvfParams(n_form, n_ac, n_rows, rec_stride, dt, tau_phi, tau_v, ke, kd, kr, v_c, W[0], W[1],
+                      1 if X0f is not None else 0, 0, (C.c_double * 3)(*stop_tol))
+        n_rec = (n_rows + rec_stride - 1) // rec_stride
+        out = {}
+        out['X'] = self.zeros(n_rec, 5, N) if 'X' in record else None
+        out['U'] = self.zeros(n_rec, 2, N) if 'U' in record else None
+        out['Rr'] = self.zeros(n_rec, N) if 'Rr' in record else None
+        out['eth'] = self.zeros(n_rec, n_form * max(n_ac - 1, 0)) if ('eth' in record and n_ac > 1) else None
+        out['X_final'] = self.empty(5, N)
+        out['stop_row'] = torch.empty(n_form, dtype=torch.int32, device=self.device)
+        _check(self.lib.d2d_sim_gvf_run(self.h, C.byref(p), _ptr(X0), _ptr(centres), _ptr(radius), _hptr(B), _hptr(z_des),
+                                        _ptr(X0f), _ptr(out['X']), _ptr(out['U']), _ptr(out['Rr']), _ptr(out['eth']),
+                                        _ptr(out['X_final']), _ptr(out['stop_row'])))
+        return out
+
+    @staticmethod
+    def track_params(n, n_rows, dt, w=(0.0, 0.0), tau_phi=0.01, tau_v=1.0,
+                     err_sats=(20, 20, np.pi / 3, np.pi / 4, 1), v_min=4.0, v_max=20.0,
+                     phi_lim=np.deg2rad(60), Q=(1, 1, 0.1, 0.01, 0.01), R=(8, 1)):
+        return TrackParams(n, n_rows, dt, tau_phi, tau_v, w[0], w[1], (C.c_double * 5)(*err_sats), v_min, v_max,
+                           phi_lim, (C.c_double * 5)(*Q), (C.c_double * 2)(*R))
+
+    def ctrl_gain(self, X, Yref, **kw):
+        """X dev [5][n], Yref dev [8][n] -> Xr [5][n], dX [5][n], U [2][n], K [10][n]."""
+        n = X.shape[1]
+        p = self.track_params(n, 1, kw.pop('dt', 0.05), **kw)
+        Xr, dX, U, K = self.empty(5, n), self.empty(5, n), self.empty(2, n), self.empty(10, n)
+        _check(self.lib.d2d_ctrl_gain(self.h, C.byref(p), _ptr(X), _ptr(Yref), _ptr(Xr), _ptr(dX), _ptr(U), _ptr(K)))
+        return Xr, dX, U, K
+
+    def track_run(self, x_ref, y_ref, X0, dt, record=('X', 'U', 'Xr', 'dX', 'Yd', 'Ydd'), **kw):
+        """x_ref, y_ref dev [T][n]; X0 dev [5][n] -> dict of device histories."""
+        T, n = x_ref.shape
+        p = self.track_params(n, T, dt, **kw)
+        out = {k: (self.zeros(T, c, n) if k in record else None)
+               for k, c in (('X', 5), ('U', 2), ('Xr', 5), ('dX', 5), ('Yd', 2), ('Ydd', 2))}
+        out['X_final'] = self.empty(5, n)
+        _check(self.lib.d2d_sim_track_run(self.h, C.byref(p), _ptr(x_ref), _ptr(y_ref), _ptr(X0), _ptr(out['X']),
+                                          _ptr(out['U']), _ptr(out['Xr']), _ptr(out['dX']), _ptr(out['Yd']),
+                                          _ptr(out['Ydd']), _ptr(out['X_final'])))
+        return out
+
+
+class FitPlan:
+    """Shared basis block + solver scratch for one (S, K, duration, wref)."""
+
+    def __init__(self, ctx, S, K, duration, wref):
+        self.ctx, self.S, self.K, self.duration = ctx, S, K, float(duration)
+        self.nq = 4 * S
+        w = np.ascontiguousarray(wref, dtype=np.float64)
+        h = _P()
+        _check(ctx.lib.d2d_fit_plan_create(ctx.h, S, K, self.duration, _hptr(w), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.ctx.lib.d2d_fit_plan_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def basis(self):
+        """Host copies: G (3,K,nq), Gp (3,K,4), Z (8S,nq), Zp (8S,4), Pinit (nq,K)."""
+        S, K, nq = self.S, self.K, self.nq
+        G = np.empty((3, K, nq)); Gp = np.empty((3, K, 4)); Z = np.empty((8 * S, nq)); Zp = np.empty((8 * S, 4))
+        P = np.empty((nq, K))
+        _check(self.ctx.lib.d2d_fit_plan_get(self.h, _hptr(G), _hptr(Gp), _hptr(Z), _hptr(Zp), _hptr(P)))
+        return G, Gp, Z, Zp, P
+
+    def init(self, scen):
+        B = scen.shape[0]
+        q = self.ctx.empty(B, 2 * self.nq)
+        _check(self.ctx.lib.d2d_fit_init(self.ctx.h, self.h, B, _ptr(scen), _ptr(q)))
+        return q
+
+    def eval(self, scen, q, want_H=True):
+        torch = _torch()
+        B, n = scen.shape[0], 2 * self.nq
+        cost, g = self.ctx.empty(B), self.ctx.empty(B, n)
+        H = torch.zeros(B, n, n, dtype=torch.float32, device=self.ctx.device) if want_H else None
+        _check(self.ctx.lib.d2d_fit_eval(self.ctx.h, self.h, B, _ptr(scen), _ptr(q), _ptr(cost), _ptr(g), _ptr(H)))
+        return cost, g, H
+
+    def solve(self, scen, q, max_iter=200, check_every=8, ftol=1e-14, gtol=1e-9, xtol=1e-11):
+        """In-place LM solve of q.  Returns cost, iters, status (device) and stats (numpy[4])."""
+        torch = _torch()
+        B = scen.shape[0]
+        cost = self.ctx.empty(B)
+        iters = torch.empty(B, dtype=torch.int32, device=self.ctx.device)
+        status = torch.empty(B, dtype=torch.int32, device=self.ctx.device)
+        stats = np.zeros(4)
+        o = FitOpts(max_iter, check_every, ftol, gtol, xtol)
+        _check(self.ctx.lib.d2d_fit_solve(self.ctx.h, self.h, B, _ptr(scen), _ptr(q), C.byref(o), _ptr(cost),
+                                          _ptr(iters), _ptr(status), _hptr(stats)))
+        return cost, iters, status, stats
+
+    def coeffs(self, scen, q):
+        B = scen.shape[0]
+        z = self.ctx.empty(B, 2, self.S, 8)
+        _check(self.ctx.lib.d2d_fit_coeffs(self.ctx.h, self.h, B, _ptr(scen), _ptr(q), _ptr(z)))
+        return z
+
+    def sample(self, scen, q):
+        B = scen.shape[0]
+        Y, Xs = self.ctx.empty(B, 6, self.K), self.ctx.empty(B, 5, self.K)
+        _check(self.ctx.lib.d2d_fit_sample(self.ctx.h, self.h, B, _ptr(scen), _ptr(q), _ptr(Y), _ptr(Xs)))
+        return Y, Xs

@@ -1,0 +1,224 @@
+/*
+ * libd2dhip.so -- C ABI of the MI355X (gfx950) batched trajectory-fit and
+ * guidance-simulation engine.
+ *
+ * The reference (rajashree-srikanth/drone-sim-python) is pure Python and has no FFI; each
+ * entry point below names the Python interface it replaces (file:line relative to the
+ * reference's repository root) and is what a ctypes binding on the reference side would
+ * bind (INTEGRATION.md shows the stubs).
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative D2D_E* code; d2d_last_error()
+ *     returns a thread-local message for the last failure.  No exception crosses the ABI.
+ *   - "dev" pointers are device (HBM) addresses owned by the caller (e.g.
+ *     torch.Tensor.data_ptr() of a contiguous ROCm tensor); "host" pointers are ordinary
+ *     host memory.  The library allocates only scratch tied to a context or a fit plan.
+ *   - all work is enqueued on the hipStream_t given to d2d_ctx_create and is asynchronous
+ *     unless stated; the caller synchronises the stream.
+ *   - one context per GPU per host thread; calls are re-entrant across contexts.
+ *   - device arrays are "plane-major" (structure of arrays): a state history is
+ *     [row][component][drone] so that one wavefront writes 64 consecutive doubles.
+ */
+#ifndef D2D_H
+#define D2D_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define D2D_VERSION 100
+
+/* error codes */
+#define D2D_OK 0
+#define D2D_EINVAL (-1)   /* bad argument (shape, null pointer, unsupported size) */
+#define D2D_EHIP (-2)     /* a HIP runtime call failed */
+#define D2D_ENOMEM (-3)
+#define D2D_ESTATE (-4)   /* call order / plan mismatch */
+
+typedef struct d2d_ctx d2d_ctx;
+typedef struct d2d_fit_plan d2d_fit_plan;
+
+int d2d_version(void);
+const char *d2d_last_error(void);
+
+/* device = HIP device ordinal; stream = hipStream_t (NULL = the default stream). */
+int d2d_ctx_create(int device, void *stream, d2d_ctx **out);
+int d2d_ctx_destroy(d2d_ctx *ctx);
+int d2d_ctx_sync(d2d_ctx *ctx);   /* hipStreamSynchronize on the context's stream */
+
+/* ------------------------------------------------------------------------------------
+ * Plant and guidance (fp64).  State components: x, y, psi, phi, v; inputs: phi_c, v_c.
+ * ------------------------------------------------------------------------------------ */
+
+/* Gauss-Legendre Runge-Kutta quadrature of the plant step: D2D_GL_PANELS panels on
+ * dt*[edge_p, edge_p+1], D2D_GL_STAGES stages each; phi and v (first-order lags under
+ * a zero-order-hold input) are integrated exactly. */
+#define D2D_GL_STAGES 4
+#define D2D_GL_PANELS 5
+
+/* One batched plant step.  Replaces Aircraft.disc_dyn(Xk, Uk, W, t, dt)
+ * (src/d2d/dynamic.py:25-28; model :14-23, heading wrap :27 / src/d2d/utils.py:7).
+ * X, Xout: dev [5][n]; U: dev [2][n]; wind (wx, wy) constant. */
+int d2d_step(d2d_ctx *ctx, int n, const double *X, const double *U, double wx, double wy,
+             double tau_phi, double tau_v, double dt, double *Xout);
+
+typedef struct {
+  int32_t n_form;      /* independent formations                                   */
+  int32_t n_ac;        /* aircraft per formation, 1..64                            */
+  int32_t n_rows;      /* rows of the time grid, len(arange(t_start,t_end,t_step)) */
+  int32_t rec_stride;  /* history rows are kept for i % rec_stride == 0 (>=1)      */
+  double dt, tau_phi, tau_v;
+  double ke, kd, kr;   /* GVF / DCF gains (src/11_full_sim_case1.py:108-110)       */
+  double v_c;          /* commanded airspeed (the `v` argument, :93)               */
+  double wx, wy;       /* wind                                                     */
+  int32_t use_stop;    /* 1: apply the phase-1 stop rule (:140,170-175)            */
+  int32_t pad_;
+  double stop_tol[3];  /* |x|,|y|,|psi| tolerances, reference: 3, 3, 0.5 deg       */
+} d2d_gvf_params;
+
+/* Circular-formation phase: DCF phase consensus + GVF circle following + plant step, the
+ * whole time loop on the device.  Replaces CircularFormationGVF(c, r, v, n_ac, X0f, ...)
+ * (src/11_full_sim_case1.py:93-177; identical loop src/09_CircularFormation_diffcentre.py
+ * :91-115) and the per-step calls it makes: DCFController.get (src/d2d/guidance.py:103-126),
+ * CircleTraj.get (:137-146), GVFcontroller.get (:155-181), atan(U/9.81) (11_*:160),
+ * Aircraft.disc_dyn (src/d2d/dynamic.py:25-28).
+ * N = n_form*n_ac drones, drone d = formation d/n_ac, aircraft d%n_ac.
+ *   X0       dev [5][N]   initial states (row 0 of the history)
+ *   centres  dev [2][N]   circle centre of each drone
+ *   radius   dev [N]      nominal radius r
+ *   Bmat     host [n_ac][n_ac-1] incidence matrix (ConstructBMatrix, 11_*:81-91)
+ *   z_des    host [n_ac-1] desired inter-vehicle angles
+ *   X0f      dev [3][N] or NULL: x,y,psi targets of the stop rule
+ *   X_hist   dev [n_rec][5][N] or NULL; U_hist dev [n_rec][2][N] or NULL (row i-1 holds the
+ *            input applied during step i, as the reference writes U_array[i-1]);
+ *   Rr_hist  dev [n_rec][N] or NULL (commanded radius, row i); eth_hist dev
+ *            [n_rec][n_form*(n_ac-1)] or NULL (phase errors in degrees, row i)
+ *            with n_rec = ceil(n_rows / rec_stride)
+ *   X_final  dev [5][N]: state after the last executed step
+ *   stop_row dev int32 [n_form]: value of the reference's loop index i at its `break`
+ *            (== rows kept by the reference's trim), or n_rows if the rule never fired.
+ * A formation that has stopped is frozen (its rows beyond stop_row are not written). */
+int d2d_sim_gvf_run(d2d_ctx *ctx, const d2d_gvf_params *p, const double *X0,
+                    const double *centres, const double *radius, const double *Bmat,
+                    const double *z_des, const double *X0f, double *X_hist, double *U_hist,
+                    double *Rr_hist, double *eth_hist, double *X_final, int32_t *stop_row);
+
+typedef struct {
+  int32_t n;           /* drones (independent)                                     */
+  int32_t n_rows;      /* rows of the reference time grid                          */
+  double dt, tau_phi, tau_v;
+  double wx, wy;       /* wind handed to DiffController(w) and to the plant        */
+  double err_sats[5];  /* src/Controllers.py:147                                   */
+  double v_min, v_max, phi_lim;        /* :148-149                                 */
+  double q_diag[5], r_diag[2];         /* :152                                     */
+} d2d_track_params;
+
+/* One batched evaluation of DiffController.ComputeGain (src/Controllers.py:159-186):
+ * ComputeFlatness (:62-108), error wrap/clip (:165-169), Aircraft.cont_jac
+ * (src/d2d/dynamic.py:32-43), control.lqr (:174; 5x5 continuous algebraic Riccati
+ * equation solved on the device), U = clip(Ur - K dX) (:183-185).
+ *   X dev [5][n]; Yref dev [8][n] = x,y,xd,yd,xdd,ydd,xddd,yddd
+ *   outputs (dev, any may be NULL): Xr [5][n], dX [5][n], U [2][n], Kgain [10][n]
+ *   (K row-major 2x5 per drone, plane-major across drones). */
+int d2d_ctrl_gain(d2d_ctx *ctx, const d2d_track_params *p, const double *X, const double *Yref,
+                  double *Xr, double *dX, double *U, double *Kgain);
+
+/* Trajectory-tracking phase, whole time loop on the device.  Replaces
+ * implement_controller(n_ac, time, x_ref, y_ref, v, w, X0s)
+ * (src/11_full_sim_case1.py:241-291) including ComputeDerivatives (:197-204; two passes
+ * of numpy.gradient(edge_order=2)/dt per axis).
+ *   x_ref, y_ref dev [n_rows][n]; X0 dev [5][n]
+ *   X_hist dev [n_rows][5][n]; U_hist [n_rows][2][n]; Xr_hist, dX_hist [n_rows][5][n];
+ *   Yd_hist, Ydd_hist [n_rows][2][n] (any history may be NULL); X_final dev [5][n].
+ * Row conventions as the reference: step i uses reference sample i and state i-1 and
+ * writes U, dX, Xr, Yd, Ydd at row i-1 and X at row i. */
+int d2d_sim_track_run(d2d_ctx *ctx, const d2d_track_params *p, const double *x_ref,
+                      const double *y_ref, const double *X0, double *X_hist, double *U_hist,
+                      double *Xr_hist, double *dX_hist, double *Yd_hist, double *Ydd_hist,
+                      double *X_final);
+
+/* ------------------------------------------------------------------------------------
+ * Polynomial trajectory fit: S segments x 2 axes x 8 monomial coefficients in the layout
+ * of PolynomialOne.coefs[0,:] (src/d2d/trajectory.py:47-72), K samples on
+ * linspace(t0,t1,K) (planner_timing, src/d2d/opty_utils.py:8-14), flat outputs -> (va,phi)
+ * through DiffFlatness.state_and_input_from_output (src/d2d/guidance.py:22-47), residual
+ * rows from CostInput (src/d2d/opty_utils.py:85-97) and CostObstacle kind 1 (:99-134),
+ * waypoints from triangle() (:171-187).  The C^3 junction conditions and the end
+ * conditions (x,y,psi)(t0),(t1) (src/single_opt_planner.py:46-49, speed = vref) are
+ * eliminated: z_axis = Zp d_axis + Z q_axis with nq = 4*S reduced unknowns per axis.
+ * ------------------------------------------------------------------------------------ */
+
+/* one scenario row: double[D2D_SCEN_STRIDE] per trajectory (dev [B][D2D_SCEN_STRIDE]) */
+#define D2D_SCEN_STRIDE 24
+enum {
+  D2D_SC_X0 = 0, D2D_SC_Y0, D2D_SC_PSI0, D2D_SC_X1, D2D_SC_Y1, D2D_SC_PSI1,
+  D2D_SC_VREF,  /* end-condition speed and 'tri' waypoint speed                */
+  D2D_SC_VSP,   /* CostInput.vsp                                               */
+  D2D_SC_KV, D2D_SC_KPHI, D2D_SC_KOBS,
+  D2D_SC_S,     /* obj_scale / K                                               */
+  D2D_SC_WWP,   /* waypoint row weight                                         */
+  D2D_SC_WX, D2D_SC_WY,   /* wind                                              */
+  D2D_SC_GOLEFT,          /* triangle(go_left)                                 */
+  D2D_SC_O0X, D2D_SC_O0Y, D2D_SC_O0R,   /* obstacle 0 (r<=0: absent)           */
+  D2D_SC_O1X, D2D_SC_O1Y, D2D_SC_O1R,   /* obstacle 1                          */
+  D2D_SC_WBND,  /* weight of the soft bound rows (phi in +-40 deg, v in [9,15]) */
+  D2D_SC_PAD
+};
+#define D2D_FIT_NROW 8        /* residual rows per sample */
+#define D2D_FIT_MAX_S 6
+#define D2D_FIT_NQ_MAX 24     /* 4*S */
+
+/* Levenberg-Marquardt constants (oracle/fit.py LM_*) */
+#define D2D_LM_LAMBDA0 1e-3
+#define D2D_LM_LAMBDA_MIN 1e-12
+#define D2D_LM_LAMBDA_MAX 1e12
+#define D2D_LM_DIAG_FLOOR 1e-30
+enum { D2D_ST_RUNNING = 0, D2D_ST_CONVERGED = 1, D2D_ST_MAXITER = 2, D2D_ST_NONFINITE = 3, D2D_ST_STALLED = 4 };
+
+typedef struct {
+  int32_t max_iter;     /* damped solves per trajectory (default 200)                  */
+  int32_t check_every;  /* host convergence poll period in iterations (default 8)      */
+  double ftol, gtol, xtol;   /* defaults 1e-14, 1e-9, 1e-11                            */
+} d2d_fit_opts;
+
+/* Build the shared basis block on the host (fp64) and upload it.  wref[3] = weights of the
+ * whitening metric sum_d wref[d] Phi_d^T Phi_d.  Synchronous. */
+int d2d_fit_plan_create(d2d_ctx *ctx, int S, int K, double duration, const double *wref,
+                        d2d_fit_plan **out);
+int d2d_fit_plan_destroy(d2d_fit_plan *plan);
+/* Copy the basis to host buffers (any may be NULL): G [3][K][nq], Gp [3][K][4],
+ * Z [8S][nq], Zp [8S][4], Pinit [nq][K]. */
+int d2d_fit_plan_get(const d2d_fit_plan *plan, double *G, double *Gp, double *Z, double *Zp,
+                     double *Pinit);
+
+/* q0 = projection of the 'tri' waypoints on the basis.  scen dev [B][24]; q dev [B][2*nq]. */
+int d2d_fit_init(d2d_ctx *ctx, const d2d_fit_plan *plan, int B, const double *scen, double *q);
+
+/* One evaluation at q: cost = sum r^2 (fp64), g = J^T r (fp64, dev [B][2nq]), H = J^T J
+ * (fp32 via v_mfma_f32_16x16x4_f32, dev [B][2nq][2nq]).  Any output may be NULL. */
+int d2d_fit_eval(d2d_ctx *ctx, const d2d_fit_plan *plan, int B, const double *scen,
+                 const double *q, double *cost, double *g, float *H);
+
+/* Full Levenberg-Marquardt solve from q (in/out).  cost dev [B], iters / status dev int32 [B]
+ * (any may be NULL).  stats host double[4] (may be NULL): sum cost, max |J^T r|_inf,
+ * trajectories still running, evaluations performed -- the local contribution to the
+ * cross-GPU convergence all-reduce.  Synchronises the stream before returning. */
+int d2d_fit_solve(d2d_ctx *ctx, const d2d_fit_plan *plan, int B, const double *scen, double *q,
+                  const d2d_fit_opts *opts, double *cost, int32_t *iters, int32_t *status,
+                  double *stats);
+
+/* Map q back to monomial coefficients z dev [B][2][S][8] (axis, segment, power). */
+int d2d_fit_coeffs(d2d_ctx *ctx, const d2d_fit_plan *plan, int B, const double *scen,
+                   const double *q, double *z);
+
+/* Sample a coefficient set: flat outputs and states at the K plan nodes.
+ * Y dev [B][6][K] (x,y,xd,yd,xdd,ydd) and Xs dev [B][5][K] (x,y,psi,phi,v); may be NULL. */
+int d2d_fit_sample(d2d_ctx *ctx, const d2d_fit_plan *plan, int B, const double *scen,
+                   const double *q, double *Y, double *Xs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* D2D_H */

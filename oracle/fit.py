@@ -1,0 +1,459 @@
+"""ORACLE (test infrastructure only) -- CPU/numpy fp64 restatement of the batched
+6-segment polynomial trajectory fit.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+module.  The product path (drone-sim-python_amd/) never does.
+
+What is restated from the reference (file:line relative to /root/reference):
+  * polynomial layout + Horner evaluation .... src/d2d/trajectory.py:41-82  (PolynomialOne)
+  * composite segment lookup .................. src/d2d/trajectory.py:190-208 (CompositeTraj)
+  * flatness map (x,y,derivs)->(psi,phi,va) ... src/d2d/guidance.py:22-47   (DiffFlatness)
+  * node timing ............................... src/d2d/opty_utils.py:8-14   (planner_timing)
+  * input cost s*(kv*sum(dv^2)+kphi*sum(phi^2)) src/d2d/opty_utils.py:85-97  (CostInput)
+  * obstacle cost kind 1, k=2 ................. src/d2d/opty_utils.py:99-134 (CostObstacle)
+  * 'tri' dog-leg waypoints ................... src/d2d/opty_utils.py:171-187 (triangle)
+What is build-defined (no reference counterpart): the
+re-parameterisation by polynomial coefficients, the elimination of the linear side
+conditions, and the Levenberg-Marquardt normal-equation solver.  Parity of those is
+pinned by (i) the golden vectors in tests/golden/fit_cost_golden.npz, which were
+produced by the reference's own classes evaluated on polynomial trajectories, and
+(ii) scipy.optimize.least_squares on the same residual function (the CPU arbiter).
+"""
+import math
+import numpy as np
+
+G_ACC = 9.81          # src/d2d/guidance.py:39
+OBS_K = 2.0           # src/d2d/opty_utils.py:103
+NCOEF = 8             # PolynomialOne with 4 derivatives -> 8 coefficients
+NDER_C = 4            # derivatives matched at junctions (C^3)
+
+
+# ----------------------------------------------------------------------------------
+# timing / segment bookkeeping
+# ----------------------------------------------------------------------------------
+def planner_timing(t0, t1, hz):
+    """src/d2d/opty_utils.py:8-14 (without the print)."""
+    duration = t1 - t0
+    num_nodes = int(duration * hz) + 1
+    time_step = 1.0 / hz
+    duration = (num_nodes - 1) * time_step
+    return num_nodes, time_step, duration
+
+
+def arr(k, n):
+    """a(k,n) = n!/(n-k)!  -- src/d2d/trajectory.py:41-45."""
+    a, i = 1, n
+    while i > n - k:
+        a *= i
+        i -= 1
+    return a
+
+
+def sample_segments(K, S, duration):
+    """Sample times linspace(0,duration,K); segment index and local time of each.
+
+    Mirrors CompositeTraj.get (src/d2d/trajectory.py:202-208): cur = argmax(steps_end >
+    t), except that the very last sample (t == duration) stays in the last segment
+    instead of wrapping through fmod."""
+    T = duration / S
+    t = np.linspace(0.0, duration, K)
+    ends = np.cumsum(np.full(S, T))
+    seg = np.empty(K, dtype=np.int64)
+    for k in range(K):
+        gt = ends > t[k]
+        seg[k] = int(np.argmax(gt)) if gt.any() else S - 1
+    tau = t - seg * T
+    return t, seg, tau, T
+
+
+def basis_rows(tau, der):
+    """Row of d^der/dt^der [1, t, ..., t^7] at local time tau (PolynomialOne layout:
+    coefs[d,p] = arr(d,p+d)*coefs[0,p+d], src/d2d/trajectory.py:68-72)."""
+    row = np.zeros(NCOEF)
+    for p in range(der, NCOEF):
+        row[p] = arr(der, p) * tau ** (p - der)
+    return row
+
+
+def sample_matrix(K, S, duration, der):
+    """Phi_der (K x 8S): flat output derivative `der` at the K samples = Phi @ z_axis."""
+    _, seg, tau, _ = sample_segments(K, S, duration)
+    Phi = np.zeros((K, NCOEF * S))
+    for k in range(K):
+        Phi[k, NCOEF * seg[k]:NCOEF * (seg[k] + 1)] = basis_rows(tau[k], der)
+    return Phi
+
+
+def constraint_matrix(S, T):
+    """Linear side conditions of one axis, C z = [0..0, pos0, vel0, pos1, vel1].
+
+    Rows: C^3 continuity at the S-1 junctions (4 rows each), then the four end
+    conditions.  (x,y,psi)(t0/t1) of src/single_opt_planner.py:46-49 become position
+    and velocity = vref*(cos psi, sin psi) end conditions on the flat outputs."""
+    n = NCOEF * S
+    rows = []
+    for j in range(S - 1):
+        for d in range(NDER_C):
+            r = np.zeros(n)
+            r[NCOEF * j:NCOEF * (j + 1)] = basis_rows(T, d)
+            r[NCOEF * (j + 1):NCOEF * (j + 2)] -= basis_rows(0.0, d)
+            rows.append(r)
+    for (s, tt, d) in ((0, 0.0, 0), (0, 0.0, 1), (S - 1, T, 0), (S - 1, T, 1)):
+        r = np.zeros(n)
+        r[NCOEF * s:NCOEF * (s + 1)] = basis_rows(tt, d)
+        rows.append(r)
+    return np.array(rows)
+
+
+def hermite_map(T):
+    """8x8 map [Y0(4); Y1(4)] -> coefs[0,0:8] of one segment, exactly the closed form of
+    PolynomialOne.__init__ (src/d2d/trajectory.py:54-66): low = Y0[i]/i!, high =
+    M4^-1 (Y1 - M3 low)."""
+    M1i = np.diag([1.0 / arr(i, i) for i in range(4)])
+    M3 = np.zeros((4, 4)); M4 = np.zeros((4, 4))
+    for i in range(4):
+        for j in range(i, 4):
+            M3[i, j] = arr(i, j) * T ** (j - i)
+        for j in range(4):
+            M4[i, j] = arr(i, j + 4) * T ** (j - i + 4)
+    M4i = np.linalg.inv(M4)
+    H = np.zeros((8, 8))
+    H[0:4, 0:4] = M1i
+    H[4:8, 0:4] = -M4i @ M3 @ M1i
+    H[4:8, 4:8] = M4i
+    return H
+
+
+def junction_map(S, T):
+    """N (8S x 4(S+1)): knot data (pos,vel,acc,jerk at the S+1 knots) -> coefficients of a
+    C^3 piecewise degree-7 polynomial.  This is the reference's own construction:
+    CompositeTraj([MinSnapPoly(Y_j, Y_{j+1}, T)]) (src/d2d/trajectory.py:166-208)."""
+    H = hermite_map(T)
+    N = np.zeros((NCOEF * S, 4 * (S + 1)))
+    for s in range(S):
+        N[NCOEF * s:NCOEF * (s + 1), 4 * s:4 * s + 8] = H
+    return N
+
+
+def knot_split(S):
+    """Column indices of N: fixed = (pos,vel) at the first and last knot (the end
+    conditions (x,y,psi)(t0),(t1) of src/single_opt_planner.py:46-49 with speed vref);
+    free = everything else, in knot order."""
+    fixed = [0, 1, 4 * S, 4 * S + 1]
+    free = [i for i in range(4 * (S + 1)) if i not in fixed]
+    return fixed, free
+
+
+class FitBasis:
+    """Shared (batch-independent) block: z_axis = Zp @ d_axis + Z @ q_axis.
+
+    d_axis = [pos0, vel0, pos1, vel1]; q_axis = 4S whitened knot coordinates.
+    G[d]  (K x nq) = Phi_d @ Z     -- flat-output derivative d as a function of q
+    Gp[d] (K x 4)  = Phi_d @ Zp    -- contribution of the end conditions
+    Z = Nfree L^-T with L L^T = Nfree^T Mref Nfree (so Z^T Mref Z = I),
+    Mref = sum_d w_d Phi_d^T Phi_d;  Zp = (I - Z Z^T Mref) Nfixed (minimum-Mref-energy
+    particular solution).  Pinit = (G0^T G0)^-1 G0^T projects waypoints on the basis.
+    The product builds the same block in C++ (csrc/fit_basis.cpp); GPU parity tests
+    feed the product's own arrays through FitBasis.from_arrays."""
+
+    def __init__(self, S, K, duration, wref):
+        self.S, self.K, self.duration = S, K, duration
+        self.T = duration / S
+        Phi = [sample_matrix(K, S, duration, d) for d in range(3)]
+        N = junction_map(S, self.T)
+        fixed, free = knot_split(S)
+        Nf, Nx = N[:, free], N[:, fixed]
+        self.nq = len(free)
+        M = sum(w * P.T @ P for w, P in zip(wref, Phi))
+        L = np.linalg.cholesky(Nf.T @ M @ Nf)
+        self.Z = np.linalg.solve(L, Nf.T).T                  # Nf @ L^-T
+        self.Zp = Nx - self.Z @ (self.Z.T @ (M @ Nx))
+        self.G = np.stack([P @ self.Z for P in Phi])         # (3,K,nq)
+        self.Gp = np.stack([P @ self.Zp for P in Phi])       # (3,K,4)
+        G0 = self.G[0]
+        self.Pinit = np.linalg.solve(G0.T @ G0, G0.T)        # (nq,K)
+
+    @classmethod
+    def from_arrays(cls, S, K, duration, G, Gp, Z, Zp, Pinit):
+        b = cls.__new__(cls)
+        b.S, b.K, b.duration, b.T = S, K, duration, duration / S
+        b.G, b.Gp, b.Z, b.Zp, b.Pinit = (np.asarray(a, dtype=np.float64) for a in (G, Gp, Z, Zp, Pinit))
+        b.nq = b.Z.shape[1]
+        return b
+
+
+# ----------------------------------------------------------------------------------
+# scenario parameters of one trajectory
+# ----------------------------------------------------------------------------------
+# scen row layout (float64[SCEN_STRIDE]); identical to include/d2d.h D2D_SCEN_*
+SCEN_STRIDE = 24
+(SC_X0, SC_Y0, SC_PSI0, SC_X1, SC_Y1, SC_PSI1, SC_VREF, SC_VSP, SC_KV, SC_KPHI,
+ SC_KOBS, SC_S, SC_WWP, SC_WX, SC_WY, SC_GOLEFT,
+ SC_O0X, SC_O0Y, SC_O0R, SC_O1X, SC_O1Y, SC_O1R, SC_WBND, SC_PAD) = range(SCEN_STRIDE)
+# bounds used by the hinge rows (phi in +-40 deg, v in [9,15]: src/multi_opt_planner.py:192-193)
+PHI_MAX = math.radians(40.0)
+V_MIN, V_MAX = 9.0, 15.0
+
+
+def end_data(sc):
+    """d_axis = [pos0, vel0, pos1, vel1] for x and y (end speed = vref)."""
+    v = sc[SC_VREF]
+    dx = np.array([sc[SC_X0], v * math.cos(sc[SC_PSI0]), sc[SC_X1], v * math.cos(sc[SC_PSI1])])
+    dy = np.array([sc[SC_Y0], v * math.sin(sc[SC_PSI0]), sc[SC_Y1], v * math.sin(sc[SC_PSI1])])
+    return dx, dy
+
+
+def triangle(p0, p1, va, duration, num_nodes, go_left=1.0):
+    """'tri' initial guess, src/d2d/opty_utils.py:171-187 (x,y only)."""
+    p0 = np.asarray(p0, float); p1 = np.asarray(p1, float)
+    p0p1 = p1 - p0
+    d = np.linalg.norm(p0p1)
+    u = p0p1 / d
+    v = np.array([-u[1], u[0]])
+    D = va * duration
+    p2 = p0 + p0p1 / 2
+    if D > d:
+        p2 = p2 + np.sign(go_left) * np.sqrt(D ** 2 - d ** 2) / 2 * v
+    n1 = int(num_nodes / 2); n2 = num_nodes - n1
+    pts = np.vstack((np.linspace(p0, p2, n1), np.linspace(p2, p1, n2)))
+    return pts[:, 0], pts[:, 1]
+
+
+def waypoints(sc, K, duration):
+    return triangle((sc[SC_X0], sc[SC_Y0]), (sc[SC_X1], sc[SC_Y1]), sc[SC_VREF],
+                    duration, K, sc[SC_GOLEFT])
+
+
+# ----------------------------------------------------------------------------------
+# residuals / Jacobian in reduced coordinates q = [q_x(24), q_y(24)]
+# ----------------------------------------------------------------------------------
+NROW = 8   # rows per sample: v, phi, wp_x, wp_y, obs0, obs1, hinge_phi, hinge_v
+
+
+def flat_outputs(basis, sc, q):
+    nq = basis.nq
+    dx, dy = end_data(sc)
+    Y = np.empty((3, 2, basis.K))
+    for d in range(3):
+        Y[d, 0] = basis.Gp[d] @ dx + basis.G[d] @ q[:nq]
+        Y[d, 1] = basis.Gp[d] @ dy + basis.G[d] @ q[nq:]
+    return Y
+
+
+def flatness(Y, sc):
+    """src/d2d/guidance.py:22-47: va, psi, phi from flat outputs (stationary wind)."""
+    vax = Y[1, 0] - sc[SC_WX]; vay = Y[1, 1] - sc[SC_WY]
+    va2 = vax ** 2 + vay ** 2
+    va = np.sqrt(va2)
+    psi = np.arctan2(vay, vax)
+    num = Y[2, 1] * vax - Y[2, 0] * vay
+    phi = np.arctan(num / va / G_ACC)
+    return va, psi, phi
+
+
+def residuals(basis, sc, q, wp=None, want_jac=False):
+    """r (K,NROW) and optionally the partials D (K,NROW,6) wrt (x,y,xd,yd,xdd,ydd)."""
+    K = basis.K
+    Y = flat_outputs(basis, sc, q)
+    x, y = Y[0]; a = Y[1, 0] - sc[SC_WX]; b = Y[1, 1] - sc[SC_WY]; c, d = Y[2]
+    if wp is None:
+        wp = waypoints(sc, K, basis.duration)
+    va2 = a * a + b * b; va = np.sqrt(va2)
+    n = d * a - c * b
+    w = n / (va * G_ACC)
+    phi = np.arctan(w)
+    s = sc[SC_S]
+    cv = math.sqrt(s * sc[SC_KV]); cphi = math.sqrt(s * sc[SC_KPHI]); cobs = math.sqrt(s * sc[SC_KOBS])
+    r = np.zeros((K, NROW))
+    r[:, 0] = cv * (va - sc[SC_VSP])
+    r[:, 1] = cphi * phi
+    r[:, 2] = sc[SC_WWP] * (x - wp[0])
+    r[:, 3] = sc[SC_WWP] * (y - wp[1])
+    obs = []
+    for i, (ox, oy, orr) in enumerate(((SC_O0X, SC_O0Y, SC_O0R), (SC_O1X, SC_O1Y, SC_O1R))):
+        rr = sc[orr]
+        if rr > 0:
+            ddx = (x - sc[ox]) * (OBS_K / rr); ddy = (y - sc[oy]) * (OBS_K / rr)
+            h = cobs * np.exp(-0.5 * (ddx * ddx + ddy * ddy))     # sqrt(s*kobs*e)
+            r[:, 4 + i] = h
+            obs.append((i, ddx, ddy, h, rr))
+    wb = sc[SC_WBND]
+    hphi = np.maximum(np.abs(phi) - PHI_MAX, 0.0)
+    hv = np.maximum(va - V_MAX, 0.0) + np.minimum(va - V_MIN, 0.0)
+    r[:, 6] = wb * hphi
+    r[:, 7] = wb * hv
+    if not want_jac:
+        return r
+    D = np.zeros((K, NROW, 6))
+    dva_a = a / va; dva_b = b / va
+    D[:, 0, 2] = cv * dva_a; D[:, 0, 3] = cv * dva_b
+    f = 1.0 / (1.0 + w * w)
+    ivg = 1.0 / (va * G_ACC)
+    dw_a = d * ivg - n * a / (va2 * va * G_ACC)
+    dw_b = -c * ivg - n * b / (va2 * va * G_ACC)
+    dw_c = -b * ivg
+    dw_d = a * ivg
+    dphi = np.stack([dw_a, dw_b, dw_c, dw_d], axis=1) * f[:, None]      # wrt a,b,c,d
+    D[:, 1, 2:6] = cphi * dphi
+    D[:, 2, 0] = sc[SC_WWP]
+    D[:, 3, 1] = sc[SC_WWP]
+    for (i, ddx, ddy, h, rr) in obs:
+        D[:, 4 + i, 0] = -h * ddx * (OBS_K / rr)
+        D[:, 4 + i, 1] = -h * ddy * (OBS_K / rr)
+    act = (hphi > 0) * np.sign(phi)
+    D[:, 6, 2:6] = wb * act[:, None] * dphi
+    actv = ((va > V_MAX) | (va < V_MIN)).astype(float)
+    D[:, 7, 2] = wb * actv * dva_a; D[:, 7, 3] = wb * actv * dva_b
+    return r, D
+
+
+def jacobian(basis, D):
+    """J (K*NROW x 2nq) = D_k . Gk, columns [q_x | q_y]."""
+    K, nq = basis.K, basis.nq
+    G = basis.G
+    J = np.zeros((K, NROW, 2 * nq))
+    for ax in range(2):
+        J[:, :, ax * nq:(ax + 1) * nq] = (D[:, :, 0 + ax, None] * G[0][:, None, :]
+                                          + D[:, :, 2 + ax, None] * G[1][:, None, :]
+                                          + D[:, :, 4 + ax, None] * G[2][:, None, :])
+    return J.reshape(K * NROW, 2 * nq)
+
+
+def cost(basis, sc, q, wp=None):
+    r = residuals(basis, sc, q, wp)
+    return float(np.sum(r * r))
+
+
+def eval_normal(basis, sc, q, wp=None):
+    """cost = sum r^2, g = J^T r, H = J^T J (all fp64)."""
+    r, D = residuals(basis, sc, q, wp, want_jac=True)
+    J = jacobian(basis, D)
+    rv = r.reshape(-1)
+    return float(rv @ rv), J.T @ rv, J.T @ J
+
+
+def initial_guess(basis, sc, wp=None):
+    """q0 = least-squares projection of the 'tri' waypoints on the reduced basis."""
+    if wp is None:
+        wp = waypoints(sc, basis.K, basis.duration)
+    dx, dy = end_data(sc)
+    P = basis.Pinit
+    qx = P @ (wp[0] - basis.Gp[0] @ dx)
+    qy = P @ (wp[1] - basis.Gp[0] @ dy)
+    return np.concatenate([qx, qy])
+
+
+# ----------------------------------------------------------------------------------
+# Levenberg-Marquardt on the normal equations -- the algorithm the HIP path implements
+# (csrc/fit_kernels.hip: fit_eval_kernel + fit_step_kernel); constants mirror
+# include/d2d.h D2D_LM_*.
+# ----------------------------------------------------------------------------------
+LM_LAMBDA0 = 1e-3
+LM_LAMBDA_MIN, LM_LAMBDA_MAX = 1e-12, 1e12
+LM_DIAG_FLOOR = 1e-30
+ST_RUNNING, ST_CONVERGED, ST_MAXITER, ST_NONFINITE, ST_STALLED = 0, 1, 2, 3, 4
+
+
+def lm_solve(basis, sc, q0=None, max_iter=200, ftol=1e-14, gtol=1e-9, xtol=1e-11,
+             hess_dtype=np.float64, chol_dtype=np.float64):
+    """(J^T J + lam*diag(J^T J)) delta = -J^T r with Nielsen's gain-ratio damping.
+
+    One "iteration" = one damped solve + one trial cost; J^T J is re-evaluated only
+    after an accepted step.  hess_dtype / chol_dtype = np.float32 mimic the HIP path's
+    fp32 MFMA J^T J and fp32 Cholesky (residuals, cost and J^T r stay fp64).
+    Returns q, cost, iters, status."""
+    wp = waypoints(sc, basis.K, basis.duration)
+    q = initial_guess(basis, sc, wp) if q0 is None else np.array(q0, float)
+    lam, nu = LM_LAMBDA0, 2.0
+    status = ST_MAXITER
+    c, g, H = eval_normal(basis, sc, q, wp)
+    H = H.astype(hess_dtype).astype(np.float64)
+    it = 0
+    if not np.isfinite(c):
+        return q, c, 0, ST_NONFINITE
+    for it in range(1, max_iter + 1):
+        if np.max(np.abs(g)) <= gtol:
+            status = ST_CONVERGED
+            break
+        dg = np.maximum(np.diag(H), LM_DIAG_FLOOR)
+        A = (H + lam * np.diag(dg)).astype(chol_dtype)
+        ok = True
+        try:
+            L = np.linalg.cholesky(A)
+            delta = -np.linalg.solve(L.T, np.linalg.solve(L, g.astype(chol_dtype))).astype(np.float64)
+        except np.linalg.LinAlgError:
+            ok = False
+        rho = -1.0
+        if ok:
+            ct = cost(basis, sc, q + delta, wp)
+            pred = float(delta @ (lam * dg * delta - g))
+            if np.isfinite(ct) and pred > 0:
+                rho = (c - ct) / pred
+        if rho > 0:
+            small_x = np.max(np.abs(delta)) <= xtol * (np.max(np.abs(q)) + xtol)
+            q = q + delta
+            lam = max(lam * max(1.0 / 3.0, 1.0 - (2.0 * rho - 1.0) ** 3), LM_LAMBDA_MIN); nu = 2.0
+            small_f = (c - ct) <= ftol * c and pred <= ftol * c
+            c, g, H = eval_normal(basis, sc, q, wp)
+            H = H.astype(hess_dtype).astype(np.float64)
+            if small_f or small_x:
+                status = ST_CONVERGED
+                break
+        else:
+            lam *= nu; nu *= 2.0
+            if lam > LM_LAMBDA_MAX:
+                status = ST_STALLED
+                break
+    return q, c, it, status
+
+
+def coefficients(basis, sc, q):
+    """Map q back to the reference's monomial layout coefs[0,:] per segment:
+    returns z (2, S, 8) -- axis, segment, power (src/d2d/trajectory.py:54-72)."""
+    nq = basis.nq
+    dx, dy = end_data(sc)
+    zx = basis.Zp @ dx + basis.Z @ q[:nq]
+    zy = basis.Zp @ dy + basis.Z @ q[nq:]
+    return np.stack([zx, zy]).reshape(2, basis.S, NCOEF)
+
+
+def horner(coefs8, t):
+    """PolynomialOne.get for derivative rows 0..3 (src/d2d/trajectory.py:74-82)."""
+    out = np.zeros(4)
+    for d in range(4):
+        row = [arr(d, p + d) * coefs8[p + d] for p in range(NCOEF - d)] + [0.0] * d
+        v = row[-1]
+        for j in range(NCOEF - 2, -1, -1):
+            v = v * t + row[j]
+        out[d] = v
+    return out
+
+
+# ----------------------------------------------------------------------------------
+# synthetic scenario generator (SURVEY.md 8d "synthetic inputs")
+# ----------------------------------------------------------------------------------
+def synth_scenarios(B, seed=20241008, rank=0, n_obs=2, wbnd=1.0, wwp=0.02):
+    rng = np.random.default_rng(seed + rank)
+    sc = np.zeros((B, SCEN_STRIDE))
+    p0 = rng.uniform(-100, 100, (B, 2)); psi0 = rng.uniform(-np.pi, np.pi, B)
+    dist = rng.uniform(30, 55, B); beta = rng.uniform(-np.pi, np.pi, B)
+    p1 = p0 + dist[:, None] * np.stack([np.cos(beta), np.sin(beta)], 1)
+    psi1 = rng.uniform(-np.pi, np.pi, B)
+    sc[:, SC_X0], sc[:, SC_Y0], sc[:, SC_PSI0] = p0[:, 0], p0[:, 1], psi0
+    sc[:, SC_X1], sc[:, SC_Y1], sc[:, SC_PSI1] = p1[:, 0], p1[:, 1], psi1
+    sc[:, SC_VREF] = 12.0; sc[:, SC_VSP] = 12.0
+    sc[:, SC_KV] = 5.0; sc[:, SC_KPHI] = 1.0; sc[:, SC_KOBS] = 1.0
+    sc[:, SC_WWP] = wwp; sc[:, SC_GOLEFT] = -1.0; sc[:, SC_WBND] = wbnd
+    along = rng.uniform(0.2, 0.8, (B, 2)); lat = rng.uniform(5, 15, (B, 2)) * rng.choice([-1.0, 1.0], (B, 2))
+    rad = rng.uniform(5, 15, (B, 2))
+    u = (p1 - p0) / dist[:, None]; nrm = np.stack([-u[:, 1], u[:, 0]], 1)
+    for i, (ox, oy, orr) in enumerate(((SC_O0X, SC_O0Y, SC_O0R), (SC_O1X, SC_O1Y, SC_O1R))):
+        c = p0 + along[:, i, None] * (p1 - p0) + lat[:, i, None] * nrm
+        sc[:, ox], sc[:, oy] = c[:, 0], c[:, 1]
+        sc[:, orr] = rad[:, i] if i < n_obs else 0.0
+    return sc
+
+
+def set_scale(sc, obj_scale, K):
+    sc[..., SC_S] = obj_scale / K
+    return sc

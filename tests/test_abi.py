@@ -1,0 +1,47 @@
+"""CPU: the C-ABI library loads and exports every symbol include/d2d.h declares
+(no compute calls -- there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, 'include', 'd2d.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(d2d_[a-z_0-9]+)\s*\(', src)))
+
+
+def test_header_symbols_exported():
+    import d2dhip
+    if not os.path.exists(d2dhip.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    lib = ctypes.CDLL(d2dhip.LIB_PATH)
+    names = _declared()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), f'{n} declared in include/d2d.h but not exported'
+    # the binding declares exactly the header's functions
+    assert sorted(d2dhip.EXPORTS) == names
+    lib.d2d_version.restype = ctypes.c_int
+    assert lib.d2d_version() == 100
+
+
+def test_struct_layouts_match_header():
+    import d2dhip
+    assert ctypes.sizeof(d2dhip.GvfParams) == 4 * 4 + 9 * 8 + 2 * 4 + 3 * 8
+    assert ctypes.sizeof(d2dhip.TrackParams) == 2 * 4 + 5 * 8 + 5 * 8 + 3 * 8 + 7 * 8
+    assert ctypes.sizeof(d2dhip.FitOpts) == 2 * 4 + 3 * 8
+    assert d2dhip.SCEN_STRIDE == 24
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    import d2dhip
+    monkeypatch.setattr(d2dhip, '_lib', None)
+    monkeypatch.setattr(d2dhip, 'LIB_PATH', '/nonexistent/libd2dhip.so')
+    with pytest.raises(d2dhip.D2DError):
+        d2dhip.load()

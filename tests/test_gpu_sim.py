@@ -1,0 +1,186 @@
+"""GPU parity: plant / guidance / tracking kernels (through the C-ABI) against the oracle
+and the golden vectors captured from the reference."""
+import numpy as np
+import pytest
+
+from oracle import sim as S
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    import d2dhip
+    c = d2dhip.Context(0)
+    yield c
+    c.close()
+
+
+def _planes(a):          # (n, c) -> plane-major (c, n)
+    return np.ascontiguousarray(np.asarray(a, float).T)
+
+
+def test_step_vs_reference_odeint_and_oracle(ctx, gold):
+    g = gold('plant')
+    X, U, W = g['X'], g['U'], g['W']
+    for tau in (0.01, 0.9667):
+        out = np.empty_like(X)
+        for i in range(len(X)):   # wind differs per row in the fixture -> one call per row
+            o = ctx.step(ctx.dev(_planes(X[i:i + 1])), ctx.dev(_planes(U[i:i + 1])), W[i], tau, 1.0, 0.05)
+            out[i] = o.cpu().numpy()[:, 0]
+        ora = np.array([S.disc_dyn_glrk(X[i], U[i], W[i], 0.05, tau) for i in range(len(X))])
+        d = out - ora; d[:, 2] = S.norm_mpi_pi(d[:, 2])
+        assert np.abs(d).max() < 1e-11                          # same algorithm, fp64
+        d = out - g[f'Xnext_tau{tau}']; d[:, 2] = S.norm_mpi_pi(d[:, 2])
+        assert np.abs(d).max() < 1e-6                           # vs the reference's LSODA output
+
+
+def test_step_large_batch_matches_oracle(ctx):
+    rng = np.random.default_rng(3)
+    n = 10007
+    X = np.stack([rng.uniform(-100, 100, n), rng.uniform(-100, 100, n), rng.uniform(-np.pi, np.pi, n),
+                  rng.uniform(-0.7, 0.7, n), rng.uniform(8, 16, n)], 1)
+    U = np.stack([rng.uniform(-1, 1, n), rng.uniform(9, 16, n)], 1)
+    o = ctx.step(ctx.dev(_planes(X)), ctx.dev(_planes(U)), (0.7, -0.4), 0.01, 1.0, 0.05).cpu().numpy().T
+    ora = S.disc_dyn_glrk(X, U, (0.7, -0.4), 0.05, 0.01, 1.0)
+    d = o - ora; d[:, 2] = S.norm_mpi_pi(d[:, 2])
+    assert np.abs(d).max() < 1e-10
+
+
+def _gvf(ctx, g, n_rows, X0, n_form=1, **kw):
+    c = np.tile(g['centres'], (n_form, 1)); N = 4 * n_form
+    out = ctx.gvf_run(ctx.dev(_planes(np.tile(X0, (n_form, 1)))), ctx.dev(_planes(c)), ctx.dev(np.full(N, float(g['r']))),
+                      4, n_rows, float(g['dt']), float(g['v_c']), float(g['ke']), float(g['kd']), float(g['kr']),
+                      tau_phi=float(g['tau_phi']), **kw)
+    ctx.sync()
+    return out
+
+
+def test_gvf_one_step_ahead_vs_reference_log(ctx, gold):
+    """Every consecutive pair of rows kept from src/states_over_time.csv."""
+    g = gold('states_over_time_sub')
+    rows, X = g['rows'], g['X']
+    worst = np.zeros(5)
+    for a in range(len(rows) - 1):
+        if rows[a + 1] != rows[a] + 1:
+            continue
+        out = _gvf(ctx, g, 2, X[a])
+        Xn = out['X'].cpu().numpy()[1].T
+        d = Xn - X[a + 1]; d[:, 2] = S.norm_mpi_pi(d[:, 2])
+        worst = np.maximum(worst, np.abs(d).max(0))
+    assert (worst[:2] < 5e-6).all() and (worst[2:] < 1e-6).all(), worst
+
+
+def test_gvf_closed_loop_vs_oracle_and_log(ctx, gold):
+    g = gold('states_over_time_sub')
+    T = 401
+    out = _gvf(ctx, g, T, g['X'][0], n_form=3)
+    Xh = out['X'].cpu().numpy().transpose(0, 2, 1).reshape(T, 3, 4, 5)
+    assert np.array_equal(Xh[:, 0], Xh[:, 1]) and np.array_equal(Xh[:, 0], Xh[:, 2])     # identical formations
+    c = g['centres']; kw = dict(ke=float(g['ke']), kd=float(g['kd']), kr=float(g['kr']), tau_phi=float(g['tau_phi']))
+    Xo, Uo, Rro, etho, _ = S.formation_gvf_run(c, float(g['r']), float(g['v_c']), g['X'][0], T, float(g['dt']), **kw)
+    d = Xh[:, 0] - Xo; d[..., 2] = S.norm_mpi_pi(d[..., 2])
+    assert np.abs(d).max() < 1e-8                                    # fp64 same algorithm over 400 steps
+    d = Xh[:, 0] - g['X'][:T]; d[..., 2] = S.norm_mpi_pi(d[..., 2])
+    assert np.abs(d).max() < 2e-4                                    # drift of the reference's LSODA tolerance
+    U = out['U'].cpu().numpy().transpose(0, 2, 1)[:, :4]
+    np.testing.assert_allclose(U[:T - 1], Uo[:T - 1], atol=1e-9)
+    Rr = out['Rr'].cpu().numpy()[:, :4]
+    np.testing.assert_allclose(Rr, Rro, atol=1e-7)
+    eth = out['eth'].cpu().numpy()[:, :3]
+    np.testing.assert_allclose(eth, etho, atol=1e-7)
+    assert (out['stop_row'].cpu().numpy() == T).all()
+
+
+def test_gvf_stop_rule_and_general_B(ctx):
+    rng = np.random.default_rng(5)
+    n_ac, n_form, T = 3, 5, 300
+    c = rng.uniform(-20, 20, (n_form, n_ac, 2)); X0 = np.zeros((n_form, n_ac, 5))
+    X0[..., 0] = rng.uniform(10, 40, (n_form, n_ac)); X0[..., 1] = rng.uniform(10, 40, (n_form, n_ac))
+    X0[..., 2] = rng.uniform(-3, 3, (n_form, n_ac)); X0[..., 4] = 12.0
+    B = np.array([[-1.0, 0.5], [1.0, -1.0], [0.0, 0.5]]); zd = np.array([0.3, -0.2])
+    # oracle first, to pick stop targets that are actually reached
+    ref = [S.formation_gvf_run(c[f], 50.0, 13.0, X0[f], T, 0.05, ke=4e-4, kd=25.0, kr=5.0, z_des=zd, B=B) for f in range(n_form)]
+    X0f = np.array([ref[f][0][60 + 20 * f] for f in range(n_form)])          # state at a known step
+    tol = (0.5, 0.5, 0.05)
+    refs = [S.formation_gvf_run(c[f], 50.0, 13.0, X0[f], T, 0.05, ke=4e-4, kd=25.0, kr=5.0, z_des=zd, B=B,
+                                X0f=X0f[f], stop_tol=tol) for f in range(n_form)]
+    N = n_form * n_ac
+    out = ctx.gvf_run(ctx.dev(_planes(X0.reshape(N, 5))), ctx.dev(_planes(c.reshape(N, 2))), ctx.dev(np.full(N, 50.0)),
+                      n_ac, T, 0.05, 13.0, 4e-4, 25.0, 5.0, B=B, z_des=zd, X0f=ctx.dev(_planes(X0f.reshape(N, 5)[:, :3])),
+                      stop_tol=tol)
+    ctx.sync()
+    stop = out['stop_row'].cpu().numpy()
+    Xh = out['X'].cpu().numpy().transpose(0, 2, 1).reshape(T, n_form, n_ac, 5)
+    for f in range(n_form):
+        assert stop[f] == refs[f][4], (f, stop[f], refs[f][4])
+        s = stop[f]
+        d = Xh[:s, f] - refs[f][0][:s]; d[..., 2] = S.norm_mpi_pi(d[..., 2])
+        assert np.abs(d).max() < 1e-8
+        assert stop[f] < T
+
+
+def test_ctrl_gain_vs_golden_and_oracle(ctx, gold):
+    g = gold('flatness_ctrl')
+    n = len(g['Y'])
+    Yref = np.concatenate([g['Y'], g['Yd'], g['Ydd'], g['Yddd']], 1)       # (n, 8)
+    for i in range(n):        # wind differs per row
+        Xr, dX, U, K = ctx.ctrl_gain(ctx.dev(_planes(g['X'][i:i + 1])), ctx.dev(_planes(Yref[i:i + 1])), w=tuple(g['W'][i]))
+        Xr, dX, U, K = (t.cpu().numpy()[:, 0] for t in (Xr, dX, U, K))
+        np.testing.assert_allclose(Xr, g['gain_Xr_carestandin'][i], rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(dX, g['gain_dX_carestandin'][i], rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(K.reshape(2, 5), g['gain_K_carestandin'][i], rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(U, g['gain_U_carestandin'][i], rtol=1e-8, atol=1e-9)
+
+
+def test_ctrl_gain_batch_and_tau(ctx):
+    rng = np.random.default_rng(11)
+    n = 777
+    psi = rng.uniform(-np.pi, np.pi, n); sp = rng.uniform(9, 15, n)
+    Y = np.stack([rng.uniform(-80, 80, n), rng.uniform(-80, 80, n), sp * np.cos(psi), sp * np.sin(psi),
+                  rng.uniform(-4, 4, n), rng.uniform(-4, 4, n), np.zeros(n), np.zeros(n)], 1)
+    X = np.stack([Y[:, 0] + rng.uniform(-5, 5, n), Y[:, 1] + rng.uniform(-5, 5, n), psi + rng.uniform(-0.5, 0.5, n),
+                  rng.uniform(-0.3, 0.3, n), sp + rng.uniform(-1, 1, n)], 1)
+    for tau in (0.01, 0.9667):
+        Xr, dX, U, K = ctx.ctrl_gain(ctx.dev(_planes(X)), ctx.dev(_planes(Y)), tau_phi=tau)
+        K = K.cpu().numpy().T.reshape(n, 2, 5); U = U.cpu().numpy().T
+        for i in range(0, n, 37):
+            _, _, Uo, Ko = S.compute_gain(X[i], Y[i, 0:2], Y[i, 2:4], Y[i, 4:6], Y[i, 6:8], (0, 0), tau, 1.0)
+            np.testing.assert_allclose(K[i], Ko, rtol=1e-8, atol=1e-9)
+            np.testing.assert_allclose(U[i], Uo, rtol=1e-8, atol=1e-9)
+
+
+def test_track_run_vs_reference_trace(ctx, gold):
+    """100-step phase-2/3 loop body executed by the reference's classes (CARE stand-in)."""
+    g = gold('tracking_trace_carestandin')
+    T, n = g['x_ref'].shape
+    dt = g['time'][1] - g['time'][0]
+    out = ctx.track_run(ctx.dev(g['x_ref']), ctx.dev(g['y_ref']), ctx.dev(_planes(g['X'][0])), dt,
+                        tau_phi=float(g['tau_phi']), tau_v=float(g['tau_v']))
+    ctx.sync()
+    X = out['X'].cpu().numpy().transpose(0, 2, 1); U = out['U'].cpu().numpy().transpose(0, 2, 1)
+    Xr = out['Xr'].cpu().numpy().transpose(0, 2, 1); dX = out['dX'].cpu().numpy().transpose(0, 2, 1)
+    # closed loop over 100 steps against the LSODA-integrated reference: tolerance = accumulated
+    # integrator difference (reference local error ~1e-6 m per step on |x| ~ 100 m)
+    d = X - g['X']; d[..., 2] = S.norm_mpi_pi(d[..., 2])
+    assert np.abs(d).max() < 2e-4, np.abs(d).max()
+    np.testing.assert_allclose(Xr[:T - 1], g['Xr'][:T - 1], rtol=1e-10, atol=1e-10)
+    assert np.abs(U[:T - 1] - g['U'][:T - 1]).max() < 2e-3
+    # and against the oracle running the same integrator: tight
+    Xo, Uo, Xro, Ydo, Yddo, dXo, Ko = S.track_run(g['time'], g['x_ref'], g['y_ref'], g['X'][0], (0, 0),
+                                                  float(g['tau_phi']), float(g['tau_v']))
+    d = X - Xo; d[..., 2] = S.norm_mpi_pi(d[..., 2])
+    assert np.abs(d).max() < 1e-7
+    np.testing.assert_allclose(U[:T - 1], Uo[:T - 1], atol=1e-6)
+    np.testing.assert_allclose(dX[:T - 1], dXo[:T - 1], atol=1e-7)
+    Yd = out['Yd'].cpu().numpy().transpose(0, 2, 1); Ydd = out['Ydd'].cpu().numpy().transpose(0, 2, 1)
+    np.testing.assert_allclose(Yd[:T - 1], Ydo[:T - 1], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(Ydd[:T - 1], Yddo[:T - 1], rtol=1e-11, atol=1e-10)
+
+
+def test_error_paths(ctx):
+    import d2dhip
+    with pytest.raises(d2dhip.D2DError):
+        ctx.step(ctx.zeros(5, 4), ctx.zeros(2, 4), (0, 0), -1.0, 1.0, 0.05)
+    with pytest.raises(d2dhip.D2DError):
+        ctx.gvf_run(ctx.zeros(5, 130), ctx.zeros(2, 130), ctx.zeros(130), 65, 3, 0.05, 12.0)
