@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""Headline benchmark: trajectory-optimisations/sec (6-segment polynomial, 50 waypoints).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one complete Levenberg-Marquardt solve of the per-GPU batch (BASELINE.json
+configs[1]: 4096 independent single-drone fits, S=6, K=50) with the scenarios and the
+initial guesses already resident in HBM.  With N > 1 the batch shards by trajectory
+(4096 per rank, weak scaling); the only collective is the all-reduce of the convergence
+statistics [sum cost, max |J^T r|, trajectories still running] every `check_every`
+iterations (RCCL; `nccl` backend).  Rank 0 prints ONE JSON line.
+
+Besides the contract fields the line carries
+  roofline      -- the fit_eval (J^T J, fp32 MFMA) kernel over an instrumented repeat of the
+                   timed region: algorithmic flop = 200*48*49 per trajectory evaluation
+                   (DESIGN.md "J^T J kernel") x evaluations / summed HIP-event kernel time
+  roofline_isolated -- the same kernel on the full resident batch (every trajectory active)
+  cpu_baseline  -- scipy.optimize.least_squares (method 'lm', analytic Jacobian) on the
+                   oracle's residual function over a process pool, bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, 'drone-sim-python_amd')):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np   # noqa: E402
+
+K, S_ = 50, 6
+OBJ_SCALE = 0.1
+FP32_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: f32-input MFMA peak
+ROWS_CONTRACTED = 200             # v, phi, obs0, obs1 rows of the 50 samples
+NQ2 = 48
+ALG_FLOP_PER_EVAL = ROWS_CONTRACTED * NQ2 * (NQ2 + 1)      # M*P*(P+1), SURVEY.md 8d
+
+
+def _plan_consts():
+    from d2dhip import synth
+    return synth.planner_timing(0, 4.9, 10)[2], synth.default_wref(OBJ_SCALE, K)
+
+
+# ---------------------------------------------------------------------------------------
+# CPU baseline (rank 0, N == 1): runs BEFORE anything touches the GPU so that the worker
+# processes are plain forks of a HIP-free parent.
+# ---------------------------------------------------------------------------------------
+def _cpu_fit_one(args):
+    from scipy.optimize import least_squares
+    from oracle import fit as F
+    basis, sc = args
+    wp = F.waypoints(sc, basis.K, basis.duration)
+    fun = lambda qq: F.residuals(basis, sc, qq, wp).reshape(-1)                        # noqa: E731
+    jac = lambda qq: F.jacobian(basis, F.residuals(basis, sc, qq, wp, True)[1])        # noqa: E731
+    res = least_squares(fun, F.initial_guess(basis, sc, wp), jac=jac, method='lm', xtol=1e-12, ftol=1e-12, gtol=1e-12)
+    return 2 * res.cost
+
+
+def cpu_baseline(n_sample=192):
+    import multiprocessing as mp
+    from oracle import fit as F               # the oracle is the thing timed in this leg only
+    from d2dhip import synth
+    dur, wref = _plan_consts()
+    basis = F.FitBasis(S_, K, dur, wref)
+    sc = synth.synth_scenarios(n_sample, seed=20241008, obj_scale=OBJ_SCALE, K=K)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else os.cpu_count()
+    with mp.get_context('fork').Pool(cores) as pool:
+        pool.map(_cpu_fit_one, [(basis, sc[i]) for i in range(min(cores, n_sample))])   # warm the workers
+        t0 = time.perf_counter()
+        costs = pool.map(_cpu_fit_one, [(basis, sc[i]) for i in range(n_sample)], chunksize=1)
+        dt = time.perf_counter() - t0
+    return {'value': n_sample / dt, 'unit': 'trajectory-optimisations/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{n_sample} of the {4096} bench trajectories, scipy.optimize.least_squares(method=lm, analytic '
+                      f'Jacobian, tol 1e-12) on oracle/fit.py residuals, multiprocessing.Pool({cores}), {dt:.1f} s wall',
+            'mean_cost': float(np.mean(costs))}
+
+
+# ---------------------------------------------------------------------------------------
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch', type=int, default=4096, help='trajectories per GPU')
+    ap.add_argument('--check-every', type=int, default=8)
+    ap.add_argument('--max-iter', type=int, default=200)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-sample', type=int, default=192)
+    a = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0)); world = int(os.environ.get('WORLD_SIZE', 1))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            sys.exit('bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)')
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(a.cpu_sample)
+
+    import torch
+    import d2dhip
+    from d2dhip import synth
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+    ctx = d2dhip.Context(local_rank)
+    dur, wref = _plan_consts()
+    plan = d2dhip.FitPlan(ctx, S_, K, dur, wref)
+    B = a.batch
+    sc = synth.synth_scenarios(B, seed=20241008, rank=rank, obj_scale=OBJ_SCALE, K=K)
+    dsc = ctx.dev(sc)
+    q0 = plan.init(dsc)
+    stats_t = torch.zeros(3, dtype=torch.float64, device=ctx.device)
+
+    def one_step():
+        """Full LM solve of the resident batch; returns (local stats, global running count)."""
+        q = q0.clone()
+        plan.begin(B)
+        while True:
+            running = plan.iterate(dsc, q, a.check_every, max_iter=a.max_iter)
+            if dist is not None:
+                # cross-GPU convergence check: 3 scalars over RCCL / xGMI
+                stats_t[0] = 0.0; stats_t[1] = 0.0; stats_t[2] = float(running)
+                dist.all_reduce(stats_t, op=dist.ReduceOp.SUM)
+                running = int(stats_t[2].item())
+            if running == 0:
+                break
+        return plan.finish(dsc, q), q
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        one_step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        (cost, iters, status, stats), q = one_step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=ctx.device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    st = status.cpu().numpy()
+    conv = float(np.isin(st, (d2dhip.ST_CONVERGED, d2dhip.ST_STALLED)).mean())
+
+    # ---- instrumented repeat (same workload) for the per-kernel roofline -------------
+    roof = roof_iso = None
+    if rank == 0:
+        plan.profile(True)
+    nrep = max(1, min(a.steps, 3))
+    n_evals = 0.0
+    for _ in range(nrep):                  # every rank runs it (the loop holds a collective)
+        (c_, i_, s_, stt), _q = one_step()
+        n_evals += stt[3]                  # gated evaluations only (finish()'s refresh is not counted)
+    if rank == 0:
+        ev_ms, ev_n, stp_ms, stp_n = plan.profile_read()
+        plan.profile(False)
+        ach = ALG_FLOP_PER_EVAL * n_evals / (ev_ms * 1e-3) / 1e12
+        roof = {'bound': 'mfma', 'kernel': 'fit_eval_kernel<3> (J^T J, v_mfma_f32_16x16x4_f32)', 'achieved': ach,
+                'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / FP32_PEAK_TFLOPS, 'traffic': None,
+                'alg_flop_per_unit': ALG_FLOP_PER_EVAL, 'units_per_launch_avg': n_evals / ev_n,
+                'avg_launch_us': 1e3 * ev_ms / ev_n, 'launches': int(ev_n),
+                'step_kernel_avg_launch_us': 1e3 * stp_ms / stp_n, 'eval_ms_total': ev_ms, 'step_ms_total': stp_ms}
+        # isolated: every trajectory active in one launch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(3):
+            plan.eval(dsc, q0)
+        nit = 20
+        torch.cuda.synchronize()
+        e0.record(ctx.stream)
+        for _ in range(nit):
+            plan.eval(dsc, q0)
+        e1.record(ctx.stream)
+        torch.cuda.synchronize()
+        iso_ms = e0.elapsed_time(e1) / nit
+        ach_i = ALG_FLOP_PER_EVAL * B / (iso_ms * 1e-3) / 1e12
+        roof_iso = {'bound': 'mfma', 'achieved': ach_i, 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': ach_i / FP32_PEAK_TFLOPS, 'avg_launch_us': 1e3 * iso_ms, 'units_per_launch': B,
+                    'note': 'fit_eval + symmetrize launch pair on the full batch (public d2d_fit_eval)'}
+
+    if rank == 0:
+        total = B * world * a.steps
+        line = {
+            'metric': 'trajectory-optimisations/sec (6-seg poly, 50 wpts)', 'value': total / dt,
+            'unit': 'trajectory-optimisations/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+            'ms_per_step': 1e3 * dt / a.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f64 residual/gradient + f32 MFMA J^T J', 'data': 'synthetic',
+            'config': {'workload': f'batch={B} per GPU independent single-drone 6-seg poly fits, 50 waypoints (BASELINE configs[1])',
+                       'segments': S_, 'samples': K, 'unknowns_reduced': NQ2, 'max_iter': a.max_iter,
+                       'check_every': a.check_every, 'parallelism': f'trajectory-sharded x{world}'},
+            'converged_frac': conv, 'mean_iters': float(iters.double().mean().item()),
+            'evals_per_fit': float(stats[3] / B), 'mean_cost': float(stats[0] / B),
+            'roofline': roof, 'roofline_isolated': roof_iso, 'cpu_baseline': cpu,
+        }
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -587,6 +587,7 @@ int d2d_fit_plan_create(d2d_ctx *ctx, int S, int K, double duration, const doubl
 int d2d_fit_plan_destroy(d2d_fit_plan *pl) {
   if (!pl) return D2D_OK;
   hipSetDevice(pl->device);
+  for (hipEvent_t e : pl->prof_ev) (void)hipEventDestroy(e);
   void *ptrs[] = {pl->d_G, pl->d_Gp, pl->d_G32, pl->d_W32, pl->d_Z, pl->d_Zp, pl->d_Pinit,
                   pl->d_g, pl->d_H, pl->d_cost, pl->d_lm, pl->d_flags};
   for (void *p : ptrs)
@@ -626,33 +627,95 @@ int d2d_fit_eval(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, const double *scen
   return D2D_OK;
 }
 
-int d2d_fit_solve(d2d_ctx *ctx, const d2d_fit_plan *plc, int B, const double *scen, double *q,
-                  const d2d_fit_opts *opts, double *cost, int32_t *iters, int32_t *status, double *stats) {
-  D2D_REQUIRE(ctx && plc && scen && q, "d2d_fit_solve: null argument");
-  D2D_REQUIRE(B >= 1, "d2d_fit_solve: B must be >= 1");
-  d2d_fit_plan *pl = const_cast<d2d_fit_plan *>(plc);
+// ---- profiling: HIP event pairs around every eval / step launch of the LM loop -------
+static int prof_begin(d2d_ctx *ctx, d2d_fit_plan *pl, int kind) {
+  if (!pl->prof_on) return D2D_OK;
+  hipEvent_t a, b;
+  D2D_CHECK_HIP(hipEventCreate(&a));
+  D2D_CHECK_HIP(hipEventCreate(&b));
+  pl->prof_ev.push_back(a);
+  pl->prof_ev.push_back(b);
+  pl->prof_kind.push_back(kind);
+  D2D_CHECK_HIP(hipEventRecord(a, ctx->stream));
+  return D2D_OK;
+}
+static int prof_end(d2d_ctx *ctx, d2d_fit_plan *pl) {
+  if (!pl->prof_on) return D2D_OK;
+  D2D_CHECK_HIP(hipEventRecord(pl->prof_ev.back(), ctx->stream));
+  return D2D_OK;
+}
+
+int d2d_fit_profile(d2d_fit_plan *pl, int enable) {
+  D2D_REQUIRE(pl != nullptr, "d2d_fit_profile: plan is NULL");
+  for (hipEvent_t e : pl->prof_ev) (void)hipEventDestroy(e);
+  pl->prof_ev.clear();
+  pl->prof_kind.clear();
+  pl->prof_on = enable != 0;
+  return D2D_OK;
+}
+
+int d2d_fit_profile_read(d2d_fit_plan *pl, double *out) {
+  D2D_REQUIRE(pl && out, "d2d_fit_profile_read: null argument");
+  for (int i = 0; i < 4; ++i) out[i] = 0.0;
+  for (size_t i = 0; i < pl->prof_kind.size(); ++i) {
+    D2D_CHECK_HIP(hipEventSynchronize(pl->prof_ev[2 * i + 1]));
+    float ms = 0.f;
+    D2D_CHECK_HIP(hipEventElapsedTime(&ms, pl->prof_ev[2 * i], pl->prof_ev[2 * i + 1]));
+    out[2 * pl->prof_kind[i]] += ms;
+    out[2 * pl->prof_kind[i] + 1] += 1.0;
+  }
+  return D2D_OK;
+}
+
+static d2d_fit_opts opts_or_default(const d2d_fit_opts *opts) {
   d2d_fit_opts o = {200, 8, 1e-14, 1e-9, 1e-11};
   if (opts) o = *opts;
-  D2D_REQUIRE(o.max_iter >= 1 && o.check_every >= 1, "d2d_fit_solve: max_iter and check_every must be >= 1");
+  return o;
+}
+
+int d2d_fit_begin(d2d_ctx *ctx, d2d_fit_plan *pl, int B) {
+  D2D_REQUIRE(ctx && pl, "d2d_fit_begin: null argument");
+  D2D_REQUIRE(B >= 1, "d2d_fit_begin: B must be >= 1");
   if (int rc = ensure_scratch(pl, B)) return rc;
-  const dim3 g1((B + 255) / 256), b1(256);
-  hipLaunchKernelGGL(fit_state_init_kernel, g1, b1, 0, ctx->stream, B, pl->d_lm, pl->d_flags);
+  hipLaunchKernelGGL(fit_state_init_kernel, dim3((B + 255) / 256), dim3(256), 0, ctx->stream, B, pl->d_lm, pl->d_flags);
   D2D_LAUNCH_CHECK();
-  int it = 0;
-  while (it < o.max_iter) {
+  pl->it_done = 0;
+  pl->active_B = B;
+  return D2D_OK;
+}
+
+int d2d_fit_iterate(d2d_ctx *ctx, d2d_fit_plan *pl, int B, const double *scen, double *q,
+                    const d2d_fit_opts *opts, int n_iters, int32_t *n_running) {
+  D2D_REQUIRE(ctx && pl && scen && q, "d2d_fit_iterate: null argument");
+  if (pl->active_B != B) { d2d_set_error("d2d_fit_iterate: call d2d_fit_begin(B=%d) first", B); return D2D_ESTATE; }
+  const d2d_fit_opts o = opts_or_default(opts);
+  D2D_REQUIRE(o.max_iter >= 1 && n_iters >= 1, "d2d_fit_iterate: max_iter and n_iters must be >= 1");
+  const dim3 g1((B + 255) / 256), b1(256);
+  for (int i = 0; i < n_iters && pl->it_done < o.max_iter; ++i, ++pl->it_done) {
+    if (int rc = prof_begin(ctx, pl, 0)) return rc;
     if (int rc = launch_eval(ctx, pl, B, scen, q, pl->d_flags, pl->d_cost, pl->d_g, pl->d_H)) return rc;
+    if (int rc = prof_end(ctx, pl)) return rc;
+    if (int rc = prof_begin(ctx, pl, 1)) return rc;
     if (int rc = launch_step(ctx, pl, B, scen, q, o)) return rc;
-    ++it;
-    if (it % o.check_every == 0 || it == o.max_iter) {
-      D2D_CHECK_HIP(hipMemsetAsync(ctx->counter_dev, 0, sizeof(int32_t), ctx->stream));
-      hipLaunchKernelGGL(fit_count_kernel, g1, b1, 0, ctx->stream, B, pl->d_flags, ctx->counter_dev);
-      D2D_LAUNCH_CHECK();
-      D2D_CHECK_HIP(hipMemcpyAsync(ctx->counter_host, ctx->counter_dev, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-      D2D_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-      if (ctx->counter_host[0] == 0) break;
-    }
+    if (int rc = prof_end(ctx, pl)) return rc;
   }
-  // converged trajectories carry a pending evaluation at the accepted point: refresh cost/gmax
+  if (n_running) {
+    D2D_CHECK_HIP(hipMemsetAsync(ctx->counter_dev, 0, sizeof(int32_t), ctx->stream));
+    hipLaunchKernelGGL(fit_count_kernel, g1, b1, 0, ctx->stream, B, pl->d_flags, ctx->counter_dev);
+    D2D_LAUNCH_CHECK();
+    D2D_CHECK_HIP(hipMemcpyAsync(ctx->counter_host, ctx->counter_dev, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    D2D_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    *n_running = (pl->it_done >= o.max_iter) ? 0 : ctx->counter_host[0];
+  }
+  return D2D_OK;
+}
+
+int d2d_fit_finish(d2d_ctx *ctx, d2d_fit_plan *pl, int B, const double *scen, const double *q,
+                   double *cost, int32_t *iters, int32_t *status, double *stats) {
+  D2D_REQUIRE(ctx && pl && scen && q, "d2d_fit_finish: null argument");
+  if (pl->active_B != B) { d2d_set_error("d2d_fit_finish: call d2d_fit_begin(B=%d) first", B); return D2D_ESTATE; }
+  const dim3 g1((B + 255) / 256), b1(256);
+  // converged trajectories carry a pending evaluation at the accepted point: refresh cost / J^T r
   if (int rc = launch_eval(ctx, pl, B, scen, q, nullptr, pl->d_cost, pl->d_g, nullptr)) return rc;
   if (cost) D2D_CHECK_HIP(hipMemcpyAsync(cost, pl->d_cost, (size_t)B * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
   hipLaunchKernelGGL(fit_export_kernel, g1, b1, 0, ctx->stream, B, pl->d_flags, iters, status);
@@ -667,6 +730,20 @@ int d2d_fit_solve(d2d_ctx *ctx, const d2d_fit_plan *plc, int B, const double *sc
   if (stats)
     for (int i = 0; i < 4; ++i) stats[i] = ctx->stats_host[i];
   return D2D_OK;
+}
+
+int d2d_fit_solve(d2d_ctx *ctx, const d2d_fit_plan *plc, int B, const double *scen, double *q,
+                  const d2d_fit_opts *opts, double *cost, int32_t *iters, int32_t *status, double *stats) {
+  D2D_REQUIRE(ctx && plc && scen && q, "d2d_fit_solve: null argument");
+  D2D_REQUIRE(B >= 1, "d2d_fit_solve: B must be >= 1");
+  d2d_fit_plan *pl = const_cast<d2d_fit_plan *>(plc);
+  const d2d_fit_opts o = opts_or_default(opts);
+  D2D_REQUIRE(o.max_iter >= 1 && o.check_every >= 1, "d2d_fit_solve: max_iter and check_every must be >= 1");
+  if (int rc = d2d_fit_begin(ctx, pl, B)) return rc;
+  int32_t running = B;
+  while (running > 0)
+    if (int rc = d2d_fit_iterate(ctx, pl, B, scen, q, &o, o.check_every, &running)) return rc;
+  return d2d_fit_finish(ctx, pl, B, scen, q, cost, iters, status, stats);
 }
 
 int d2d_fit_coeffs(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, const double *scen, const double *q, double *z) {

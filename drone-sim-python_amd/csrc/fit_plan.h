@@ -26,6 +26,11 @@ struct d2d_fit_plan {
   double *d_cost = nullptr;  // [B]
   double *d_lm = nullptr;    // [B][4] lambda, nu, gmax, pad
   int32_t *d_flags = nullptr;  // [B][4] status, iters, need_eval, nevals
+  int it_done = 0, active_B = 0;   // LM loop state between d2d_fit_begin / iterate / finish
+  // optional per-launch timing (d2d_fit_profile)
+  bool prof_on = false;
+  std::vector<hipEvent_t> prof_ev;   // start/stop pairs
+  std::vector<int> prof_kind;        // 0 = eval (J^T J) launch, 1 = step launch
 };
 
 int fit_basis_build(d2d_fit_plan *pl);   // fills the host vectors

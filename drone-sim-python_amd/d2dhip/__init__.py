@@ -60,6 +60,11 @@ _SIGS = {
     'd2d_fit_init': (C.c_int, [_P, _P, C.c_int, _P, _P]),
     'd2d_fit_eval': (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P, _P]),
     'd2d_fit_solve': (C.c_int, [_P, _P, C.c_int, _P, _P, C.POINTER(FitOpts), _P, _P, _P, _P]),
+    'd2d_fit_begin': (C.c_int, [_P, _P, C.c_int]),
+    'd2d_fit_iterate': (C.c_int, [_P, _P, C.c_int, _P, _P, C.POINTER(FitOpts), C.c_int, C.POINTER(C.c_int32)]),
+    'd2d_fit_finish': (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P, _P, _P]),
+    'd2d_fit_profile': (C.c_int, [_P, C.c_int]),
+    'd2d_fit_profile_read': (C.c_int, [_P, _P]),
     'd2d_fit_coeffs': (C.c_int, [_P, _P, C.c_int, _P, _P, _P]),
     'd2d_fit_sample': (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P]),
 }
@@ -265,6 +270,38 @@ class FitPlan:
         _check(self.ctx.lib.d2d_fit_solve(self.ctx.h, self.h, B, _ptr(scen), _ptr(q), C.byref(o), _ptr(cost),
                                           _ptr(iters), _ptr(status), _hptr(stats)))
         return cost, iters, status, stats
+
+    # -- the same loop in parts (for a caller-side / cross-GPU convergence check) -------
+    def begin(self, B):
+        _check(self.ctx.lib.d2d_fit_begin(self.ctx.h, self.h, B))
+
+    def iterate(self, scen, q, n_iters, max_iter=200, ftol=1e-14, gtol=1e-9, xtol=1e-11):
+        """Run n_iters more damped solves; returns the number of trajectories still running."""
+        o = FitOpts(max_iter, n_iters, ftol, gtol, xtol)
+        running = C.c_int32(0)
+        _check(self.ctx.lib.d2d_fit_iterate(self.ctx.h, self.h, scen.shape[0], _ptr(scen), _ptr(q), C.byref(o), n_iters,
+                                            C.byref(running)))
+        return running.value
+
+    def finish(self, scen, q):
+        torch = _torch()
+        B = scen.shape[0]
+        cost = self.ctx.empty(B)
+        iters = torch.empty(B, dtype=torch.int32, device=self.ctx.device)
+        status = torch.empty(B, dtype=torch.int32, device=self.ctx.device)
+        stats = np.zeros(4)
+        _check(self.ctx.lib.d2d_fit_finish(self.ctx.h, self.h, B, _ptr(scen), _ptr(q), _ptr(cost), _ptr(iters),
+                                           _ptr(status), _hptr(stats)))
+        return cost, iters, status, stats
+
+    def profile(self, enable):
+        _check(self.ctx.lib.d2d_fit_profile(self.h, 1 if enable else 0))
+
+    def profile_read(self):
+        """(eval_ms_total, eval_launches, step_ms_total, step_launches) from HIP events."""
+        out = np.zeros(4)
+        _check(self.ctx.lib.d2d_fit_profile_read(self.h, _hptr(out)))
+        return out
 
     def coeffs(self, scen, q):
         B = scen.shape[0]

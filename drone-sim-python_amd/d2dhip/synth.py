@@ -1,0 +1,49 @@
+"""Synthetic fit scenarios of SURVEY.md 8d ("synthetic inputs") and the default plan
+constants -- host-side input generation for benchmarks and batch planning (numpy only;
+no numerics of the hot path live here)."""
+import numpy as np
+
+from . import (SCEN_STRIDE, SC_X0, SC_Y0, SC_PSI0, SC_X1, SC_Y1, SC_PSI1, SC_VREF, SC_VSP, SC_KV, SC_KPHI,
+               SC_KOBS, SC_S, SC_WWP, SC_GOLEFT, SC_O0X, SC_O0Y, SC_O0R, SC_O1X, SC_O1Y, SC_O1R, SC_WBND)
+
+G_ACC = 9.81
+
+
+def planner_timing(t0, t1, hz):
+    """Node count / step / rounded duration, as the reference's planner_timing
+    (src/d2d/opty_utils.py:8-14) computes them."""
+    num_nodes = int((t1 - t0) * hz) + 1
+    time_step = 1.0 / hz
+    return num_nodes, time_step, (num_nodes - 1) * time_step
+
+
+def default_wref(obj_scale, K, kv=5.0, kphi=1.0, wwp=0.02):
+    """Weights of the whitening metric: the quadratic skeleton of the cost."""
+    s = obj_scale / K
+    return (wwp ** 2, s * kv, s * kphi / G_ACC ** 2)
+
+
+def synth_scenarios(B, seed=20241008, rank=0, n_obs=2, wbnd=1.0, wwp=0.02, obj_scale=0.1, K=50):
+    """B scenario rows (float64 [B][24]): start/end poses 30-55 m apart with random
+    headings, vref = vsp = 12, kv = 5, kphi = 1 (src/multi_opt_planner.py:187-188), two
+    circular obstacles beside the straight line, soft bounds phi in +-40 deg, v in [9,15]."""
+    rng = np.random.default_rng(seed + rank)
+    sc = np.zeros((B, SCEN_STRIDE))
+    p0 = rng.uniform(-100, 100, (B, 2)); psi0 = rng.uniform(-np.pi, np.pi, B)
+    dist = rng.uniform(30, 55, B); beta = rng.uniform(-np.pi, np.pi, B)
+    p1 = p0 + dist[:, None] * np.stack([np.cos(beta), np.sin(beta)], 1)
+    psi1 = rng.uniform(-np.pi, np.pi, B)
+    sc[:, SC_X0], sc[:, SC_Y0], sc[:, SC_PSI0] = p0[:, 0], p0[:, 1], psi0
+    sc[:, SC_X1], sc[:, SC_Y1], sc[:, SC_PSI1] = p1[:, 0], p1[:, 1], psi1
+    sc[:, SC_VREF] = 12.0; sc[:, SC_VSP] = 12.0
+    sc[:, SC_KV] = 5.0; sc[:, SC_KPHI] = 1.0; sc[:, SC_KOBS] = 1.0
+    sc[:, SC_WWP] = wwp; sc[:, SC_GOLEFT] = -1.0; sc[:, SC_WBND] = wbnd
+    along = rng.uniform(0.2, 0.8, (B, 2)); lat = rng.uniform(5, 15, (B, 2)) * rng.choice([-1.0, 1.0], (B, 2))
+    rad = rng.uniform(5, 15, (B, 2))
+    u = (p1 - p0) / dist[:, None]; nrm = np.stack([-u[:, 1], u[:, 0]], 1)
+    for i, (ox, oy, orr) in enumerate(((SC_O0X, SC_O0Y, SC_O0R), (SC_O1X, SC_O1Y, SC_O1R))):
+        c = p0 + along[:, i, None] * (p1 - p0) + lat[:, i, None] * nrm
+        sc[:, ox], sc[:, oy] = c[:, 0], c[:, 1]
+        sc[:, orr] = rad[:, i] if i < n_obs else 0.0
+    sc[:, SC_S] = obj_scale / K
+    return sc

@@ -209,6 +209,24 @@ int d2d_fit_solve(d2d_ctx *ctx, const d2d_fit_plan *plan, int B, const double *s
                   const d2d_fit_opts *opts, double *cost, int32_t *iters, int32_t *status,
                   double *stats);
 
+/* The same loop in three parts, for callers that interleave their own convergence check
+ * (the cross-GPU all-reduce of the statistics): begin resets the per-trajectory LM state;
+ * iterate runs up to n_iters more damped solves (never beyond opts->max_iter in total) and,
+ * if n_running != NULL, synchronises and returns how many trajectories are still running
+ * (0 once max_iter is reached); finish refreshes cost / J^T r and exports as d2d_fit_solve. */
+int d2d_fit_begin(d2d_ctx *ctx, d2d_fit_plan *plan, int B);
+int d2d_fit_iterate(d2d_ctx *ctx, d2d_fit_plan *plan, int B, const double *scen, double *q,
+                    const d2d_fit_opts *opts, int n_iters, int32_t *n_running);
+int d2d_fit_finish(d2d_ctx *ctx, d2d_fit_plan *plan, int B, const double *scen, const double *q,
+                   double *cost, int32_t *iters, int32_t *status, double *stats);
+
+/* Per-launch timing of the LM loop with HIP events on the context's stream: enable = 1
+ * starts a fresh recording, 0 stops.  d2d_fit_profile_read waits for the recorded events:
+ * out[0] = sum of fit_eval (J^T J) kernel ms, out[1] = its launches, out[2] = sum of
+ * fit_step kernel ms, out[3] = its launches. */
+int d2d_fit_profile(d2d_fit_plan *plan, int enable);
+int d2d_fit_profile_read(d2d_fit_plan *plan, double *out);
+
 /* Map q back to monomial coefficients z dev [B][2][S][8] (axis, segment, power). */
 int d2d_fit_coeffs(d2d_ctx *ctx, const d2d_fit_plan *plan, int B, const double *scen,
                    const double *q, double *z);
