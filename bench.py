@@ -60,6 +60,19 @@ def _cpu_fit_one(args):
     return 2 * res.cost
 
 
+def _host_cores():
+    """Cores this process may really use: affinity mask, capped by the cgroup CPU quota and by
+    the GPU box's per-GPU CPU share (16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, int(os.environ.get('D2D_BENCH_CORES', 16))))
+
+
 def cpu_baseline(n_sample=192):
     import multiprocessing as mp
     from oracle import fit as F               # the oracle is the thing timed in this leg only
@@ -67,7 +80,7 @@ def cpu_baseline(n_sample=192):
     dur, wref = _plan_consts()
     basis = F.FitBasis(S_, K, dur, wref)
     sc = synth.synth_scenarios(n_sample, seed=20241008, obj_scale=OBJ_SCALE, K=K)
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else os.cpu_count()
+    cores = _host_cores()
     with mp.get_context('fork').Pool(cores) as pool:
         pool.map(_cpu_fit_one, [(basis, sc[i]) for i in range(min(cores, n_sample))])   # warm the workers
         t0 = time.perf_counter()
