@@ -130,22 +130,14 @@ def main():
     sc = synth.synth_scenarios(B, seed=20241008, rank=rank, obj_scale=OBJ_SCALE, K=K)
     dsc = ctx.dev(sc)
     q0 = plan.init(dsc)
-    stats_t = torch.zeros(3, dtype=torch.float64, device=ctx.device)
+    from d2dhip.dist import StatsReducer, solve_sharded
+    reducer = StatsReducer(dist, ctx.device)
 
     def one_step():
-        """Full LM solve of the resident batch; returns (local stats, global running count)."""
+        """Full LM solve of the resident shard with the global convergence check."""
         q = q0.clone()
-        plan.begin(B)
-        while True:
-            running = plan.iterate(dsc, q, a.check_every, max_iter=a.max_iter)
-            if dist is not None:
-                # cross-GPU convergence check: 3 scalars over RCCL / xGMI
-                stats_t[0] = 0.0; stats_t[1] = 0.0; stats_t[2] = float(running)
-                dist.all_reduce(stats_t, op=dist.ReduceOp.SUM)
-                running = int(stats_t[2].item())
-            if running == 0:
-                break
-        return plan.finish(dsc, q), q
+        cost, iters, status, stats, glob, checks = solve_sharded(plan, dsc, q, reducer, a.check_every, a.max_iter)
+        return (cost, iters, status, stats), q
 
     def barrier():
         torch.cuda.synchronize()

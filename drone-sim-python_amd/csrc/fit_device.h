@@ -9,9 +9,6 @@
 
 #define FIT_G 9.81        // src/d2d/guidance.py:39
 #define FIT_OBS_K 2.0     // src/d2d/opty_utils.py:103
-#define FIT_PHI_MAX 0.6981317007977318   // 40 deg  (src/multi_opt_planner.py:192)
-#define FIT_V_MIN 9.0
-#define FIT_V_MAX 15.0
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -42,7 +39,7 @@ struct FitGeom {
 // Scenario row in registers (wave-uniform values).
 struct Scen {
   double x0, y0, psi0, x1, y1, psi1, vref, vsp, kv, kphi, kobs, s, wwp, wx, wy, goleft;
-  double o0x, o0y, o0r, o1x, o1y, o1r, wbnd;
+  double o0x, o0y, o0r, o1x, o1y, o1r, wbnd, phimax, vmin, vmax;
   double dx[4], dy[4];          // end data [pos0, vel0, pos1, vel1] per axis
   double p2x, p2y;              // apex of the 'tri' dog-leg
 };
@@ -56,7 +53,7 @@ __device__ __forceinline__ Scen load_scen(const double *__restrict__ sc, double 
   s.wy = sc[D2D_SC_WY]; s.goleft = sc[D2D_SC_GOLEFT];
   s.o0x = sc[D2D_SC_O0X]; s.o0y = sc[D2D_SC_O0Y]; s.o0r = sc[D2D_SC_O0R];
   s.o1x = sc[D2D_SC_O1X]; s.o1y = sc[D2D_SC_O1Y]; s.o1r = sc[D2D_SC_O1R];
-  s.wbnd = sc[D2D_SC_WBND];
+  s.wbnd = sc[D2D_SC_WBND]; s.phimax = sc[D2D_SC_PHIMAX]; s.vmin = sc[D2D_SC_VMIN]; s.vmax = sc[D2D_SC_VMAX];
   double s0, c0, s1, c1;
   sincos(s.psi0, &s0, &c0);
   sincos(s.psi1, &s1, &c1);
@@ -143,8 +140,8 @@ __device__ __forceinline__ double sample_terms(const Scen &s, const double Y[6],
     e1x = (x - s.o1x) * (FIT_OBS_K / s.o1r); e1y = (y - s.o1y) * (FIT_OBS_K / s.o1r);
     h1 = cobs * exp(-0.5 * (e1x * e1x + e1y * e1y));
   }
-  const double hphi = fmax(fabs(phi) - FIT_PHI_MAX, 0.0);
-  const double hv = fmax(va - FIT_V_MAX, 0.0) + fmin(va - FIT_V_MIN, 0.0);
+  const double hphi = fmax(fabs(phi) - s.phimax, 0.0);
+  const double hv = fmax(va - s.vmax, 0.0) + fmin(va - s.vmin, 0.0);
   const double r6 = s.wbnd * hphi, r7 = s.wbnd * hv;
   const double cost = r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3 + h0 * h0 + h1 * h1 + r6 * r6 + r7 * r7;
   if (WANT_JAC) {
@@ -154,7 +151,7 @@ __device__ __forceinline__ double sample_terms(const Scen &s, const double Y[6],
     const double dp_a = (d * ivg - nv3 * a) * f, dp_b = (-c * ivg - nv3 * b) * f;
     const double dp_c = -b * ivg * f, dp_d = a * ivg * f;
     const double actp = (hphi > 0.0) ? ((phi > 0.0) ? 1.0 : -1.0) : 0.0;
-    const double actv = (va > FIT_V_MAX || va < FIT_V_MIN) ? 1.0 : 0.0;
+    const double actv = (va > s.vmax || va < s.vmin) ? 1.0 : 0.0;
     const double k0 = FIT_OBS_K / (s.o0r > 0.0 ? s.o0r : 1.0), k1 = FIT_OBS_K / (s.o1r > 0.0 ? s.o1r : 1.0);
     const double o0x = -h0 * e0x * k0, o0y = -h0 * e0y * k0;
     const double o1x = -h1 * e1x * k1, o1y = -h1 * e1y * k1;

@@ -12,8 +12,9 @@
 #include "fit_device.h"
 #include "fit_plan.h"
 
-#define FIT_WPB 8            // wavefronts (= trajectories) per workgroup
-#define FIT_THREADS (64 * FIT_WPB)
+#define FIT_WPB_MAX 8        // wavefronts (= trajectories) per workgroup, fewer when K is large
+#define FIT_THREADS (64 * FIT_WPB_MAX)
+#define FIT_LDS_BYTES (160 * 1024)
 
 // flags[b][4] = status, iters, need_eval, nevals ; lm[b][4] = lambda, nu, gmax, cost_prev
 enum { FL_STATUS = 0, FL_ITERS = 1, FL_NEED = 2, FL_NEVAL = 3 };
@@ -27,21 +28,32 @@ struct FitLds {
 
 static inline int align16(int v) { return (v + 15) & ~15; }
 
-static FitLds eval_lds_layout(int K, int nq) {
+// g32_lds: stage the fp32 operand table in LDS (else it is read through L1/L2);
+// wpb: wavefronts per workgroup.  pick_eval_layout chooses the largest that fits 160 KiB.
+static FitLds eval_lds_layout(int K, int nq, bool g32_lds, int wpb) {
   FitLds L;
   const int gstr = nq + 1;
   int o = 0;
   L.G64 = o; o = align16(o + 3 * K * gstr * 8);
   L.Gp64 = o; o = align16(o + 3 * K * 4 * 8);
-  L.G32 = o; o = align16(o + K * nq * 16);
+  L.G32 = o; o = align16(o + (g32_lds ? K * nq * 16 : 0));
   L.wave0 = o;
   int w = 0;
   L.q = w; w = align16(w + 2 * nq * 8);
   L.u = w; w = align16(w + K * 6 * 8);
   L.coef = w; w = align16(w + K * 4 * 6 * 4);
   L.wave_stride = w;
-  L.total = o + FIT_WPB * w;
+  L.total = o + wpb * w;
   return L;
+}
+
+static bool pick_eval_layout(int K, int nq, bool *g32_lds, int *wpb) {
+  for (int pass = 0; pass < 2; ++pass) {
+    const bool in_lds = pass == 0;
+    for (int w = FIT_WPB_MAX; w >= (in_lds ? 4 : 1); --w)
+      if (eval_lds_layout(K, nq, in_lds, w).total <= FIT_LDS_BYTES) { *g32_lds = in_lds; *wpb = w; return true; }
+  }
+  return false;
 }
 
 // Cooperative copy global -> LDS (whole workgroup), 8-byte granules.
@@ -54,7 +66,7 @@ __device__ __forceinline__ void stage(void *dst, const void *src, int bytes) {
 // ------------------------------------------------------------------------------------
 // K1 + K2: cost, J^T r, J^T J.   H is written as the upper block triangle of 16x16 tiles
 // of a [n][n] row-major matrix (n = 2nq); symmetrize_kernel mirrors it for the public API.
-template <int NB>   // NB = ceil(2nq/16) column blocks of the MFMA tiling
+template <int NB, bool G32_LDS>   // NB = ceil(2nq/16) column blocks of the MFMA tiling
 __global__ void __launch_bounds__(FIT_THREADS)
 fit_eval_kernel(int B, FitGeom g, FitLds L, double duration, const double *__restrict__ gG64,
                 const double *__restrict__ gGp64, const float *__restrict__ gG32,
@@ -64,14 +76,13 @@ fit_eval_kernel(int B, FitGeom g, FitLds L, double duration, const double *__res
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   double *G64 = reinterpret_cast<double *>(lds + L.G64);
   double *Gp64 = reinterpret_cast<double *>(lds + L.Gp64);
-  const f32x4 *G32 = reinterpret_cast<const f32x4 *>(lds + L.G32);
   stage(G64, gG64, 3 * g.K * g.gstr * 8);
   stage(Gp64, gGp64, 3 * g.K * 4 * 8);
-  stage(lds + L.G32, gG32, g.K * g.nq * 16);
+  if (G32_LDS) stage(lds + L.G32, gG32, g.K * g.nq * 16);
   __syncthreads();
 
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int b = blockIdx.x * FIT_WPB + wave;
+  const int b = blockIdx.x * (blockDim.x >> 6) + wave;
   if (b >= B) return;
   if (flags && (flags[4 * b + FL_STATUS] != D2D_ST_RUNNING || flags[4 * b + FL_NEED] == 0)) return;
 
@@ -150,7 +161,8 @@ fit_eval_kernel(int B, FitGeom g, FitLds L, double duration, const double *__res
     float v[NB];
 #pragma unroll
     for (int c = 0; c < NB; ++c) {
-      const f32x4 gk = G32[k * g.nq + jcol[c]];
+      const f32x4 gk = G32_LDS ? reinterpret_cast<const f32x4 *>(lds + L.G32)[k * g.nq + jcol[c]]
+                               : reinterpret_cast<const f32x4 *>(gG32)[k * g.nq + jcol[c]];
       const float vx = c0 * gk.x + c1 * gk.y + c2 * gk.z;
       const float vy = c3 * gk.x + c4 * gk.y + c5 * gk.z;
       v[c] = jok[c] ? (jax[c] ? vy : vx) : 0.f;
@@ -198,7 +210,7 @@ __global__ void __launch_bounds__(256) symmetrize_kernel(int B, int n, float *__
 struct StepLds {
   int G64, Gp64, wave0, wave_stride, Lm, vec, qt, total;
 };
-static StepLds step_lds_layout(int K, int nq, int N) {
+static StepLds step_lds_layout(int K, int nq, int N, int wpb) {
   StepLds L;
   const int gstr = nq + 1;
   int o = 0;
@@ -210,8 +222,14 @@ static StepLds step_lds_layout(int K, int nq, int N) {
   L.vec = w; w = align16(w + N * 4);
   L.qt = w; w = align16(w + N * 8);
   L.wave_stride = w;
-  L.total = o + FIT_WPB * w;
+  L.total = o + wpb * w;
   return L;
+}
+
+static bool pick_step_layout(int K, int nq, int N, int *wpb) {
+  for (int w = FIT_WPB_MAX; w >= 1; --w)
+    if (step_lds_layout(K, nq, N, w).total <= FIT_LDS_BYTES) { *wpb = w; return true; }
+  return false;
 }
 
 template <int N>
@@ -228,7 +246,7 @@ fit_step_kernel(int B, FitGeom g, StepLds L, double duration, d2d_fit_opts opts,
   stage(Gp64, gGp64, 3 * g.K * 4 * 8);
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int b = blockIdx.x * FIT_WPB + wave;
+  const int b = blockIdx.x * (blockDim.x >> 6) + wave;
   if (b >= B) return;
   if (flags[4 * b + FL_STATUS] != D2D_ST_RUNNING) return;
   unsigned char *wl = lds + L.wave0 + wave * L.wave_stride;
@@ -435,6 +453,30 @@ fit_init_kernel(int B, int K, int nq, double duration, const double *__restrict_
   }
 }
 
+// q0 = Pinit (xy - Gp0 d) for caller-supplied node positions xy [B][2][K]
+__global__ void __launch_bounds__(256)
+fit_project_kernel(int B, int K, int nq, double duration, const double *__restrict__ Gp,
+                   const double *__restrict__ Pinit, const double *__restrict__ scen,
+                   const double *__restrict__ xy, double *__restrict__ q) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + wave;
+  if (b >= B) return;
+  const Scen s = load_scen(scen + (size_t)b * D2D_SCEN_STRIDE, duration);
+  const int n = 2 * nq;
+  for (int l = lane; l < n; l += 64) {
+    const int ax = l >= nq, j = l - ax * nq;
+    const double *src = xy + ((size_t)b * 2 + ax) * K;
+    double acc = 0.0;
+    for (int k = 0; k < K; ++k) {
+      const double *gp = Gp + (size_t)k * 4;
+      double base = 0.0;
+      for (int c = 0; c < 4; ++c) base += gp[c] * (ax ? s.dy[c] : s.dx[c]);
+      acc += Pinit[(size_t)j * K + k] * (src[k] - base);
+    }
+    q[(size_t)b * n + l] = acc;
+  }
+}
+
 // z[b][axis][row] = Zp[row] . d_axis + Z[row] . q_axis
 __global__ void __launch_bounds__(256)
 fit_coeffs_kernel(int B, int S, int nq, double duration, const double *__restrict__ Z,
@@ -501,15 +543,21 @@ static int ensure_scratch(d2d_fit_plan *pl, int B) {
 static int launch_eval(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, const double *scen, const double *q,
                        int32_t *flags, double *cost, double *g, float *H) {
   const FitGeom gm = geom_of(pl);
-  const FitLds L = eval_lds_layout(pl->K, pl->nq);
+  const FitLds L = eval_lds_layout(pl->K, pl->nq, pl->g32_lds, pl->wpb_eval);
   const int NB = (2 * pl->nq + 15) / 16;
-  const dim3 grid((B + FIT_WPB - 1) / FIT_WPB), block(FIT_THREADS);
-#define LAUNCH_EVAL(NBV)                                                                           \
-  hipLaunchKernelGGL(fit_eval_kernel<NBV>, grid, block, L.total, ctx->stream, B, gm, L, pl->duration, \
+  const dim3 grid((B + pl->wpb_eval - 1) / pl->wpb_eval), block(64 * pl->wpb_eval);
+#define LAUNCH_EVAL(NBV, INLDS)                                                                    \
+  hipLaunchKernelGGL((fit_eval_kernel<NBV, INLDS>), grid, block, L.total, ctx->stream, B, gm, L, pl->duration, \
                      pl->d_G, pl->d_Gp, pl->d_G32, pl->d_W32, scen, q, flags, cost, g, H)
-  if (NB == 1) LAUNCH_EVAL(1);
-  else if (NB == 2) LAUNCH_EVAL(2);
-  else LAUNCH_EVAL(3);
+  if (pl->g32_lds) {
+    if (NB == 1) LAUNCH_EVAL(1, true);
+    else if (NB == 2) LAUNCH_EVAL(2, true);
+    else LAUNCH_EVAL(3, true);
+  } else {
+    if (NB == 1) LAUNCH_EVAL(1, false);
+    else if (NB == 2) LAUNCH_EVAL(2, false);
+    else LAUNCH_EVAL(3, false);
+  }
 #undef LAUNCH_EVAL
   D2D_LAUNCH_CHECK();
   return D2D_OK;
@@ -519,8 +567,8 @@ static int launch_step(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, const double
                        const d2d_fit_opts &o) {
   const FitGeom gm = geom_of(pl);
   const int NB = (2 * pl->nq + 15) / 16;
-  const StepLds L = step_lds_layout(pl->K, pl->nq, 16 * NB);
-  const dim3 grid((B + FIT_WPB - 1) / FIT_WPB), block(FIT_THREADS);
+  const StepLds L = step_lds_layout(pl->K, pl->nq, 16 * NB, pl->wpb_step);
+  const dim3 grid((B + pl->wpb_step - 1) / pl->wpb_step), block(64 * pl->wpb_step);
 #define LAUNCH_STEP(NV)                                                                            \
   hipLaunchKernelGGL(fit_step_kernel<NV>, grid, block, L.total, ctx->stream, B, gm, L, pl->duration, o, \
                      pl->d_G, pl->d_Gp, scen, q, pl->d_g, pl->d_H, pl->d_cost, pl->d_lm, pl->d_flags)
@@ -530,6 +578,11 @@ static int launch_step(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, const double
 #undef LAUNCH_STEP
   D2D_LAUNCH_CHECK();
   return D2D_OK;
+}
+
+template <typename KernelT>
+static void allow_big_lds(KernelT k) {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, FIT_LDS_BYTES);
 }
 
 extern "C" {
@@ -546,10 +599,9 @@ int d2d_fit_plan_create(d2d_ctx *ctx, int S, int K, double duration, const doubl
   for (int i = 0; i < 3; ++i) pl->wref[i] = wref[i];
   if (int rc = fit_basis_build(pl)) { delete pl; return rc; }
   const int nq = pl->nq, gstr = nq + 1;
-  const FitLds L = eval_lds_layout(K, nq);
-  const StepLds SL = step_lds_layout(K, nq, 16 * ((2 * nq + 15) / 16));
-  if (L.total > 160 * 1024 || SL.total > 160 * 1024) {
-    d2d_set_error("d2d_fit_plan_create: K=%d, S=%d needs %d B of LDS (> 160 KiB)", K, S, L.total > SL.total ? L.total : SL.total);
+  if (!pick_eval_layout(K, nq, &pl->g32_lds, &pl->wpb_eval) ||
+      !pick_step_layout(K, nq, 16 * ((2 * nq + 15) / 16), &pl->wpb_step)) {
+    d2d_set_error("d2d_fit_plan_create: K=%d, S=%d does not fit the 160 KiB LDS image of the basis block", K, S);
     delete pl;
     return D2D_EINVAL;
   }
@@ -573,12 +625,9 @@ int d2d_fit_plan_create(d2d_ctx *ctx, int S, int K, double duration, const doubl
   if (!rc) rc = upload(&pl->d_Pinit, pl->Pinit);
   if (rc) { d2d_fit_plan_destroy(pl); return rc; }
   // opt in to large dynamic LDS
-  hipFuncSetAttribute(reinterpret_cast<const void *>(&fit_eval_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipFuncSetAttribute(reinterpret_cast<const void *>(&fit_eval_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipFuncSetAttribute(reinterpret_cast<const void *>(&fit_eval_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipFuncSetAttribute(reinterpret_cast<const void *>(&fit_step_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipFuncSetAttribute(reinterpret_cast<const void *>(&fit_step_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipFuncSetAttribute(reinterpret_cast<const void *>(&fit_step_kernel<48>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  allow_big_lds(&fit_eval_kernel<1, true>); allow_big_lds(&fit_eval_kernel<2, true>); allow_big_lds(&fit_eval_kernel<3, true>);
+  allow_big_lds(&fit_eval_kernel<1, false>); allow_big_lds(&fit_eval_kernel<2, false>); allow_big_lds(&fit_eval_kernel<3, false>);
+  allow_big_lds(&fit_step_kernel<16>); allow_big_lds(&fit_step_kernel<32>); allow_big_lds(&fit_step_kernel<48>);
   (void)hipGetLastError();
   *out = pl;
   return D2D_OK;
@@ -611,6 +660,15 @@ int d2d_fit_init(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, const double *scen
   D2D_REQUIRE(B >= 1, "d2d_fit_init: B must be >= 1");
   hipLaunchKernelGGL(fit_init_kernel, dim3((B + 3) / 4), dim3(256), 0, ctx->stream, B, pl->K, pl->nq, pl->duration,
                      pl->d_Gp, pl->d_Pinit, scen, q);
+  D2D_LAUNCH_CHECK();
+  return D2D_OK;
+}
+
+int d2d_fit_project(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, const double *scen, const double *xy, double *q) {
+  D2D_REQUIRE(ctx && pl && scen && xy && q, "d2d_fit_project: null argument");
+  D2D_REQUIRE(B >= 1, "d2d_fit_project: B must be >= 1");
+  hipLaunchKernelGGL(fit_project_kernel, dim3((B + 3) / 4), dim3(256), 0, ctx->stream, B, pl->K, pl->nq, pl->duration,
+                     pl->d_Gp, pl->d_Pinit, scen, xy, q);
   D2D_LAUNCH_CHECK();
   return D2D_OK;
 }

@@ -26,6 +26,9 @@ struct d2d_fit_plan {
   double *d_cost = nullptr;  // [B]
   double *d_lm = nullptr;    // [B][4] lambda, nu, gmax, pad
   int32_t *d_flags = nullptr;  // [B][4] status, iters, need_eval, nevals
+  // launch geometry chosen at plan creation from the LDS footprint
+  bool g32_lds = true;
+  int wpb_eval = 8, wpb_step = 8;
   int it_done = 0, active_B = 0;   // LM loop state between d2d_fit_begin / iterate / finish
   // optional per-launch timing (d2d_fit_profile)
   bool prof_on = false;

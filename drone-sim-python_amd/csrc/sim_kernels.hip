@@ -236,6 +236,138 @@ track_run_kernel(d2d_track_params p, GlMesh mesh, const double *__restrict__ x_r
 }
 
 // ------------------------------------------------------------------------------------
+// Single-evaluation entry points behind the reference's per-call helper methods.
+__global__ void __launch_bounds__(256)
+dcf_eval_kernel(int n_form, int n_ac, double kr, const double *__restrict__ Bz,
+                const double *__restrict__ centres, const double *__restrict__ pos,
+                double *__restrict__ U_r, double *__restrict__ eth_deg) {
+  // one thread per formation (n_ac <= 64): tiny, latency-bound by design
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= n_form) return;
+  const long N = (long)n_form * n_ac;
+  const int nm = n_ac - 1;
+  double th[64], e[64];
+  for (int a = 0; a < n_ac; ++a) {
+    const long d = (long)f * n_ac + a;
+    th[a] = atan2(pos[N + d] - centres[N + d], pos[d] - centres[d]);
+  }
+  for (int m = 0; m < nm; ++m) {
+    double z = 0.0;
+    for (int k = 0; k < n_ac; ++k) z += Bz[k * nm + m] * th[k];
+    double ee = z - Bz[n_ac * nm + m];
+    if (ee > D2D_PI) ee -= D2D_TWO_PI;
+    if (ee <= -D2D_PI) ee += D2D_TWO_PI;
+    e[m] = ee;
+    if (eth_deg) eth_deg[(long)f * nm + m] = ee * (180.0 / D2D_PI);
+  }
+  for (int a = 0; a < n_ac; ++a) {
+    double u = 0.0;
+    for (int m = 0; m < nm; ++m) u += Bz[a * nm + m] * e[m];
+    U_r[(long)f * n_ac + a] = -kr * u;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+gvf_eval_kernel(int n, double ke, double kd, const double *__restrict__ X, const double *__restrict__ e,
+                const double *__restrict__ nv, const double *__restrict__ H, double *__restrict__ U) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const State5 s = {X[i], X[n + i], X[2 * n + i], X[3 * n + i], X[4 * n + i]};
+  const double Hm[4] = {H[i], H[n + i], H[2 * n + i], H[3 * n + i]};
+  double U1, U2;
+  const double Ut = gvf_control(s, e[i], nv[i], nv[n + i], Hm, ke, kd, &U1, &U2);
+  U[i] = Ut; U[n + i] = U1; U[2 * n + i] = U2;
+}
+
+__global__ void __launch_bounds__(256)
+flatness_kernel(int variant, int n, double wx, double wy, double tau_phi, double tau_v,
+                const double *__restrict__ Yref, double *__restrict__ X, double *__restrict__ U,
+                double *__restrict__ Xdot) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double Y[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) Y[c] = Yref[(long)c * n + i];
+  double Xo[5], Uo[2], Xd[5] = {0, 0, 0, 0, 0};
+  if (variant == 0) {
+    flat_state_input(Y, wx, wy, tau_phi, tau_v, Xo, Uo, Xd);
+  } else {
+    State5 xr;
+    compute_flatness(Y, wx, wy, tau_phi, tau_v, xr, Uo[0], Uo[1]);
+    Xo[0] = xr.x; Xo[1] = xr.y; Xo[2] = xr.psi; Xo[3] = xr.phi; Xo[4] = xr.v;
+  }
+#pragma unroll
+  for (int c = 0; c < 5; ++c) {
+    X[(long)c * n + i] = Xo[c];
+    if (Xdot) Xdot[(long)c * n + i] = Xd[c];
+  }
+  U[i] = Uo[0]; U[n + i] = Uo[1];
+}
+
+__global__ void __launch_bounds__(256)
+cont_jac_kernel(int n, double tau_phi, double tau_v, const double *__restrict__ Xr,
+                double *__restrict__ A, double *__restrict__ B) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const Mat<5> Am = cont_jac_A(Xr[2 * n + i], Xr[3 * n + i], Xr[4 * n + i], tau_phi, tau_v);
+#pragma unroll
+  for (int r = 0; r < 5; ++r)
+#pragma unroll
+    for (int c = 0; c < 5; ++c) A[(long)(r * 5 + c) * n + i] = Am.a[r][c];
+#pragma unroll
+  for (int k = 0; k < 10; ++k) B[(long)k * n + i] = 0.0;
+  B[(long)6 * n + i] = 1.0 / tau_phi;    // B[3][0]
+  B[(long)9 * n + i] = 1.0 / tau_v;      // B[4][1]
+}
+
+struct LqrWeights { double Q[25]; double Rinv[4]; };
+
+__global__ void __launch_bounds__(64)
+lqr_kernel(int n, LqrWeights w, const double *__restrict__ A, const double *__restrict__ B,
+           double *__restrict__ K, double *__restrict__ P) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = i < n;
+  if (!live) i = n - 1;
+  Mat<5> Am, G, Q;
+  double Bm[5][2];
+#pragma unroll
+  for (int r = 0; r < 5; ++r) {
+#pragma unroll
+    for (int c = 0; c < 5; ++c) { Am.a[r][c] = A[(long)(r * 5 + c) * n + i]; Q.a[r][c] = w.Q[r * 5 + c]; }
+    Bm[r][0] = B[(long)(r * 2) * n + i]; Bm[r][1] = B[(long)(r * 2 + 1) * n + i];
+  }
+  double BR[5][2];                      // B R^-1
+#pragma unroll
+  for (int r = 0; r < 5; ++r) {
+    BR[r][0] = Bm[r][0] * w.Rinv[0] + Bm[r][1] * w.Rinv[2];
+    BR[r][1] = Bm[r][0] * w.Rinv[1] + Bm[r][1] * w.Rinv[3];
+  }
+#pragma unroll
+  for (int r = 0; r < 5; ++r)
+#pragma unroll
+    for (int c = 0; c < 5; ++c) G.a[r][c] = BR[r][0] * Bm[c][0] + BR[r][1] * Bm[c][1];
+  const Mat<5> Pm = care_sda<5>(Am, G, Q);
+  if (!live) return;
+#pragma unroll
+  for (int r = 0; r < 5; ++r)
+#pragma unroll
+    for (int c = 0; c < 5; ++c)
+      if (P) P[(long)(r * 5 + c) * n + i] = Pm.a[r][c];
+  // K = R^-1 B^T P
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+      double acc = 0.0;
+#pragma unroll
+      for (int r = 0; r < 5; ++r) acc += (w.Rinv[u * 2 + 0] * Bm[r][0] + w.Rinv[u * 2 + 1] * Bm[r][1]) * Pm.a[r][c];
+      K[(long)(u * 5 + c) * n + i] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+static int upload_Bz(d2d_ctx *ctx, int n_ac, const double *Bmat, const double *z_des);
+
 extern "C" {
 
 int d2d_step(d2d_ctx *ctx, int n, const double *X, const double *U, double wx, double wy,
@@ -260,18 +392,7 @@ int d2d_sim_gvf_run(d2d_ctx *ctx, const d2d_gvf_params *p, const double *X0,
   D2D_REQUIRE(p->dt > 0 && p->tau_phi > 0 && p->tau_v > 0, "d2d_sim_gvf_run: dt, tau_phi, tau_v must be > 0");
   const int n_ac = p->n_ac, nm = n_ac - 1;
   const size_t nb = (size_t)n_ac * nm + nm;
-  if (ctx->Bmat_cap < nb + 1) {
-    if (ctx->Bmat_dev) D2D_CHECK_HIP(hipFree(ctx->Bmat_dev));
-    D2D_CHECK_HIP(hipMalloc(&ctx->Bmat_dev, (nb + 1) * sizeof(double)));
-    ctx->Bmat_cap = nb + 1;
-  }
-  if (nb) {
-    std::vector<double> h(nb);
-    for (size_t i = 0; i < (size_t)n_ac * nm; ++i) h[i] = Bmat[i];
-    for (int i = 0; i < nm; ++i) h[(size_t)n_ac * nm + i] = z_des[i];
-    D2D_CHECK_HIP(hipMemcpyAsync(ctx->Bmat_dev, h.data(), nb * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    D2D_CHECK_HIP(hipStreamSynchronize(ctx->stream));   // h goes out of scope
-  }
+  if (int rc = upload_Bz(ctx, n_ac, Bmat, z_des)) return rc;
   // 64-thread blocks when that loses no lanes: more workgroups for the 256 CUs
   const int threads = (64 % n_ac == 0) ? 64 : 256;
   const int fpb = threads / n_ac;
@@ -324,6 +445,77 @@ int d2d_sim_track_run(d2d_ctx *ctx, const d2d_track_params *p, const double *x_r
                      yd, xdd, ydd, X0, X_hist, U_hist, Xr_hist, dX_hist, Yd_hist, Ydd_hist, X_final);
   D2D_LAUNCH_CHECK();
   D2D_CHECK_HIP(hipFreeAsync(deriv, ctx->stream));
+  return D2D_OK;
+}
+
+static int upload_Bz(d2d_ctx *ctx, int n_ac, const double *Bmat, const double *z_des) {
+  const int nm = n_ac - 1;
+  const size_t nb = (size_t)n_ac * nm + nm;
+  if (ctx->Bmat_cap < nb + 1) {
+    if (ctx->Bmat_dev) D2D_CHECK_HIP(hipFree(ctx->Bmat_dev));
+    D2D_CHECK_HIP(hipMalloc(&ctx->Bmat_dev, (nb + 1) * sizeof(double)));
+    ctx->Bmat_cap = nb + 1;
+  }
+  if (nb) {
+    std::vector<double> h(nb);
+    for (size_t i = 0; i < (size_t)n_ac * nm; ++i) h[i] = Bmat[i];
+    for (int i = 0; i < nm; ++i) h[(size_t)n_ac * nm + i] = z_des[i];
+    D2D_CHECK_HIP(hipMemcpyAsync(ctx->Bmat_dev, h.data(), nb * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    D2D_CHECK_HIP(hipStreamSynchronize(ctx->stream));   // h goes out of scope
+  }
+  return D2D_OK;
+}
+
+int d2d_dcf_eval(d2d_ctx *ctx, int n_form, int n_ac, const double *Bmat, const double *z_des, double kr,
+                 const double *centres, const double *pos, double *U_r, double *eth_deg) {
+  D2D_REQUIRE(ctx && centres && pos && U_r, "d2d_dcf_eval: null argument");
+  D2D_REQUIRE(n_ac >= 1 && n_ac <= 64 && n_form >= 1, "d2d_dcf_eval: n_ac=%d (1..64), n_form=%d", n_ac, n_form);
+  D2D_REQUIRE(n_ac == 1 || (Bmat && z_des), "d2d_dcf_eval: Bmat / z_des missing");
+  if (int rc = upload_Bz(ctx, n_ac, Bmat, z_des)) return rc;
+  hipLaunchKernelGGL(dcf_eval_kernel, dim3((n_form + 255) / 256), dim3(256), 0, ctx->stream, n_form, n_ac, kr,
+                     ctx->Bmat_dev, centres, pos, U_r, eth_deg);
+  D2D_LAUNCH_CHECK();
+  return D2D_OK;
+}
+
+int d2d_gvf_eval(d2d_ctx *ctx, int n, const double *X, const double *e, const double *nvec, const double *H,
+                 double ke, double kd, double *U) {
+  D2D_REQUIRE(ctx && X && e && nvec && H && U, "d2d_gvf_eval: null argument");
+  D2D_REQUIRE(n >= 1, "d2d_gvf_eval: n must be >= 1");
+  hipLaunchKernelGGL(gvf_eval_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, ke, kd, X, e, nvec, H, U);
+  D2D_LAUNCH_CHECK();
+  return D2D_OK;
+}
+
+int d2d_flatness(d2d_ctx *ctx, int variant, int n, const double *Yref, double wx, double wy, double tau_phi,
+                 double tau_v, double *X, double *U, double *Xdot) {
+  D2D_REQUIRE(ctx && Yref && X && U, "d2d_flatness: null argument");
+  D2D_REQUIRE(n >= 1 && (variant == 0 || variant == 1), "d2d_flatness: n=%d, variant=%d", n, variant);
+  hipLaunchKernelGGL(flatness_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, variant, n, wx, wy, tau_phi,
+                     tau_v, Yref, X, U, Xdot);
+  D2D_LAUNCH_CHECK();
+  return D2D_OK;
+}
+
+int d2d_cont_jac(d2d_ctx *ctx, int n, const double *Xr, double tau_phi, double tau_v, double *A, double *B) {
+  D2D_REQUIRE(ctx && Xr && A && B, "d2d_cont_jac: null argument");
+  D2D_REQUIRE(n >= 1 && tau_phi > 0 && tau_v > 0, "d2d_cont_jac: n, tau_phi, tau_v must be > 0");
+  hipLaunchKernelGGL(cont_jac_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, tau_phi, tau_v, Xr, A, B);
+  D2D_LAUNCH_CHECK();
+  return D2D_OK;
+}
+
+int d2d_lqr(d2d_ctx *ctx, int n, const double *A, const double *B, const double *Q, const double *R, double *K,
+            double *P) {
+  D2D_REQUIRE(ctx && A && B && Q && R && K, "d2d_lqr: null argument");
+  D2D_REQUIRE(n >= 1, "d2d_lqr: n must be >= 1");
+  const double det = R[0] * R[3] - R[1] * R[2];
+  D2D_REQUIRE(det != 0.0, "d2d_lqr: R is singular");
+  LqrWeights w;
+  for (int i = 0; i < 25; ++i) w.Q[i] = Q[i];
+  w.Rinv[0] = R[3] / det; w.Rinv[1] = -R[1] / det; w.Rinv[2] = -R[2] / det; w.Rinv[3] = R[0] / det;
+  hipLaunchKernelGGL(lqr_kernel, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, n, w, A, B, K, P);
+  D2D_LAUNCH_CHECK();
   return D2D_OK;
 }
 

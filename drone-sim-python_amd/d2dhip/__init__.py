@@ -12,10 +12,10 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), 'lib', 'libd2dhip.so')
 
-SCEN_STRIDE = 24
+SCEN_STRIDE = 32
 (SC_X0, SC_Y0, SC_PSI0, SC_X1, SC_Y1, SC_PSI1, SC_VREF, SC_VSP, SC_KV, SC_KPHI, SC_KOBS, SC_S,
  SC_WWP, SC_WX, SC_WY, SC_GOLEFT, SC_O0X, SC_O0Y, SC_O0R, SC_O1X, SC_O1Y, SC_O1R, SC_WBND,
- SC_PAD) = range(SCEN_STRIDE)
+ SC_PHIMAX, SC_VMIN, SC_VMAX) = range(26)
 ST_RUNNING, ST_CONVERGED, ST_MAXITER, ST_NONFINITE, ST_STALLED = range(5)
 
 
@@ -54,10 +54,16 @@ _SIGS = {
     'd2d_sim_gvf_run': (C.c_int, [_P, C.POINTER(GvfParams)] + [_P] * 12),
     'd2d_ctrl_gain': (C.c_int, [_P, C.POINTER(TrackParams)] + [_P] * 6),
     'd2d_sim_track_run': (C.c_int, [_P, C.POINTER(TrackParams)] + [_P] * 10),
+    'd2d_dcf_eval': (C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.c_double, _P, _P, _P, _P]),
+    'd2d_gvf_eval': (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_double, C.c_double, _P]),
+    'd2d_flatness': (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_double, C.c_double, C.c_double, C.c_double, _P, _P, _P]),
+    'd2d_cont_jac': (C.c_int, [_P, C.c_int, _P, C.c_double, C.c_double, _P, _P]),
+    'd2d_lqr': (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P]),
     'd2d_fit_plan_create': (C.c_int, [_P, C.c_int, C.c_int, C.c_double, _P, C.POINTER(_P)]),
     'd2d_fit_plan_destroy': (C.c_int, [_P]),
     'd2d_fit_plan_get': (C.c_int, [_P] * 6),
     'd2d_fit_init': (C.c_int, [_P, _P, C.c_int, _P, _P]),
+    'd2d_fit_project': (C.c_int, [_P, _P, C.c_int, _P, _P, _P]),
     'd2d_fit_eval': (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P, _P]),
     'd2d_fit_solve': (C.c_int, [_P, _P, C.c_int, _P, _P, C.POINTER(FitOpts), _P, _P, _P, _P]),
     'd2d_fit_begin': (C.c_int, [_P, _P, C.c_int]),
@@ -190,6 +196,43 @@ class Context:
                                         _ptr(out['X_final']), _ptr(out['stop_row'])))
         return out
 
+    # -- single evaluations behind the reference's per-call helpers --------------------
+    def dcf_eval(self, centres, pos, n_ac, B, z_des, kr):
+        """centres, pos dev [2][N] -> U_r dev [N], e_theta_deg dev [n_form*(n_ac-1)]."""
+        N = pos.shape[1]; n_form = N // n_ac
+        B = np.ascontiguousarray(B, dtype=np.float64); z = np.ascontiguousarray(z_des, dtype=np.float64).reshape(-1)
+        Ur = self.empty(N); eth = self.empty(max(n_form * (n_ac - 1), 1))
+        _check(self.lib.d2d_dcf_eval(self.h, n_form, n_ac, _hptr(B), _hptr(z), kr, _ptr(centres), _ptr(pos), _ptr(Ur), _ptr(eth)))
+        return Ur, eth
+
+    def gvf_eval(self, X, e, nvec, H, ke, kd):
+        """X dev [5][n], e dev [n], nvec dev [2][n], H dev [4][n] -> dev [3][n] = U, U1, U2."""
+        n = X.shape[1]
+        U = self.empty(3, n)
+        _check(self.lib.d2d_gvf_eval(self.h, n, _ptr(X), _ptr(e), _ptr(nvec), _ptr(H), ke, kd, _ptr(U)))
+        return U
+
+    def flatness(self, variant, Yref, W=(0.0, 0.0), tau_phi=0.01, tau_v=1.0):
+        """Yref dev [8][n] -> X [5][n], U [2][n], Xdot [5][n]."""
+        n = Yref.shape[1]
+        X, U, Xd = self.empty(5, n), self.empty(2, n), self.empty(5, n)
+        _check(self.lib.d2d_flatness(self.h, variant, n, _ptr(Yref), W[0], W[1], tau_phi, tau_v, _ptr(X), _ptr(U), _ptr(Xd)))
+        return X, U, Xd
+
+    def cont_jac(self, Xr, tau_phi=0.01, tau_v=1.0):
+        n = Xr.shape[1]
+        A, B = self.empty(25, n), self.empty(10, n)
+        _check(self.lib.d2d_cont_jac(self.h, n, _ptr(Xr), tau_phi, tau_v, _ptr(A), _ptr(B)))
+        return A, B
+
+    def lqr(self, A, B, Q, R):
+        """A dev [25][n], B dev [10][n]; Q (5,5), R (2,2) host -> K dev [10][n], P dev [25][n]."""
+        n = A.shape[1]
+        Q = np.ascontiguousarray(Q, dtype=np.float64).reshape(25); R = np.ascontiguousarray(R, dtype=np.float64).reshape(4)
+        K, P = self.empty(10, n), self.empty(25, n)
+        _check(self.lib.d2d_lqr(self.h, n, _ptr(A), _ptr(B), _hptr(Q), _hptr(R), _ptr(K), _ptr(P)))
+        return K, P
+
     @staticmethod
     def track_params(n, n_rows, dt, w=(0.0, 0.0), tau_phi=0.01, tau_v=1.0,
                      err_sats=(20, 20, np.pi / 3, np.pi / 4, 1), v_min=4.0, v_max=20.0,
@@ -216,6 +259,17 @@ class Context:
                                           _ptr(out['U']), _ptr(out['Xr']), _ptr(out['dX']), _ptr(out['Yd']),
                                           _ptr(out['Ydd']), _ptr(out['X_final'])))
         return out
+
+
+_default_ctx = None
+
+
+def default_context():
+    """Process-wide context on cuda:LOCAL_RANK used by the reference-named mirror classes."""
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(int(os.environ.get('LOCAL_RANK', 0)))
+    return _default_ctx
 
 
 class FitPlan:
@@ -248,6 +302,13 @@ class FitPlan:
         B = scen.shape[0]
         q = self.ctx.empty(B, 2 * self.nq)
         _check(self.ctx.lib.d2d_fit_init(self.ctx.h, self.h, B, _ptr(scen), _ptr(q)))
+        return q
+
+    def project(self, scen, xy):
+        """xy dev [B][2][K] node positions -> q0 dev [B][2nq]."""
+        B = scen.shape[0]
+        q = self.ctx.empty(B, 2 * self.nq)
+        _check(self.ctx.lib.d2d_fit_project(self.ctx.h, self.h, B, _ptr(scen), _ptr(xy), _ptr(q)))
         return q
 
     def eval(self, scen, q, want_H=True):

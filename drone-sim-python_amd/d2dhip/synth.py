@@ -4,7 +4,8 @@ no numerics of the hot path live here)."""
 import numpy as np
 
 from . import (SCEN_STRIDE, SC_X0, SC_Y0, SC_PSI0, SC_X1, SC_Y1, SC_PSI1, SC_VREF, SC_VSP, SC_KV, SC_KPHI,
-               SC_KOBS, SC_S, SC_WWP, SC_GOLEFT, SC_O0X, SC_O0Y, SC_O0R, SC_O1X, SC_O1Y, SC_O1R, SC_WBND)
+               SC_KOBS, SC_S, SC_WWP, SC_GOLEFT, SC_O0X, SC_O0Y, SC_O0R, SC_O1X, SC_O1Y, SC_O1R, SC_WBND,
+               SC_PHIMAX, SC_VMIN, SC_VMAX)
 
 G_ACC = 9.81
 
@@ -38,6 +39,7 @@ def synth_scenarios(B, seed=20241008, rank=0, n_obs=2, wbnd=1.0, wwp=0.02, obj_s
     sc[:, SC_VREF] = 12.0; sc[:, SC_VSP] = 12.0
     sc[:, SC_KV] = 5.0; sc[:, SC_KPHI] = 1.0; sc[:, SC_KOBS] = 1.0
     sc[:, SC_WWP] = wwp; sc[:, SC_GOLEFT] = -1.0; sc[:, SC_WBND] = wbnd
+    sc[:, SC_PHIMAX] = np.deg2rad(40.0); sc[:, SC_VMIN] = 9.0; sc[:, SC_VMAX] = 15.0
     along = rng.uniform(0.2, 0.8, (B, 2)); lat = rng.uniform(5, 15, (B, 2)) * rng.choice([-1.0, 1.0], (B, 2))
     rad = rng.uniform(5, 15, (B, 2))
     u = (p1 - p0) / dist[:, None]; nrm = np.stack([-u[:, 1], u[:, 0]], 1)

@@ -1,0 +1,125 @@
+"""Script-level simulation functions of src/11_full_sim_case1.py (that file runs main() at
+import, so its functions are mirrored here under their own names) with the time loops on the
+GPU, plus batched variants over many independent formations.
+
+  CircularFormationGVF(c, r, v, n_ac, X0f, ...)      src/11_full_sim_case1.py:93-177
+  implement_controller(n_ac, time, x_ref, y_ref, ..)  :241-291
+  ConstructBMatrix, ComputeDerivatives, ExtractTrajData, ExtendTraj_symm   :81-91, :197-239
+"""
+import numpy as np
+
+import d2dhip
+import d2d.dynamic as ddyn
+
+KE, KD, KR = 0.0004, 25, 20            # src/11_full_sim_case1.py:108-110
+X1_START = np.array([20, 30, -np.pi / 2, 0, 10])     # :113
+
+
+def ConstructBMatrix(n_ac):
+    B = np.zeros((n_ac, n_ac - 1))
+    for j in range(n_ac - 1):
+        B[j, j], B[j + 1, j] = -1, 1
+    return B
+
+
+def _planes(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64).T)
+
+
+def CircularFormationGVF_batch(c, r, v, n_ac, X0f=None, t_start=0, t_step=0.05, t_end=1000, X0=None,
+                               tau_phi=None, rec_stride=1, record=('X', 'U', 'Rr', 'eth'), W=(0., 0.)):
+    """Many formations at once.  c (n_form, n_ac, 2) centres; r scalar or (n_form, n_ac); X0
+    (n_form, n_ac, 5) or None (every aircraft starts at the reference's X1); X0f (n_form, n_ac, >=3)
+    or None.  Returns the raw device dictionary of d2dhip.Context.gvf_run plus `time`."""
+    ctx = d2dhip.default_context()
+    c = np.asarray(c, dtype=np.float64).reshape(-1, n_ac, 2)
+    n_form = c.shape[0]
+    N = n_form * n_ac
+    time = np.arange(t_start, t_end, t_step)
+    X0 = np.tile(X1_START, (N, 1)) if X0 is None else np.asarray(X0, dtype=np.float64).reshape(N, 5)
+    R = np.broadcast_to(np.asarray(r, dtype=np.float64), (n_form, n_ac)).reshape(N) if np.ndim(r) else np.full(N, float(r))
+    ac = ddyn.Aircraft()
+    x0f = None if X0f is None else ctx.dev(_planes(np.asarray(X0f, dtype=np.float64).reshape(N, -1)[:, :3]))
+    out = ctx.gvf_run(ctx.dev(_planes(X0)), ctx.dev(_planes(c.reshape(N, 2))), ctx.dev(np.ascontiguousarray(R)), n_ac,
+                      len(time), t_step, float(v), KE, KD, KR, B=ConstructBMatrix(n_ac), z_des=np.zeros(max(n_ac - 1, 0)),
+                      tau_phi=ac.tau_phi if tau_phi is None else tau_phi, tau_v=ac.tau_v, W=W, X0f=x0f,
+                      rec_stride=rec_stride, record=record)
+    out['time'] = time
+    return out
+
+
+def CircularFormationGVF(c, r, v, n_ac, X0f, t_start=0, t_step=0.05, t_end=1000):
+    """One formation, the reference's 8-tuple: X_array, U_array, U1_array, U2_array, Ur_array,
+    e_theta_array, time, t_f -- trimmed at the stop row like the reference (its U2 slice quirk,
+    `U2_array[i,:]`, is reproduced)."""
+    out = CircularFormationGVF_batch(np.asarray(c)[None], r, v, n_ac, X0f=np.asarray(X0f, dtype=float)[None],
+                                     t_start=t_start, t_step=t_step, t_end=t_end)
+    d2dhip.default_context().sync()
+    time = out['time']
+    i = int(out['stop_row'].cpu().numpy()[0])
+    X = out['X'].cpu().numpy().transpose(0, 2, 1)
+    U = out['U'].cpu().numpy().transpose(0, 2, 1)
+    Rr = out['Rr'].cpu().numpy(); eth = out['eth'].cpu().numpy()
+    # U1/U2 (debug decomposition of the GVF command) are not kept by the fused loop
+    U1 = np.zeros((len(time), n_ac)); U2 = np.zeros((len(time), n_ac))
+    if i < len(time):
+        t_f = time[i - 1]
+        return X[:i], U[:i], U1[:i], U2[i, :], Rr[:i], eth[:i], time[:i], t_f
+    return X, U, U1, U2, Rr, eth, time, t_end
+
+
+def ComputeDerivatives(x_ref, y_ref, dt):
+    """Two passes of second-order-edge central differences (src/11_full_sim_case1.py:197-204); the
+    tracking kernel computes the same on the device -- this host version serves callers that only
+    want the derivatives."""
+    Fdx = np.gradient(x_ref, edge_order=2) / dt
+    Fdy = np.gradient(y_ref, edge_order=2) / dt
+    return Fdx, Fdy, np.gradient(Fdx, edge_order=2) / dt, np.gradient(Fdy, edge_order=2) / dt
+
+
+def ExtractTrajData(df, n_ac):
+    """CSV columns time, x_i, y_i, psi_i (1-based) -> arrays (src/11_full_sim_case1.py:206-217)."""
+    t = np.array(df['time'])
+    cols = lambda k: np.stack([np.array(df[f'{k}_{i + 1}']) for i in range(n_ac)], 1)   # noqa: E731
+    return t, cols('x'), cols('y'), cols('psi')
+
+
+def ExtendTraj_symm(n_ac, x_ref, y_ref, psi_ref, time):
+    """Append the mirrored half taken from the aircraft whose start equals this one's end
+    (src/11_full_sim_case1.py:219-239; psi is extended with y values, as the reference does)."""
+    time = np.append(time, time + time[-1])
+    x0, xf, y0, yf = x_ref[0, :], x_ref[-1, :], y_ref[0, :], y_ref[-1, :]
+    ax = [int(np.nonzero((x0 == xf[i]) & (y0 == yf[i]))[0][0]) for i in range(n_ac)]
+    xs, ys = x_ref[:, ax], y_ref[:, ax]
+    return time, np.append(x_ref, xs, axis=0), np.append(y_ref, ys, axis=0), np.append(psi_ref, ys, axis=0)
+
+
+def implement_controller_batch(time, x_ref, y_ref, w, X0s, record=('X', 'U', 'Xr', 'dX', 'Yd', 'Ydd')):
+    """x_ref, y_ref (T, n) for n independent drones; X0s (n, 5).  Device dictionary out."""
+    ctx = d2dhip.default_context()
+    ac = ddyn.Aircraft()
+    dt = time[1] - time[0]
+    return ctx.track_run(ctx.dev(np.ascontiguousarray(x_ref, dtype=np.float64)), ctx.dev(np.ascontiguousarray(y_ref, dtype=np.float64)),
+                         ctx.dev(_planes(np.asarray(X0s, dtype=np.float64))), float(dt), record=record,
+                         w=(float(w[0]), float(w[1])), tau_phi=ac.tau_phi, tau_v=ac.tau_v)
+
+
+def implement_controller(n_ac, time, x_ref, y_ref, v, w, X0s):
+    """The reference's 6-tuple X_array, U_array, X_ref_array, Yd_ref_array, Ydd_ref_array, dX_array
+    (src/11_full_sim_case1.py:241-291), each (T, n_ac, .)."""
+    out = implement_controller_batch(time, x_ref, y_ref, w, X0s)
+    d2dhip.default_context().sync()
+    t = lambda k: out[k].cpu().numpy().transpose(0, 2, 1)      # noqa: E731
+    return t('X'), t('U'), t('Xr'), t('Yd'), t('Ydd'), t('dX')
+
+
+def plan_batch(scen_rows, K, duration, obj_scale_over_n, q0=None, **solve_kw):
+    """Batched planning entry point: scen_rows (B, 32) in the d2dhip layout -> dict with device
+    tensors q, cost, iters, status and host stats."""
+    import single_opt_planner as sop
+    ctx = d2dhip.default_context()
+    plan = sop.get_plan(K, duration, obj_scale_over_n)
+    dsc = ctx.dev(np.ascontiguousarray(scen_rows, dtype=np.float64))
+    q = plan.init(dsc) if q0 is None else q0
+    cost, iters, status, stats = plan.solve(dsc, q, **solve_kw)
+    return dict(plan=plan, scen=dsc, q=q, cost=cost, iters=iters, status=status, stats=stats)

@@ -1,0 +1,215 @@
+"""Mirror of src/single_opt_planner.py: the single-aircraft trajectory planner, solved on the
+GPU.  Where the reference hands a direct-collocation NLP to opty/IPOPT
+(src/single_opt_planner.py:62-71,124), this Planner fits a 6-segment C^3 degree-7 polynomial
+to the same objective (flat outputs -> (psi, phi, v), the kinematic constraints hold
+identically) with libd2dhip's batched Levenberg-Marquardt solver, then samples it at the
+reference's nodes so that `solution`, `sol_*`, save/load keep the reference's layout."""
+import os
+
+import numpy as np
+
+import d2dhip
+import d2d.opty_utils as d2ou
+import d2d.multiopty_utils as d2mou
+import d2d.optyplan_scenarios as d2oscen
+
+seed = None
+N_SEG = 6
+W_WAYPOINT = 0.02      # weight of the 'tri' waypoint rows (regulariser)
+W_BOUND = 1.0          # weight of the soft phi / v bound rows
+
+_plans = {}
+
+
+def get_plan(K, duration, obj_scale_over_n, kv=5., kphi=1.):
+    """Fit plans are cached per (K, duration): the basis block is shared by every trajectory."""
+    ctx = d2dhip.default_context()
+    key = (K, round(float(duration), 9))
+    if key not in _plans:
+        s = obj_scale_over_n
+        _plans[key] = d2dhip.FitPlan(ctx, N_SEG, K, duration, (W_WAYPOINT ** 2, s * max(kv, 1e-3), s * max(kphi, 1e-3) / 9.81 ** 2))
+    return _plans[key]
+
+
+def lower_cost(cost):
+    """Recognise the reference's cost plug-ins structurally -> (vsp, kv, kphi, kobs, obstacles,
+    kcol, rcol).  Anything else has no kernel and raises (there is no CPU solver to fall back to)."""
+    nan = float('nan')
+    if isinstance(cost, d2ou.CostAirVel):
+        return cost.vsp, 1., 0., 0., (), nan, 0.
+    if isinstance(cost, d2ou.CostBank):
+        if not cost.use_mean:
+            raise NotImplementedError('CostBank(use_mean=False): the max-bank objective is not a sum of squares')
+        return 0., 0., 1., 0., (), nan, 0.
+    if isinstance(cost, (d2ou.CostInput, d2mou.CostInput)):
+        return cost.vsp, cost.kv, cost.kphi, 0., (), nan, 0.
+    if isinstance(cost, d2mou.CostNull):
+        return 0., 0., 0., 0., (), nan, 0.
+    if isinstance(cost, d2ou.CostComposit):
+        obss = [(o.c[0], o.c[1], o.r) for o in cost.cobs.obss] if hasattr(cost, 'cobs') else []
+        if obss and cost.cobs.obss[0].kind != 1:
+            raise NotImplementedError('CostObstacle kind 0 (clipped exp(r^2-d^2)) is not contracted by the HIP fit; use obs_kind=1')
+        return cost.cvel.vsp, cost.kvel, cost.kbank, cost.kobs, tuple(obss), nan, 0.
+    if isinstance(cost, d2mou.CostComposit):
+        obss = ()
+        kobs = 0.
+        if not np.isnan(cost.kobs):
+            obss = tuple((o[0], o[1], o[2]) for o in cost.obss)
+            kobs = cost.kobs
+            if obss and cost.obs_kind != 1:
+                raise NotImplementedError('CostObstacle kind 0 is not contracted by the HIP fit; use obs_kind=1')
+        return cost.vsp, cost.kvel, cost.kbank, kobs, obss, cost.kcol, cost.rcol
+    raise NotImplementedError(f'cost plug-in {type(cost).__name__} has no HIP lowering')
+
+
+def scen_row(p0, p1, vref, lowered, s, wind, phi_c, v_c, go_left=-1.):
+    """One d2dhip scenario row.  The reference's symbolic model adds the wind with the opposite
+    sign to the plant (src/d2d/opty_utils.py:42-44 vs src/d2d/dynamic.py:18-19); the planner keeps
+    that convention, hence -w."""
+    vsp, kv, kphi, kobs, obss, _, _ = lowered
+    if len(obss) > 2:
+        raise NotImplementedError('at most two static obstacles per trajectory in this build')
+    r = np.zeros(d2dhip.SCEN_STRIDE)
+    r[d2dhip.SC_X0], r[d2dhip.SC_Y0], r[d2dhip.SC_PSI0] = p0[0], p0[1], p0[2]
+    r[d2dhip.SC_X1], r[d2dhip.SC_Y1], r[d2dhip.SC_PSI1] = p1[0], p1[1], p1[2]
+    r[d2dhip.SC_VREF], r[d2dhip.SC_VSP] = vref, vsp
+    r[d2dhip.SC_KV], r[d2dhip.SC_KPHI], r[d2dhip.SC_KOBS], r[d2dhip.SC_S] = kv, kphi, kobs, s
+    r[d2dhip.SC_WWP], r[d2dhip.SC_WBND], r[d2dhip.SC_GOLEFT] = W_WAYPOINT, W_BOUND, go_left
+    r[d2dhip.SC_WX], r[d2dhip.SC_WY] = -wind[0], -wind[1]
+    for i, o in enumerate(obss):
+        r[d2dhip.SC_O0X + 3 * i:d2dhip.SC_O0X + 3 * i + 3] = o
+    r[d2dhip.SC_PHIMAX] = max(abs(phi_c[0]), abs(phi_c[1]))
+    r[d2dhip.SC_VMIN], r[d2dhip.SC_VMAX] = v_c
+    return r
+
+
+class _FitProblem:
+    """Stands where the reference keeps its opty Problem (`Planner.prob`): num_free, the two
+    option spellings the reference uses, and solve(x0) -> (solution, info)."""
+
+    def __init__(self, planner, n_ac):
+        self._p = planner
+        self.num_free = 5 * planner.num_nodes * n_ac
+        self.options = {'tol': 1e-8, 'max_iter': 200}
+
+    def addOption(self, k, v):
+        self.options[k] = v
+    add_option = addOption
+
+    def solve(self, x0):
+        return self._p._solve(np.asarray(x0, dtype=np.float64))
+
+
+class Planner:
+    def __init__(self, exp, initialize=True):
+        self.exp = exp
+        self.obj_scale = exp.obj_scale
+        self.num_nodes, self.time_step, self.duration = d2ou.planner_timing(exp.t0, exp.t1, exp.hz)
+        self.wind = exp.wind
+        self.aircraft = d2ou.Aircraft()
+        N = self.num_nodes
+        self._slice_x, self._slice_y, self._slice_psi, self._slice_phi, self._slice_v = (
+            slice(i * N, (i + 1) * N, 1) for i in range(5))
+        self.obstacles = exp.obstacles
+        if initialize:
+            self.prob = _FitProblem(self, 1)
+
+    def configure(self, tol=1e-8, max_iter=3000):
+        self.prob.addOption('tol', tol)
+        self.prob.addOption('max_iter', max_iter)
+
+    def get_initial_guess(self, kind='tri'):
+        """Node-vector guess [x, y, psi, phi, v] (src/single_opt_planner.py:79-115)."""
+        g = np.zeros(self.prob.num_free)
+        N = self.num_nodes
+        if kind == 'rnd':
+            rng = np.random.default_rng(seed)
+            cx = self.exp.x_constraint or [-100, 100]
+            cy = self.exp.y_constraint or [-100, 100]
+            g[self._slice_x] = rng.uniform(cx[0], cx[1], N)
+            g[self._slice_y] = rng.uniform(cy[0], cy[1], N)
+            g[self._slice_psi] = rng.uniform(-np.pi, np.pi, N)
+        elif kind == 'tri':
+            x, y, psi, phi, v = d2ou.triangle(self.exp.p0[:2], self.exp.p1[:2], self.exp.vref, self.duration, N, go_left=-1.)
+            g[self._slice_x], g[self._slice_y], g[self._slice_psi], g[self._slice_phi], g[self._slice_v] = x, y, psi, phi, v
+        else:
+            g[self._slice_x] = np.linspace(self.exp.p0[0], self.exp.p1[0], N)
+            g[self._slice_y] = np.linspace(self.exp.p0[1], self.exp.p1[1], N)
+        return g
+
+    def _solve(self, x0):
+        ctx = d2dhip.default_context()
+        N = self.num_nodes
+        low = lower_cost(self.exp.cost)
+        s = self.obj_scale / N
+        plan = get_plan(N, self.duration, s, low[1], low[2])
+        row = scen_row(self.exp.p0, self.exp.p1, self.exp.vref, low, s, self.wind.w, self.exp.phi_constraint,
+                       self.exp.v_constraint)
+        dsc = ctx.dev(row[None, :])
+        xy = np.stack([x0[self._slice_x], x0[self._slice_y]])[None]
+        q = plan.project(dsc, ctx.dev(xy))
+        max_iter = int(min(max(self.prob.options.get('max_iter', 200), 1), 2000))
+        cost, iters, status, stats = plan.solve(dsc, q, max_iter=max_iter)
+        _, Xs = plan.sample(dsc, q)
+        self.fit_q, self.fit_plan, self.fit_scen = q, plan, dsc
+        self.fit_coefs = plan.coeffs(dsc, q).cpu().numpy()[0]
+        info = {'status': int(status.cpu().numpy()[0]), 'iters': int(iters.cpu().numpy()[0]),
+                'obj_val': float(cost.cpu().numpy()[0]), 'status_msg': ('running', 'converged', 'max_iter', 'non-finite', 'stalled')[int(status.cpu().numpy()[0])]}
+        return Xs.cpu().numpy()[0].reshape(-1), info
+
+    def run(self, initial_guess=None):
+        if initial_guess is None:
+            initial_guess = self.get_initial_guess('tri')
+        self.solution, self.info = self.prob.solve(initial_guess)
+        self.interpret_solution()
+
+    def interpret_solution(self):
+        self.sol_time = np.linspace(0.0, self.duration, num=self.num_nodes)
+        self.sol_x, self.sol_y = self.solution[self._slice_x], self.solution[self._slice_y]
+        self.sol_psi, self.sol_phi, self.sol_v = (self.solution[s] for s in (self._slice_psi, self._slice_phi, self._slice_v))
+
+    def save_solution(self, filename):
+        wind = np.array([self.wind.sample_num(t, x, y) for t, x, y in zip(self.sol_time, self.sol_x, self.sol_y)])
+        np.savez(filename, sol_time=self.sol_time, sol_x=self.sol_x, sol_y=self.sol_y, sol_psi=self.sol_psi,
+                 sol_phi=self.sol_phi, sol_v=self.sol_v, wind=wind)
+        print('saved {}'.format(filename))
+
+    def load_solution(self, filename):
+        d = np.load(filename)
+        self.sol_time, self.sol_x, self.sol_y, self.sol_psi, self.sol_phi, self.sol_v = (
+            d[k] for k in ('sol_time', 'sol_x', 'sol_y', 'sol_psi', 'sol_phi', 'sol_v'))
+        print(f'loaded {filename}')
+
+
+def compute_or_load(_p, force_recompute=False, filename='/tmp/optyplan.npz', tol=1e-5, max_iter=1500, initial_guess=None):
+    """Result cache keyed by file name (src/single_opt_planner.py:152-164)."""
+    if force_recompute or not os.path.exists(filename):
+        _p.configure(tol, max_iter)
+        _p.run(_p.get_initial_guess())
+        _p.save_solution(filename)
+    else:
+        _p.load_solution(filename)
+
+
+def plot2d(_p, _f=None, _a=None, label=''):
+    import matplotlib.pyplot as plt
+    _f = _f or plt.figure()
+    _a = _a or plt.gca()
+    _a.plot(_p.sol_x, _p.sol_y, solid_capstyle='butt', label=label)
+    for cx, cy, rm in _p.obstacles:
+        _a.add_patch(plt.Circle((cx, cy), rm, color='r', alpha=0.1))
+    _a.axis('equal')
+    return _f, _a
+
+
+def plot_chrono(_p, _f=None, _a=None):
+    import matplotlib.pyplot as plt
+    if _f is None:
+        _f, _a = plt.subplots(5, 1)
+    for ax, (v, lab) in zip(_a, ((_p.sol_x, 'x'), (_p.sol_y, 'y'), (np.rad2deg(_p.sol_psi), 'psi'),
+                                  (np.rad2deg(_p.sol_phi), 'phi'), (_p.sol_v, 'v'))):
+        ax.plot(_p.sol_time, v); ax.set_ylabel(lab)
+    return _f, _a
+
+
+exp_0, exp_1 = d2oscen.exp_0, d2oscen.exp_1

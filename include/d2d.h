@@ -139,6 +139,30 @@ int d2d_sim_track_run(d2d_ctx *ctx, const d2d_track_params *p, const double *x_r
                       double *Xr_hist, double *dX_hist, double *Yd_hist, double *Ydd_hist,
                       double *X_final);
 
+/* Single batched evaluations behind the reference's per-call helper methods (the time
+ * loops above fuse them; these exist so that host code written against the reference's
+ * classes reaches the same device functions).
+ *  d2d_dcf_eval : DCFController.get(n_ac, B, c, p, z_des, kr) (src/d2d/guidance.py:103-126);
+ *                 centres, pos dev [2][N]; U_r dev [N]; eth_deg dev [n_form*(n_ac-1)] or NULL.
+ *  d2d_gvf_eval : GVFcontroller.get(X, ke, kd, e, n, H) (:155-181); X dev [5][n], e dev [n],
+ *                 nvec dev [2][n], H dev [4][n] (row-major 2x2); U dev [3][n] = U, U1, U2.
+ *  d2d_flatness : variant 0 = DiffFlatness.state_and_input_from_output (:22-47),
+ *                 variant 1 = DiffFlatness.ComputeFlatness (src/Controllers.py:62-108);
+ *                 Yref dev [8][n]; X dev [5][n], U dev [2][n], Xdot dev [5][n] or NULL.
+ *  d2d_cont_jac : Aircraft.cont_jac (src/d2d/dynamic.py:32-43); A dev [25][n], B dev [10][n].
+ *  d2d_lqr      : control.lqr(A, B, Q, R) (call sites src/Controllers.py:174,
+ *                 src/d2d/guidance.py:76,80) for 5-state / 2-input systems; Q host [25],
+ *                 R host [4]; K dev [10][n], P dev [25][n] or NULL. */
+int d2d_dcf_eval(d2d_ctx *ctx, int n_form, int n_ac, const double *Bmat, const double *z_des, double kr,
+                 const double *centres, const double *pos, double *U_r, double *eth_deg);
+int d2d_gvf_eval(d2d_ctx *ctx, int n, const double *X, const double *e, const double *nvec, const double *H,
+                 double ke, double kd, double *U);
+int d2d_flatness(d2d_ctx *ctx, int variant, int n, const double *Yref, double wx, double wy, double tau_phi,
+                 double tau_v, double *X, double *U, double *Xdot);
+int d2d_cont_jac(d2d_ctx *ctx, int n, const double *Xr, double tau_phi, double tau_v, double *A, double *B);
+int d2d_lqr(d2d_ctx *ctx, int n, const double *A, const double *B, const double *Q, const double *R, double *K,
+            double *P);
+
 /* ------------------------------------------------------------------------------------
  * Polynomial trajectory fit: S segments x 2 axes x 8 monomial coefficients in the layout
  * of PolynomialOne.coefs[0,:] (src/d2d/trajectory.py:47-72), K samples on
@@ -151,7 +175,7 @@ int d2d_sim_track_run(d2d_ctx *ctx, const d2d_track_params *p, const double *x_r
  * ------------------------------------------------------------------------------------ */
 
 /* one scenario row: double[D2D_SCEN_STRIDE] per trajectory (dev [B][D2D_SCEN_STRIDE]) */
-#define D2D_SCEN_STRIDE 24
+#define D2D_SCEN_STRIDE 32
 enum {
   D2D_SC_X0 = 0, D2D_SC_Y0, D2D_SC_PSI0, D2D_SC_X1, D2D_SC_Y1, D2D_SC_PSI1,
   D2D_SC_VREF,  /* end-condition speed and 'tri' waypoint speed                */
@@ -163,8 +187,10 @@ enum {
   D2D_SC_GOLEFT,          /* triangle(go_left)                                 */
   D2D_SC_O0X, D2D_SC_O0Y, D2D_SC_O0R,   /* obstacle 0 (r<=0: absent)           */
   D2D_SC_O1X, D2D_SC_O1Y, D2D_SC_O1R,   /* obstacle 1                          */
-  D2D_SC_WBND,  /* weight of the soft bound rows (phi in +-40 deg, v in [9,15]) */
-  D2D_SC_PAD
+  D2D_SC_WBND,  /* weight of the soft bound rows                                 */
+  D2D_SC_PHIMAX, D2D_SC_VMIN, D2D_SC_VMAX,   /* bounds of those rows: |phi| <= PHIMAX,
+                   VMIN <= va <= VMAX (phi_constraint / v_constraint of the scenario)   */
+  D2D_SC_SPARE0  /* .. D2D_SCEN_STRIDE-1 unused, must be 0                              */
 };
 #define D2D_FIT_NROW 8        /* residual rows per sample */
 #define D2D_FIT_MAX_S 6
@@ -193,8 +219,14 @@ int d2d_fit_plan_destroy(d2d_fit_plan *plan);
 int d2d_fit_plan_get(const d2d_fit_plan *plan, double *G, double *Gp, double *Z, double *Zp,
                      double *Pinit);
 
-/* q0 = projection of the 'tri' waypoints on the basis.  scen dev [B][24]; q dev [B][2*nq]. */
+/* q0 = projection of the 'tri' waypoints on the basis.  scen dev [B][32]; q dev [B][2*nq]. */
 int d2d_fit_init(d2d_ctx *ctx, const d2d_fit_plan *plan, int B, const double *scen, double *q);
+
+/* q0 = least-squares projection of caller-supplied node positions xy dev [B][2][K] (the x and
+ * y blocks of an initial-guess vector as Planner.get_initial_guess builds it,
+ * src/single_opt_planner.py:79-115) on the basis. */
+int d2d_fit_project(d2d_ctx *ctx, const d2d_fit_plan *plan, int B, const double *scen, const double *xy,
+                    double *q);
 
 /* One evaluation at q: cost = sum r^2 (fp64), g = J^T r (fp64, dev [B][2nq]), H = J^T J
  * (fp32 via v_mfma_f32_16x16x4_f32, dev [B][2nq][2nq]).  Any output may be NULL. */

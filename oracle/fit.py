@@ -186,11 +186,11 @@ class FitBasis:
 # scenario parameters of one trajectory
 # ----------------------------------------------------------------------------------
 # scen row layout (float64[SCEN_STRIDE]); identical to include/d2d.h D2D_SCEN_*
-SCEN_STRIDE = 24
+SCEN_STRIDE = 32
 (SC_X0, SC_Y0, SC_PSI0, SC_X1, SC_Y1, SC_PSI1, SC_VREF, SC_VSP, SC_KV, SC_KPHI,
  SC_KOBS, SC_S, SC_WWP, SC_WX, SC_WY, SC_GOLEFT,
- SC_O0X, SC_O0Y, SC_O0R, SC_O1X, SC_O1Y, SC_O1R, SC_WBND, SC_PAD) = range(SCEN_STRIDE)
-# bounds used by the hinge rows (phi in +-40 deg, v in [9,15]: src/multi_opt_planner.py:192-193)
+ SC_O0X, SC_O0Y, SC_O0R, SC_O1X, SC_O1Y, SC_O1R, SC_WBND, SC_PHIMAX, SC_VMIN, SC_VMAX) = range(26)
+# default bounds of the soft bound rows (phi in +-40 deg, v in [9,15]: src/multi_opt_planner.py:192-193)
 PHI_MAX = math.radians(40.0)
 V_MIN, V_MAX = 9.0, 15.0
 
@@ -278,8 +278,8 @@ def residuals(basis, sc, q, wp=None, want_jac=False):
             r[:, 4 + i] = h
             obs.append((i, ddx, ddy, h, rr))
     wb = sc[SC_WBND]
-    hphi = np.maximum(np.abs(phi) - PHI_MAX, 0.0)
-    hv = np.maximum(va - V_MAX, 0.0) + np.minimum(va - V_MIN, 0.0)
+    hphi = np.maximum(np.abs(phi) - sc[SC_PHIMAX], 0.0)
+    hv = np.maximum(va - sc[SC_VMAX], 0.0) + np.minimum(va - sc[SC_VMIN], 0.0)
     r[:, 6] = wb * hphi
     r[:, 7] = wb * hv
     if not want_jac:
@@ -302,7 +302,7 @@ def residuals(basis, sc, q, wp=None, want_jac=False):
         D[:, 4 + i, 1] = -h * ddy * (OBS_K / rr)
     act = (hphi > 0) * np.sign(phi)
     D[:, 6, 2:6] = wb * act[:, None] * dphi
-    actv = ((va > V_MAX) | (va < V_MIN)).astype(float)
+    actv = ((va > sc[SC_VMAX]) | (va < sc[SC_VMIN])).astype(float)
     D[:, 7, 2] = wb * actv * dva_a; D[:, 7, 3] = wb * actv * dva_b
     return r, D
 
@@ -444,6 +444,7 @@ def synth_scenarios(B, seed=20241008, rank=0, n_obs=2, wbnd=1.0, wwp=0.02):
     sc[:, SC_VREF] = 12.0; sc[:, SC_VSP] = 12.0
     sc[:, SC_KV] = 5.0; sc[:, SC_KPHI] = 1.0; sc[:, SC_KOBS] = 1.0
     sc[:, SC_WWP] = wwp; sc[:, SC_GOLEFT] = -1.0; sc[:, SC_WBND] = wbnd
+    sc[:, SC_PHIMAX] = PHI_MAX; sc[:, SC_VMIN] = V_MIN; sc[:, SC_VMAX] = V_MAX
     along = rng.uniform(0.2, 0.8, (B, 2)); lat = rng.uniform(5, 15, (B, 2)) * rng.choice([-1.0, 1.0], (B, 2))
     rad = rng.uniform(5, 15, (B, 2))
     u = (p1 - p0) / dist[:, None]; nrm = np.stack([-u[:, 1], u[:, 0]], 1)

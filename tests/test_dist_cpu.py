@@ -1,0 +1,104 @@
+"""CPU, world_size 2 over gloo: trajectory sharding + the convergence all-reduce of
+d2dhip.dist, driven with a stand-in plan that runs the oracle's LM on the shard (the HIP
+plan has the same begin / iterate / finish surface)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from d2dhip.dist import shard_bounds, StatsReducer, solve_sharded
+from oracle import fit as F
+
+
+def test_shard_bounds_cover_everything():
+    for total in (1, 7, 8, 4096, 262144, 4097):
+        for world in (1, 2, 3, 8):
+            b = [shard_bounds(total, r, world) for r in range(world)]
+            assert b[0][0] == 0 and b[-1][1] == total
+            assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 1
+
+
+class OraclePlan:
+    """begin / iterate / finish with the oracle's LM; each trajectory advances `n_iters` solves per call."""
+
+    def __init__(self, basis):
+        self.b = basis
+
+    def begin(self, B):
+        self.state = None
+
+    def iterate(self, scen, q, n_iters, max_iter=200, **tol):
+        if self.state is None:
+            self.state = [dict(done=False, it=0) for _ in range(scen.shape[0])]
+        running = 0
+        for i, st in enumerate(self.state):
+            if st['done']:
+                continue
+            st['it'] += n_iters
+            qi, c, it, status = F.lm_solve(self.b, scen[i].numpy(), max_iter=min(st['it'], max_iter))
+            q[i] = torch.from_numpy(qi)
+            st.update(cost=c, iters=it, status=status)
+            if status != F.ST_MAXITER or st['it'] >= max_iter:
+                st['done'] = True
+            else:
+                running += 1
+        return running
+
+    def finish(self, scen, q):
+        cost = torch.tensor([s['cost'] for s in self.state], dtype=torch.float64); iters = torch.tensor([s['iters'] for s in self.state])
+        status = torch.tensor([s['status'] for s in self.state])
+        gmax = max(np.abs(F.eval_normal(self.b, scen[i].numpy(), q[i].numpy())[1]).max() for i in range(len(self.state)))
+        notconv = sum(1 for s in self.state if s['status'] not in (F.ST_CONVERGED, F.ST_STALLED))
+        return cost, iters, status, np.array([float(cost.sum()), gmax, notconv, 0.0])
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, total, out):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    K, S_ = 50, 6
+    dur = F.planner_timing(0, 4.9, 10)[2]
+    s = 0.1 / K
+    basis = F.FitBasis(S_, K, dur, (0.02 ** 2, s * 5.0, s / F.G_ACC ** 2))
+    sc_all = F.set_scale(F.synth_scenarios(total, seed=3), 0.1, K)
+    lo, hi = shard_bounds(total, rank, world)
+    scen = torch.from_numpy(sc_all[lo:hi]); q = torch.zeros(hi - lo, 2 * basis.nq, dtype=torch.float64)
+    cost, iters, status, stats, glob, checks = solve_sharded(OraclePlan(basis), scen, q, StatsReducer(dist, 'cpu'),
+                                                            check_every=16, max_iter=200)
+    out[rank] = dict(lo=lo, hi=hi, cost=cost.numpy(), glob=glob, checks=checks, local_sum=stats[0])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_gloo_sharded_solve():
+    world, total = 2, 5
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), total, out), nprocs=world, join=True)
+    r0, r1 = out[0], out[1]
+    assert (r0['lo'], r0['hi'], r1['lo'], r1['hi']) == (0, 3, 3, 5)
+    # both ranks leave the loop together and agree on the global statistics
+    assert r0['checks'] == r1['checks']
+    assert r0['glob'] == r1['glob']
+    np.testing.assert_allclose(r0['glob'][0], r0['local_sum'] + r1['local_sum'], rtol=1e-12)
+    assert r0['glob'][2] == 0
+    # the sharded result equals the unsharded one
+    K = 50
+    dur = F.planner_timing(0, 4.9, 10)[2]
+    s = 0.1 / K
+    basis = F.FitBasis(6, K, dur, (0.02 ** 2, s * 5.0, s / F.G_ACC ** 2))
+    sc_all = F.set_scale(F.synth_scenarios(total, seed=3), 0.1, K)
+    ref = np.array([F.lm_solve(basis, sc_all[i])[1] for i in range(total)])
+    np.testing.assert_allclose(np.concatenate([r0['cost'], r1['cost']]), ref, rtol=1e-9)

@@ -1,0 +1,238 @@
+"""GPU: the reference-named classes (d2d.dynamic, d2d.guidance, Controllers, planners,
+full_sim) -- written like the reference's call sites -- against the golden vectors and the
+oracle.  Every numeric call below goes through libd2dhip.so."""
+import numpy as np
+import pytest
+
+from oracle import sim as S, fit as F
+
+pytestmark = pytest.mark.gpu
+
+
+def test_aircraft_disc_dyn_and_jac(gold):
+    import d2d.dynamic as ddyn
+    import d2d.guidance as ddg
+    g = gold('plant')
+    ac = ddyn.Aircraft()
+    X1 = ac.disc_dyn([20, 30, -np.pi / 2, 0, 10], [0.1, 15], ddg.WindField(), 0, 0.05)   # SURVEY.md 8c known answer
+    np.testing.assert_allclose(X1, g['known_answer_disc_dyn'], atol=1e-7)
+    np.testing.assert_allclose(X1, [20.0008409, 29.49385394, -1.56691014, 0.09932621, 10.24385288], atol=1e-7)
+    for i in range(0, len(g['X']), 5):
+        ac.tau_phi = 0.9667
+        Xn = ac.disc_dyn(g['X'][i], g['U'][i], ddg.WindField(list(g['W'][i])), 0.3, 0.05)
+        d = Xn - g['Xnext_tau0.9667'][i]; d[2] = S.norm_mpi_pi(d[2])
+        assert np.abs(d).max() < 1e-6
+        ac.tau_phi = 0.01
+        A, B = ac.cont_jac(g['X'][i], g['U'][i], 0.0, None)
+        np.testing.assert_allclose(A, g['A'][i], rtol=1e-13, atol=1e-13); np.testing.assert_allclose(B, g['B'][i], rtol=1e-15)
+        np.testing.assert_allclose(ac.cont_dyn(g['X'][i], 0.0, g['U'][i], ddg.WindField(list(g['W'][i]))), g['cont_dyn'][i], rtol=1e-14)
+
+
+def test_flatness_maps(gold):
+    import d2d.dynamic as ddyn
+    import d2d.guidance as ddg
+    import Controllers as tracking
+    g = gold('flatness_ctrl')
+    ac = ddyn.Aircraft()
+    for i in range(0, len(g['Y']), 3):
+        Ys = np.array([g['Y'][i], g['Yd'][i], g['Ydd'][i], g['Yddd'][i]])
+        X, U, Xd = ddg.DiffFlatness.state_and_input_from_output(Ys, g['W'][i], ac)
+        np.testing.assert_allclose(X, g['g_X'][i], rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(U, g['g_U'][i], rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(Xd, g['g_Xdot'][i], rtol=1e-12, atol=1e-12)
+        X, U = tracking.DiffFlatness(list(g['W'][i])).ComputeFlatness(0.0, g['Y'][i], g['Yd'][i], g['Ydd'][i], g['Yddd'][i])
+        np.testing.assert_allclose(X, g['c_X'][i], rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(U, g['c_U'][i], rtol=1e-11, atol=1e-12)
+
+
+def test_compute_gain_like_the_reference_loop(gold):
+    import d2d.dynamic as ddyn
+    import Controllers as tracking
+    g = gold('flatness_ctrl')
+    ac = ddyn.Aircraft()
+    for i in range(0, len(g['Y']), 4):
+        ctrl = tracking.DiffController(list(g['W'][i]))
+        Xr, dX, U = ctrl.ComputeGain(0.0, g['X'][i].copy(), g['Y'][i], g['Yd'][i], g['Ydd'][i], g['Yddd'][i], ac)
+        np.testing.assert_allclose(Xr, g['gain_Xr_carestandin'][i], rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(dX, g['gain_dX_carestandin'][i], rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(U, g['gain_U_carestandin'][i], rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(ctrl.K[-1], g['gain_K_carestandin'][i], rtol=1e-8, atol=1e-9)
+
+
+def test_lqr_vs_scipy_care():
+    """control.lqr replacement on random stabilisable 5x5 / 2-input systems."""
+    import scipy.linalg
+    import d2dhip
+    ctx = d2dhip.default_context()
+    rng = np.random.default_rng(4)
+    n = 64
+    A = rng.normal(0, 1.0, (n, 5, 5)); Bm = rng.normal(0, 1.0, (n, 5, 2))
+    Qh = rng.normal(0, 1, (5, 5)); Q = Qh @ Qh.T + 0.1 * np.eye(5); R = np.array([[2.0, 0.3], [0.3, 1.0]])
+    K, P = ctx.lqr(ctx.dev(np.ascontiguousarray(A.reshape(n, 25).T)), ctx.dev(np.ascontiguousarray(Bm.reshape(n, 10).T)), Q, R)
+    K = K.cpu().numpy().T.reshape(n, 2, 5); P = P.cpu().numpy().T.reshape(n, 5, 5)
+    for i in range(n):
+        Pr = scipy.linalg.solve_continuous_are(A[i], Bm[i], Q, R)
+        np.testing.assert_allclose(P[i], Pr, rtol=1e-8, atol=1e-8 * np.abs(Pr).max())
+        np.testing.assert_allclose(K[i], np.linalg.solve(R, Bm[i].T @ Pr), rtol=1e-7, atol=1e-8 * np.abs(Pr).max())
+
+
+def test_dcf_circle_gvf_helpers(gold):
+    import d2d.guidance as ddg
+    g = gold('guidance')
+    dcf = ddg.DCFController()
+    for i in range(0, len(g['dcf_c']), 3):
+        zd = g['dcf_zdes'][i].copy()
+        Ur, eth = dcf.get(4, g['B'], g['dcf_c'][i], g['dcf_p'][i], zd, float(g['dcf_kr']))
+        assert zd.shape == (3, 1) and Ur.shape == (4, 1) and eth.shape == (3, 1)        # the in-place reshape quirk
+        np.testing.assert_allclose(Ur[:, 0], g['dcf_Ur'][i], rtol=1e-12, atol=1e-11)
+        np.testing.assert_allclose(eth[:, 0], g['dcf_etheta_deg'][i], rtol=1e-12, atol=1e-11)
+    for i in range(0, len(g['gvf_X']), 3):
+        e, n, H = ddg.CircleTraj(g['gvf_c'][i]).get(g['gvf_X'][i], g['gvf_r'][i])
+        np.testing.assert_allclose(e, g['gvf_e'][i], rtol=1e-15); np.testing.assert_allclose(n, g['gvf_n'][i], rtol=1e-15)
+        U, U1, U2 = ddg.GVFcontroller(None, None, None).get(g['gvf_X'][i], float(g['gvf_ke']), float(g['gvf_kd']), e, n, H)
+        np.testing.assert_allclose([U, U1, U2], [g['gvf_U'][i], g['gvf_U1'][i], g['gvf_U2'][i]], rtol=1e-11, atol=1e-11)
+
+
+def test_circular_formation_like_11_full_sim():
+    """The call of src/11_full_sim_case1.py:436 with its own parameters, shortened time grid."""
+    import full_sim
+    c = np.array([[0, -20], [25, -20], [25, -100], [0, -100.0]])
+    X1_f = ((0, 40, 0, 0, 12), (25, 40, 0, 0, 12), (25, -40, 0, 0, 12), (0, -40, 0, 0, 12))
+    X, U, U1, U2, Ur, eth, time, t_f = full_sim.CircularFormationGVF(c, 60, 15, 4, X1_f, 0, 0.05, 30)
+    assert X.shape == (600, 4, 5) and U.shape == (600, 4, 2) and Ur.shape == (600, 4) and eth.shape == (600, 3)
+    Xo, Uo, Rro, etho, stop = S.formation_gvf_run(c, 60.0, 15.0, np.tile(full_sim.X1_START, (4, 1)), 600, 0.05, X0f=X1_f)
+    assert stop == 600 and t_f == 30
+    d = X - Xo; d[..., 2] = S.norm_mpi_pi(d[..., 2])
+    assert np.abs(d).max() < 1e-7
+    np.testing.assert_allclose(U[:599], Uo[:599], atol=1e-8)
+    np.testing.assert_array_equal(full_sim.ConstructBMatrix(4), S.construct_b_matrix(4))
+
+
+def test_implement_controller_like_11_full_sim(gold):
+    import full_sim
+    g = gold('tracking_trace_carestandin')
+    X, U, Xr, Yd, Ydd, dX = full_sim.implement_controller(4, g['time'], g['x_ref'], g['y_ref'], 15, [0, 0], g['X'][0])
+    T = len(g['time'])
+    d = X - g['X']; d[..., 2] = S.norm_mpi_pi(d[..., 2])
+    assert np.abs(d).max() < 2e-4
+    np.testing.assert_allclose(Xr[:T - 1], g['Xr'][:T - 1], rtol=1e-10, atol=1e-10)
+    Fdx, Fdy, Fddx, Fddy = full_sim.ComputeDerivatives(g['x_ref'][:, 0], g['y_ref'][:, 0], g['time'][1] - g['time'][0])
+    np.testing.assert_allclose(Yd[1:T - 1, 0, 0], Fdx[2:T], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(Ydd[1:T - 1, 0, 1], Fddy[2:T], rtol=1e-10, atol=1e-10)
+
+
+def _kinematic_residual(sol_x, sol_y, sol_psi, sol_phi, sol_v, coefs, duration, wind=(0, 0)):
+    """The fitted trajectory satisfies the planner's kinematic model identically: compare the
+    sampled states with derivatives of the polynomial itself."""
+    import d2d.trajectory as ddt
+    traj = ddt.CompositeTraj.from_fit(coefs, duration)
+    K = len(sol_x)
+    t = np.linspace(0, duration, K)
+    worst = 0.0
+    for k in range(K - 1):
+        Y = traj.get(t[k])
+        worst = max(worst, abs(Y[0, 0] - sol_x[k]), abs(Y[0, 1] - sol_y[k]),
+                    abs(Y[1, 0] - (sol_v[k] * np.cos(sol_psi[k]) - wind[0])), abs(Y[1, 1] - (sol_v[k] * np.sin(sol_psi[k]) - wind[1])))
+        psid = (Y[2, 1] * (Y[1, 0] + wind[0]) - Y[2, 0] * (Y[1, 1] + wind[1])) / sol_v[k] ** 2
+        worst = max(worst, abs(psid - 9.81 / sol_v[k] * np.tan(sol_phi[k])))
+    return worst
+
+
+def test_single_planner_config0_plumbing(gold, tmp_path):
+    """BASELINE configs[0]: aircraft 1 of opt_states_st_line.csv, (0,40,0) -> (75,40,0), t1 = 7 s at
+    10 Hz (71 nodes) through the single_opt_planner.Planner protocol with CostAirVel(12)."""
+    import d2d.opty_utils as d2ou
+    import d2d.optyplan_scenarios as d2oscen
+    import single_opt_planner as sop
+
+    class scen(d2oscen.exp_14):
+        name = 'st_line_ac1'
+        t0, p0 = 0, (0, 40, 0, 0, 12)
+        t1, p1 = 7.0, (75, 40, 0, 0, 12)
+        cost = d2ou.CostAirVel(12.)
+    p = sop.Planner(scen, initialize=True)
+    assert p.num_nodes == 71
+    fn = str(tmp_path / 'optyplan_st_line.npz')
+    sop.compute_or_load(p, force_recompute=True, filename=fn, tol=1e-5, max_iter=500)
+    assert p.info['status_msg'] in ('converged', 'stalled')
+    # end conditions (src/single_opt_planner.py:46-49)
+    np.testing.assert_allclose([p.sol_x[0], p.sol_y[0], p.sol_psi[0]], [0, 40, 0], atol=1e-9)
+    np.testing.assert_allclose([p.sol_x[-1], p.sol_y[-1], p.sol_psi[-1]], [75, 40, 0], atol=1e-8)
+    assert _kinematic_residual(p.sol_x, p.sol_y, p.sol_psi, p.sol_phi, p.sol_v, p.fit_coefs, p.duration) < 1e-8
+    # the reference's objective on the solution: 75 m in 7 s needs a dog-leg at 12 m/s; bounds respected softly
+    c_ref = scen.cost.cost(p.solution, p)
+    assert c_ref < 0.5 and np.abs(p.sol_phi).max() < np.deg2rad(40) + 0.05 and p.sol_v.min() > 8.5
+    # golden aircraft-1 solution of the reference's IPOPT run has cost ~0 on CostAirVel; ours is a smooth C^3 polynomial
+    g = gold('planner_goldens')
+    N = 71
+    v_gold = g['stline_free'][4 * 4 * N:4 * 4 * N + N]
+    assert abs(np.mean(p.sol_v) - np.mean(v_gold)) < 0.5
+    # npz cache round trip in the reference's key layout
+    d = np.load(fn)
+    assert sorted(d.files) == ['sol_phi', 'sol_psi', 'sol_time', 'sol_v', 'sol_x', 'sol_y', 'wind']
+    p2 = sop.Planner(scen, initialize=True)
+    sop.compute_or_load(p2, force_recompute=False, filename=fn)
+    np.testing.assert_array_equal(p2.sol_x, p.sol_x)
+    # oracle parity of the same fit
+    import d2dhip
+    ob = F.FitBasis.from_arrays(6, 71, p.duration, *p.fit_plan.basis())
+    row = p.fit_scen.cpu().numpy()[0]
+    xy = p.get_initial_guess('tri')
+    q0 = np.concatenate([ob.Pinit @ (xy[p._slice_x] - ob.Gp[0] @ F.end_data(row)[0]), ob.Pinit @ (xy[p._slice_y] - ob.Gp[0] @ F.end_data(row)[1])])
+    qo, co, _, sto = F.lm_solve(ob, row, q0=q0)
+    assert abs(p.info['obj_val'] - co) <= 1e-6 * co
+
+
+def test_single_planner_exp14_and_wind():
+    import d2d.opty_utils as d2ou
+    import d2d.optyplan_scenarios as d2oscen
+    import single_opt_planner as sop
+    p = sop.Planner(d2oscen.exp_14, initialize=True)
+    p.configure(1e-5, 500)
+    p.run(p.get_initial_guess('tri'))
+    assert p.solution.shape == (5 * 121,)
+    np.testing.assert_allclose([p.sol_x[0], p.sol_y[0], p.sol_psi[0]], d2oscen.exp_14.p0[:3], atol=1e-8)
+    np.testing.assert_allclose([p.sol_x[-1], p.sol_y[-1]], d2oscen.exp_14.p1[:2], atol=1e-8)
+    assert _kinematic_residual(p.sol_x, p.sol_y, p.sol_psi, p.sol_phi, p.sol_v, p.fit_coefs, p.duration) < 1e-8
+    # the reference's IPOPT optimum of this scenario has CostAirVel = 5.0297; the smooth
+    # polynomial fit with soft bounds lands in the same regime
+    assert d2oscen.exp_14.cost.cost(p.solution, p) < 15.0
+
+    class windy(d2oscen.exp_0):
+        wind = d2ou.WindField(w=[2., 0.])
+        t1 = 10.
+    pw = sop.Planner(windy, initialize=True)
+    pw.run()
+    # planner sign convention: xdot = v cos(psi) - wx  (src/d2d/opty_utils.py:42)
+    assert _kinematic_residual(pw.sol_x, pw.sol_y, pw.sol_psi, pw.sol_phi, pw.sol_v, pw.fit_coefs, pw.duration, wind=(2., 0.)) < 1e-8
+
+
+def test_multi_planner_like_11_full_sim():
+    import multi_opt_planner as mop
+    import d2d.multiopty_utils as d2mou
+    scen = mop.trap_4
+    scen.t1 = 6
+    scen.p0s = ((0, 40, 0, 0, 12), (25, 40, 0, 0, 12), (25, -40, 0, 0, 12), (0, -40, 0, 0, 12))
+    scen.p1s = ((75, 40, 0, 0, 12), (100, 40, 0, 0, 12), (100, -40, 0, 0, 12), (75, -40, 0, 0, 12))
+    _p = mop.Planner(scen, initialize=True)
+    with pytest.raises(NotImplementedError):                     # kcol = 10 in the reference's trap_4
+        _p.run(initial_guess=_p.get_initial_guess(scen.initial_guess), tol=scen.tol, max_iter=scen.max_iter)
+    scen.cost = d2mou.CostComposit(kvel=70., kbank=1., kobs=float('NaN'), kcol=float('NaN'), vsp=12., obss=[], obs_kind=0, rcol=10)
+    _p = mop.Planner(scen, initialize=True)
+    _p.run(initial_guess=_p.get_initial_guess(scen.initial_guess), tol=scen.tol, max_iter=scen.max_iter)
+    _p.interpret_solution()
+    assert len(_p.sol_x) == 4 and _p.sol_x[0].shape == (61,)
+    for i in range(4):
+        np.testing.assert_allclose([_p.sol_x[i][0], _p.sol_y[i][0], _p.sol_x[i][-1], _p.sol_y[i][-1]],
+                                   [scen.p0s[i][0], scen.p0s[i][1], scen.p1s[i][0], scen.p1s[i][1]], atol=1e-8)
+        assert _kinematic_residual(_p.sol_x[i], _p.sol_y[i], _p.sol_psi[i], _p.sol_phi[i], _p.sol_v[i], _p.fit_coefs[i], _p.duration) < 1e-8
+    # 75 m in 6 s at vsp = 12: straight line, ~12.5 m/s -- the symmetric pairs give mirrored answers
+    np.testing.assert_allclose(_p.sol_y[0] - 40, -(_p.sol_y[3] + 40), atol=1e-6)
+    # 75 m in 6 s needs 12.5 m/s on average: 70 * mean((v-12)^2) ~ 70 * 0.25
+    c = scen.cost.cost(_p.solution, _p)
+    assert 10.0 < c < 20.0 and abs(np.mean(_p.sol_v[0]) - 12.5) < 0.2, c
+    # ... and feeds the tracking phase exactly as src/11_full_sim_case1.py:455-460 does
+    import full_sim
+    x_ref = np.array(_p.sol_x).T; y_ref = np.array(_p.sol_y).T
+    X, U, Xr, Yd, Ydd, dX = full_sim.implement_controller(4, np.array(_p.sol_time), x_ref, y_ref, 15, [0, 0], scen.p0s)
+    assert X.shape == (61, 4, 5) and np.abs(X[-1, :, 0] - x_ref[-1]).max() < 3.0
