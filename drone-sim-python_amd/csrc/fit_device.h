@@ -88,9 +88,10 @@ __device__ __forceinline__ void waypoint_at(const Scen &s, int K, int k, double 
 }
 
 // Flat outputs at sample k:  Y = [x, y, xd, yd, xdd, ydd]  (oracle/fit.py flat_outputs)
+template <typename ScenT>
 __device__ __forceinline__ void flat_outputs(const FitGeom &g, const double *__restrict__ G64,
                                              const double *__restrict__ Gp64,
-                                             const double *__restrict__ q, const Scen &s, int k,
+                                             const double *__restrict__ q, const ScenT &s, int k,
                                              double Y[6]) {
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
@@ -112,13 +113,74 @@ __device__ __forceinline__ void flat_outputs(const FitGeom &g, const double *__r
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Hot-path scenario row: everything that is uniform per trajectory is derived once by
+// fit_prep_kernel (double[FIT_PREP_STRIDE] per trajectory) so that the eval / step kernels
+// fetch it with scalar loads instead of recomputing sincos / sqrt / divisions in all 64 lanes.
+#define FIT_PREP_STRIDE 40
+enum { PR_DX = 0, PR_DY = 4, PR_P2X = 8, PR_P2Y, PR_SAX, PR_SAY, PR_SBX, PR_SBY, PR_CV, PR_CPHI, PR_COBS,
+       PR_K0, PR_K1, PR_CV2, PR_CPHI2, PR_WB2, PR_WWP, PR_WBND, PR_VSP, PR_WX, PR_WY, PR_PHIMAX, PR_VMIN,
+       PR_VMAX, PR_O0X, PR_O0Y, PR_O1X, PR_O1Y, PR_X0, PR_Y0, PR_X1, PR_Y1 };
+
+struct ScenP {
+  double dx[4], dy[4];
+  double p2x, p2y, sax, say, sbx, sby;      // dog-leg apex and the two linspace steps
+  double cv, cphi, cobs, k0, k1, cv2, cphi2, wb2, wwp, wbnd, vsp, wx, wy, phimax, vmin, vmax;
+  double o0x, o0y, o1x, o1y, x0, y0, x1, y1;
+};
+
+__device__ __forceinline__ void prep_row(const double *__restrict__ sc, double duration, int K,
+                                         double *__restrict__ o) {
+  const Scen s = load_scen(sc, duration);
+  for (int c = 0; c < 4; ++c) { o[PR_DX + c] = s.dx[c]; o[PR_DY + c] = s.dy[c]; }
+  const int n1 = K / 2, n2 = K - n1;
+  o[PR_P2X] = s.p2x; o[PR_P2Y] = s.p2y;
+  o[PR_SAX] = n1 > 1 ? (s.p2x - s.x0) / (n1 - 1) : 0.0; o[PR_SAY] = n1 > 1 ? (s.p2y - s.y0) / (n1 - 1) : 0.0;
+  o[PR_SBX] = n2 > 1 ? (s.x1 - s.p2x) / (n2 - 1) : 0.0; o[PR_SBY] = n2 > 1 ? (s.y1 - s.p2y) / (n2 - 1) : 0.0;
+  o[PR_CV2] = s.s * s.kv; o[PR_CPHI2] = s.s * s.kphi;
+  o[PR_CV] = sqrt(s.s * s.kv); o[PR_CPHI] = sqrt(s.s * s.kphi); o[PR_COBS] = sqrt(s.s * s.kobs);
+  o[PR_K0] = s.o0r > 0.0 ? FIT_OBS_K / s.o0r : 0.0; o[PR_K1] = s.o1r > 0.0 ? FIT_OBS_K / s.o1r : 0.0;
+  o[PR_WB2] = s.wbnd * s.wbnd; o[PR_WWP] = s.wwp; o[PR_WBND] = s.wbnd; o[PR_VSP] = s.vsp;
+  o[PR_WX] = s.wx; o[PR_WY] = s.wy; o[PR_PHIMAX] = s.phimax; o[PR_VMIN] = s.vmin; o[PR_VMAX] = s.vmax;
+  o[PR_O0X] = s.o0x; o[PR_O0Y] = s.o0y; o[PR_O1X] = s.o1x; o[PR_O1Y] = s.o1y;
+  o[PR_X0] = s.x0; o[PR_Y0] = s.y0; o[PR_X1] = s.x1; o[PR_Y1] = s.y1;
+}
+
+__device__ __forceinline__ ScenP load_scenp(const double *__restrict__ p) {
+  ScenP s;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { s.dx[c] = p[PR_DX + c]; s.dy[c] = p[PR_DY + c]; }
+  s.p2x = p[PR_P2X]; s.p2y = p[PR_P2Y]; s.sax = p[PR_SAX]; s.say = p[PR_SAY]; s.sbx = p[PR_SBX]; s.sby = p[PR_SBY];
+  s.cv = p[PR_CV]; s.cphi = p[PR_CPHI]; s.cobs = p[PR_COBS]; s.k0 = p[PR_K0]; s.k1 = p[PR_K1];
+  s.cv2 = p[PR_CV2]; s.cphi2 = p[PR_CPHI2]; s.wb2 = p[PR_WB2]; s.wwp = p[PR_WWP]; s.wbnd = p[PR_WBND];
+  s.vsp = p[PR_VSP]; s.wx = p[PR_WX]; s.wy = p[PR_WY]; s.phimax = p[PR_PHIMAX]; s.vmin = p[PR_VMIN]; s.vmax = p[PR_VMAX];
+  s.o0x = p[PR_O0X]; s.o0y = p[PR_O0Y]; s.o1x = p[PR_O1X]; s.o1y = p[PR_O1Y];
+  s.x0 = p[PR_X0]; s.y0 = p[PR_Y0]; s.x1 = p[PR_X1]; s.y1 = p[PR_Y1];
+  return s;
+}
+
+// numpy.linspace semantics with the step precomputed: start + i*step, last element = stop
+__device__ __forceinline__ void waypoint_at(const ScenP &s, int K, int k, double &wx, double &wy) {
+  const int n1 = K / 2, n2 = K - n1;
+  if (k < n1) {
+    wx = (k == n1 - 1 && n1 > 1) ? s.p2x : k * s.sax + s.x0;
+    wy = (k == n1 - 1 && n1 > 1) ? s.p2y : k * s.say + s.y0;
+  } else {
+    const int i = k - n1;
+    wx = (i == n2 - 1 && n2 > 1) ? s.x1 : i * s.sbx + s.p2x;
+    wy = (i == n2 - 1 && n2 > 1) ? s.y1 : i * s.sby + s.p2y;
+  }
+}
+
 // Residual rows of one sample (oracle/fit.py residuals).  Returns sum r^2.
-// With WANT_JAC: u[6] = D^T r (for J^T r, fp64) and the fp32 row coefficients of the four
-// rows contracted by the MFMA -- v, phi (bound rows merged into their weights), obs0, obs1:
-//   coef[rho][0..2] = d row / d (x, xd, xdd),  coef[rho][3..5] = d row / d (y, yd, ydd)
+// With WANT_JAC: u[6] = D^T r (for J^T r, fp64) and the fp32 coefficients of the four rows the
+// MFMA contracts -- v, phi (bound rows merged into their weights), obs0, obs1.  Row rho's entry
+// for unknown j of axis a is  cA[rho][a]*TA_rho[k][j] + cB[rho][a]*TB_rho[k][j]  with
+// (TA,TB) = (G1,-) for v, (G1,G2) for phi, (G0,-) for the obstacles:
+//   coef[rho] = {cA_x, cB_x, cA_y, cB_y}
 template <bool WANT_JAC>
-__device__ __forceinline__ double sample_terms(const Scen &s, const double Y[6], double wpx,
-                                               double wpy, double u[6], float coef[4][6]) {
+__device__ __forceinline__ double sample_terms(const ScenP &s, const double Y[6], double wpx,
+                                               double wpy, double u[6], f32x4 coef[4]) {
   const double x = Y[0], y = Y[1];
   const double a = Y[2] - s.wx, b = Y[3] - s.wy, c = Y[4], d = Y[5];
   const double va2 = a * a + b * b, va = sqrt(va2);
@@ -126,38 +188,36 @@ __device__ __forceinline__ double sample_terms(const Scen &s, const double Y[6],
   const double ivg = 1.0 / (va * FIT_G);
   const double w = n * ivg;
   const double phi = atan(w);                       // src/d2d/guidance.py:40
-  const double cv2 = s.s * s.kv, cphi2 = s.s * s.kphi, cobs = sqrt(s.s * s.kobs);
-  const double cv = sqrt(cv2), cphi = sqrt(cphi2);
-  const double r0 = cv * (va - s.vsp);              // CostInput, src/d2d/opty_utils.py:85-97
-  const double r1 = cphi * phi;
+  const double r0 = s.cv * (va - s.vsp);            // CostInput, src/d2d/opty_utils.py:85-97
+  const double r1 = s.cphi * phi;
   const double r2 = s.wwp * (x - wpx), r3 = s.wwp * (y - wpy);
   double h0 = 0.0, h1 = 0.0, e0x = 0.0, e0y = 0.0, e1x = 0.0, e1y = 0.0;
-  if (s.o0r > 0.0) {                                // CostObstacle kind 1, :99-134
-    e0x = (x - s.o0x) * (FIT_OBS_K / s.o0r); e0y = (y - s.o0y) * (FIT_OBS_K / s.o0r);
-    h0 = cobs * exp(-0.5 * (e0x * e0x + e0y * e0y));
+  if (s.k0 > 0.0) {                                 // CostObstacle kind 1, :99-134
+    e0x = (x - s.o0x) * s.k0; e0y = (y - s.o0y) * s.k0;
+    h0 = s.cobs * exp(-0.5 * (e0x * e0x + e0y * e0y));
   }
-  if (s.o1r > 0.0) {
-    e1x = (x - s.o1x) * (FIT_OBS_K / s.o1r); e1y = (y - s.o1y) * (FIT_OBS_K / s.o1r);
-    h1 = cobs * exp(-0.5 * (e1x * e1x + e1y * e1y));
+  if (s.k1 > 0.0) {
+    e1x = (x - s.o1x) * s.k1; e1y = (y - s.o1y) * s.k1;
+    h1 = s.cobs * exp(-0.5 * (e1x * e1x + e1y * e1y));
   }
   const double hphi = fmax(fabs(phi) - s.phimax, 0.0);
   const double hv = fmax(va - s.vmax, 0.0) + fmin(va - s.vmin, 0.0);
   const double r6 = s.wbnd * hphi, r7 = s.wbnd * hv;
   const double cost = r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3 + h0 * h0 + h1 * h1 + r6 * r6 + r7 * r7;
   if (WANT_JAC) {
-    const double dva_a = a / va, dva_b = b / va;
+    const double iva = 1.0 / va;
+    const double dva_a = a * iva, dva_b = b * iva;
     const double f = 1.0 / (1.0 + w * w);
-    const double nv3 = n / (va2 * va * FIT_G);
+    const double nv3 = n * ivg * iva * iva;
     const double dp_a = (d * ivg - nv3 * a) * f, dp_b = (-c * ivg - nv3 * b) * f;
     const double dp_c = -b * ivg * f, dp_d = a * ivg * f;
     const double actp = (hphi > 0.0) ? ((phi > 0.0) ? 1.0 : -1.0) : 0.0;
     const double actv = (va > s.vmax || va < s.vmin) ? 1.0 : 0.0;
-    const double k0 = FIT_OBS_K / (s.o0r > 0.0 ? s.o0r : 1.0), k1 = FIT_OBS_K / (s.o1r > 0.0 ? s.o1r : 1.0);
-    const double o0x = -h0 * e0x * k0, o0y = -h0 * e0y * k0;
-    const double o1x = -h1 * e1x * k1, o1y = -h1 * e1y * k1;
+    const double o0x = -h0 * e0x * s.k0, o0y = -h0 * e0y * s.k0;
+    const double o1x = -h1 * e1x * s.k1, o1y = -h1 * e1y * s.k1;
     // u = D^T r over all eight rows
-    const double tv = cv * r0 + s.wbnd * actv * r7;                 // multiplies d va
-    const double tp = cphi * r1 + s.wbnd * actp * r6;               // multiplies d phi
+    const double tv = s.cv * r0 + s.wbnd * actv * r7;               // multiplies d va
+    const double tp = s.cphi * r1 + s.wbnd * actp * r6;             // multiplies d phi
     u[0] = s.wwp * r2 + o0x * h0 + o1x * h1;
     u[1] = s.wwp * r3 + o0y * h0 + o1y * h1;
     u[2] = tv * dva_a + tp * dp_a;
@@ -165,23 +225,19 @@ __device__ __forceinline__ double sample_terms(const Scen &s, const double Y[6],
     u[4] = tp * dp_c;
     u[5] = tp * dp_d;
     // merged row weights for J^T J: (cv^2 + wb^2 actv) dva dva^T, (cphi^2 + wb^2 |actp|) dphi dphi^T
-    const double mv = sqrt(cv2 + s.wbnd * s.wbnd * actv);
-    const double mp = sqrt(cphi2 + s.wbnd * s.wbnd * actp * actp);
-    coef[0][0] = 0.f; coef[0][1] = (float)(mv * dva_a); coef[0][2] = 0.f;
-    coef[0][3] = 0.f; coef[0][4] = (float)(mv * dva_b); coef[0][5] = 0.f;
-    coef[1][0] = 0.f; coef[1][1] = (float)(mp * dp_a); coef[1][2] = (float)(mp * dp_c);
-    coef[1][3] = 0.f; coef[1][4] = (float)(mp * dp_b); coef[1][5] = (float)(mp * dp_d);
-    coef[2][0] = (float)o0x; coef[2][1] = 0.f; coef[2][2] = 0.f;
-    coef[2][3] = (float)o0y; coef[2][4] = 0.f; coef[2][5] = 0.f;
-    coef[3][0] = (float)o1x; coef[3][1] = 0.f; coef[3][2] = 0.f;
-    coef[3][3] = (float)o1y; coef[3][4] = 0.f; coef[3][5] = 0.f;
+    const double mv = sqrt(s.cv2 + s.wb2 * actv);
+    const double mp = sqrt(s.cphi2 + s.wb2 * actp * actp);
+    coef[0] = f32x4{(float)(mv * dva_a), 0.f, (float)(mv * dva_b), 0.f};
+    coef[1] = f32x4{(float)(mp * dp_a), (float)(mp * dp_c), (float)(mp * dp_b), (float)(mp * dp_d)};
+    coef[2] = f32x4{(float)o0x, 0.f, (float)o0y, 0.f};
+    coef[3] = f32x4{(float)o1x, 0.f, (float)o1y, 0.f};
   }
   return cost;
 }
 
 // Cost at q (wave-cooperative): sum over samples of sum r^2.
 __device__ __forceinline__ double wave_cost(const FitGeom &g, const double *G64, const double *Gp64,
-                                            const double *q, const Scen &s, int lane) {
+                                            const double *q, const ScenP &s, int lane) {
   double acc = 0.0;
   for (int k0 = 0; k0 < g.K; k0 += 64) {
     const int k = k0 + lane;

@@ -6,13 +6,14 @@
 // One wavefront per trajectory; the basis block shared by the whole batch is staged in LDS
 // once per workgroup.  Restates oracle/fit.py (lm_solve, eval_normal).
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
 #include "fit_device.h"
 #include "fit_plan.h"
 
-#define FIT_WPB_MAX 8        // wavefronts (= trajectories) per workgroup, fewer when K is large
+#define FIT_WPB_MAX 16       // wavefronts (= trajectories) per workgroup, fewer when K is large
 #define FIT_THREADS (64 * FIT_WPB_MAX)
 #define FIT_LDS_BYTES (160 * 1024)
 
@@ -28,7 +29,7 @@ struct FitLds {
 
 static inline int align16(int v) { return (v + 15) & ~15; }
 
-// g32_lds: stage the fp32 operand table in LDS (else it is read through L1/L2);
+// g32_lds: stage the fp32 operand tables in LDS (else they are read through L1/L2);
 // wpb: wavefronts per workgroup.  pick_eval_layout chooses the largest that fits 160 KiB.
 static FitLds eval_lds_layout(int K, int nq, bool g32_lds, int wpb) {
   FitLds L;
@@ -36,12 +37,12 @@ static FitLds eval_lds_layout(int K, int nq, bool g32_lds, int wpb) {
   int o = 0;
   L.G64 = o; o = align16(o + 3 * K * gstr * 8);
   L.Gp64 = o; o = align16(o + 3 * K * 4 * 8);
-  L.G32 = o; o = align16(o + (g32_lds ? K * nq * 16 : 0));
+  L.G32 = o; o = align16(o + (g32_lds ? (3 * K + 1) * nq * 4 : 0));   // + one padded sample row
   L.wave0 = o;
   int w = 0;
   L.q = w; w = align16(w + 2 * nq * 8);
   L.u = w; w = align16(w + K * 6 * 8);
-  L.coef = w; w = align16(w + K * 4 * 6 * 4);
+  L.coef = w; w = align16(w + (K + 1) * 4 * 16);   // + one padded sample
   L.wave_stride = w;
   L.total = o + wpb * w;
   return L;
@@ -64,70 +65,85 @@ __device__ __forceinline__ void stage(void *dst, const void *src, int bytes) {
 }
 
 // ------------------------------------------------------------------------------------
+// derived scenario rows (fit_device.h prep_row), one thread per trajectory
+__global__ void __launch_bounds__(256)
+fit_prep_kernel(int B, int K, double duration, const double *__restrict__ scen, double *__restrict__ prep) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  prep_row(scen + (size_t)b * D2D_SCEN_STRIDE, duration, K, prep + (size_t)b * FIT_PREP_STRIDE);
+}
+
+// ------------------------------------------------------------------------------------
 // K1 + K2: cost, J^T r, J^T J.   H is written as the upper block triangle of 16x16 tiles
 // of a [n][n] row-major matrix (n = 2nq); symmetrize_kernel mirrors it for the public API.
-template <int NB, bool G32_LDS>   // NB = ceil(2nq/16) column blocks of the MFMA tiling
+template <int NB, int NQ, bool G32_LDS>   // NB = ceil(2nq/16) column blocks of the MFMA tiling; NQ = nq or 0 (runtime)
 __global__ void __launch_bounds__(FIT_THREADS)
-fit_eval_kernel(int B, FitGeom g, FitLds L, double duration, const double *__restrict__ gG64,
+fit_eval_kernel(int B, FitGeom g, FitLds L, int dbg, const double *__restrict__ gG64,
                 const double *__restrict__ gGp64, const float *__restrict__ gG32,
-                const float *__restrict__ gW32, const double *__restrict__ scen,
+                const float *__restrict__ gW32, const double *__restrict__ prep,
                 const double *__restrict__ q_in, int32_t *__restrict__ flags,
                 double *__restrict__ cost_out, double *__restrict__ g_out, float *__restrict__ H_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  const int b = blockIdx.x * wpb + wave;
+  bool active = b < B;
+  if (active && flags) active = flags[4 * b + FL_STATUS] == D2D_ST_RUNNING && flags[4 * b + FL_NEED] != 0;
+  // nothing to do for this workgroup: leave before paying for the LDS image
+  if (!__syncthreads_or(active ? 1 : 0)) return;
+
+  // issue the per-trajectory loads first: their latency hides under the staging of the shared block
+  const int n = 2 * g.nq;
+  const double q_lane = (active && lane < n) ? q_in[(size_t)b * n + lane] : 0.0;
+  ScenP s;
+  if (active) s = load_scenp(prep + (size_t)b * FIT_PREP_STRIDE);
   double *G64 = reinterpret_cast<double *>(lds + L.G64);
   double *Gp64 = reinterpret_cast<double *>(lds + L.Gp64);
-  stage(G64, gG64, 3 * g.K * g.gstr * 8);
-  stage(Gp64, gGp64, 3 * g.K * 4 * 8);
-  if (G32_LDS) stage(lds + L.G32, gG32, g.K * g.nq * 16);
-  __syncthreads();
-
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int b = blockIdx.x * (blockDim.x >> 6) + wave;
-  if (b >= B) return;
-  if (flags && (flags[4 * b + FL_STATUS] != D2D_ST_RUNNING || flags[4 * b + FL_NEED] == 0)) return;
-
+  if (!(dbg & 16)) {
+    stage(G64, gG64, 3 * g.K * g.gstr * 8);
+    stage(Gp64, gGp64, 3 * g.K * 4 * 8);
+    if (G32_LDS) stage(lds + L.G32, gG32, (3 * g.K + 1) * g.nq * 4);
+  }
   unsigned char *wl = lds + L.wave0 + wave * L.wave_stride;
   double *qs = reinterpret_cast<double *>(wl + L.q);
   double *us = reinterpret_cast<double *>(wl + L.u);
-  float *cf = reinterpret_cast<float *>(wl + L.coef);
-  const int n = 2 * g.nq;
-  if (lane < n) qs[lane] = q_in[(size_t)b * n + lane];
-  const Scen s = load_scen(scen + (size_t)b * D2D_SCEN_STRIDE, duration);
-  wave_lds_sync();
+  f32x4 *cf = reinterpret_cast<f32x4 *>(wl + L.coef);
+  if (lane < n) qs[lane] = q_lane;
+  __syncthreads();
+  if (!active) return;
 
   // ---- phase 1: lane = sample ------------------------------------------------------
   double cacc = 0.0;
   for (int k0 = 0; k0 < g.K; k0 += 64) {
     const int k = k0 + lane;
     if (k < g.K) {
-      double Y[6], wpx, wpy, u[6];
-      float coef[4][6];
-      flat_outputs(g, G64, Gp64, qs, s, k, Y);
+      double Y[6] = {1.0 + k, 2.0, 11.0, 3.0, 0.1, 0.2}, wpx, wpy, u[6] = {0, 0, 0, 0, 0, 0};
+      f32x4 coef[4] = {f32x4{1.f, 0.f, 1.f, 0.f}, f32x4{1.f, 0.f, 1.f, 0.f}, f32x4{1.f, 0.f, 1.f, 0.f}, f32x4{1.f, 0.f, 1.f, 0.f}};
+      if (!(dbg & 8)) flat_outputs(g, G64, Gp64, qs, s, k, Y);
       waypoint_at(s, g.K, k, wpx, wpy);
-      cacc += sample_terms<true>(s, Y, wpx, wpy, u, coef);
+      if (!(dbg & 1)) cacc += sample_terms<true>(s, Y, wpx, wpy, u, coef);
 #pragma unroll
       for (int c = 0; c < 6; ++c) us[k * 6 + c] = u[c];
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 6; ++c) cf[(k * 4 + r) * 6 + c] = coef[r][c];
+      for (int r = 0; r < 4; ++r) cf[k * 4 + r] = coef[r];
     }
   }
   const double cost = wave_sum(cacc);
   wave_lds_sync();
 
-  // ---- phase 2: J^T r, lane = unknown (fp64) ----------------------------------------
-  if (lane < n) {
+  // ---- phase 2: J^T r, lane = unknown (fp64), three independent accumulation chains ----
+  if (lane < n && !(dbg & 2)) {
     const int ax = lane >= g.nq ? 1 : 0, jj = lane - ax * g.nq;
     const double *g0 = G64 + jj, *g1 = g0 + (size_t)g.K * g.gstr, *g2 = g1 + (size_t)g.K * g.gstr;
-    double acc = 0.0;
+    const double *uk = us + ax;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+#pragma unroll 5
     for (int k = 0; k < g.K; ++k) {
-      const double *uk = us + k * 6;
-      acc = fma(uk[ax], g0[k * g.gstr], acc);
-      acc = fma(uk[2 + ax], g1[k * g.gstr], acc);
-      acc = fma(uk[4 + ax], g2[k * g.gstr], acc);
+      a0 = fma(uk[k * 6], g0[k * g.gstr], a0);
+      a1 = fma(uk[k * 6 + 2], g1[k * g.gstr], a1);
+      a2 = fma(uk[k * 6 + 4], g2[k * g.gstr], a2);
     }
-    if (g_out) g_out[(size_t)b * n + lane] = acc;
+    if (g_out) g_out[(size_t)b * n + lane] = (a0 + a1) + a2;
   }
   if (lane == 0) {
     if (cost_out) cost_out[b] = cost;
@@ -141,67 +157,82 @@ fit_eval_kernel(int B, FitGeom g, FitLds L, double duration, const double *__res
 
   // ---- phase 3: J^T J by v_mfma_f32_16x16x4_f32 --------------------------------------
   // One MFMA k-step = the four contracted rows (v, phi, obs0, obs1) of one sample.
-  // Lane l supplies J[row rho = l>>4][col 16c + (l&15)] as A- and as B-operand alike.
+  // Lane l supplies J[row rho = l>>4][col 16c + (l&15)] as A- and as B-operand alike:
+  //   J = cA * TA[k][j] + cB * TB[k][j],  TA = G1 (v, phi) or G0 (obstacles), TB = G2 (phi only).
+  // Operands of sample k+1 are fetched before the MFMAs of sample k are issued.
   const int rho = lane >> 4, ci = lane & 15;
-  int jcol[NB], jax[NB];
+  const int nq = NQ ? NQ : g.nq;
+  const int plane = g.K * nq;
+  const float *T32 = G32_LDS ? reinterpret_cast<const float *>(lds + L.G32) : gG32;
   bool jok[NB];
+  const float *pc[NB], *pa[NB], *pb[NB];   // per-lane running pointers: (cA,cB) pair, TA entry, TB entry
 #pragma unroll
   for (int c = 0; c < NB; ++c) {
     const int col = 16 * c + ci;
     jok[c] = col < n;
-    jax[c] = (col >= g.nq) ? 1 : 0;
-    jcol[c] = jok[c] ? col - jax[c] * g.nq : 0;
+    const bool ay = col >= nq;
+    const int j = jok[c] ? col - (ay ? nq : 0) : 0;
+    pc[c] = reinterpret_cast<const float *>(cf + rho) + (ay ? 2 : 0);
+    pa[c] = T32 + ((rho < 2) ? plane : 0) + j;
+    pb[c] = T32 + 2 * plane + j;
   }
   f32x4 acc[NB * (NB + 1) / 2];
 #pragma unroll
   for (int t = 0; t < NB * (NB + 1) / 2; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int k = 0; k < g.K; ++k) {
-    const float *cr = cf + (k * 4 + rho) * 6;
-    const float c0 = cr[0], c1 = cr[1], c2 = cr[2], c3 = cr[3], c4 = cr[4], c5 = cr[5];
+  const int Kmf = (dbg & 4) ? 1 : g.K;
+  float2 cc[NB];
+  float ta[NB], tb[NB];
+#pragma unroll
+  for (int c = 0; c < NB; ++c) {
+    cc[c] = *reinterpret_cast<const float2 *>(pc[c]);
+    ta[c] = *pa[c]; tb[c] = *pb[c];
+  }
+#pragma unroll 5
+  for (int k = 0; k < Kmf; ++k) {
     float v[NB];
 #pragma unroll
     for (int c = 0; c < NB; ++c) {
-      const f32x4 gk = G32_LDS ? reinterpret_cast<const f32x4 *>(lds + L.G32)[k * g.nq + jcol[c]]
-                               : reinterpret_cast<const f32x4 *>(gG32)[k * g.nq + jcol[c]];
-      const float vx = c0 * gk.x + c1 * gk.y + c2 * gk.z;
-      const float vy = c3 * gk.x + c4 * gk.y + c5 * gk.z;
-      v[c] = jok[c] ? (jax[c] ? vy : vx) : 0.f;
+      const float val = fmaf(cc[c].y, tb[c], cc[c].x * ta[c]);
+      v[c] = (2 * nq == 16 * NB || jok[c]) ? val : 0.f;
     }
+    // operands of sample k+1 (the tables carry one padded row, so k+1 == K is in bounds)
+#pragma unroll
+    for (int c = 0; c < NB; ++c) {
+      cc[c] = *reinterpret_cast<const float2 *>(pc[c] + (k + 1) * 16);
+      ta[c] = pa[c][(k + 1) * nq]; tb[c] = pb[c][(k + 1) * nq];
+    }
+    __builtin_amdgcn_sched_barrier(0);
     int t = 0;
 #pragma unroll
     for (int I = 0; I < NB; ++I)
 #pragma unroll
       for (int J = I; J < NB; ++J, ++t)
         acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[I], v[J], acc[t], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
   }
-  // epilogue: + wwp^2 G0^T G0 on the xx / yy blocks; C/D layout row = (l>>4)*4 + reg, col = l&15
+  // epilogue: + wwp^2 G0^T G0 (pre-tiled constant) ; tile-major store: [tile][reg][lane], 256 B per store
   const float ww = (float)(s.wwp * s.wwp);
-  float *Hb = H_out + (size_t)b * n * n;
-  int t = 0;
+  float *Hb = H_out + (size_t)b * (NB * (NB + 1) / 2) * 256;
 #pragma unroll
-  for (int I = 0; I < NB; ++I)
+  for (int t = 0; t < NB * (NB + 1) / 2; ++t)
 #pragma unroll
-    for (int J = I; J < NB; ++J, ++t) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 16 * I + rho * 4 + r, col = 16 * J + ci;
-        if (row < n && col < n) {
-          float val = acc[t][r];
-          const int ra = row >= g.nq, ca = col >= g.nq;
-          if (ra == ca) val += ww * gW32[(row - ra * g.nq) * g.nq + (col - ca * g.nq)];
-          Hb[(size_t)row * n + col] = val;
-        }
-      }
-    }
+    for (int r = 0; r < 4; ++r) Hb[(t * 4 + r) * 64 + lane] = fmaf(ww, gW32[(t * 4 + r) * 64 + lane], acc[t][r]);
 }
 
-// mirror the upper block triangle written by fit_eval_kernel into a full symmetric matrix
-__global__ void __launch_bounds__(256) symmetrize_kernel(int B, int n, float *__restrict__ H) {
+// tile-major J^T J (fit_eval_kernel's layout: [tile (I<=J)][reg][lane], C/D map row = 16I + 4(lane>>4) + reg,
+// col = 16J + (lane&15)) -> full symmetric row-major [n][n] for the public d2d_fit_eval
+__global__ void __launch_bounds__(256)
+untile_kernel(int B, int n, int NB, const float *__restrict__ Ht, float *__restrict__ H) {
   const int b = blockIdx.x;
-  float *Hb = H + (size_t)b * n * n;
+  const float *src = Ht + (size_t)b * (NB * (NB + 1) / 2) * 256;
+  float *dst = H + (size_t)b * n * n;
   for (int i = threadIdx.x; i < n * n; i += blockDim.x) {
-    const int r = i / n, c = i - r * n;
-    if ((r >> 4) > (c >> 4)) Hb[i] = Hb[(size_t)c * n + r];
+    int r = i / n, c = i - r * n;
+    if ((r >> 4) > (c >> 4)) { const int t = r; r = c; c = t; }
+    const int I = r >> 4, J = c >> 4;
+    const int tile = I * NB - I * (I - 1) / 2 + (J - I);
+    const int rr = r & 15, reg = rr & 3, ln = (rr >> 2) * 16 + (c & 15);
+    dst[i] = src[(tile * 4 + reg) * 64 + ln];
   }
 }
 
@@ -218,7 +249,11 @@ static StepLds step_lds_layout(int K, int nq, int N, int wpb) {
   L.Gp64 = o; o = align16(o + 3 * K * 4 * 8);
   L.wave0 = o;
   int w = 0;
-  L.Lm = w; w = align16(w + N * (N + 1) * 4);
+  {
+    const int nb = N / 16, tiles = nb * (nb + 1) / 2;
+    const int bytes = (N * (N + 1) > tiles * 256 ? N * (N + 1) : tiles * 256) * 4;
+    L.Lm = w; w = align16(w + bytes);
+  }
   L.vec = w; w = align16(w + N * 4);
   L.qt = w; w = align16(w + N * 8);
   L.wave_stride = w;
@@ -234,21 +269,22 @@ static bool pick_step_layout(int K, int nq, int N, int *wpb) {
 
 template <int N>
 __global__ void __launch_bounds__(FIT_THREADS)
-fit_step_kernel(int B, FitGeom g, StepLds L, double duration, d2d_fit_opts opts,
+fit_step_kernel(int B, FitGeom g, StepLds L, d2d_fit_opts opts,
                 const double *__restrict__ gG64, const double *__restrict__ gGp64,
-                const double *__restrict__ scen, double *__restrict__ q_io,
+                const double *__restrict__ prep, double *__restrict__ q_io,
                 const double *__restrict__ g_in, const float *__restrict__ H_in,
                 double *__restrict__ cost_io, double *__restrict__ lm, int32_t *__restrict__ flags) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int b = blockIdx.x * (blockDim.x >> 6) + wave;
+  const bool active = b < B && flags[4 * b + FL_STATUS] == D2D_ST_RUNNING;
+  if (!__syncthreads_or(active ? 1 : 0)) return;
   double *G64 = reinterpret_cast<double *>(lds + L.G64);
   double *Gp64 = reinterpret_cast<double *>(lds + L.Gp64);
   stage(G64, gG64, 3 * g.K * g.gstr * 8);
   stage(Gp64, gGp64, 3 * g.K * 4 * 8);
   __syncthreads();
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int b = blockIdx.x * (blockDim.x >> 6) + wave;
-  if (b >= B) return;
-  if (flags[4 * b + FL_STATUS] != D2D_ST_RUNNING) return;
+  if (!active) return;
   unsigned char *wl = lds + L.wave0 + wave * L.wave_stride;
   float *Lm = reinterpret_cast<float *>(wl + L.Lm);       // [N][N+1]
   double *qt = reinterpret_cast<double *>(wl + L.qt);     // trial point
@@ -268,19 +304,32 @@ fit_step_kernel(int B, FitGeom g, StepLds L, double duration, d2d_fit_opts opts,
     return;
   }
   // ---- row `lane` of A = H + lam*diag(max(H_ii, floor)) into registers ---------------
-  const float *Hb = H_in + (size_t)b * n * n;
+  // H arrives tile-major (fit_eval_kernel): stage the wave's 16x16 tiles in LDS with
+  // coalesced loads, then gather row `lane`.
+  constexpr int NBs = N / 16, NT = NBs * (NBs + 1) / 2;
+  {
+    const float *Hb = H_in + (size_t)b * NT * 256;
+#pragma unroll
+    for (int i = 0; i < NT * 4; ++i) Lm[i * 64 + lane] = Hb[i * 64 + lane];
+  }
+  wave_lds_sync();
   float row[N];
   float dgi = 1.f;
 #pragma unroll
   for (int j = 0; j < N; ++j) {
     float v = 0.f;
     if (act && j < n) {
-      // upper block triangle is stored; mirror the rest
-      const bool up = (lane >> 4) <= (j >> 4);
-      v = up ? Hb[(size_t)lane * n + j] : Hb[(size_t)j * n + lane];
+      const int J = j >> 4, I = lane >> 4;
+      const bool up = I <= J;
+      const int r = up ? lane : j, c = up ? j : lane;                 // element (r, c) of the upper block triangle
+      const int ti = r >> 4, tj = c >> 4;
+      const int tile = ti * NBs - ti * (ti - 1) / 2 + (tj - ti);
+      const int rr = r & 15;
+      v = Lm[(tile * 4 + (rr & 3)) * 64 + (rr >> 2) * 16 + (c & 15)];
     }
     row[j] = v;
   }
+  wave_lds_sync();     // Lm is reused for the Cholesky factor below
   // diagonal
   {
     float d = 1.f;
@@ -343,7 +392,7 @@ fit_step_kernel(int B, FitGeom g, StepLds L, double duration, d2d_fit_opts opts,
   // ---- trial point, predicted and actual reduction ------------------------------------
   if (lane < N) qt[lane] = qi + delta;
   wave_lds_sync();
-  const Scen s = load_scen(scen + (size_t)b * D2D_SCEN_STRIDE, duration);
+  const ScenP s = load_scenp(prep + (size_t)b * FIT_PREP_STRIDE);
   double ct = wave_cost(g, G64, Gp64, qt, s, lane);
   const double pred = wave_sum(delta * (lam * (double)dgi * delta - gi));
   const double dmax = wave_max(fabs(delta)), qmax = wave_max(fabs(qi));
@@ -530,9 +579,13 @@ static FitGeom geom_of(const d2d_fit_plan *pl) { return FitGeom{pl->K, pl->nq, p
 static int ensure_scratch(d2d_fit_plan *pl, int B) {
   if (B <= pl->cap_B) return D2D_OK;
   const size_t n = 2 * pl->nq;
-  if (pl->d_g) { hipFree(pl->d_g); hipFree(pl->d_H); hipFree(pl->d_cost); hipFree(pl->d_lm); hipFree(pl->d_flags); }
+  if (pl->d_g) { hipFree(pl->d_g); hipFree(pl->d_H); hipFree(pl->d_cost); hipFree(pl->d_lm); hipFree(pl->d_flags); hipFree(pl->d_prep); }
+  D2D_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&pl->d_prep), (size_t)B * FIT_PREP_STRIDE * sizeof(double)));
   D2D_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&pl->d_g), (size_t)B * n * sizeof(double)));
-  D2D_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&pl->d_H), (size_t)B * n * n * sizeof(float)));
+  {
+    const size_t nb = (n + 15) / 16, tiles = nb * (nb + 1) / 2;
+    D2D_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&pl->d_H), (size_t)B * tiles * 256 * sizeof(float)));
+  }
   D2D_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&pl->d_cost), (size_t)B * sizeof(double)));
   D2D_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&pl->d_lm), (size_t)B * 4 * sizeof(double)));
   D2D_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&pl->d_flags), (size_t)B * 4 * sizeof(int32_t)));
@@ -540,15 +593,27 @@ static int ensure_scratch(d2d_fit_plan *pl, int B) {
   return D2D_OK;
 }
 
-static int launch_eval(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, const double *scen, const double *q,
+static int launch_prep(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, const double *scen) {
+  hipLaunchKernelGGL(fit_prep_kernel, dim3((B + 255) / 256), dim3(256), 0, ctx->stream, B, pl->K, pl->duration, scen, pl->d_prep);
+  D2D_LAUNCH_CHECK();
+  return D2D_OK;
+}
+
+// d_prep must hold the rows of `scen` (launch_prep) before either kernel runs
+static int launch_eval(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, const double *q,
                        int32_t *flags, double *cost, double *g, float *H) {
   const FitGeom gm = geom_of(pl);
   const FitLds L = eval_lds_layout(pl->K, pl->nq, pl->g32_lds, pl->wpb_eval);
   const int NB = (2 * pl->nq + 15) / 16;
   const dim3 grid((B + pl->wpb_eval - 1) / pl->wpb_eval), block(64 * pl->wpb_eval);
+  static const int dbg = getenv("D2D_FIT_ABLATE") ? atoi(getenv("D2D_FIT_ABLATE")) : 0;   // timing experiments only
 #define LAUNCH_EVAL(NBV, INLDS)                                                                    \
-  hipLaunchKernelGGL((fit_eval_kernel<NBV, INLDS>), grid, block, L.total, ctx->stream, B, gm, L, pl->duration, \
-                     pl->d_G, pl->d_Gp, pl->d_G32, pl->d_W32, scen, q, flags, cost, g, H)
+  if (pl->nq == 24 && NBV == 3)                                                                    \
+    hipLaunchKernelGGL((fit_eval_kernel<3, 24, INLDS>), grid, block, L.total, ctx->stream, B, gm, L, dbg, \
+                       pl->d_G, pl->d_Gp, pl->d_G32, pl->d_W32, pl->d_prep, q, flags, cost, g, H);  \
+  else                                                                                             \
+  hipLaunchKernelGGL((fit_eval_kernel<NBV, 0, INLDS>), grid, block, L.total, ctx->stream, B, gm, L, dbg, \
+                     pl->d_G, pl->d_Gp, pl->d_G32, pl->d_W32, pl->d_prep, q, flags, cost, g, H)
   if (pl->g32_lds) {
     if (NB == 1) LAUNCH_EVAL(1, true);
     else if (NB == 2) LAUNCH_EVAL(2, true);
@@ -563,15 +628,14 @@ static int launch_eval(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, const double
   return D2D_OK;
 }
 
-static int launch_step(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, const double *scen, double *q,
-                       const d2d_fit_opts &o) {
+static int launch_step(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, double *q, const d2d_fit_opts &o) {
   const FitGeom gm = geom_of(pl);
   const int NB = (2 * pl->nq + 15) / 16;
   const StepLds L = step_lds_layout(pl->K, pl->nq, 16 * NB, pl->wpb_step);
   const dim3 grid((B + pl->wpb_step - 1) / pl->wpb_step), block(64 * pl->wpb_step);
 #define LAUNCH_STEP(NV)                                                                            \
-  hipLaunchKernelGGL(fit_step_kernel<NV>, grid, block, L.total, ctx->stream, B, gm, L, pl->duration, o, \
-                     pl->d_G, pl->d_Gp, scen, q, pl->d_g, pl->d_H, pl->d_cost, pl->d_lm, pl->d_flags)
+  hipLaunchKernelGGL(fit_step_kernel<NV>, grid, block, L.total, ctx->stream, B, gm, L, o, \
+                     pl->d_G, pl->d_Gp, pl->d_prep, q, pl->d_g, pl->d_H, pl->d_cost, pl->d_lm, pl->d_flags)
   if (NB == 1) LAUNCH_STEP(16);
   else if (NB == 2) LAUNCH_STEP(32);
   else LAUNCH_STEP(48);
@@ -610,11 +674,22 @@ int d2d_fit_plan_create(d2d_ctx *ctx, int S, int K, double duration, const doubl
   for (int d = 0; d < 3; ++d)
     for (int k = 0; k < K; ++k)
       for (int j = 0; j < nq; ++j) g64[((size_t)d * K + k) * gstr + j] = pl->G[((size_t)d * K + k) * nq + j];
-  std::vector<float> g32((size_t)K * nq * 4, 0.f), w32((size_t)nq * nq);
-  for (int k = 0; k < K; ++k)
-    for (int j = 0; j < nq; ++j)
-      for (int d = 0; d < 3; ++d) g32[((size_t)k * nq + j) * 4 + d] = (float)pl->G[((size_t)d * K + k) * nq + j];
-  for (size_t i = 0; i < w32.size(); ++i) w32[i] = (float)pl->G0tG0[i];
+  std::vector<float> g32((size_t)(3 * K + 1) * nq, 0.f), w32((size_t)nq * nq);
+  for (size_t i = 0; i < (size_t)3 * K * nq; ++i) g32[i] = (float)pl->G[i];        // [d][k][j] planes + one zero row
+  {
+    // waypoint rows' constant J^T J block, pre-arranged in the MFMA C/D tile layout
+    const int n = 2 * nq, NBh = (n + 15) / 16, NT = NBh * (NBh + 1) / 2;
+    w32.assign((size_t)NT * 256, 0.f);
+    int t = 0;
+    for (int I = 0; I < NBh; ++I)
+      for (int J = I; J < NBh; ++J, ++t)
+        for (int r = 0; r < 4; ++r)
+          for (int l = 0; l < 64; ++l) {
+            const int row = 16 * I + 4 * (l >> 4) + r, col = 16 * J + (l & 15);
+            if (row < n && col < n && (row >= nq) == (col >= nq))
+              w32[((size_t)t * 4 + r) * 64 + l] = (float)pl->G0tG0[(size_t)(row % nq) * nq + (col % nq)];
+          }
+  }
   D2D_CHECK_HIP(hipSetDevice(ctx->device));
   int rc = upload(&pl->d_G, g64);
   if (!rc) rc = upload(&pl->d_Gp, pl->Gp);
@@ -625,8 +700,9 @@ int d2d_fit_plan_create(d2d_ctx *ctx, int S, int K, double duration, const doubl
   if (!rc) rc = upload(&pl->d_Pinit, pl->Pinit);
   if (rc) { d2d_fit_plan_destroy(pl); return rc; }
   // opt in to large dynamic LDS
-  allow_big_lds(&fit_eval_kernel<1, true>); allow_big_lds(&fit_eval_kernel<2, true>); allow_big_lds(&fit_eval_kernel<3, true>);
-  allow_big_lds(&fit_eval_kernel<1, false>); allow_big_lds(&fit_eval_kernel<2, false>); allow_big_lds(&fit_eval_kernel<3, false>);
+  allow_big_lds(&fit_eval_kernel<1, 0, true>); allow_big_lds(&fit_eval_kernel<2, 0, true>); allow_big_lds(&fit_eval_kernel<3, 0, true>);
+  allow_big_lds(&fit_eval_kernel<1, 0, false>); allow_big_lds(&fit_eval_kernel<2, 0, false>); allow_big_lds(&fit_eval_kernel<3, 0, false>);
+  allow_big_lds(&fit_eval_kernel<3, 24, true>); allow_big_lds(&fit_eval_kernel<3, 24, false>);
   allow_big_lds(&fit_step_kernel<16>); allow_big_lds(&fit_step_kernel<32>); allow_big_lds(&fit_step_kernel<48>);
   (void)hipGetLastError();
   *out = pl;
@@ -638,7 +714,7 @@ int d2d_fit_plan_destroy(d2d_fit_plan *pl) {
   hipSetDevice(pl->device);
   for (hipEvent_t e : pl->prof_ev) (void)hipEventDestroy(e);
   void *ptrs[] = {pl->d_G, pl->d_Gp, pl->d_G32, pl->d_W32, pl->d_Z, pl->d_Zp, pl->d_Pinit,
-                  pl->d_g, pl->d_H, pl->d_cost, pl->d_lm, pl->d_flags};
+                  pl->d_g, pl->d_H, pl->d_cost, pl->d_lm, pl->d_flags, pl->d_prep};
   for (void *p : ptrs)
     if (p) hipFree(p);
   delete pl;
@@ -677,9 +753,14 @@ int d2d_fit_eval(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, const double *scen
                  double *cost, double *g, float *H) {
   D2D_REQUIRE(ctx && pl && scen && q, "d2d_fit_eval: null argument");
   D2D_REQUIRE(B >= 1, "d2d_fit_eval: B must be >= 1");
-  if (int rc = launch_eval(ctx, pl, B, scen, q, nullptr, cost, g, H)) return rc;
+  d2d_fit_plan *plm = const_cast<d2d_fit_plan *>(pl);
+  if (plm->active_B != 0 && B > plm->cap_B) { d2d_set_error("d2d_fit_eval: a solve of a smaller batch is in progress on this plan"); return D2D_ESTATE; }
+  if (int rc = ensure_scratch(plm, B)) return rc;
+  if (int rc = launch_prep(ctx, pl, B, scen)) return rc;
+  if (int rc = launch_eval(ctx, pl, B, q, nullptr, cost, g, H ? plm->d_H : nullptr)) return rc;
+  plm->prep_valid_for = nullptr;
   if (H) {
-    hipLaunchKernelGGL(symmetrize_kernel, dim3(B), dim3(256), 0, ctx->stream, B, 2 * pl->nq, H);
+    hipLaunchKernelGGL(untile_kernel, dim3(B), dim3(256), 0, ctx->stream, B, 2 * pl->nq, (2 * pl->nq + 15) / 16, plm->d_H, H);
     D2D_LAUNCH_CHECK();
   }
   return D2D_OK;
@@ -739,6 +820,7 @@ int d2d_fit_begin(d2d_ctx *ctx, d2d_fit_plan *pl, int B) {
   D2D_LAUNCH_CHECK();
   pl->it_done = 0;
   pl->active_B = B;
+  pl->prep_valid_for = nullptr;
   return D2D_OK;
 }
 
@@ -749,12 +831,16 @@ int d2d_fit_iterate(d2d_ctx *ctx, d2d_fit_plan *pl, int B, const double *scen, d
   const d2d_fit_opts o = opts_or_default(opts);
   D2D_REQUIRE(o.max_iter >= 1 && n_iters >= 1, "d2d_fit_iterate: max_iter and n_iters must be >= 1");
   const dim3 g1((B + 255) / 256), b1(256);
+  if (pl->prep_valid_for != scen) {
+    if (int rc = launch_prep(ctx, pl, B, scen)) return rc;
+    pl->prep_valid_for = scen;
+  }
   for (int i = 0; i < n_iters && pl->it_done < o.max_iter; ++i, ++pl->it_done) {
     if (int rc = prof_begin(ctx, pl, 0)) return rc;
-    if (int rc = launch_eval(ctx, pl, B, scen, q, pl->d_flags, pl->d_cost, pl->d_g, pl->d_H)) return rc;
+    if (int rc = launch_eval(ctx, pl, B, q, pl->d_flags, pl->d_cost, pl->d_g, pl->d_H)) return rc;
     if (int rc = prof_end(ctx, pl)) return rc;
     if (int rc = prof_begin(ctx, pl, 1)) return rc;
-    if (int rc = launch_step(ctx, pl, B, scen, q, o)) return rc;
+    if (int rc = launch_step(ctx, pl, B, q, o)) return rc;
     if (int rc = prof_end(ctx, pl)) return rc;
   }
   if (n_running) {
@@ -774,7 +860,11 @@ int d2d_fit_finish(d2d_ctx *ctx, d2d_fit_plan *pl, int B, const double *scen, co
   if (pl->active_B != B) { d2d_set_error("d2d_fit_finish: call d2d_fit_begin(B=%d) first", B); return D2D_ESTATE; }
   const dim3 g1((B + 255) / 256), b1(256);
   // converged trajectories carry a pending evaluation at the accepted point: refresh cost / J^T r
-  if (int rc = launch_eval(ctx, pl, B, scen, q, nullptr, pl->d_cost, pl->d_g, nullptr)) return rc;
+  if (pl->prep_valid_for != scen) {
+    if (int rc = launch_prep(ctx, pl, B, scen)) return rc;
+    pl->prep_valid_for = scen;
+  }
+  if (int rc = launch_eval(ctx, pl, B, q, nullptr, pl->d_cost, pl->d_g, nullptr)) return rc;
   if (cost) D2D_CHECK_HIP(hipMemcpyAsync(cost, pl->d_cost, (size_t)B * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
   hipLaunchKernelGGL(fit_export_kernel, g1, b1, 0, ctx->stream, B, pl->d_flags, iters, status);
   D2D_LAUNCH_CHECK();
@@ -787,6 +877,7 @@ int d2d_fit_finish(d2d_ctx *ctx, d2d_fit_plan *pl, int B, const double *scen, co
   D2D_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   if (stats)
     for (int i = 0; i < 4; ++i) stats[i] = ctx->stats_host[i];
+  pl->active_B = 0;
   return D2D_OK;
 }
 

@@ -14,7 +14,7 @@ struct d2d_fit_plan {
   // device copies
   double *d_G = nullptr;     // [3][K][GSTR]   GSTR = nq+1 (odd stride: conflict-free LDS image)
   double *d_Gp = nullptr;    // [3][K][4]
-  float *d_G32 = nullptr;    // [K][nq][4] = (G0,G1,G2,0) for the MFMA operand generation
+  float *d_G32 = nullptr;    // [3][K][nq] fp32 planes for the MFMA operand generation
   float *d_W32 = nullptr;    // [nq][nq]  G0^T G0 (waypoint rows' constant J^T J block)
   double *d_Z = nullptr;     // [8S][nq]
   double *d_Zp = nullptr;    // [8S][4]
@@ -26,6 +26,8 @@ struct d2d_fit_plan {
   double *d_cost = nullptr;  // [B]
   double *d_lm = nullptr;    // [B][4] lambda, nu, gmax, pad
   int32_t *d_flags = nullptr;  // [B][4] status, iters, need_eval, nevals
+  double *d_prep = nullptr;    // [B][FIT_PREP_STRIDE] derived scenario rows (fit_prep_kernel)
+  const double *prep_valid_for = nullptr;   // scen pointer d_prep was derived from
   // launch geometry chosen at plan creation from the LDS footprint
   bool g32_lds = true;
   int wpb_eval = 8, wpb_step = 8;
