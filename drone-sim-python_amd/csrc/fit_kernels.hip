@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "fit_device.h"
+#include "fit_phases.h"
 #include "fit_plan.h"
 
 #define FIT_WPB_MAX 16       // wavefronts (= trajectories) per workgroup, fewer when K is large
@@ -112,39 +113,9 @@ fit_eval_kernel(int B, FitGeom g, FitLds L, int dbg, const double *__restrict__ 
   __syncthreads();
   if (!active) return;
 
-  // ---- phase 1: lane = sample ------------------------------------------------------
-  double cacc = 0.0;
-  for (int k0 = 0; k0 < g.K; k0 += 64) {
-    const int k = k0 + lane;
-    if (k < g.K) {
-      double Y[6] = {1.0 + k, 2.0, 11.0, 3.0, 0.1, 0.2}, wpx, wpy, u[6] = {0, 0, 0, 0, 0, 0};
-      f32x4 coef[4] = {f32x4{1.f, 0.f, 1.f, 0.f}, f32x4{1.f, 0.f, 1.f, 0.f}, f32x4{1.f, 0.f, 1.f, 0.f}, f32x4{1.f, 0.f, 1.f, 0.f}};
-      if (!(dbg & 8)) flat_outputs(g, G64, Gp64, qs, s, k, Y);
-      waypoint_at(s, g.K, k, wpx, wpy);
-      if (!(dbg & 1)) cacc += sample_terms<true>(s, Y, wpx, wpy, u, coef);
-#pragma unroll
-      for (int c = 0; c < 6; ++c) us[k * 6 + c] = u[c];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) cf[k * 4 + r] = coef[r];
-    }
-  }
-  const double cost = wave_sum(cacc);
-  wave_lds_sync();
-
-  // ---- phase 2: J^T r, lane = unknown (fp64), three independent accumulation chains ----
-  if (lane < n && !(dbg & 2)) {
-    const int ax = lane >= g.nq ? 1 : 0, jj = lane - ax * g.nq;
-    const double *g0 = G64 + jj, *g1 = g0 + (size_t)g.K * g.gstr, *g2 = g1 + (size_t)g.K * g.gstr;
-    const double *uk = us + ax;
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-#pragma unroll 5
-    for (int k = 0; k < g.K; ++k) {
-      a0 = fma(uk[k * 6], g0[k * g.gstr], a0);
-      a1 = fma(uk[k * 6 + 2], g1[k * g.gstr], a1);
-      a2 = fma(uk[k * 6 + 4], g2[k * g.gstr], a2);
-    }
-    if (g_out) g_out[(size_t)b * n + lane] = (a0 + a1) + a2;
-  }
+  double g_lane;
+  const double cost = eval_cost_grad(g, G64, Gp64, qs, us, cf, s, lane, dbg, g_lane);
+  if (lane < n && g_out) g_out[(size_t)b * n + lane] = g_lane;
   if (lane == 0) {
     if (cost_out) cost_out[b] = cost;
     if (flags) {
@@ -154,62 +125,9 @@ fit_eval_kernel(int B, FitGeom g, FitLds L, int dbg, const double *__restrict__ 
     }
   }
   if (!H_out) return;
-
-  // ---- phase 3: J^T J by v_mfma_f32_16x16x4_f32 --------------------------------------
-  // One MFMA k-step = the four contracted rows (v, phi, obs0, obs1) of one sample.
-  // Lane l supplies J[row rho = l>>4][col 16c + (l&15)] as A- and as B-operand alike:
-  //   J = cA * TA[k][j] + cB * TB[k][j],  TA = G1 (v, phi) or G0 (obstacles), TB = G2 (phi only).
-  // Operands of sample k+1 are fetched before the MFMAs of sample k are issued.
-  const int rho = lane >> 4, ci = lane & 15;
-  const int nq = NQ ? NQ : g.nq;
-  const int plane = g.K * nq;
   const float *T32 = G32_LDS ? reinterpret_cast<const float *>(lds + L.G32) : gG32;
-  bool jok[NB];
-  const float *pc[NB], *pa[NB], *pb[NB];   // per-lane running pointers: (cA,cB) pair, TA entry, TB entry
-#pragma unroll
-  for (int c = 0; c < NB; ++c) {
-    const int col = 16 * c + ci;
-    jok[c] = col < n;
-    const bool ay = col >= nq;
-    const int j = jok[c] ? col - (ay ? nq : 0) : 0;
-    pc[c] = reinterpret_cast<const float *>(cf + rho) + (ay ? 2 : 0);
-    pa[c] = T32 + ((rho < 2) ? plane : 0) + j;
-    pb[c] = T32 + 2 * plane + j;
-  }
   f32x4 acc[NB * (NB + 1) / 2];
-#pragma unroll
-  for (int t = 0; t < NB * (NB + 1) / 2; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int Kmf = (dbg & 4) ? 1 : g.K;
-  float2 cc[NB];
-  float ta[NB], tb[NB];
-#pragma unroll
-  for (int c = 0; c < NB; ++c) {
-    cc[c] = *reinterpret_cast<const float2 *>(pc[c]);
-    ta[c] = *pa[c]; tb[c] = *pb[c];
-  }
-#pragma unroll 5
-  for (int k = 0; k < Kmf; ++k) {
-    float v[NB];
-#pragma unroll
-    for (int c = 0; c < NB; ++c) {
-      const float val = fmaf(cc[c].y, tb[c], cc[c].x * ta[c]);
-      v[c] = (2 * nq == 16 * NB || jok[c]) ? val : 0.f;
-    }
-    // operands of sample k+1 (the tables carry one padded row, so k+1 == K is in bounds)
-#pragma unroll
-    for (int c = 0; c < NB; ++c) {
-      cc[c] = *reinterpret_cast<const float2 *>(pc[c] + (k + 1) * 16);
-      ta[c] = pa[c][(k + 1) * nq]; tb[c] = pb[c][(k + 1) * nq];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    int t = 0;
-#pragma unroll
-    for (int I = 0; I < NB; ++I)
-#pragma unroll
-      for (int J = I; J < NB; ++J, ++t)
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[I], v[J], acc[t], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-  }
+  jtj_mfma<NB, NQ>(g, T32, cf, lane, (dbg & 4) ? 1 : g.K, acc);
   // epilogue: + wwp^2 G0^T G0 (pre-tiled constant) ; tile-major store: [tile][reg][lane], 256 B per store
   const float ww = (float)(s.wwp * s.wwp);
   float *Hb = H_out + (size_t)b * (NB * (NB + 1) / 2) * 256;
@@ -303,9 +221,8 @@ fit_step_kernel(int B, FitGeom g, StepLds L, d2d_fit_opts opts,
     if (lane == 0) flags[4 * b + FL_STATUS] = D2D_ST_CONVERGED;
     return;
   }
-  // ---- row `lane` of A = H + lam*diag(max(H_ii, floor)) into registers ---------------
-  // H arrives tile-major (fit_eval_kernel): stage the wave's 16x16 tiles in LDS with
-  // coalesced loads, then gather row `lane`.
+  // H arrives tile-major (fit_eval_kernel): stage the wave's 16x16 tiles in LDS with coalesced
+  // loads, gather row `lane`, then reuse the LDS block for the Cholesky factor.
   constexpr int NBs = N / 16, NT = NBs * (NBs + 1) / 2;
   {
     const float *Hb = H_in + (size_t)b * NT * 256;
@@ -313,109 +230,28 @@ fit_step_kernel(int B, FitGeom g, StepLds L, d2d_fit_opts opts,
     for (int i = 0; i < NT * 4; ++i) Lm[i * 64 + lane] = Hb[i * 64 + lane];
   }
   wave_lds_sync();
-  float row[N];
-  float dgi = 1.f;
-#pragma unroll
-  for (int j = 0; j < N; ++j) {
-    float v = 0.f;
-    if (act && j < n) {
-      const int J = j >> 4, I = lane >> 4;
-      const bool up = I <= J;
-      const int r = up ? lane : j, c = up ? j : lane;                 // element (r, c) of the upper block triangle
-      const int ti = r >> 4, tj = c >> 4;
-      const int tile = ti * NBs - ti * (ti - 1) / 2 + (tj - ti);
-      const int rr = r & 15;
-      v = Lm[(tile * 4 + (rr & 3)) * 64 + (rr >> 2) * 16 + (c & 15)];
-    }
-    row[j] = v;
-  }
-  wave_lds_sync();     // Lm is reused for the Cholesky factor below
-  // diagonal
-  {
-    float d = 1.f;
-#pragma unroll
-    for (int j = 0; j < N; ++j)
-      if (j == lane) d = row[j];
-    if (!act) d = 1.f;
-    dgi = fmaxf(d, (float)D2D_LM_DIAG_FLOOR);
-    const float add = (float)(lam * (double)dgi);
-#pragma unroll
-    for (int j = 0; j < N; ++j)
-      if (j == lane) row[j] = act ? (d + add) : 1.f;
-  }
-  // ---- Cholesky, left-looking: lane = row, row j broadcast by v_readlane --------------
-  bool ok = true;
-#pragma unroll
-  for (int j = 0; j < N; ++j) {
-    float sacc = row[j];
-#pragma unroll
-    for (int k = 0; k < j; ++k) {
-      const float ljk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, row[k]), j));
-      sacc = fmaf(-row[k], ljk, sacc);
-    }
-    const float djj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sacc), j));
-    ok = ok && (djj > 0.f);
-    const float inv = rsqrtf(fmaxf(djj, 1e-30f));
-    row[j] = (lane >= j) ? sacc * inv : 0.f;   // L[lane][j]; diagonal = sqrt(djj)
-  }
-  // ---- forward substitution L y = -g (lane i keeps y_i) ------------------------------
-  float y = (float)(-gi);
-#pragma unroll
-  for (int j = 0; j < N; ++j) {
-    float ljj = 1.f;
-#pragma unroll
-    for (int t = 0; t < N; ++t)
-      if (t == j) ljj = row[t];
-    const float yj_own = y / ljj;                                  // valid on lane j
-    const float yj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, yj_own), j));
-    if (lane == j) y = yj;
-    else if (lane > j) y = fmaf(-row[j], yj, y);
-  }
-  // ---- back substitution L^T delta = y: needs columns of L -> stage L in LDS ----------
-#pragma unroll
-  for (int j = 0; j < N; ++j)
-    if (lane < N) Lm[lane * LS + j] = row[j];
+  float hrow[N];
+  gather_row<N>(Lm, lane, n, act, hrow);
   wave_lds_sync();
-  float dl = y;
-#pragma unroll
-  for (int i = N - 1; i >= 0; --i) {
-    float lii = 1.f;
-#pragma unroll
-    for (int t = 0; t < N; ++t)
-      if (t == i) lii = row[t];
-    const float di_own = dl / lii;                                 // valid on lane i
-    const float di = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, di_own), i));
-    if (lane == i) dl = di;
-    else if (lane < i) dl = fmaf(-Lm[i * LS + lane], di, dl);      // L[i][lane]
-  }
-  const double delta = act ? (double)dl : 0.0;
+  float dgi, dl;
+  const bool ok = damped_solve<N>(hrow, lam, gi, act, lane, Lm, dgi, dl);
+  const double delta = (double)dl;
   // ---- trial point, predicted and actual reduction ------------------------------------
   if (lane < N) qt[lane] = qi + delta;
   wave_lds_sync();
   const ScenP s = load_scenp(prep + (size_t)b * FIT_PREP_STRIDE);
-  double ct = wave_cost(g, G64, Gp64, qt, s, lane);
+  const double ct = wave_cost(g, G64, Gp64, qt, s, lane);
   const double pred = wave_sum(delta * (lam * (double)dgi * delta - gi));
   const double dmax = wave_max(fabs(delta)), qmax = wave_max(fabs(qi));
-  const bool fin = ok && (fabs(ct) <= 1.79e308) && (pred > 0.0);
-  const double rho = fin ? (c - ct) / pred : -1.0;
-  int status = D2D_ST_RUNNING;
-  double lam_n = lam, nu_n = nu;
-  if (rho > 0.0) {
+  const StepOutcome so = judge_step(ok, c, ct, pred, dmax, qmax, lam, nu, opts);
+  int status = so.status;
+  const double lam_n = so.lam, nu_n = so.nu;
+  if (so.accept) {
     if (act) q_io[(size_t)b * n + lane] = qi + delta;
-    const double t = 2.0 * rho - 1.0;
-    lam_n = fmax(lam * fmax(1.0 / 3.0, 1.0 - t * t * t), D2D_LM_LAMBDA_MIN);
-    nu_n = 2.0;
-    const bool small_x = dmax <= opts.xtol * (qmax + opts.xtol);
-    const bool small_f = ((c - ct) <= opts.ftol * c) && (pred <= opts.ftol * c);
-    if (small_f || small_x) status = D2D_ST_CONVERGED;
     if (lane == 0) {
       cost_io[b] = ct;
       flags[4 * b + FL_NEED] = 1;     // gradient / Hessian at the new point (also when converged)
     }
-  } else {
-    lam_n = lam * nu;
-    nu_n = nu * 2.0;
-    if (lam_n > D2D_LM_LAMBDA_MAX) status = D2D_ST_STALLED;
   }
   if (lane == 0) {
     lm[4 * b + 0] = lam_n;
@@ -423,6 +259,150 @@ fit_step_kernel(int B, FitGeom g, StepLds L, d2d_fit_opts opts,
     flags[4 * b + FL_ITERS] = iters + 1;
     if (status == D2D_ST_RUNNING && iters + 1 >= opts.max_iter) status = D2D_ST_MAXITER;
     flags[4 * b + FL_STATUS] = status;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// The whole Levenberg-Marquardt loop in ONE persistent launch: a wavefront takes a trajectory,
+// runs eval -> damped solve -> trial -> accept/reject until the trajectory stops (or its
+// iteration budget for this launch is spent), stores the state and takes its next trajectory.  J^T J never leaves the CU (MFMA accumulators -> LDS tiles -> the
+// Cholesky's registers), waves drift apart so that one wave's MFMA phase overlaps another's
+// fp64 VALU phases, and trajectories that converge early free their wave for the tail.
+#define FIT_LM_WPB_MAX 8
+struct FusedLds {
+  int G64, Gp64, G32, wave0, wave_stride;
+  int qs, qt, big, cf;      // inside a wave's block; `big` holds us+cf, then the tiles, then the factor
+  int total;
+};
+static FusedLds fused_lds_layout(int K, int nq, int N, int wpb) {
+  FusedLds L;
+  const int gstr = nq + 1;
+  int o = 0;
+  L.G64 = o; o = align16(o + 3 * K * gstr * 8);
+  L.Gp64 = o; o = align16(o + 3 * K * 4 * 8);
+  L.G32 = o; o = align16(o + (3 * K + 1) * nq * 4);
+  L.wave0 = o;
+  int w = 0;
+  L.qs = w; w = align16(w + N * 8);
+  L.qt = w; w = align16(w + N * 8);
+  L.big = w;
+  const int us_bytes = align16(K * 6 * 8), cf_bytes = (K + 1) * 4 * 16;
+  L.cf = w + us_bytes;
+  const int nb = N / 16, tiles = nb * (nb + 1) / 2;
+  int big = us_bytes + cf_bytes;
+  if (tiles * 1024 > big) big = tiles * 1024;
+  if (N * (N + 1) * 4 > big) big = N * (N + 1) * 4;
+  w = align16(w + big);
+  L.wave_stride = w;
+  L.total = o + wpb * w;
+  return L;
+}
+static bool pick_fused_layout(int K, int nq, int N, int *wpb) {
+  for (int w = FIT_LM_WPB_MAX; w >= 4; --w)
+    if (fused_lds_layout(K, nq, N, w).total <= FIT_LDS_BYTES) { *wpb = w; return true; }
+  return false;
+}
+
+template <int NB, int NQ>
+__global__ void __launch_bounds__(64 * FIT_LM_WPB_MAX)
+fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_budget,
+              const double *__restrict__ gG64, const double *__restrict__ gGp64,
+              const float *__restrict__ gG32, const float *__restrict__ gWt,
+              const double *__restrict__ prep, double *__restrict__ q_io, double *__restrict__ cost_io,
+              double *__restrict__ g_io, double *__restrict__ lm, int32_t *__restrict__ flags,
+              int32_t *__restrict__ work) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  constexpr int N = 16 * NB, NT = NB * (NB + 1) / 2;
+  double *G64 = reinterpret_cast<double *>(lds + L.G64);
+  double *Gp64 = reinterpret_cast<double *>(lds + L.Gp64);
+  const float *T32 = reinterpret_cast<const float *>(lds + L.G32);
+  stage(G64, gG64, 3 * g.K * g.gstr * 8);
+  stage(Gp64, gGp64, 3 * g.K * 4 * 8);
+  stage(lds + L.G32, gG32, (3 * g.K + 1) * g.nq * 4);
+  __syncthreads();
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  unsigned char *wl = lds + L.wave0 + wave * L.wave_stride;
+  double *qs = reinterpret_cast<double *>(wl + L.qs);
+  double *qt = reinterpret_cast<double *>(wl + L.qt);
+  double *us = reinterpret_cast<double *>(wl + L.big);
+  f32x4 *cf = reinterpret_cast<f32x4 *>(wl + L.cf);
+  float *big = reinterpret_cast<float *>(wl + L.big);          // tiles, then the Cholesky factor
+  const int n = 2 * g.nq;
+  const bool act = lane < n;
+
+  // static striding over the batch: wave w of workgroup g takes trajectories g*wpb + w, + gridDim*wpb, ...
+  (void)work;
+  const int stride = gridDim.x * (blockDim.x >> 6);
+  for (int b = blockIdx.x * (blockDim.x >> 6) + wave; b < B; b += stride) {
+    if (flags[4 * b + FL_STATUS] != D2D_ST_RUNNING) continue;
+    const double *prow = prep + (size_t)b * FIT_PREP_STRIDE;
+    double qi = act ? q_io[(size_t)b * n + lane] : 0.0;
+    double lam = lm[4 * b + 0], nu = lm[4 * b + 1];          // scalar loads: uniform
+    int iters = flags[4 * b + FL_ITERS];
+    int nev = 0, local = 0, status = D2D_ST_RUNNING;
+    double c = 0.0, gi = 0.0;
+    float hrow[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) hrow[j] = 0.f;
+    bool need_eval = true;
+    // every value that steers the loop below is made scalar (uniform_*): the control flow is
+    // wave-uniform by construction and must compile to scalar branches
+    for (;;) {
+      if (need_eval) {
+        if (lane < N) qs[lane] = qi;
+        wave_lds_sync();
+        const ScenP s = load_scenp(prow);
+        c = uniform_d(eval_cost_grad(g, G64, Gp64, qs, us, cf, s, lane, 0, gi));
+        ++nev;
+        if (!(fabs(c) <= 1.79e308)) { status = D2D_ST_NONFINITE; break; }
+        if (status != D2D_ST_RUNNING) break;             // accepted + converged: cost / J^T r refreshed
+        f32x4 acc[NT];
+        jtj_mfma<NB, NQ>(g, T32, cf, lane, g.K, acc);
+        wave_lds_sync();                                 // every lane is done with cf before it is overwritten
+        const float ww = (float)(s.wwp * s.wwp);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) big[(t * 4 + r) * 64 + lane] = fmaf(ww, gWt[(t * 4 + r) * 64 + lane], acc[t][r]);
+        wave_lds_sync();
+        gather_row<N>(big, lane, n, act, hrow);
+        wave_lds_sync();
+        need_eval = false;
+      }
+      if (local >= iter_budget || iters >= opts.max_iter) break;
+      const double gmax = uniform_d(wave_max(fabs(gi)));
+      if (gmax <= opts.gtol) { status = D2D_ST_CONVERGED; break; }
+      float dgi, dl;
+      const int ok = uniform_i(damped_solve<N>(hrow, lam, gi, act, lane, big, dgi, dl) ? 1 : 0);
+      const double delta = (double)dl;
+      if (lane < N) qt[lane] = qi + delta;
+      wave_lds_sync();
+      double ct;
+      {
+        const ScenP s = load_scenp(prow);
+        ct = uniform_d(wave_cost(g, G64, Gp64, qt, s, lane));
+      }
+      const double pred = uniform_d(wave_sum(delta * (lam * (double)dgi * delta - gi)));
+      const double dmax = uniform_d(wave_max(fabs(delta))), qmax = uniform_d(wave_max(fabs(qi)));
+      const StepOutcome so = judge_step(ok != 0, c, ct, pred, dmax, qmax, lam, nu, opts);
+      ++iters; ++local;
+      lam = so.lam; nu = so.nu; status = so.status;
+      if (so.accept) {
+        qi += delta; c = ct;
+        need_eval = true;                                // also when converged: refresh cost / J^T r
+      } else if (status != D2D_ST_RUNNING) {
+        break;
+      }
+    }
+    if (status == D2D_ST_RUNNING && iters >= opts.max_iter) status = D2D_ST_MAXITER;
+    const double gmax = uniform_d(wave_max(fabs(gi)));
+    if (act) { q_io[(size_t)b * n + lane] = qi; g_io[(size_t)b * n + lane] = gi; }
+    if (lane == 0) {
+      cost_io[b] = c;
+      lm[4 * b + 0] = lam; lm[4 * b + 1] = nu; lm[4 * b + 2] = gmax;
+      flags[4 * b + FL_STATUS] = status; flags[4 * b + FL_ITERS] = iters; flags[4 * b + FL_NEED] = 1;
+      flags[4 * b + FL_NEVAL] += nev;
+    }
   }
 }
 
@@ -644,6 +624,19 @@ static int launch_step(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, double *q, c
   return D2D_OK;
 }
 
+static int launch_lm(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, double *q, const d2d_fit_opts &o, int budget) {
+  const FitGeom gm = geom_of(pl);
+  const FusedLds L = fused_lds_layout(pl->K, pl->nq, 48, pl->wpb_lm);
+  D2D_CHECK_HIP(hipMemsetAsync(ctx->counter_dev + 4, 0, sizeof(int32_t), ctx->stream));
+  int blocks = (B + pl->wpb_lm - 1) / pl->wpb_lm;
+  if (blocks > pl->n_cu) blocks = pl->n_cu;           // persistent: one workgroup per CU pulls work
+  hipLaunchKernelGGL((fit_lm_kernel<3, 24>), dim3(blocks), dim3(64 * pl->wpb_lm), L.total, ctx->stream, B, gm, L, o, budget,
+                     pl->d_G, pl->d_Gp, pl->d_G32, pl->d_W32, pl->d_prep, q, pl->d_cost, pl->d_g, pl->d_lm, pl->d_flags,
+                     ctx->counter_dev + 4);
+  D2D_LAUNCH_CHECK();
+  return D2D_OK;
+}
+
 template <typename KernelT>
 static void allow_big_lds(KernelT k) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, FIT_LDS_BYTES);
@@ -668,6 +661,12 @@ int d2d_fit_plan_create(d2d_ctx *ctx, int S, int K, double duration, const doubl
     d2d_set_error("d2d_fit_plan_create: K=%d, S=%d does not fit the 160 KiB LDS image of the basis block", K, S);
     delete pl;
     return D2D_EINVAL;
+  }
+  pl->use_lm = (nq == 24) && pick_fused_layout(K, nq, 48, &pl->wpb_lm) && !getenv("D2D_FIT_SPLIT");
+  {
+    hipDeviceProp_t prop;
+    D2D_CHECK_HIP(hipGetDeviceProperties(&prop, ctx->device));
+    pl->n_cu = prop.multiProcessorCount;
   }
   // device images: G64 with odd row stride, G32 interleaved (G0,G1,G2,0), W32 = G0^T G0
   std::vector<double> g64((size_t)3 * K * gstr, 0.0);
@@ -703,6 +702,7 @@ int d2d_fit_plan_create(d2d_ctx *ctx, int S, int K, double duration, const doubl
   allow_big_lds(&fit_eval_kernel<1, 0, true>); allow_big_lds(&fit_eval_kernel<2, 0, true>); allow_big_lds(&fit_eval_kernel<3, 0, true>);
   allow_big_lds(&fit_eval_kernel<1, 0, false>); allow_big_lds(&fit_eval_kernel<2, 0, false>); allow_big_lds(&fit_eval_kernel<3, 0, false>);
   allow_big_lds(&fit_eval_kernel<3, 24, true>); allow_big_lds(&fit_eval_kernel<3, 24, false>);
+  allow_big_lds(&fit_lm_kernel<3, 24>);
   allow_big_lds(&fit_step_kernel<16>); allow_big_lds(&fit_step_kernel<32>); allow_big_lds(&fit_step_kernel<48>);
   (void)hipGetLastError();
   *out = pl;
@@ -795,7 +795,7 @@ int d2d_fit_profile(d2d_fit_plan *pl, int enable) {
 
 int d2d_fit_profile_read(d2d_fit_plan *pl, double *out) {
   D2D_REQUIRE(pl && out, "d2d_fit_profile_read: null argument");
-  for (int i = 0; i < 4; ++i) out[i] = 0.0;
+  for (int i = 0; i < 6; ++i) out[i] = 0.0;
   for (size_t i = 0; i < pl->prof_kind.size(); ++i) {
     D2D_CHECK_HIP(hipEventSynchronize(pl->prof_ev[2 * i + 1]));
     float ms = 0.f;
@@ -835,6 +835,16 @@ int d2d_fit_iterate(d2d_ctx *ctx, d2d_fit_plan *pl, int B, const double *scen, d
     if (int rc = launch_prep(ctx, pl, B, scen)) return rc;
     pl->prep_valid_for = scen;
   }
+  if (pl->use_lm) {
+    int budget = o.max_iter - pl->it_done;
+    if (budget > n_iters) budget = n_iters;
+    if (budget > 0) {
+      if (int rc = prof_begin(ctx, pl, 2)) return rc;
+      if (int rc = launch_lm(ctx, pl, B, q, o, budget)) return rc;
+      if (int rc = prof_end(ctx, pl)) return rc;
+      pl->it_done += budget;
+    }
+  } else
   for (int i = 0; i < n_iters && pl->it_done < o.max_iter; ++i, ++pl->it_done) {
     if (int rc = prof_begin(ctx, pl, 0)) return rc;
     if (int rc = launch_eval(ctx, pl, B, q, pl->d_flags, pl->d_cost, pl->d_g, pl->d_H)) return rc;

@@ -1,0 +1,226 @@
+// Wave-level building blocks of the fit kernels (one wavefront = one trajectory), shared by
+// fit_eval_kernel / fit_step_kernel (one LM iteration per launch pair) and fit_lm_kernel (the
+// whole LM loop in one persistent launch).
+#pragma once
+#include "fit_device.h"
+
+// ---- phases 1+2: cost and J^T r ------------------------------------------------------------
+// qs: q of this trajectory in LDS; us [K][6] fp64 and cf [K+1][4] f32x4 are the wave's scratch.
+// Returns sum r^2; g_lane = (J^T r)[lane] for lane < 2nq.
+__device__ __forceinline__ double eval_cost_grad(const FitGeom &g, const double *G64, const double *Gp64,
+                                                 const double *qs, double *us, f32x4 *cf, const ScenP &s,
+                                                 int lane, int dbg, double &g_lane) {
+  const int n = 2 * g.nq;
+  // phase 1: lane = sample
+  double cacc = 0.0;
+  for (int k0 = 0; k0 < g.K; k0 += 64) {
+    const int k = k0 + lane;
+    if (k < g.K) {
+      double Y[6] = {1.0 + k, 2.0, 11.0, 3.0, 0.1, 0.2}, wpx, wpy, u[6] = {0, 0, 0, 0, 0, 0};
+      f32x4 coef[4] = {f32x4{1.f, 0.f, 1.f, 0.f}, f32x4{1.f, 0.f, 1.f, 0.f}, f32x4{1.f, 0.f, 1.f, 0.f}, f32x4{1.f, 0.f, 1.f, 0.f}};
+      if (!(dbg & 8)) flat_outputs(g, G64, Gp64, qs, s, k, Y);
+      waypoint_at(s, g.K, k, wpx, wpy);
+      if (!(dbg & 1)) cacc += sample_terms<true>(s, Y, wpx, wpy, u, coef);
+#pragma unroll
+      for (int c = 0; c < 6; ++c) us[k * 6 + c] = u[c];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cf[k * 4 + r] = coef[r];
+    }
+  }
+  const double cost = wave_sum(cacc);
+  wave_lds_sync();
+  // phase 2: lane = unknown, three independent fp64 accumulation chains
+  g_lane = 0.0;
+  if (lane < n && !(dbg & 2)) {
+    const int ax = lane >= g.nq ? 1 : 0, jj = lane - ax * g.nq;
+    const double *g0 = G64 + jj, *g1 = g0 + (size_t)g.K * g.gstr, *g2 = g1 + (size_t)g.K * g.gstr;
+    const double *uk = us + ax;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+#pragma unroll 5
+    for (int k = 0; k < g.K; ++k) {
+      a0 = fma(uk[k * 6], g0[k * g.gstr], a0);
+      a1 = fma(uk[k * 6 + 2], g1[k * g.gstr], a1);
+      a2 = fma(uk[k * 6 + 4], g2[k * g.gstr], a2);
+    }
+    g_lane = (a0 + a1) + a2;
+  }
+  return cost;
+}
+
+// ---- phase 3: J^T J by v_mfma_f32_16x16x4_f32 ------------------------------------------------
+// One MFMA k-step = the four contracted rows (v, phi, obs0, obs1) of one sample.  Lane l supplies
+// J[row rho = l>>4][col 16c + (l&15)] as A- and as B-operand alike:
+//   J = cA * TA[k][j] + cB * TB[k][j],  TA = G1 (v, phi) or G0 (obstacles), TB = G2 (phi only).
+// Operands of sample k+1 are fetched before the MFMAs of sample k are issued (the tables carry
+// one padded row).  acc: upper triangle of the NB x NB grid of 16x16 tiles.
+template <int NB, int NQ>
+__device__ __forceinline__ void jtj_mfma(const FitGeom &g, const float *T32, const f32x4 *cf, int lane,
+                                         int Kmf, f32x4 (&acc)[NB * (NB + 1) / 2]) {
+  const int rho = lane >> 4, ci = lane & 15;
+  const int nq = NQ ? NQ : g.nq;
+  const int n = 2 * nq;
+  const int plane = g.K * nq;
+  bool jok[NB];
+  const float *pc[NB], *pa[NB], *pb[NB];   // per-lane pointers: (cA,cB) pair, TA entry, TB entry
+#pragma unroll
+  for (int c = 0; c < NB; ++c) {
+    const int col = 16 * c + ci;
+    jok[c] = col < n;
+    const bool ay = col >= nq;
+    const int j = jok[c] ? col - (ay ? nq : 0) : 0;
+    pc[c] = reinterpret_cast<const float *>(cf + rho) + (ay ? 2 : 0);
+    pa[c] = T32 + ((rho < 2) ? plane : 0) + j;
+    pb[c] = T32 + 2 * plane + j;
+  }
+#pragma unroll
+  for (int t = 0; t < NB * (NB + 1) / 2; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float2 cc[NB];
+  float ta[NB], tb[NB];
+#pragma unroll
+  for (int c = 0; c < NB; ++c) {
+    cc[c] = *reinterpret_cast<const float2 *>(pc[c]);
+    ta[c] = *pa[c]; tb[c] = *pb[c];
+  }
+  for (int k = 0; k < Kmf; ++k) {
+    float v[NB];
+#pragma unroll
+    for (int c = 0; c < NB; ++c) {
+      const float val = fmaf(cc[c].y, tb[c], cc[c].x * ta[c]);
+      v[c] = (2 * nq == 16 * NB || jok[c]) ? val : 0.f;
+    }
+#pragma unroll
+    for (int c = 0; c < NB; ++c) {
+      cc[c] = *reinterpret_cast<const float2 *>(pc[c] + (k + 1) * 16);
+      ta[c] = pa[c][(k + 1) * nq]; tb[c] = pb[c][(k + 1) * nq];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    int t = 0;
+#pragma unroll
+    for (int I = 0; I < NB; ++I)
+#pragma unroll
+      for (int J = I; J < NB; ++J, ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[I], v[J], acc[t], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// Row `lane` of the symmetric matrix whose upper block triangle sits tile-major in `tiles`
+// ([tile][reg][lane], MFMA C/D map: row = 16I + 4(lane>>4) + reg, col = 16J + (lane&15)).
+template <int N>
+__device__ __forceinline__ void gather_row(const float *tiles, int lane, int n, bool act, float (&row)[N]) {
+  constexpr int NBs = N / 16;
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    float v = 0.f;
+    if (act && j < n) {
+      const int J = j >> 4, I = lane >> 4;
+      const bool up = I <= J;
+      const int r = up ? lane : j, c = up ? j : lane;
+      const int ti = r >> 4, tj = c >> 4;
+      const int tile = ti * NBs - ti * (ti - 1) / 2 + (tj - ti);
+      const int rr = r & 15;
+      v = tiles[(tile * 4 + (rr & 3)) * 64 + (rr >> 2) * 16 + (c & 15)];
+    }
+    row[j] = v;
+  }
+}
+
+// ---- damped normal-equation solve -----------------------------------------------------------
+// hrow = row `lane` of J^T J.  Solves (J^T J + lam*diag(max(J^T J_ii, floor))) delta = -g in fp32:
+// left-looking Cholesky with the row owned by each lane in registers and row j broadcast by
+// v_readlane (all indices compile-time), forward substitution in registers, back substitution
+// through an LDS copy Lm [N][N+1] of the factor.  Returns false if a pivot is not positive.
+template <int N>
+__device__ __forceinline__ bool damped_solve(const float (&hrow)[N], double lam, double gi, bool act, int lane,
+                                             float *Lm, float &dgi, float &delta) {
+  constexpr int LS = N + 1;
+  float row[N];
+  float d = 1.f;
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    row[j] = hrow[j];
+    if (j == lane) d = hrow[j];
+  }
+  if (!act) d = 1.f;
+  dgi = fmaxf(d, (float)D2D_LM_DIAG_FLOOR);
+  const float add = (float)(lam * (double)dgi);
+#pragma unroll
+  for (int j = 0; j < N; ++j)
+    if (j == lane) row[j] = act ? (d + add) : 1.f;
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    float sacc = row[j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) {
+      const float ljk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, row[k]), j));
+      sacc = fmaf(-row[k], ljk, sacc);
+    }
+    const float djj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sacc), j));
+    ok = ok && (djj > 0.f);
+    const float inv = rsqrtf(fmaxf(djj, 1e-30f));
+    row[j] = (lane >= j) ? sacc * inv : 0.f;   // L[lane][j]; diagonal = sqrt(djj)
+  }
+  // forward substitution L y = -g (lane i keeps y_i)
+  float y = (float)(-gi);
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    float ljj = 1.f;
+#pragma unroll
+    for (int t = 0; t < N; ++t)
+      if (t == j) ljj = row[t];
+    const float yj_own = y / ljj;                                  // valid on lane j
+    const float yj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, yj_own), j));
+    if (lane == j) y = yj;
+    else if (lane > j) y = fmaf(-row[j], yj, y);
+  }
+  // back substitution L^T delta = y: needs columns of L -> stage L in LDS
+#pragma unroll
+  for (int j = 0; j < N; ++j)
+    if (lane < N) Lm[lane * LS + j] = row[j];
+  wave_lds_sync();
+  float dl = y;
+#pragma unroll
+  for (int i = N - 1; i >= 0; --i) {
+    float lii = 1.f;
+#pragma unroll
+    for (int t = 0; t < N; ++t)
+      if (t == i) lii = row[t];
+    const float di_own = dl / lii;                                 // valid on lane i
+    const float di = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, di_own), i));
+    if (lane == i) dl = di;
+    else if (lane < i) dl = fmaf(-Lm[i * LS + lane], di, dl);      // L[i][lane]
+  }
+  delta = act ? dl : 0.f;
+  return ok;
+}
+
+// Outcome of one damped step (Nielsen gain-ratio rule, oracle/fit.py lm_solve).  All values are
+// wave-uniform.
+struct StepOutcome {
+  bool accept;
+  int status;
+  double lam, nu, ct;
+};
+__device__ __forceinline__ StepOutcome judge_step(bool ok, double c, double ct, double pred, double dmax,
+                                                  double qmax, double lam, double nu, const d2d_fit_opts &o) {
+  StepOutcome r;
+  const bool fin = ok && (fabs(ct) <= 1.79e308) && (pred > 0.0);
+  const double rho = fin ? (c - ct) / pred : -1.0;
+  r.status = D2D_ST_RUNNING;
+  r.ct = ct;
+  r.accept = rho > 0.0;
+  if (r.accept) {
+    const double t = 2.0 * rho - 1.0;
+    r.lam = fmax(lam * fmax(1.0 / 3.0, 1.0 - t * t * t), D2D_LM_LAMBDA_MIN);
+    r.nu = 2.0;
+    const bool small_x = dmax <= o.xtol * (qmax + o.xtol);
+    const bool small_f = ((c - ct) <= o.ftol * c) && (pred <= o.ftol * c);
+    if (small_f || small_x) r.status = D2D_ST_CONVERGED;
+  } else {
+    r.lam = lam * nu;
+    r.nu = nu * 2.0;
+    if (r.lam > D2D_LM_LAMBDA_MAX) r.status = D2D_ST_STALLED;
+  }
+  return r;
+}

@@ -30,12 +30,14 @@ struct d2d_fit_plan {
   const double *prep_valid_for = nullptr;   // scen pointer d_prep was derived from
   // launch geometry chosen at plan creation from the LDS footprint
   bool g32_lds = true;
-  int wpb_eval = 8, wpb_step = 8;
+  int wpb_eval = 8, wpb_step = 8, wpb_lm = 0;
+  bool use_lm = false;      // whole LM loop in one persistent launch (fit_lm_kernel)
+  int n_cu = 256;
   int it_done = 0, active_B = 0;   // LM loop state between d2d_fit_begin / iterate / finish
   // optional per-launch timing (d2d_fit_profile)
   bool prof_on = false;
   std::vector<hipEvent_t> prof_ev;   // start/stop pairs
-  std::vector<int> prof_kind;        // 0 = eval (J^T J) launch, 1 = step launch
+  std::vector<int> prof_kind;        // 0 = eval (J^T J) launch, 1 = step launch, 2 = fused LM launch
 };
 
 int fit_basis_build(d2d_fit_plan *pl);   // fills the host vectors

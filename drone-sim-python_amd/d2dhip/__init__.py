@@ -359,8 +359,8 @@ class FitPlan:
         _check(self.ctx.lib.d2d_fit_profile(self.h, 1 if enable else 0))
 
     def profile_read(self):
-        """(eval_ms_total, eval_launches, step_ms_total, step_launches) from HIP events."""
-        out = np.zeros(4)
+        """(eval_ms, eval_launches, step_ms, step_launches, fused_lm_ms, fused_lm_launches) from HIP events."""
+        out = np.zeros(6)
         _check(self.ctx.lib.d2d_fit_profile_read(self.h, _hptr(out)))
         return out
 
