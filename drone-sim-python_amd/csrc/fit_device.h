@@ -126,16 +126,25 @@ __device__ __forceinline__ void flat_outputs(const FitGeom &g, const double *__r
 // Hot-path scenario row: everything that is uniform per trajectory is derived once by
 // fit_prep_kernel (double[FIT_PREP_STRIDE] per trajectory) so that the eval / step kernels
 // fetch it with scalar loads instead of recomputing sincos / sqrt / divisions in all 64 lanes.
-#define FIT_PREP_STRIDE 40
+#define FIT_PREP_STRIDE 48
 enum { PR_DX = 0, PR_DY = 4, PR_P2X = 8, PR_P2Y, PR_SAX, PR_SAY, PR_SBX, PR_SBY, PR_CV, PR_CPHI, PR_COBS,
        PR_K0, PR_K1, PR_CV2, PR_CPHI2, PR_WB2, PR_WWP, PR_WBND, PR_VSP, PR_WX, PR_WY, PR_PHIMAX, PR_VMIN,
-       PR_VMAX, PR_O0X, PR_O0Y, PR_O1X, PR_O1Y, PR_X0, PR_Y0, PR_X1, PR_Y1 };
+       PR_VMAX, PR_O0X, PR_O0Y, PR_O1X, PR_O1Y, PR_X0, PR_Y0, PR_X1, PR_Y1, PR_CCOL, PR_KC, PR_PMASK };
 
 struct ScenP {
   double dx[4], dy[4];
   double p2x, p2y, sax, say, sbx, sby;      // dog-leg apex and the two linspace steps
   double cv, cphi, cobs, k0, k1, cv2, cphi2, wb2, wwp, wbnd, vsp, wx, wy, phimax, vmin, vmax;
   double o0x, o0y, o1x, o1y, x0, y0, x1, y1;
+  double ccol, kc;      // collision rows: sqrt(s_col*kcol), k / rcol
+  int pmask;            // bit j: coupled with aircraft j of the group
+};
+
+// Group coupling context of one trajectory (collision rows against the other aircraft of its
+// scenario, whose sampled positions pos [B][2][K] are frozen during this block's solve).
+struct GroupCtx {
+  const double *pos;    // NULL: uncoupled
+  int n_ac, self, gbase, nds;   // group size, own index, first trajectory of the group, padded row slots
 };
 
 __device__ __forceinline__ void prep_row(const double *__restrict__ sc, double duration, int K,
@@ -153,6 +162,10 @@ __device__ __forceinline__ void prep_row(const double *__restrict__ sc, double d
   o[PR_WX] = s.wx; o[PR_WY] = s.wy; o[PR_PHIMAX] = s.phimax; o[PR_VMIN] = s.vmin; o[PR_VMAX] = s.vmax;
   o[PR_O0X] = s.o0x; o[PR_O0Y] = s.o0y; o[PR_O1X] = s.o1x; o[PR_O1Y] = s.o1y;
   o[PR_X0] = s.x0; o[PR_Y0] = s.y0; o[PR_X1] = s.x1; o[PR_Y1] = s.y1;
+  const double kcol = sc[D2D_SC_KCOL], rcol = sc[D2D_SC_RCOL], scol = sc[D2D_SC_SCOL];
+  o[PR_CCOL] = (kcol > 0.0 && scol > 0.0) ? sqrt(scol * kcol) : 0.0;
+  o[PR_KC] = rcol > 0.0 ? FIT_OBS_K / rcol : 0.0;
+  o[PR_PMASK] = sc[D2D_SC_PMASK];
 }
 
 __device__ __forceinline__ ScenP load_scenp(const double *__restrict__ p) {
@@ -165,6 +178,7 @@ __device__ __forceinline__ ScenP load_scenp(const double *__restrict__ p) {
   s.vsp = p[PR_VSP]; s.wx = p[PR_WX]; s.wy = p[PR_WY]; s.phimax = p[PR_PHIMAX]; s.vmin = p[PR_VMIN]; s.vmax = p[PR_VMAX];
   s.o0x = p[PR_O0X]; s.o0y = p[PR_O0Y]; s.o1x = p[PR_O1X]; s.o1y = p[PR_O1Y];
   s.x0 = p[PR_X0]; s.y0 = p[PR_Y0]; s.x1 = p[PR_X1]; s.y1 = p[PR_Y1];
+  s.ccol = p[PR_CCOL]; s.kc = p[PR_KC]; s.pmask = (int)p[PR_PMASK];
   return s;
 }
 
@@ -244,9 +258,38 @@ __device__ __forceinline__ double sample_terms(const ScenP &s, const double Y[6]
   return cost;
 }
 
+// Collision rows of sample k against the coupled aircraft of the group (CostCollision,
+// src/d2d/multiopty_utils.py:120-153, as residual rows sqrt(s_col*kcol*e)).  Adds to u[0..1]; writes
+// the fp32 row coefficients (d row/dx, d row/dy) into cfd_k[0..nds) (zero for unused slots).
+template <bool WANT_JAC>
+__device__ __forceinline__ double partner_terms(const ScenP &s, const GroupCtx &gc, int K, int k, double x, double y,
+                                                double u[6], float2 *cfd_k) {
+  double cost = 0.0;
+  int slot = 0;
+  if (gc.pos && s.ccol > 0.0) {
+    for (int m = 0; m < gc.n_ac; ++m) {
+      if (m == gc.self || !((s.pmask >> m) & 1)) continue;
+      const double *pm = gc.pos + (size_t)(gc.gbase + m) * 2 * K;
+      const double ex = (x - pm[k]) * s.kc, ey = (y - pm[K + k]) * s.kc;
+      const double h = s.ccol * exp(-0.5 * (ex * ex + ey * ey));
+      cost += h * h;
+      if (WANT_JAC) {
+        const double ox = -h * ex * s.kc, oy = -h * ey * s.kc;
+        u[0] += ox * h; u[1] += oy * h;
+        if (slot < gc.nds) cfd_k[slot] = float2{(float)ox, (float)oy};
+      }
+      ++slot;
+    }
+  }
+  if (WANT_JAC)
+    for (; slot < gc.nds; ++slot) cfd_k[slot] = float2{0.f, 0.f};
+  return cost;
+}
+
 // Cost at q (wave-cooperative): sum over samples of sum r^2.
 __device__ __forceinline__ double wave_cost(const FitGeom &g, const double *G64, const double *Gp64,
-                                            const double *q, const ScenP &s, int lane) {
+                                            const double *q, const ScenP &s, int lane,
+                                            const GroupCtx &gc = GroupCtx{nullptr, 1, 0, 0, 0}) {
   double acc = 0.0;
   for (int k0 = 0; k0 < g.K; k0 += 64) {
     const int k = k0 + lane;
@@ -255,6 +298,7 @@ __device__ __forceinline__ double wave_cost(const FitGeom &g, const double *G64,
       flat_outputs(g, G64, Gp64, q, s, k, Y);
       waypoint_at(s, g.K, k, wpx, wpy);
       acc += sample_terms<false>(s, Y, wpx, wpy, nullptr, nullptr);
+      acc += partner_terms<false>(s, gc, g.K, k, Y[0], Y[1], nullptr, nullptr);
     }
   }
   return wave_sum(acc);

@@ -24,15 +24,21 @@ enum { FL_STATUS = 0, FL_ITERS = 1, FL_NEED = 2, FL_NEVAL = 3 };
 struct FitLds {
   // byte offsets into dynamic LDS
   int G64, Gp64, G32, wave0, wave_stride;
-  int q, u, coef;     // offsets inside a wave's private block
+  int q, u, coef, cfd;     // offsets inside a wave's private block
   int total;
+};
+
+// sub-batch addressing and group coupling of one launch: trajectory t = off + i*stride, i < B
+struct GroupArgs {
+  const double *pos;      // [Btotal][2][K] sampled positions, NULL when uncoupled
+  int n_ac, off, stride, nds;
 };
 
 static inline int align16(int v) { return (v + 15) & ~15; }
 
 // g32_lds: stage the fp32 operand tables in LDS (else they are read through L1/L2);
 // wpb: wavefronts per workgroup.  pick_eval_layout chooses the largest that fits 160 KiB.
-static FitLds eval_lds_layout(int K, int nq, bool g32_lds, int wpb) {
+static FitLds eval_lds_layout(int K, int nq, bool g32_lds, int wpb, int nds = 0) {
   FitLds L;
   const int gstr = nq + 1;
   int o = 0;
@@ -44,16 +50,17 @@ static FitLds eval_lds_layout(int K, int nq, bool g32_lds, int wpb) {
   L.q = w; w = align16(w + 2 * nq * 8);
   L.u = w; w = align16(w + K * 6 * 8);
   L.coef = w; w = align16(w + (K + 1) * 4 * 16);   // + one padded sample
+  L.cfd = w; w = align16(w + (K + 1) * nds * 8);
   L.wave_stride = w;
   L.total = o + wpb * w;
   return L;
 }
 
-static bool pick_eval_layout(int K, int nq, bool *g32_lds, int *wpb) {
+static bool pick_eval_layout(int K, int nq, bool *g32_lds, int *wpb, int nds = 0) {
   for (int pass = 0; pass < 2; ++pass) {
     const bool in_lds = pass == 0;
     for (int w = FIT_WPB_MAX; w >= (in_lds ? 4 : 1); --w)
-      if (eval_lds_layout(K, nq, in_lds, w).total <= FIT_LDS_BYTES) { *g32_lds = in_lds; *wpb = w; return true; }
+      if (eval_lds_layout(K, nq, in_lds, w, nds).total <= FIT_LDS_BYTES) { *g32_lds = in_lds; *wpb = w; return true; }
   }
   return false;
 }
@@ -79,7 +86,7 @@ fit_prep_kernel(int B, int K, double duration, const double *__restrict__ scen, 
 // of a [n][n] row-major matrix (n = 2nq); symmetrize_kernel mirrors it for the public API.
 template <int NB, int NQ, bool G32_LDS>   // NB = ceil(2nq/16) column blocks of the MFMA tiling; NQ = nq or 0 (runtime)
 __global__ void __launch_bounds__(FIT_THREADS)
-fit_eval_kernel(int B, FitGeom g, FitLds L, int dbg, const double *__restrict__ gG64,
+fit_eval_kernel(int B, FitGeom g, FitLds L, int dbg, GroupArgs ga, const double *__restrict__ gG64,
                 const double *__restrict__ gGp64, const float *__restrict__ gG32,
                 const float *__restrict__ gW32, const double *__restrict__ prep,
                 const double *__restrict__ q_in, int32_t *__restrict__ flags,
@@ -87,8 +94,9 @@ fit_eval_kernel(int B, FitGeom g, FitLds L, int dbg, const double *__restrict__ 
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int wpb = blockDim.x >> 6;
-  const int b = blockIdx.x * wpb + wave;
-  bool active = b < B;
+  const int bl = blockIdx.x * wpb + wave;
+  const int b = ga.off + bl * ga.stride;
+  bool active = bl < B;
   if (active && flags) active = flags[4 * b + FL_STATUS] == D2D_ST_RUNNING && flags[4 * b + FL_NEED] != 0;
   // nothing to do for this workgroup: leave before paying for the LDS image
   if (!__syncthreads_or(active ? 1 : 0)) return;
@@ -114,7 +122,9 @@ fit_eval_kernel(int B, FitGeom g, FitLds L, int dbg, const double *__restrict__ 
   if (!active) return;
 
   double g_lane;
-  const double cost = eval_cost_grad(g, G64, Gp64, qs, us, cf, s, lane, dbg, g_lane);
+  const GroupCtx gc{ga.pos, ga.n_ac, ga.n_ac > 0 ? b % ga.n_ac : 0, ga.n_ac > 0 ? (b / ga.n_ac) * ga.n_ac : 0, ga.pos ? ga.nds : 0};
+  float2 *cfd = reinterpret_cast<float2 *>(wl + L.cfd);
+  const double cost = eval_cost_grad(g, G64, Gp64, qs, us, cf, s, lane, dbg, g_lane, gc, cfd);
   if (lane < n && g_out) g_out[(size_t)b * n + lane] = g_lane;
   if (lane == 0) {
     if (cost_out) cost_out[b] = cost;
@@ -127,7 +137,7 @@ fit_eval_kernel(int B, FitGeom g, FitLds L, int dbg, const double *__restrict__ 
   if (!H_out) return;
   const float *T32 = G32_LDS ? reinterpret_cast<const float *>(lds + L.G32) : gG32;
   f32x4 acc[NB * (NB + 1) / 2];
-  jtj_mfma<NB, NQ>(g, T32, cf, lane, (dbg & 4) ? 1 : g.K, acc);
+  jtj_mfma<NB, NQ>(g, T32, cf, lane, (dbg & 4) ? 1 : g.K, acc, cfd, gc.nds);
   // epilogue: + wwp^2 G0^T G0 (pre-tiled constant) ; tile-major store: [tile][reg][lane], 256 B per store
   const float ww = (float)(s.wwp * s.wwp);
   float *Hb = H_out + (size_t)b * (NB * (NB + 1) / 2) * 256;
@@ -187,15 +197,16 @@ static bool pick_step_layout(int K, int nq, int N, int *wpb) {
 
 template <int N>
 __global__ void __launch_bounds__(FIT_THREADS)
-fit_step_kernel(int B, FitGeom g, StepLds L, d2d_fit_opts opts,
+fit_step_kernel(int B, FitGeom g, StepLds L, d2d_fit_opts opts, GroupArgs ga,
                 const double *__restrict__ gG64, const double *__restrict__ gGp64,
                 const double *__restrict__ prep, double *__restrict__ q_io,
                 const double *__restrict__ g_in, const float *__restrict__ H_in,
                 double *__restrict__ cost_io, double *__restrict__ lm, int32_t *__restrict__ flags) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int b = blockIdx.x * (blockDim.x >> 6) + wave;
-  const bool active = b < B && flags[4 * b + FL_STATUS] == D2D_ST_RUNNING;
+  const int bl = blockIdx.x * (blockDim.x >> 6) + wave;
+  const int b = ga.off + bl * ga.stride;
+  const bool active = bl < B && flags[4 * b + FL_STATUS] == D2D_ST_RUNNING;
   if (!__syncthreads_or(active ? 1 : 0)) return;
   double *G64 = reinterpret_cast<double *>(lds + L.G64);
   double *Gp64 = reinterpret_cast<double *>(lds + L.Gp64);
@@ -240,7 +251,8 @@ fit_step_kernel(int B, FitGeom g, StepLds L, d2d_fit_opts opts,
   if (lane < N) qt[lane] = qi + delta;
   wave_lds_sync();
   const ScenP s = load_scenp(prep + (size_t)b * FIT_PREP_STRIDE);
-  const double ct = wave_cost(g, G64, Gp64, qt, s, lane);
+  const GroupCtx gc{ga.pos, ga.n_ac, ga.n_ac > 0 ? b % ga.n_ac : 0, ga.n_ac > 0 ? (b / ga.n_ac) * ga.n_ac : 0, ga.pos ? ga.nds : 0};
+  const double ct = wave_cost(g, G64, Gp64, qt, s, lane, gc);
   const double pred = wave_sum(delta * (lam * (double)dgi * delta - gi));
   const double dmax = wave_max(fabs(delta)), qmax = wave_max(fabs(qi));
   const StepOutcome so = judge_step(ok, c, ct, pred, dmax, qmax, lam, nu, opts);
@@ -408,12 +420,44 @@ fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_budget,
 
 // ------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-fit_state_init_kernel(int B, double *__restrict__ lm, int32_t *__restrict__ flags) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
+fit_state_init_kernel(int B, int off, int stride, double *__restrict__ lm, int32_t *__restrict__ flags) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B) return;
+  const int b = off + i * stride;
   lm[4 * b + 0] = D2D_LM_LAMBDA0; lm[4 * b + 1] = 2.0; lm[4 * b + 2] = 0.0; lm[4 * b + 3] = 0.0;
   flags[4 * b + FL_STATUS] = D2D_ST_RUNNING; flags[4 * b + FL_ITERS] = 0; flags[4 * b + FL_NEED] = 1;
-  flags[4 * b + FL_NEVAL] = 0;
+  if (stride == 1) flags[4 * b + FL_NEVAL] = 0;       // group sweeps keep counting across visits
+}
+
+// sampled x, y of every trajectory: pos [B][2][K]
+__global__ void __launch_bounds__(256)
+fit_pos_kernel(int B, FitGeom g, const double *__restrict__ G64, const double *__restrict__ Gp64,
+               const double *__restrict__ prep, const double *__restrict__ q, double *__restrict__ pos) {
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= (long)B * g.K) return;
+  const int b = i / g.K, k = i - (long)b * g.K;
+  const double *pr = prep + (size_t)b * FIT_PREP_STRIDE;
+  const double *qa = q + (size_t)b * 2 * g.nq;
+  const double *gp = Gp64 + (size_t)k * 4, *g0 = G64 + (size_t)k * g.gstr;
+  double x = 0.0, y = 0.0;
+  for (int c = 0; c < 4; ++c) { x = fma(gp[c], pr[PR_DX + c], x); y = fma(gp[c], pr[PR_DY + c], y); }
+  for (int j = 0; j < g.nq; ++j) { x = fma(g0[j], qa[j], x); y = fma(g0[j], qa[g.nq + j], y); }
+  pos[((size_t)b * 2) * g.K + k] = x;
+  pos[((size_t)b * 2 + 1) * g.K + k] = y;
+}
+
+// moved[0] = max over trajectories of max|q - q_prev| / (1 + max|q_prev|)   (bit pattern of a non-negative double)
+__global__ void __launch_bounds__(256)
+fit_moved_kernel(int B, int n, const double *__restrict__ q, const double *__restrict__ qp, double *__restrict__ moved) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  double m = 0.0;
+  if (b < B) {
+    double d = 0.0, a = 0.0;
+    for (int j = 0; j < n; ++j) { d = fmax(d, fabs(q[(size_t)b * n + j] - qp[(size_t)b * n + j])); a = fmax(a, fabs(qp[(size_t)b * n + j])); }
+    m = d / (1.0 + a);
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned long long *>(moved), (unsigned long long)__double_as_longlong(m));
 }
 
 // counts trajectories still running -> counter[0]
@@ -561,6 +605,9 @@ static int ensure_scratch(d2d_fit_plan *pl, int B) {
   const size_t n = 2 * pl->nq;
   if (pl->d_g) { hipFree(pl->d_g); hipFree(pl->d_H); hipFree(pl->d_cost); hipFree(pl->d_lm); hipFree(pl->d_flags); hipFree(pl->d_prep); }
   D2D_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&pl->d_prep), (size_t)B * FIT_PREP_STRIDE * sizeof(double)));
+  if (pl->d_pos) { hipFree(pl->d_pos); hipFree(pl->d_qprev); }
+  D2D_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&pl->d_pos), (size_t)B * 2 * pl->K * sizeof(double)));
+  D2D_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&pl->d_qprev), (size_t)B * n * sizeof(double)));
   D2D_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&pl->d_g), (size_t)B * n * sizeof(double)));
   {
     const size_t nb = (n + 15) / 16, tiles = nb * (nb + 1) / 2;
@@ -580,19 +627,21 @@ static int launch_prep(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, const double
 }
 
 // d_prep must hold the rows of `scen` (launch_prep) before either kernel runs
+static GroupArgs no_groups() { return GroupArgs{nullptr, 0, 0, 1, 0}; }
+
 static int launch_eval(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, const double *q,
-                       int32_t *flags, double *cost, double *g, float *H) {
+                       int32_t *flags, double *cost, double *g, float *H, GroupArgs ga = no_groups()) {
   const FitGeom gm = geom_of(pl);
-  const FitLds L = eval_lds_layout(pl->K, pl->nq, pl->g32_lds, pl->wpb_eval);
+  const FitLds L = eval_lds_layout(pl->K, pl->nq, pl->g32_lds, pl->wpb_eval, pl->nds);
   const int NB = (2 * pl->nq + 15) / 16;
   const dim3 grid((B + pl->wpb_eval - 1) / pl->wpb_eval), block(64 * pl->wpb_eval);
   static const int dbg = getenv("D2D_FIT_ABLATE") ? atoi(getenv("D2D_FIT_ABLATE")) : 0;   // timing experiments only
 #define LAUNCH_EVAL(NBV, INLDS)                                                                    \
   if (pl->nq == 24 && NBV == 3)                                                                    \
-    hipLaunchKernelGGL((fit_eval_kernel<3, 24, INLDS>), grid, block, L.total, ctx->stream, B, gm, L, dbg, \
+    hipLaunchKernelGGL((fit_eval_kernel<3, 24, INLDS>), grid, block, L.total, ctx->stream, B, gm, L, dbg, ga, \
                        pl->d_G, pl->d_Gp, pl->d_G32, pl->d_W32, pl->d_prep, q, flags, cost, g, H);  \
   else                                                                                             \
-  hipLaunchKernelGGL((fit_eval_kernel<NBV, 0, INLDS>), grid, block, L.total, ctx->stream, B, gm, L, dbg, \
+  hipLaunchKernelGGL((fit_eval_kernel<NBV, 0, INLDS>), grid, block, L.total, ctx->stream, B, gm, L, dbg, ga, \
                      pl->d_G, pl->d_Gp, pl->d_G32, pl->d_W32, pl->d_prep, q, flags, cost, g, H)
   if (pl->g32_lds) {
     if (NB == 1) LAUNCH_EVAL(1, true);
@@ -608,13 +657,14 @@ static int launch_eval(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, const double
   return D2D_OK;
 }
 
-static int launch_step(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, double *q, const d2d_fit_opts &o) {
+static int launch_step(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, double *q, const d2d_fit_opts &o,
+                       GroupArgs ga = no_groups()) {
   const FitGeom gm = geom_of(pl);
   const int NB = (2 * pl->nq + 15) / 16;
   const StepLds L = step_lds_layout(pl->K, pl->nq, 16 * NB, pl->wpb_step);
   const dim3 grid((B + pl->wpb_step - 1) / pl->wpb_step), block(64 * pl->wpb_step);
 #define LAUNCH_STEP(NV)                                                                            \
-  hipLaunchKernelGGL(fit_step_kernel<NV>, grid, block, L.total, ctx->stream, B, gm, L, o, \
+  hipLaunchKernelGGL(fit_step_kernel<NV>, grid, block, L.total, ctx->stream, B, gm, L, o, ga, \
                      pl->d_G, pl->d_Gp, pl->d_prep, q, pl->d_g, pl->d_H, pl->d_cost, pl->d_lm, pl->d_flags)
   if (NB == 1) LAUNCH_STEP(16);
   else if (NB == 2) LAUNCH_STEP(32);
@@ -656,7 +706,7 @@ int d2d_fit_plan_create(d2d_ctx *ctx, int S, int K, double duration, const doubl
   for (int i = 0; i < 3; ++i) pl->wref[i] = wref[i];
   if (int rc = fit_basis_build(pl)) { delete pl; return rc; }
   const int nq = pl->nq, gstr = nq + 1;
-  if (!pick_eval_layout(K, nq, &pl->g32_lds, &pl->wpb_eval) ||
+  if (!pick_eval_layout(K, nq, &pl->g32_lds, &pl->wpb_eval, 0) ||
       !pick_step_layout(K, nq, 16 * ((2 * nq + 15) / 16), &pl->wpb_step)) {
     d2d_set_error("d2d_fit_plan_create: K=%d, S=%d does not fit the 160 KiB LDS image of the basis block", K, S);
     delete pl;
@@ -714,7 +764,7 @@ int d2d_fit_plan_destroy(d2d_fit_plan *pl) {
   hipSetDevice(pl->device);
   for (hipEvent_t e : pl->prof_ev) (void)hipEventDestroy(e);
   void *ptrs[] = {pl->d_G, pl->d_Gp, pl->d_G32, pl->d_W32, pl->d_Z, pl->d_Zp, pl->d_Pinit,
-                  pl->d_g, pl->d_H, pl->d_cost, pl->d_lm, pl->d_flags, pl->d_prep};
+                  pl->d_g, pl->d_H, pl->d_cost, pl->d_lm, pl->d_flags, pl->d_prep, pl->d_pos, pl->d_qprev};
   for (void *p : ptrs)
     if (p) hipFree(p);
   delete pl;
@@ -816,7 +866,7 @@ int d2d_fit_begin(d2d_ctx *ctx, d2d_fit_plan *pl, int B) {
   D2D_REQUIRE(ctx && pl, "d2d_fit_begin: null argument");
   D2D_REQUIRE(B >= 1, "d2d_fit_begin: B must be >= 1");
   if (int rc = ensure_scratch(pl, B)) return rc;
-  hipLaunchKernelGGL(fit_state_init_kernel, dim3((B + 255) / 256), dim3(256), 0, ctx->stream, B, pl->d_lm, pl->d_flags);
+  hipLaunchKernelGGL(fit_state_init_kernel, dim3((B + 255) / 256), dim3(256), 0, ctx->stream, B, 0, 1, pl->d_lm, pl->d_flags);
   D2D_LAUNCH_CHECK();
   pl->it_done = 0;
   pl->active_B = B;
@@ -835,7 +885,7 @@ int d2d_fit_iterate(d2d_ctx *ctx, d2d_fit_plan *pl, int B, const double *scen, d
     if (int rc = launch_prep(ctx, pl, B, scen)) return rc;
     pl->prep_valid_for = scen;
   }
-  if (pl->use_lm) {
+  if (pl->use_lm && pl->n_group <= 1) {
     int budget = o.max_iter - pl->it_done;
     if (budget > n_iters) budget = n_iters;
     if (budget > 0) {
@@ -903,6 +953,81 @@ int d2d_fit_solve(d2d_ctx *ctx, const d2d_fit_plan *plc, int B, const double *sc
   while (running > 0)
     if (int rc = d2d_fit_iterate(ctx, pl, B, scen, q, &o, o.check_every, &running)) return rc;
   return d2d_fit_finish(ctx, pl, B, scen, q, cost, iters, status, stats);
+}
+
+int d2d_fit_plan_set_groups(d2d_fit_plan *pl, int n_ac) {
+  D2D_REQUIRE(pl != nullptr, "d2d_fit_plan_set_groups: plan is NULL");
+  D2D_REQUIRE(n_ac >= 1 && n_ac <= 8, "d2d_fit_plan_set_groups: n_ac=%d not in 1..8", n_ac);
+  const int nds = n_ac > 1 ? 4 * ((n_ac - 1 + 3) / 4) : 0;
+  bool g32;
+  int we, ws;
+  const int N = 16 * ((2 * pl->nq + 15) / 16);
+  if (!pick_eval_layout(pl->K, pl->nq, &g32, &we, nds) || !pick_step_layout(pl->K, pl->nq, N, &ws)) {
+    d2d_set_error("d2d_fit_plan_set_groups: K=%d with %d coupled aircraft does not fit the LDS", pl->K, n_ac);
+    return D2D_EINVAL;
+  }
+  pl->n_group = n_ac; pl->nds = nds; pl->g32_lds = g32; pl->wpb_eval = we; pl->wpb_step = ws;
+  return D2D_OK;
+}
+
+int d2d_fit_solve_groups(d2d_ctx *ctx, d2d_fit_plan *pl, int R, const double *scen, double *q,
+                         const d2d_fit_opts *opts, int max_sweeps, int inner_iters, double tol,
+                         double *cost, int32_t *sweeps_done, double *stats) {
+  D2D_REQUIRE(ctx && pl && scen && q, "d2d_fit_solve_groups: null argument");
+  D2D_REQUIRE(R >= 1 && max_sweeps >= 1 && inner_iters >= 1, "d2d_fit_solve_groups: R, max_sweeps, inner_iters must be >= 1");
+  D2D_REQUIRE(pl->n_group >= 2, "d2d_fit_solve_groups: call d2d_fit_plan_set_groups(n_ac >= 2) first");
+  const int n_ac = pl->n_group, B = R * n_ac, n = 2 * pl->nq;
+  d2d_fit_opts o = opts_or_default(opts);
+  o.max_iter = inner_iters;
+  if (int rc = ensure_scratch(pl, B)) return rc;
+  if (int rc = launch_prep(ctx, pl, B, scen)) return rc;
+  pl->prep_valid_for = nullptr;
+  pl->active_B = 0;
+  const FitGeom gm = geom_of(pl);
+  const dim3 gB((B + 255) / 256), b1(256), gR((R + 255) / 256);
+  hipLaunchKernelGGL(fit_state_init_kernel, gB, b1, 0, ctx->stream, B, 0, 1, pl->d_lm, pl->d_flags);
+  D2D_LAUNCH_CHECK();
+  int sw = 0;
+  for (sw = 1; sw <= max_sweeps; ++sw) {
+    D2D_CHECK_HIP(hipMemcpyAsync(pl->d_qprev, q, (size_t)B * n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    for (int i = 0; i < n_ac; ++i) {
+      // freeze the others where they are now
+      hipLaunchKernelGGL(fit_pos_kernel, dim3(((long)B * pl->K + 255) / 256), b1, 0, ctx->stream, B, gm, pl->d_G, pl->d_Gp, pl->d_prep, q, pl->d_pos);
+      hipLaunchKernelGGL(fit_state_init_kernel, gR, b1, 0, ctx->stream, R, i, n_ac, pl->d_lm, pl->d_flags);
+      D2D_LAUNCH_CHECK();
+      const GroupArgs ga{pl->d_pos, n_ac, i, n_ac, pl->nds};
+      for (int it = 0; it < inner_iters; ++it) {
+        if (int rc = launch_eval(ctx, pl, R, q, pl->d_flags, pl->d_cost, pl->d_g, pl->d_H, ga)) return rc;
+        if (int rc = launch_step(ctx, pl, R, q, o, ga)) return rc;
+      }
+    }
+    D2D_CHECK_HIP(hipMemsetAsync(ctx->stats_dev + 8, 0, sizeof(double), ctx->stream));
+    hipLaunchKernelGGL(fit_moved_kernel, gB, b1, 0, ctx->stream, B, n, q, pl->d_qprev, ctx->stats_dev + 8);
+    D2D_LAUNCH_CHECK();
+    D2D_CHECK_HIP(hipMemcpyAsync(ctx->stats_host + 8, ctx->stats_dev + 8, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    D2D_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->stats_host[8] <= tol) break;
+  }
+  if (sw > max_sweeps) sw = max_sweeps;
+  // final per-aircraft sub-problem costs / gradients with everybody's final positions
+  hipLaunchKernelGGL(fit_pos_kernel, dim3(((long)B * pl->K + 255) / 256), b1, 0, ctx->stream, B, gm, pl->d_G, pl->d_Gp, pl->d_prep, q, pl->d_pos);
+  D2D_LAUNCH_CHECK();
+  const GroupArgs gall{pl->d_pos, n_ac, 0, 1, pl->nds};
+  if (int rc = launch_eval(ctx, pl, B, q, nullptr, pl->d_cost, pl->d_g, nullptr, gall)) return rc;
+  if (cost) D2D_CHECK_HIP(hipMemcpyAsync(cost, pl->d_cost, (size_t)B * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  if (stats) {
+    D2D_CHECK_HIP(hipMemsetAsync(ctx->stats_dev, 0, 4 * sizeof(double), ctx->stream));
+    hipLaunchKernelGGL(fit_stats_kernel, gB, b1, 0, ctx->stream, B, n, pl->d_cost, pl->d_g, pl->d_flags, ctx->stats_dev);
+    D2D_LAUNCH_CHECK();
+    D2D_CHECK_HIP(hipMemcpyAsync(ctx->stats_host, ctx->stats_dev, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  }
+  D2D_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  if (stats) {
+    for (int i = 0; i < 4; ++i) stats[i] = ctx->stats_host[i];
+    stats[2] = ctx->stats_host[8];       // last sweep's largest relative move instead of the LM status count
+  }
+  if (sweeps_done) *sweeps_done = sw;
+  return D2D_OK;
 }
 
 int d2d_fit_coeffs(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, const double *scen, const double *q, double *z) {

@@ -7,9 +7,11 @@
 // ---- phases 1+2: cost and J^T r ------------------------------------------------------------
 // qs: q of this trajectory in LDS; us [K][6] fp64 and cf [K+1][4] f32x4 are the wave's scratch.
 // Returns sum r^2; g_lane = (J^T r)[lane] for lane < 2nq.
+// cfd [K+1][nds] float2: row coefficients of the collision rows (only with a coupled group).
 __device__ __forceinline__ double eval_cost_grad(const FitGeom &g, const double *G64, const double *Gp64,
                                                  const double *qs, double *us, f32x4 *cf, const ScenP &s,
-                                                 int lane, int dbg, double &g_lane) {
+                                                 int lane, int dbg, double &g_lane,
+                                                 const GroupCtx &gc = GroupCtx{nullptr, 1, 0, 0, 0}, float2 *cfd = nullptr) {
   const int n = 2 * g.nq;
   // phase 1: lane = sample
   double cacc = 0.0;
@@ -21,6 +23,7 @@ __device__ __forceinline__ double eval_cost_grad(const FitGeom &g, const double 
       if (!(dbg & 8)) flat_outputs(g, G64, Gp64, qs, s, k, Y);
       waypoint_at(s, g.K, k, wpx, wpy);
       if (!(dbg & 1)) cacc += sample_terms<true>(s, Y, wpx, wpy, u, coef);
+      if (gc.nds) cacc += partner_terms<true>(s, gc, g.K, k, Y[0], Y[1], u, cfd + (size_t)k * gc.nds);
 #pragma unroll
       for (int c = 0; c < 6; ++c) us[k * 6 + c] = u[c];
 #pragma unroll
@@ -55,7 +58,8 @@ __device__ __forceinline__ double eval_cost_grad(const FitGeom &g, const double 
 // one padded row).  acc: upper triangle of the NB x NB grid of 16x16 tiles.
 template <int NB, int NQ>
 __device__ __forceinline__ void jtj_mfma(const FitGeom &g, const float *T32, const f32x4 *cf, int lane,
-                                         int Kmf, f32x4 (&acc)[NB * (NB + 1) / 2]) {
+                                         int Kmf, f32x4 (&acc)[NB * (NB + 1) / 2],
+                                         const float2 *cfd = nullptr, int nds = 0) {
   const int rho = lane >> 4, ci = lane & 15;
   const int nq = NQ ? NQ : g.nq;
   const int n = 2 * nq;
@@ -101,6 +105,32 @@ __device__ __forceinline__ void jtj_mfma(const FitGeom &g, const float *T32, con
       for (int J = I; J < NB; ++J, ++t)
         acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[I], v[J], acc[t], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
+  }
+  // collision rows of a coupled group: further k-steps of four rows each, all of the form c * G0[k][j]
+  for (int grp = 0; grp * 4 < nds; ++grp) {
+    const float *p0[NB];
+    bool ayc[NB];
+#pragma unroll
+    for (int c = 0; c < NB; ++c) {
+      const int col = 16 * c + ci;
+      ayc[c] = col >= nq;
+      p0[c] = T32 + (jok[c] ? col - (ayc[c] ? nq : 0) : 0);
+    }
+    for (int k = 0; k < Kmf; ++k) {
+      const float2 c2 = cfd[(size_t)k * nds + grp * 4 + rho];
+      float v[NB];
+#pragma unroll
+      for (int c = 0; c < NB; ++c) {
+        const float val = (ayc[c] ? c2.y : c2.x) * p0[c][k * nq];
+        v[c] = (2 * nq == 16 * NB || jok[c]) ? val : 0.f;
+      }
+      int t = 0;
+#pragma unroll
+      for (int I = 0; I < NB; ++I)
+#pragma unroll
+        for (int J = I; J < NB; ++J, ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[I], v[J], acc[t], 0, 0, 0);
+    }
   }
 }
 

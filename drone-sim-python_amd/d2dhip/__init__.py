@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), 'lib', 'libd2dhip.so')
 SCEN_STRIDE = 32
 (SC_X0, SC_Y0, SC_PSI0, SC_X1, SC_Y1, SC_PSI1, SC_VREF, SC_VSP, SC_KV, SC_KPHI, SC_KOBS, SC_S,
  SC_WWP, SC_WX, SC_WY, SC_GOLEFT, SC_O0X, SC_O0Y, SC_O0R, SC_O1X, SC_O1Y, SC_O1R, SC_WBND,
- SC_PHIMAX, SC_VMIN, SC_VMAX) = range(26)
+ SC_PHIMAX, SC_VMIN, SC_VMAX, SC_KCOL, SC_RCOL, SC_SCOL, SC_PMASK) = range(30)
 ST_RUNNING, ST_CONVERGED, ST_MAXITER, ST_NONFINITE, ST_STALLED = range(5)
 
 
@@ -69,6 +69,9 @@ _SIGS = {
     'd2d_fit_begin': (C.c_int, [_P, _P, C.c_int]),
     'd2d_fit_iterate': (C.c_int, [_P, _P, C.c_int, _P, _P, C.POINTER(FitOpts), C.c_int, C.POINTER(C.c_int32)]),
     'd2d_fit_finish': (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P, _P, _P]),
+    'd2d_fit_plan_set_groups': (C.c_int, [_P, C.c_int]),
+    'd2d_fit_solve_groups': (C.c_int, [_P, _P, C.c_int, _P, _P, C.POINTER(FitOpts), C.c_int, C.c_int, C.c_double, _P,
+                                       C.POINTER(C.c_int32), _P]),
     'd2d_fit_profile': (C.c_int, [_P, C.c_int]),
     'd2d_fit_profile_read': (C.c_int, [_P, _P]),
     'd2d_fit_coeffs': (C.c_int, [_P, _P, C.c_int, _P, _P, _P]),
@@ -354,6 +357,25 @@ class FitPlan:
         _check(self.ctx.lib.d2d_fit_finish(self.ctx.h, self.h, B, _ptr(scen), _ptr(q), _ptr(cost), _ptr(iters),
                                            _ptr(status), _hptr(stats)))
         return cost, iters, status, stats
+
+    def set_groups(self, n_ac):
+        _check(self.ctx.lib.d2d_fit_plan_set_groups(self.h, n_ac))
+        self.n_group = n_ac
+
+    def solve_groups(self, scen, q, n_ac, max_sweeps=60, inner_iters=8, tol=1e-12, ftol=1e-14, gtol=1e-9, xtol=1e-11):
+        """Block Gauss-Seidel over the aircraft of every group (scen / q rows g*n_ac + i).  Returns the
+        per-aircraft sub-problem costs (device), sweeps used and stats (numpy[4])."""
+        if getattr(self, 'n_group', 1) != n_ac:
+            self.set_groups(n_ac)
+        B = scen.shape[0]
+        assert B % n_ac == 0
+        cost = self.ctx.empty(B)
+        o = FitOpts(inner_iters, 1, ftol, gtol, xtol)
+        sw = C.c_int32(0)
+        stats = np.zeros(4)
+        _check(self.ctx.lib.d2d_fit_solve_groups(self.ctx.h, self.h, B // n_ac, _ptr(scen), _ptr(q), C.byref(o), max_sweeps,
+                                                 inner_iters, tol, _ptr(cost), C.byref(sw), _hptr(stats)))
+        return cost, sw.value, stats
 
     def profile(self, enable):
         _check(self.ctx.lib.d2d_fit_profile(self.h, 1 if enable else 0))

@@ -55,9 +55,9 @@ class Planner:
         ctx = d2dhip.default_context()
         N, n = self.num_nodes, self.acs.nb_aicraft
         low = sop.lower_cost(self.scen.cost)
-        if not np.isnan(low[5]):
-            raise NotImplementedError('collision coupling (kcol) between aircraft is not contracted by this build of '
-                                      'the HIP fit (SURVEY.md 8f); pass kcol=float("NaN")')
+        coupled = not np.isnan(low[5]) and n >= 2
+        if coupled and n > 8:
+            raise NotImplementedError('collision coupling is built for groups of at most 8 aircraft')
         s = self.obj_scale / N / n                   # src/d2d/multiopty_utils.py:62
         plan = sop.get_plan(N, self.duration, s, low[1], low[2])
         rows = np.stack([sop.scen_row(p0, p1, self.scen.vref, low if i == 0 else low[:4] + ((),) + low[5:], s,
@@ -66,11 +66,22 @@ class Planner:
         # (static obstacles act on aircraft 0 only, src/d2d/multiopty_utils.py:74)
         if low[4]:
             rows[:, d2dhip.SC_KOBS] *= n             # obstacle scale has no 1/n_ac (:91)
+        if coupled:
+            # CostCollision acts on the pair (aircraft 0, aircraft 1) only (src/d2d/multiopty_utils.py:124-125);
+            # scale obj_scale/N without 1/n_ac (:132)
+            rows[:, d2dhip.SC_KCOL], rows[:, d2dhip.SC_RCOL], rows[:, d2dhip.SC_SCOL] = low[5], low[6], self.obj_scale / N
+            rows[0, d2dhip.SC_PMASK], rows[1, d2dhip.SC_PMASK] = 0b10, 0b01
         dsc = ctx.dev(rows)
         xy = np.stack([np.stack([x0[self._slice_x[i]], x0[self._slice_y[i]]]) for i in range(n)])
         q = plan.project(dsc, ctx.dev(xy))
         max_iter = int(min(max(self.prob.options.get('max_iter', 200), 1), 2000))
-        cost, iters, status, stats = plan.solve(dsc, q, max_iter=max_iter)
+        if coupled:
+            cost, sweeps, stats = plan.solve_groups(dsc, q, n, max_sweeps=max(1, max_iter // 8), inner_iters=8)
+            plan.set_groups(1)
+            torch = d2dhip._torch()
+            iters = torch.full((n,), sweeps, dtype=torch.int32); status = torch.full((n,), 1 if stats[2] <= 1e-9 else 2, dtype=torch.int32)
+        else:
+            cost, iters, status, stats = plan.solve(dsc, q, max_iter=max_iter)
         _, Xs = plan.sample(dsc, q)
         Xs = Xs.cpu().numpy()                        # (n, 5, N)
         self.fit_q, self.fit_plan, self.fit_scen = q, plan, dsc

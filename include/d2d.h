@@ -190,7 +190,10 @@ enum {
   D2D_SC_WBND,  /* weight of the soft bound rows                                 */
   D2D_SC_PHIMAX, D2D_SC_VMIN, D2D_SC_VMAX,   /* bounds of those rows: |phi| <= PHIMAX,
                    VMIN <= va <= VMAX (phi_constraint / v_constraint of the scenario)   */
-  D2D_SC_SPARE0  /* .. D2D_SCEN_STRIDE-1 unused, must be 0                              */
+  D2D_SC_KCOL, D2D_SC_RCOL,  /* collision rows between the aircraft of one group: weight, radius */
+  D2D_SC_SCOL,  /* their scale, obj_scale / K (src/d2d/multiopty_utils.py:132: no 1/n_ac)  */
+  D2D_SC_PMASK, /* bit j set: coupled with aircraft j of the same group (stored as a double) */
+  D2D_SC_SPARE0 /* .. D2D_SCEN_STRIDE-1 unused, must be 0                               */
 };
 #define D2D_FIT_NROW 8        /* residual rows per sample */
 #define D2D_FIT_MAX_S 6
@@ -251,6 +254,22 @@ int d2d_fit_iterate(d2d_ctx *ctx, d2d_fit_plan *plan, int B, const double *scen,
                     const d2d_fit_opts *opts, int n_iters, int32_t *n_running);
 int d2d_fit_finish(d2d_ctx *ctx, d2d_fit_plan *plan, int B, const double *scen, const double *q,
                    double *cost, int32_t *iters, int32_t *status, double *stats);
+
+/* Coupled groups (BASELINE configs[2], multi_opt_planner): trajectories g*n_ac .. g*n_ac+n_ac-1 are
+ * the aircraft of one scenario and repel each other through CostCollision rows
+ * (src/d2d/multiopty_utils.py:120-153; D2D_SC_KCOL/RCOL/SCOL/PMASK select weight, radius, scale and
+ * partners).  d2d_fit_plan_set_groups(n_ac <= 8) sizes the kernels' LDS for the extra rows;
+ * d2d_fit_solve_groups runs block Gauss-Seidel over the aircraft index (all R groups in one batch
+ * per visit, the others' sampled positions frozen, LM state restarted, at most inner_iters damped
+ * solves per visit) until no unknown moved by more than tol*(1+|q|) in a sweep or max_sweeps.
+ * scen dev [R*n_ac][32], q dev [R*n_ac][2nq] in/out, cost dev [R*n_ac] (per-aircraft sub-problem cost:
+ * own rows + its collision rows) or NULL, sweeps_done host or NULL, stats host [4] or NULL
+ * (sum of sub-problem costs, max |J^T r|, last sweep's largest relative move, evaluations).
+ * Synchronises the stream. */
+int d2d_fit_plan_set_groups(d2d_fit_plan *plan, int n_ac);
+int d2d_fit_solve_groups(d2d_ctx *ctx, d2d_fit_plan *plan, int R, const double *scen, double *q,
+                         const d2d_fit_opts *opts, int max_sweeps, int inner_iters, double tol,
+                         double *cost, int32_t *sweeps_done, double *stats);
 
 /* Per-launch timing of the LM loop with HIP events on the context's stream: enable = 1
  * starts a fresh recording, 0 stops.  d2d_fit_profile_read waits for the recorded events:

@@ -189,7 +189,10 @@ class FitBasis:
 SCEN_STRIDE = 32
 (SC_X0, SC_Y0, SC_PSI0, SC_X1, SC_Y1, SC_PSI1, SC_VREF, SC_VSP, SC_KV, SC_KPHI,
  SC_KOBS, SC_S, SC_WWP, SC_WX, SC_WY, SC_GOLEFT,
- SC_O0X, SC_O0Y, SC_O0R, SC_O1X, SC_O1Y, SC_O1R, SC_WBND, SC_PHIMAX, SC_VMIN, SC_VMAX) = range(26)
+ SC_O0X, SC_O0Y, SC_O0R, SC_O1X, SC_O1Y, SC_O1R, SC_WBND, SC_PHIMAX, SC_VMIN, SC_VMAX,
+ SC_KCOL, SC_RCOL, SC_SCOL, SC_PMASK) = range(30)
+# SC_KCOL/RCOL/SCOL: collision weight, radius and scale (obj_scale/N, src/d2d/multiopty_utils.py:132);
+# SC_PMASK: bit j set <=> coupled with aircraft j of the same group (CostCollision pairs)
 # default bounds of the soft bound rows (phi in +-40 deg, v in [9,15]: src/multi_opt_planner.py:192-193)
 PHI_MAX = math.radians(40.0)
 V_MIN, V_MAX = 9.0, 15.0
@@ -251,9 +254,13 @@ def flatness(Y, sc):
     return va, psi, phi
 
 
-def residuals(basis, sc, q, wp=None, want_jac=False):
-    """r (K,NROW) and optionally the partials D (K,NROW,6) wrt (x,y,xd,yd,xdd,ydd)."""
+def residuals(basis, sc, q, wp=None, want_jac=False, others=None):
+    """r (K,NROW+n_others) and optionally the partials D (K,rows,6) wrt (x,y,xd,yd,xdd,ydd).
+
+    others (n_others,2,K): sampled positions of the coupled aircraft (held fixed): one extra row
+    sqrt(s_col*kcol*e) each, e as CostCollision (src/d2d/multiopty_utils.py:120-153)."""
     K = basis.K
+    n_oth = 0 if others is None else len(others)
     Y = flat_outputs(basis, sc, q)
     x, y = Y[0]; a = Y[1, 0] - sc[SC_WX]; b = Y[1, 1] - sc[SC_WY]; c, d = Y[2]
     if wp is None:
@@ -264,7 +271,7 @@ def residuals(basis, sc, q, wp=None, want_jac=False):
     phi = np.arctan(w)
     s = sc[SC_S]
     cv = math.sqrt(s * sc[SC_KV]); cphi = math.sqrt(s * sc[SC_KPHI]); cobs = math.sqrt(s * sc[SC_KOBS])
-    r = np.zeros((K, NROW))
+    r = np.zeros((K, NROW + n_oth))
     r[:, 0] = cv * (va - sc[SC_VSP])
     r[:, 1] = cphi * phi
     r[:, 2] = sc[SC_WWP] * (x - wp[0])
@@ -282,9 +289,17 @@ def residuals(basis, sc, q, wp=None, want_jac=False):
     hv = np.maximum(va - sc[SC_VMAX], 0.0) + np.minimum(va - sc[SC_VMIN], 0.0)
     r[:, 6] = wb * hphi
     r[:, 7] = wb * hv
+    col = []
+    if n_oth:
+        ccol = math.sqrt(sc[SC_SCOL] * sc[SC_KCOL]); kc = OBS_K / sc[SC_RCOL]
+        for m in range(n_oth):
+            ex = (x - others[m][0]) * kc; ey = (y - others[m][1]) * kc
+            h = ccol * np.exp(-0.5 * (ex * ex + ey * ey))
+            r[:, NROW + m] = h
+            col.append((ex, ey, h, kc))
     if not want_jac:
         return r
-    D = np.zeros((K, NROW, 6))
+    D = np.zeros((K, NROW + n_oth, 6))
     dva_a = a / va; dva_b = b / va
     D[:, 0, 2] = cv * dva_a; D[:, 0, 3] = cv * dva_b
     f = 1.0 / (1.0 + w * w)
@@ -304,6 +319,9 @@ def residuals(basis, sc, q, wp=None, want_jac=False):
     D[:, 6, 2:6] = wb * act[:, None] * dphi
     actv = ((va > sc[SC_VMAX]) | (va < sc[SC_VMIN])).astype(float)
     D[:, 7, 2] = wb * actv * dva_a; D[:, 7, 3] = wb * actv * dva_b
+    for m, (ex, ey, h, kc) in enumerate(col):
+        D[:, NROW + m, 0] = -h * ex * kc
+        D[:, NROW + m, 1] = -h * ey * kc
     return r, D
 
 
@@ -311,22 +329,23 @@ def jacobian(basis, D):
     """J (K*NROW x 2nq) = D_k . Gk, columns [q_x | q_y]."""
     K, nq = basis.K, basis.nq
     G = basis.G
-    J = np.zeros((K, NROW, 2 * nq))
+    nrow = D.shape[1]
+    J = np.zeros((K, nrow, 2 * nq))
     for ax in range(2):
         J[:, :, ax * nq:(ax + 1) * nq] = (D[:, :, 0 + ax, None] * G[0][:, None, :]
                                           + D[:, :, 2 + ax, None] * G[1][:, None, :]
                                           + D[:, :, 4 + ax, None] * G[2][:, None, :])
-    return J.reshape(K * NROW, 2 * nq)
+    return J.reshape(K * nrow, 2 * nq)
 
 
-def cost(basis, sc, q, wp=None):
-    r = residuals(basis, sc, q, wp)
+def cost(basis, sc, q, wp=None, others=None):
+    r = residuals(basis, sc, q, wp, others=others)
     return float(np.sum(r * r))
 
 
-def eval_normal(basis, sc, q, wp=None):
+def eval_normal(basis, sc, q, wp=None, others=None):
     """cost = sum r^2, g = J^T r, H = J^T J (all fp64)."""
-    r, D = residuals(basis, sc, q, wp, want_jac=True)
+    r, D = residuals(basis, sc, q, wp, want_jac=True, others=others)
     J = jacobian(basis, D)
     rv = r.reshape(-1)
     return float(rv @ rv), J.T @ rv, J.T @ J
@@ -355,7 +374,7 @@ ST_RUNNING, ST_CONVERGED, ST_MAXITER, ST_NONFINITE, ST_STALLED = 0, 1, 2, 3, 4
 
 
 def lm_solve(basis, sc, q0=None, max_iter=200, ftol=1e-14, gtol=1e-9, xtol=1e-11,
-             hess_dtype=np.float64, chol_dtype=np.float64):
+             hess_dtype=np.float64, chol_dtype=np.float64, others=None):
     """(J^T J + lam*diag(J^T J)) delta = -J^T r with Nielsen's gain-ratio damping.
 
     One "iteration" = one damped solve + one trial cost; J^T J is re-evaluated only
@@ -366,7 +385,7 @@ def lm_solve(basis, sc, q0=None, max_iter=200, ftol=1e-14, gtol=1e-9, xtol=1e-11
     q = initial_guess(basis, sc, wp) if q0 is None else np.array(q0, float)
     lam, nu = LM_LAMBDA0, 2.0
     status = ST_MAXITER
-    c, g, H = eval_normal(basis, sc, q, wp)
+    c, g, H = eval_normal(basis, sc, q, wp, others)
     H = H.astype(hess_dtype).astype(np.float64)
     it = 0
     if not np.isfinite(c):
@@ -385,7 +404,7 @@ def lm_solve(basis, sc, q0=None, max_iter=200, ftol=1e-14, gtol=1e-9, xtol=1e-11
             ok = False
         rho = -1.0
         if ok:
-            ct = cost(basis, sc, q + delta, wp)
+            ct = cost(basis, sc, q + delta, wp, others)
             pred = float(delta @ (lam * dg * delta - g))
             if np.isfinite(ct) and pred > 0:
                 rho = (c - ct) / pred
@@ -394,7 +413,7 @@ def lm_solve(basis, sc, q0=None, max_iter=200, ftol=1e-14, gtol=1e-9, xtol=1e-11
             q = q + delta
             lam = max(lam * max(1.0 / 3.0, 1.0 - (2.0 * rho - 1.0) ** 3), LM_LAMBDA_MIN); nu = 2.0
             small_f = (c - ct) <= ftol * c and pred <= ftol * c
-            c, g, H = eval_normal(basis, sc, q, wp)
+            c, g, H = eval_normal(basis, sc, q, wp, others)
             H = H.astype(hess_dtype).astype(np.float64)
             if small_f or small_x:
                 status = ST_CONVERGED
@@ -405,6 +424,68 @@ def lm_solve(basis, sc, q0=None, max_iter=200, ftol=1e-14, gtol=1e-9, xtol=1e-11
                 status = ST_STALLED
                 break
     return q, c, it, status
+
+
+# ----------------------------------------------------------------------------------
+# groups of coupled aircraft (collision rows between the aircraft of one scenario)
+# ----------------------------------------------------------------------------------
+def partners(sc, self_idx, n_ac):
+    m = int(sc[SC_PMASK])
+    return [j for j in range(n_ac) if j != self_idx and (m >> j) & 1]
+
+
+def group_positions(basis, scs, qs):
+    """(n_ac, 2, K) sampled x, y of every aircraft of the group."""
+    return np.array([flat_outputs(basis, scs[i], qs[i])[0] for i in range(len(scs))])
+
+
+def group_cost(basis, scs, qs):
+    """Joint cost: own rows of every aircraft + each coupled pair ONCE."""
+    n = len(scs)
+    pos = group_positions(basis, scs, qs)
+    tot = sum(cost(basis, scs[i], qs[i]) for i in range(n))
+    for i in range(n):
+        for j in partners(scs[i], i, n):
+            if j > i:
+                kc = OBS_K / scs[i][SC_RCOL]
+                ex = (pos[i][0] - pos[j][0]) * kc; ey = (pos[i][1] - pos[j][1]) * kc
+                tot += scs[i][SC_SCOL] * scs[i][SC_KCOL] * float(np.sum(np.exp(-(ex * ex + ey * ey))))
+    return tot
+
+
+def group_residuals(basis, scs, qflat):
+    """Stacked residual of the joint problem (for the scipy arbiter): own rows + pair rows once."""
+    n = len(scs); nq2 = 2 * basis.nq
+    qs = qflat.reshape(n, nq2)
+    pos = group_positions(basis, scs, qs)
+    out = [residuals(basis, scs[i], qs[i]).reshape(-1) for i in range(n)]
+    for i in range(n):
+        for j in partners(scs[i], i, n):
+            if j > i:
+                kc = OBS_K / scs[i][SC_RCOL]
+                ex = (pos[i][0] - pos[j][0]) * kc; ey = (pos[i][1] - pos[j][1]) * kc
+                out.append(math.sqrt(scs[i][SC_SCOL] * scs[i][SC_KCOL]) * np.exp(-0.5 * (ex * ex + ey * ey)))
+    return np.concatenate(out)
+
+
+def bgs_solve(basis, scs, q0s=None, sweeps=30, inner_iters=8, tol=1e-12, **lm_kw):
+    """Block Gauss-Seidel over the aircraft of one group -- the algorithm d2d_fit_solve_groups runs:
+    visit aircraft 0..n-1 in order; each visit restarts the LM state and runs at most `inner_iters`
+    damped solves on that aircraft's unknowns with the others' sampled positions frozen.  Stops when
+    a whole sweep changes no unknown by more than tol*(1+|q|)."""
+    n = len(scs)
+    qs = [initial_guess(basis, scs[i]) if q0s is None else np.array(q0s[i], float) for i in range(n)]
+    for sw in range(1, sweeps + 1):
+        moved = 0.0
+        for i in range(n):
+            pos = group_positions(basis, scs, qs)
+            oth = [pos[j] for j in partners(scs[i], i, n)]
+            qn, c, it, st = lm_solve(basis, scs[i], q0=qs[i], max_iter=inner_iters, others=oth, **lm_kw)
+            moved = max(moved, float(np.max(np.abs(qn - qs[i])) / (1.0 + np.max(np.abs(qs[i])))))
+            qs[i] = qn
+        if moved <= tol:
+            break
+    return np.array(qs), group_cost(basis, scs, qs), sw
 
 
 def coefficients(basis, sc, q):

@@ -1,0 +1,103 @@
+"""GPU parity: coupled groups (BASELINE configs[2] -- multi_opt_planner with collision rows between the
+aircraft of one scenario) against the oracle's block Gauss-Seidel and the scipy joint arbiter."""
+import numpy as np
+import pytest
+
+from oracle import fit as F
+
+pytestmark = pytest.mark.gpu
+K, S_ = 50, 6
+DUR = F.planner_timing(0, 4.9, 10)[2]
+
+
+def circle_scenarios(n_ac, R, seed=0, sigma=2.0, pair01_only=False):
+    """n_ac aircraft on a circle of radius t1*vref/2/1.5 heading to their antipodes (generalises exp_2 of
+    src/07_multioptyplan.py:251-260); replicas differ by a sigma-metre perturbation of the start/end points."""
+    rng = np.random.default_rng(seed)
+    rad = DUR * 12.0 / 2 / 1.5
+    s = 1.0 / K
+    sc = np.zeros((R, n_ac, F.SCEN_STRIDE))
+    for i in range(n_ac):
+        a = 2 * np.pi * i / n_ac
+        sc[:, i, F.SC_X0], sc[:, i, F.SC_Y0], sc[:, i, F.SC_PSI0] = rad * np.cos(a), rad * np.sin(a), a + np.pi
+        sc[:, i, F.SC_X1], sc[:, i, F.SC_Y1], sc[:, i, F.SC_PSI1] = -rad * np.cos(a), -rad * np.sin(a), a + np.pi
+    sc[..., [F.SC_X0, F.SC_Y0, F.SC_X1, F.SC_Y1]] += rng.normal(0, sigma, (R, n_ac, 4))
+    sc[..., F.SC_VREF] = 12; sc[..., F.SC_VSP] = 12; sc[..., F.SC_KV] = 5; sc[..., F.SC_KPHI] = 1
+    sc[..., F.SC_S] = s / n_ac; sc[..., F.SC_WWP] = 0.02; sc[..., F.SC_GOLEFT] = -1; sc[..., F.SC_WBND] = 1
+    sc[..., F.SC_PHIMAX] = F.PHI_MAX; sc[..., F.SC_VMIN] = 9; sc[..., F.SC_VMAX] = 15
+    sc[..., F.SC_KCOL] = 10; sc[..., F.SC_RCOL] = 10; sc[..., F.SC_SCOL] = s
+    if pair01_only:
+        sc[:, 0, F.SC_PMASK] = 0b10; sc[:, 1, F.SC_PMASK] = 0b01
+    else:
+        sc[..., F.SC_PMASK] = (1 << n_ac) - 1
+    return sc
+
+
+@pytest.fixture(scope='module')
+def env():
+    import d2dhip
+    ctx = d2dhip.Context(0)
+    s = 1.0 / K
+    plan = d2dhip.FitPlan(ctx, S_, K, DUR, (0.02 ** 2, s * 5.0 / 8, s / 8 / F.G_ACC ** 2))
+    ob = F.FitBasis.from_arrays(S_, K, DUR, *plan.basis())
+    yield ctx, plan, ob
+    plan.close(); ctx.close()
+
+
+@pytest.mark.parametrize('n_ac,pair01', [(8, False), (4, False), (4, True), (2, False)])
+def test_groups_vs_oracle_bgs_and_joint_arbiter(env, n_ac, pair01):
+    from scipy.optimize import least_squares
+    ctx, plan, ob = env
+    R = 6
+    sc = circle_scenarios(n_ac, R, seed=n_ac, pair01_only=pair01)
+    dsc = ctx.dev(sc.reshape(R * n_ac, -1))
+    q = plan.init(dsc)
+    cost, sweeps, stats = plan.solve_groups(dsc, q, n_ac, max_sweeps=80, inner_iters=8, tol=1e-12)
+    plan.set_groups(1)
+    qh = q.cpu().numpy().reshape(R, n_ac, -1)
+    ch = cost.cpu().numpy().reshape(R, n_ac)
+    assert sweeps < 80, (sweeps, stats)
+    for r in range(0, R, 2):
+        # (a) joint arbiter: scipy LM on the stacked joint residual, started at the GPU solution, must not move
+        fun = lambda x: F.group_residuals(ob, sc[r], x)       # noqa: E731
+        pol = least_squares(fun, qh[r].reshape(-1), method='lm', xtol=1e-14, ftol=1e-14, gtol=1e-14)
+        zg = np.array([F.coefficients(ob, sc[r, i], qh[r, i]) for i in range(n_ac)])
+        zp = np.array([F.coefficients(ob, sc[r, i], pol.x.reshape(n_ac, -1)[i]) for i in range(n_ac)])
+        assert np.abs(zg - zp).max() <= 1e-6 * np.abs(zp).max(), np.abs(zg - zp).max() / np.abs(zp).max()
+        cj = F.group_cost(ob, sc[r], qh[r])
+        assert abs(2 * pol.cost - cj) <= 1e-6 * cj
+        # (b) the oracle's block Gauss-Seidel (same algorithm, fp64 Hessian)
+        qo, co, swo = F.bgs_solve(ob, sc[r], sweeps=80, inner_iters=8, tol=1e-12)
+        zo = np.array([F.coefficients(ob, sc[r, i], qo[i]) for i in range(n_ac)])
+        assert np.abs(zg - zo).max() <= 1e-6 * np.abs(zo).max()
+        assert abs(co - cj) <= 1e-6 * cj
+        # (c) per-aircraft sub-problem costs reported by the library
+        pos = F.group_positions(ob, sc[r], qh[r])
+        for i in range(n_ac):
+            oth = [pos[j] for j in F.partners(sc[r, i], i, n_ac)]
+            assert abs(ch[r, i] - F.cost(ob, sc[r, i], qh[r, i], others=oth)) <= 1e-9 * max(ch[r, i], 1e-3)
+    # coupling did something: aircraft do not fly through the centre together
+    if not pair01 and n_ac >= 4:       # (two aircraft already pass 30 m apart on their dog-legs)
+        pos = F.group_positions(ob, sc[0], qh[0])
+        d = min(np.hypot(*(pos[i] - pos[j])).min() for i in range(n_ac) for j in range(i + 1, n_ac))
+        q0 = plan.init(dsc); plan.solve(dsc, q0)
+        pos0 = F.group_positions(ob, sc[0], q0.cpu().numpy().reshape(R, n_ac, -1)[0])
+        d0 = min(np.hypot(*(pos0[i] - pos0[j])).min() for i in range(n_ac) for j in range(i + 1, n_ac))
+        assert d > d0 + 1.0, (d, d0)
+
+
+def test_groups_config2_batch_properties(env):
+    """configs[2] shape at reduced replica count: 8 aircraft x 256 replicas in one call; every group ends
+    stationary (largest relative move of the last sweep <= tol) and identical replicas give identical answers."""
+    ctx, plan, ob = env
+    n_ac, R = 8, 256
+    sc = circle_scenarios(n_ac, R, seed=1)
+    sc[1] = sc[0]                                             # two identical scenarios
+    dsc = ctx.dev(sc.reshape(R * n_ac, -1))
+    q = plan.init(dsc)
+    cost, sweeps, stats = plan.solve_groups(dsc, q, n_ac, max_sweeps=120, inner_iters=8, tol=1e-10)
+    plan.set_groups(1)
+    assert stats[2] <= 1e-10 and sweeps < 120, (sweeps, stats)
+    qh = q.cpu().numpy().reshape(R, n_ac, -1)
+    np.testing.assert_array_equal(qh[0], qh[1])
+    assert np.isfinite(cost.cpu().numpy()).all()

@@ -214,9 +214,12 @@ def test_multi_planner_like_11_full_sim():
     scen.t1 = 6
     scen.p0s = ((0, 40, 0, 0, 12), (25, 40, 0, 0, 12), (25, -40, 0, 0, 12), (0, -40, 0, 0, 12))
     scen.p1s = ((75, 40, 0, 0, 12), (100, 40, 0, 0, 12), (100, -40, 0, 0, 12), (75, -40, 0, 0, 12))
-    _p = mop.Planner(scen, initialize=True)
-    with pytest.raises(NotImplementedError):                     # kcol = 10 in the reference's trap_4
-        _p.run(initial_guess=_p.get_initial_guess(scen.initial_guess), tol=scen.tol, max_iter=scen.max_iter)
+    _p = mop.Planner(scen, initialize=True)                       # kcol = 10, rcol = 10: coupled pair (0, 1)
+    _p.run(initial_guess=_p.get_initial_guess(scen.initial_guess), tol=scen.tol, max_iter=scen.max_iter)
+    _p.interpret_solution()
+    c_coupled = scen.cost.cost(_p.solution, _p)
+    sep = np.hypot(_p.sol_x[0] - _p.sol_x[1], _p.sol_y[0] - _p.sol_y[1])
+    scen_cost = scen.cost
     scen.cost = d2mou.CostComposit(kvel=70., kbank=1., kobs=float('NaN'), kcol=float('NaN'), vsp=12., obss=[], obs_kind=0, rcol=10)
     _p = mop.Planner(scen, initialize=True)
     _p.run(initial_guess=_p.get_initial_guess(scen.initial_guess), tol=scen.tol, max_iter=scen.max_iter)
@@ -231,6 +234,11 @@ def test_multi_planner_like_11_full_sim():
     # 75 m in 6 s needs 12.5 m/s on average: 70 * mean((v-12)^2) ~ 70 * 0.25
     c = scen.cost.cost(_p.solution, _p)
     assert 10.0 < c < 20.0 and abs(np.mean(_p.sol_v[0]) - 12.5) < 0.2, c
+    # with the collision term the coupled pair keeps at least its uncoupled separation and the reference's
+    # own cost (which includes CostCollision on pair (0,1)) is not worse than for the uncoupled plan
+    sep0 = np.hypot(_p.sol_x[0] - _p.sol_x[1], _p.sol_y[0] - _p.sol_y[1])
+    assert sep.min() >= sep0.min() - 1e-6
+    assert c_coupled <= scen_cost.cost(_p.solution, _p) + 1e-9
     # ... and feeds the tracking phase exactly as src/11_full_sim_case1.py:455-460 does
     import full_sim
     x_ref = np.array(_p.sol_x).T; y_ref = np.array(_p.sol_y).T
