@@ -118,12 +118,18 @@ def main():
     import d2dhip
     from d2dhip import synth
     dist = None
+    # one rank per GPU; D2D_DIST_BACKEND=gloo lets several ranks share one GPU for a rehearsal of this path
+    backend = os.environ.get('D2D_DIST_BACKEND', 'nccl')
+    dev_index = local_rank % max(torch.cuda.device_count(), 1) if backend != 'nccl' else local_rank
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
-    ctx = d2dhip.Context(local_rank)
+        torch.cuda.set_device(dev_index)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', dev_index))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    ctx = d2dhip.Context(dev_index)
     dur, wref = _plan_consts()
     plan = d2dhip.FitPlan(ctx, S_, K, dur, wref)
     B = a.batch
@@ -131,7 +137,7 @@ def main():
     dsc = ctx.dev(sc)
     q0 = plan.init(dsc)
     from d2dhip.dist import StatsReducer, solve_sharded
-    reducer = StatsReducer(dist, ctx.device)
+    reducer = StatsReducer(dist, ctx.device if backend == 'nccl' else 'cpu')
 
     def one_step():
         """Full LM solve of the resident shard with the global convergence check."""
@@ -154,7 +160,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=ctx.device)
+        tt = torch.tensor([dt], dtype=torch.float64, device=ctx.device if backend == 'nccl' else 'cpu')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     st = status.cpu().numpy()

@@ -132,10 +132,8 @@ enum { PR_DX = 0, PR_DY = 4, PR_P2X = 8, PR_P2Y, PR_SAX, PR_SAY, PR_SBX, PR_SBY,
        PR_VMAX, PR_O0X, PR_O0Y, PR_O1X, PR_O1Y, PR_X0, PR_Y0, PR_X1, PR_Y1, PR_CCOL, PR_KC, PR_PMASK };
 
 struct ScenP {
-  double dx[4], dy[4];
-  double p2x, p2y, sax, say, sbx, sby;      // dog-leg apex and the two linspace steps
   double cv, cphi, cobs, k0, k1, cv2, cphi2, wb2, wwp, wbnd, vsp, wx, wy, phimax, vmin, vmax;
-  double o0x, o0y, o1x, o1y, x0, y0, x1, y1;
+  double o0x, o0y, o1x, o1y;
   double ccol, kc;      // collision rows: sqrt(s_col*kcol), k / rcol
   int pmask;            // bit j: coupled with aircraft j of the group
 };
@@ -170,28 +168,53 @@ __device__ __forceinline__ void prep_row(const double *__restrict__ sc, double d
 
 __device__ __forceinline__ ScenP load_scenp(const double *__restrict__ p) {
   ScenP s;
-#pragma unroll
-  for (int c = 0; c < 4; ++c) { s.dx[c] = p[PR_DX + c]; s.dy[c] = p[PR_DY + c]; }
-  s.p2x = p[PR_P2X]; s.p2y = p[PR_P2Y]; s.sax = p[PR_SAX]; s.say = p[PR_SAY]; s.sbx = p[PR_SBX]; s.sby = p[PR_SBY];
   s.cv = p[PR_CV]; s.cphi = p[PR_CPHI]; s.cobs = p[PR_COBS]; s.k0 = p[PR_K0]; s.k1 = p[PR_K1];
   s.cv2 = p[PR_CV2]; s.cphi2 = p[PR_CPHI2]; s.wb2 = p[PR_WB2]; s.wwp = p[PR_WWP]; s.wbnd = p[PR_WBND];
   s.vsp = p[PR_VSP]; s.wx = p[PR_WX]; s.wy = p[PR_WY]; s.phimax = p[PR_PHIMAX]; s.vmin = p[PR_VMIN]; s.vmax = p[PR_VMAX];
   s.o0x = p[PR_O0X]; s.o0y = p[PR_O0Y]; s.o1x = p[PR_O1X]; s.o1y = p[PR_O1Y];
-  s.x0 = p[PR_X0]; s.y0 = p[PR_Y0]; s.x1 = p[PR_X1]; s.y1 = p[PR_Y1];
   s.ccol = p[PR_CCOL]; s.kc = p[PR_KC]; s.pmask = (int)p[PR_PMASK];
   return s;
 }
 
-// numpy.linspace semantics with the step precomputed: start + i*step, last element = stop
-__device__ __forceinline__ void waypoint_at(const ScenP &s, int K, int k, double &wx, double &wy) {
+// Per-sample constants of one trajectory (fit_prepk_kernel), pk [B][FIT_PK][K]:
+//   rows 0..5 = the end-condition part of the flat outputs, Gp_d[k] . d_axis (x,y,xd,yd,xdd,ydd)
+//   rows 6..7 = the 'tri' waypoint of sample k (numpy.linspace semantics, src/d2d/opty_utils.py:171-187)
+#define FIT_PK 8
+__device__ __forceinline__ void prepk_entry(const double *__restrict__ pr, const double *__restrict__ Gp64, int K, int k,
+                                            double o[FIT_PK]) {
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const double *gp = Gp64 + ((size_t)d * K + k) * 4;
+    double ax = 0.0, ay = 0.0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { ax = fma(gp[c], pr[PR_DX + c], ax); ay = fma(gp[c], pr[PR_DY + c], ay); }
+    o[2 * d] = ax; o[2 * d + 1] = ay;
+  }
   const int n1 = K / 2, n2 = K - n1;
   if (k < n1) {
-    wx = (k == n1 - 1 && n1 > 1) ? s.p2x : k * s.sax + s.x0;
-    wy = (k == n1 - 1 && n1 > 1) ? s.p2y : k * s.say + s.y0;
+    o[6] = (k == n1 - 1 && n1 > 1) ? pr[PR_P2X] : k * pr[PR_SAX] + pr[PR_X0];
+    o[7] = (k == n1 - 1 && n1 > 1) ? pr[PR_P2Y] : k * pr[PR_SAY] + pr[PR_Y0];
   } else {
     const int i = k - n1;
-    wx = (i == n2 - 1 && n2 > 1) ? s.x1 : i * s.sbx + s.p2x;
-    wy = (i == n2 - 1 && n2 > 1) ? s.y1 : i * s.sby + s.p2y;
+    o[6] = (i == n2 - 1 && n2 > 1) ? pr[PR_X1] : i * pr[PR_SBX] + pr[PR_P2X];
+    o[7] = (i == n2 - 1 && n2 > 1) ? pr[PR_Y1] : i * pr[PR_SBY] + pr[PR_P2Y];
+  }
+}
+
+// Flat outputs of sample k from the per-sample base pk[0..5] plus G_d[k] . q  (oracle/fit.py flat_outputs)
+__device__ __forceinline__ void flat_outputs_pk(const FitGeom &g, const double *__restrict__ G64,
+                                                const double *__restrict__ q, const double pk[FIT_PK], int k, double Y[6]) {
+#pragma unroll
+  for (int c = 0; c < 6; ++c) Y[c] = pk[c];
+  const double *g0 = G64 + (size_t)k * g.gstr;
+  const double *g1 = g0 + (size_t)g.K * g.gstr;
+  const double *g2 = g1 + (size_t)g.K * g.gstr;
+  for (int j = 0; j < g.nq; ++j) {
+    const double qx = q[j], qy = q[g.nq + j];
+    const double a0 = g0[j], a1 = g1[j], a2 = g2[j];
+    Y[0] = fma(a0, qx, Y[0]); Y[1] = fma(a0, qy, Y[1]);
+    Y[2] = fma(a1, qx, Y[2]); Y[3] = fma(a1, qy, Y[3]);
+    Y[4] = fma(a2, qx, Y[4]); Y[5] = fma(a2, qy, Y[5]);
   }
 }
 
@@ -286,18 +309,19 @@ __device__ __forceinline__ double partner_terms(const ScenP &s, const GroupCtx &
   return cost;
 }
 
-// Cost at q (wave-cooperative): sum over samples of sum r^2.
-__device__ __forceinline__ double wave_cost(const FitGeom &g, const double *G64, const double *Gp64,
+// Cost at q (wave-cooperative): sum over samples of sum r^2.  pkb = this trajectory's [FIT_PK][K] block.
+__device__ __forceinline__ double wave_cost(const FitGeom &g, const double *G64, const double *__restrict__ pkb,
                                             const double *q, const ScenP &s, int lane,
                                             const GroupCtx &gc = GroupCtx{nullptr, 1, 0, 0, 0}) {
   double acc = 0.0;
   for (int k0 = 0; k0 < g.K; k0 += 64) {
     const int k = k0 + lane;
     if (k < g.K) {
-      double Y[6], wpx, wpy;
-      flat_outputs(g, G64, Gp64, q, s, k, Y);
-      waypoint_at(s, g.K, k, wpx, wpy);
-      acc += sample_terms<false>(s, Y, wpx, wpy, nullptr, nullptr);
+      double pk[FIT_PK], Y[6];
+#pragma unroll
+      for (int c = 0; c < FIT_PK; ++c) pk[c] = pkb[(size_t)c * g.K + k];
+      flat_outputs_pk(g, G64, q, pk, k, Y);
+      acc += sample_terms<false>(s, Y, pk[6], pk[7], nullptr, nullptr);
       acc += partner_terms<false>(s, gc, g.K, k, Y[0], Y[1], nullptr, nullptr);
     }
   }

@@ -14,7 +14,7 @@
 #include "fit_phases.h"
 #include "fit_plan.h"
 
-#define FIT_WPB_MAX 16       // wavefronts (= trajectories) per workgroup, fewer when K is large
+#define FIT_WPB_MAX 12       // wavefronts (= trajectories) per workgroup, fewer when K is large
 #define FIT_THREADS (64 * FIT_WPB_MAX)
 #define FIT_LDS_BYTES (160 * 1024)
 
@@ -43,7 +43,7 @@ static FitLds eval_lds_layout(int K, int nq, bool g32_lds, int wpb, int nds = 0)
   const int gstr = nq + 1;
   int o = 0;
   L.G64 = o; o = align16(o + 3 * K * gstr * 8);
-  L.Gp64 = o; o = align16(o + 3 * K * 4 * 8);
+  L.Gp64 = o;                                       // (end-condition part now comes from the pk table)
   L.G32 = o; o = align16(o + (g32_lds ? (3 * K + 1) * nq * 4 : 0));   // + one padded sample row
   L.wave0 = o;
   int w = 0;
@@ -81,77 +81,105 @@ fit_prep_kernel(int B, int K, double duration, const double *__restrict__ scen, 
   prep_row(scen + (size_t)b * D2D_SCEN_STRIDE, duration, K, prep + (size_t)b * FIT_PREP_STRIDE);
 }
 
+// per-sample constants of every trajectory: pk [B][FIT_PK][K] (fit_device.h prepk_entry)
+__global__ void __launch_bounds__(256)
+fit_prepk_kernel(int B, int K, const double *__restrict__ prep, const double *__restrict__ Gp64, double *__restrict__ pk) {
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= (long)B * K) return;
+  const int b = i / K, k = i - (long)b * K;
+  double o[FIT_PK];
+  prepk_entry(prep + (size_t)b * FIT_PREP_STRIDE, Gp64, K, k, o);
+#pragma unroll
+  for (int c = 0; c < FIT_PK; ++c) pk[((size_t)b * FIT_PK + c) * K + k] = o[c];
+}
+
 // ------------------------------------------------------------------------------------
 // K1 + K2: cost, J^T r, J^T J.   H is written as the upper block triangle of 16x16 tiles
 // of a [n][n] row-major matrix (n = 2nq); symmetrize_kernel mirrors it for the public API.
 template <int NB, int NQ, bool G32_LDS>   // NB = ceil(2nq/16) column blocks of the MFMA tiling; NQ = nq or 0 (runtime)
 __global__ void __launch_bounds__(FIT_THREADS)
 fit_eval_kernel(int B, FitGeom g, FitLds L, int dbg, GroupArgs ga, const double *__restrict__ gG64,
-                const double *__restrict__ gGp64, const float *__restrict__ gG32,
+                const double *__restrict__ pk, const float *__restrict__ gG32,
                 const float *__restrict__ gW32, const double *__restrict__ prep,
                 const double *__restrict__ q_in, int32_t *__restrict__ flags,
                 double *__restrict__ cost_out, double *__restrict__ g_out, float *__restrict__ H_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int wpb = blockDim.x >> 6;
-  const int bl = blockIdx.x * wpb + wave;
-  const int b = ga.off + bl * ga.stride;
-  bool active = bl < B;
-  if (active && flags) active = flags[4 * b + FL_STATUS] == D2D_ST_RUNNING && flags[4 * b + FL_NEED] != 0;
+  // persistent over the batch: wave w of workgroup g takes sub-batch entries g*wpb + w, + gridDim*wpb, ...
+  // (after their first trajectory the waves of a SIMD drift apart, so one wave's MFMA phase overlaps
+  // the fp64 VALU phases of the others)
+  const int stride_bl = gridDim.x * wpb;
+  bool any = false;
+  for (int bl = blockIdx.x * wpb + wave; bl < B; bl += stride_bl) {
+    const int b = ga.off + bl * ga.stride;
+    any = any || !flags || (flags[4 * b + FL_STATUS] == D2D_ST_RUNNING && flags[4 * b + FL_NEED] != 0);
+  }
   // nothing to do for this workgroup: leave before paying for the LDS image
-  if (!__syncthreads_or(active ? 1 : 0)) return;
+  if (!__syncthreads_or(any ? 1 : 0)) return;
 
-  // issue the per-trajectory loads first: their latency hides under the staging of the shared block
   const int n = 2 * g.nq;
-  const double q_lane = (active && lane < n) ? q_in[(size_t)b * n + lane] : 0.0;
-  ScenP s;
-  if (active) s = load_scenp(prep + (size_t)b * FIT_PREP_STRIDE);
   double *G64 = reinterpret_cast<double *>(lds + L.G64);
-  double *Gp64 = reinterpret_cast<double *>(lds + L.Gp64);
   if (!(dbg & 16)) {
     stage(G64, gG64, 3 * g.K * g.gstr * 8);
-    stage(Gp64, gGp64, 3 * g.K * 4 * 8);
     if (G32_LDS) stage(lds + L.G32, gG32, (3 * g.K + 1) * g.nq * 4);
   }
   unsigned char *wl = lds + L.wave0 + wave * L.wave_stride;
   double *qs = reinterpret_cast<double *>(wl + L.q);
   double *us = reinterpret_cast<double *>(wl + L.u);
   f32x4 *cf = reinterpret_cast<f32x4 *>(wl + L.coef);
-  if (lane < n) qs[lane] = q_lane;
-  __syncthreads();
-  if (!active) return;
-
-  double g_lane;
-  const GroupCtx gc{ga.pos, ga.n_ac, ga.n_ac > 0 ? b % ga.n_ac : 0, ga.n_ac > 0 ? (b / ga.n_ac) * ga.n_ac : 0, ga.pos ? ga.nds : 0};
   float2 *cfd = reinterpret_cast<float2 *>(wl + L.cfd);
-  const double cost = eval_cost_grad(g, G64, Gp64, qs, us, cf, s, lane, dbg, g_lane, gc, cfd);
-  if (lane < n && g_out) g_out[(size_t)b * n + lane] = g_lane;
-  if (lane == 0) {
-    if (cost_out) cost_out[b] = cost;
-    if (flags) {
-      flags[4 * b + FL_NEED] = 0;
-      flags[4 * b + FL_NEVAL] += 1;
-      if (!(fabs(cost) <= 1.79e308)) flags[4 * b + FL_STATUS] = D2D_ST_NONFINITE;
-    }
+  __syncthreads();
+  // De-phase the waves that share a SIMD (HW_ID.WAVE_ID = slot on the SIMD): waves that start together
+  // stay in lockstep -- all in the fp64 VALU phases, then all queueing on the matrix pipe.  A start
+  // offset of about a quarter trajectory per slot lets one wave's MFMA phase run under the others'
+  // VALU phases for the rest of the launch.  Only worth it when a wave has several trajectories.
+  if (B > 2 * stride_bl) {
+    const int slot = __builtin_amdgcn_s_getreg(6148) & 3;       // hwreg(HW_REG_HW_ID, 0, 4)
+    for (int i = 0; i < slot; ++i) __builtin_amdgcn_s_sleep(100);
   }
-  if (!H_out) return;
-  const float *T32 = G32_LDS ? reinterpret_cast<const float *>(lds + L.G32) : gG32;
-  f32x4 acc[NB * (NB + 1) / 2];
-  jtj_mfma<NB, NQ>(g, T32, cf, lane, (dbg & 4) ? 1 : g.K, acc, cfd, gc.nds);
-  // epilogue: + wwp^2 G0^T G0 (pre-tiled constant) ; tile-major store: [tile][reg][lane], 256 B per store
-  const float ww = (float)(s.wwp * s.wwp);
-  float *Hb = H_out + (size_t)b * (NB * (NB + 1) / 2) * 256;
+
+  for (int bl = blockIdx.x * wpb + wave; bl < B; bl += stride_bl) {
+    const int b = ga.off + bl * ga.stride;
+    if (flags && !(flags[4 * b + FL_STATUS] == D2D_ST_RUNNING && flags[4 * b + FL_NEED] != 0)) continue;
+    if (lane < n) qs[lane] = q_in[(size_t)b * n + lane];
+    const ScenP s = load_scenp(prep + (size_t)b * FIT_PREP_STRIDE);
+    wave_lds_sync();
+    double g_lane;
+    const GroupCtx gc{ga.pos, ga.n_ac, ga.n_ac > 0 ? b % ga.n_ac : 0, ga.n_ac > 0 ? (b / ga.n_ac) * ga.n_ac : 0, ga.pos ? ga.nds : 0};
+    const double cost = eval_cost_grad(g, G64, pk + (size_t)b * FIT_PK * g.K, qs, us, cf, s, lane, dbg, g_lane, gc, cfd);
+    if (lane < n && g_out) g_out[(size_t)b * n + lane] = g_lane;
+    if (lane == 0) {
+      if (cost_out) cost_out[b] = cost;
+      if (flags) {
+        flags[4 * b + FL_NEED] = 0;
+        flags[4 * b + FL_NEVAL] += 1;
+        if (!(fabs(cost) <= 1.79e308)) flags[4 * b + FL_STATUS] = D2D_ST_NONFINITE;
+      }
+    }
+    if (H_out) {
+      f32x4 acc[NB * (NB + 1) / 2];
+      jtj_mfma<NB, NQ, G32_LDS>(g, lds, L.G32, gG32, L.wave0 + wave * L.wave_stride + L.coef, lane, (dbg & 4) ? 1 : g.K, acc,
+                                L.wave0 + wave * L.wave_stride + L.cfd, gc.nds);
+      // epilogue: tile-major store [tile][reg][lane], 256 B per store instruction.  The waypoint rows'
+      // constant block wwp^2 G0^T G0 is added by the consumer (fit_step_kernel / untile_kernel).
+      float *Hb = H_out + (size_t)b * (NB * (NB + 1) / 2) * 256;
 #pragma unroll
-  for (int t = 0; t < NB * (NB + 1) / 2; ++t)
+      for (int t = 0; t < NB * (NB + 1) / 2; ++t)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) Hb[(t * 4 + r) * 64 + lane] = fmaf(ww, gW32[(t * 4 + r) * 64 + lane], acc[t][r]);
+        for (int r = 0; r < 4; ++r) Hb[(t * 4 + r) * 64 + lane] = acc[t][r];
+    }
+    wave_lds_sync();     // the next trajectory reuses this wave's LDS block
+  }
 }
 
 // tile-major J^T J (fit_eval_kernel's layout: [tile (I<=J)][reg][lane], C/D map row = 16I + 4(lane>>4) + reg,
 // col = 16J + (lane&15)) -> full symmetric row-major [n][n] for the public d2d_fit_eval
 __global__ void __launch_bounds__(256)
-untile_kernel(int B, int n, int NB, const float *__restrict__ Ht, float *__restrict__ H) {
+untile_kernel(int B, int n, int NB, const float *__restrict__ Ht, const float *__restrict__ Wt,
+              const double *__restrict__ prep, float *__restrict__ H) {
   const int b = blockIdx.x;
+  const float ww = (float)(prep[(size_t)b * FIT_PREP_STRIDE + PR_WWP] * prep[(size_t)b * FIT_PREP_STRIDE + PR_WWP]);
   const float *src = Ht + (size_t)b * (NB * (NB + 1) / 2) * 256;
   float *dst = H + (size_t)b * n * n;
   for (int i = threadIdx.x; i < n * n; i += blockDim.x) {
@@ -160,7 +188,7 @@ untile_kernel(int B, int n, int NB, const float *__restrict__ Ht, float *__restr
     const int I = r >> 4, J = c >> 4;
     const int tile = I * NB - I * (I - 1) / 2 + (J - I);
     const int rr = r & 15, reg = rr & 3, ln = (rr >> 2) * 16 + (c & 15);
-    dst[i] = src[(tile * 4 + reg) * 64 + ln];
+    dst[i] = fmaf(ww, Wt[(tile * 4 + reg) * 64 + ln], src[(tile * 4 + reg) * 64 + ln]);
   }
 }
 
@@ -174,7 +202,7 @@ static StepLds step_lds_layout(int K, int nq, int N, int wpb) {
   const int gstr = nq + 1;
   int o = 0;
   L.G64 = o; o = align16(o + 3 * K * gstr * 8);
-  L.Gp64 = o; o = align16(o + 3 * K * 4 * 8);
+  L.Gp64 = o;
   L.wave0 = o;
   int w = 0;
   {
@@ -198,7 +226,7 @@ static bool pick_step_layout(int K, int nq, int N, int *wpb) {
 template <int N>
 __global__ void __launch_bounds__(FIT_THREADS)
 fit_step_kernel(int B, FitGeom g, StepLds L, d2d_fit_opts opts, GroupArgs ga,
-                const double *__restrict__ gG64, const double *__restrict__ gGp64,
+                const double *__restrict__ gG64, const double *__restrict__ pk, const float *__restrict__ gWt,
                 const double *__restrict__ prep, double *__restrict__ q_io,
                 const double *__restrict__ g_in, const float *__restrict__ H_in,
                 double *__restrict__ cost_io, double *__restrict__ lm, int32_t *__restrict__ flags) {
@@ -209,9 +237,7 @@ fit_step_kernel(int B, FitGeom g, StepLds L, d2d_fit_opts opts, GroupArgs ga,
   const bool active = bl < B && flags[4 * b + FL_STATUS] == D2D_ST_RUNNING;
   if (!__syncthreads_or(active ? 1 : 0)) return;
   double *G64 = reinterpret_cast<double *>(lds + L.G64);
-  double *Gp64 = reinterpret_cast<double *>(lds + L.Gp64);
   stage(G64, gG64, 3 * g.K * g.gstr * 8);
-  stage(Gp64, gGp64, 3 * g.K * 4 * 8);
   __syncthreads();
   if (!active) return;
   unsigned char *wl = lds + L.wave0 + wave * L.wave_stride;
@@ -237,8 +263,10 @@ fit_step_kernel(int B, FitGeom g, StepLds L, d2d_fit_opts opts, GroupArgs ga,
   constexpr int NBs = N / 16, NT = NBs * (NBs + 1) / 2;
   {
     const float *Hb = H_in + (size_t)b * NT * 256;
+    const double wwp = prep[(size_t)b * FIT_PREP_STRIDE + PR_WWP];
+    const float ww = (float)(wwp * wwp);
 #pragma unroll
-    for (int i = 0; i < NT * 4; ++i) Lm[i * 64 + lane] = Hb[i * 64 + lane];
+    for (int i = 0; i < NT * 4; ++i) Lm[i * 64 + lane] = fmaf(ww, gWt[i * 64 + lane], Hb[i * 64 + lane]);
   }
   wave_lds_sync();
   float hrow[N];
@@ -252,7 +280,7 @@ fit_step_kernel(int B, FitGeom g, StepLds L, d2d_fit_opts opts, GroupArgs ga,
   wave_lds_sync();
   const ScenP s = load_scenp(prep + (size_t)b * FIT_PREP_STRIDE);
   const GroupCtx gc{ga.pos, ga.n_ac, ga.n_ac > 0 ? b % ga.n_ac : 0, ga.n_ac > 0 ? (b / ga.n_ac) * ga.n_ac : 0, ga.pos ? ga.nds : 0};
-  const double ct = wave_cost(g, G64, Gp64, qt, s, lane, gc);
+  const double ct = wave_cost(g, G64, pk + (size_t)b * FIT_PK * g.K, qt, s, lane, gc);
   const double pred = wave_sum(delta * (lam * (double)dgi * delta - gi));
   const double dmax = wave_max(fabs(delta)), qmax = wave_max(fabs(qi));
   const StepOutcome so = judge_step(ok, c, ct, pred, dmax, qmax, lam, nu, opts);
@@ -291,7 +319,7 @@ static FusedLds fused_lds_layout(int K, int nq, int N, int wpb) {
   const int gstr = nq + 1;
   int o = 0;
   L.G64 = o; o = align16(o + 3 * K * gstr * 8);
-  L.Gp64 = o; o = align16(o + 3 * K * 4 * 8);
+  L.Gp64 = o;
   L.G32 = o; o = align16(o + (3 * K + 1) * nq * 4);
   L.wave0 = o;
   int w = 0;
@@ -318,7 +346,7 @@ static bool pick_fused_layout(int K, int nq, int N, int *wpb) {
 template <int NB, int NQ>
 __global__ void __launch_bounds__(64 * FIT_LM_WPB_MAX)
 fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_budget,
-              const double *__restrict__ gG64, const double *__restrict__ gGp64,
+              const double *__restrict__ gG64, const double *__restrict__ pk,
               const float *__restrict__ gG32, const float *__restrict__ gWt,
               const double *__restrict__ prep, double *__restrict__ q_io, double *__restrict__ cost_io,
               double *__restrict__ g_io, double *__restrict__ lm, int32_t *__restrict__ flags,
@@ -326,10 +354,7 @@ fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_budget,
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   constexpr int N = 16 * NB, NT = NB * (NB + 1) / 2;
   double *G64 = reinterpret_cast<double *>(lds + L.G64);
-  double *Gp64 = reinterpret_cast<double *>(lds + L.Gp64);
-  const float *T32 = reinterpret_cast<const float *>(lds + L.G32);
   stage(G64, gG64, 3 * g.K * g.gstr * 8);
-  stage(Gp64, gGp64, 3 * g.K * 4 * 8);
   stage(lds + L.G32, gG32, (3 * g.K + 1) * g.nq * 4);
   __syncthreads();
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -348,6 +373,7 @@ fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_budget,
   for (int b = blockIdx.x * (blockDim.x >> 6) + wave; b < B; b += stride) {
     if (flags[4 * b + FL_STATUS] != D2D_ST_RUNNING) continue;
     const double *prow = prep + (size_t)b * FIT_PREP_STRIDE;
+    const double *pkb = pk + (size_t)b * FIT_PK * g.K;
     double qi = act ? q_io[(size_t)b * n + lane] : 0.0;
     double lam = lm[4 * b + 0], nu = lm[4 * b + 1];          // scalar loads: uniform
     int iters = flags[4 * b + FL_ITERS];
@@ -364,12 +390,12 @@ fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_budget,
         if (lane < N) qs[lane] = qi;
         wave_lds_sync();
         const ScenP s = load_scenp(prow);
-        c = uniform_d(eval_cost_grad(g, G64, Gp64, qs, us, cf, s, lane, 0, gi));
+        c = uniform_d(eval_cost_grad(g, G64, pkb, qs, us, cf, s, lane, 0, gi));
         ++nev;
         if (!(fabs(c) <= 1.79e308)) { status = D2D_ST_NONFINITE; break; }
         if (status != D2D_ST_RUNNING) break;             // accepted + converged: cost / J^T r refreshed
         f32x4 acc[NT];
-        jtj_mfma<NB, NQ>(g, T32, cf, lane, g.K, acc);
+        jtj_mfma<NB, NQ, true>(g, lds, L.G32, gG32, L.wave0 + wave * L.wave_stride + L.cf, lane, g.K, acc);
         wave_lds_sync();                                 // every lane is done with cf before it is overwritten
         const float ww = (float)(s.wwp * s.wwp);
 #pragma unroll
@@ -392,7 +418,7 @@ fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_budget,
       double ct;
       {
         const ScenP s = load_scenp(prow);
-        ct = uniform_d(wave_cost(g, G64, Gp64, qt, s, lane));
+        ct = uniform_d(wave_cost(g, G64, pkb, qt, s, lane));
       }
       const double pred = uniform_d(wave_sum(delta * (lam * (double)dgi * delta - gi)));
       const double dmax = uniform_d(wave_max(fabs(delta))), qmax = uniform_d(wave_max(fabs(qi)));
@@ -605,7 +631,8 @@ static int ensure_scratch(d2d_fit_plan *pl, int B) {
   const size_t n = 2 * pl->nq;
   if (pl->d_g) { hipFree(pl->d_g); hipFree(pl->d_H); hipFree(pl->d_cost); hipFree(pl->d_lm); hipFree(pl->d_flags); hipFree(pl->d_prep); }
   D2D_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&pl->d_prep), (size_t)B * FIT_PREP_STRIDE * sizeof(double)));
-  if (pl->d_pos) { hipFree(pl->d_pos); hipFree(pl->d_qprev); }
+  if (pl->d_pos) { hipFree(pl->d_pos); hipFree(pl->d_qprev); hipFree(pl->d_pk); }
+  D2D_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&pl->d_pk), (size_t)B * FIT_PK * pl->K * sizeof(double)));
   D2D_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&pl->d_pos), (size_t)B * 2 * pl->K * sizeof(double)));
   D2D_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&pl->d_qprev), (size_t)B * n * sizeof(double)));
   D2D_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&pl->d_g), (size_t)B * n * sizeof(double)));
@@ -622,6 +649,7 @@ static int ensure_scratch(d2d_fit_plan *pl, int B) {
 
 static int launch_prep(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, const double *scen) {
   hipLaunchKernelGGL(fit_prep_kernel, dim3((B + 255) / 256), dim3(256), 0, ctx->stream, B, pl->K, pl->duration, scen, pl->d_prep);
+  hipLaunchKernelGGL(fit_prepk_kernel, dim3(((long)B * pl->K + 255) / 256), dim3(256), 0, ctx->stream, B, pl->K, pl->d_prep, pl->d_Gp, pl->d_pk);
   D2D_LAUNCH_CHECK();
   return D2D_OK;
 }
@@ -634,15 +662,17 @@ static int launch_eval(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, const double
   const FitGeom gm = geom_of(pl);
   const FitLds L = eval_lds_layout(pl->K, pl->nq, pl->g32_lds, pl->wpb_eval, pl->nds);
   const int NB = (2 * pl->nq + 15) / 16;
-  const dim3 grid((B + pl->wpb_eval - 1) / pl->wpb_eval), block(64 * pl->wpb_eval);
+  int nblk = (B + pl->wpb_eval - 1) / pl->wpb_eval;
+  if (nblk > pl->n_cu) nblk = pl->n_cu;        // persistent beyond one workgroup per CU (LDS-limited residency)
+  const dim3 grid(nblk), block(64 * pl->wpb_eval);
   static const int dbg = getenv("D2D_FIT_ABLATE") ? atoi(getenv("D2D_FIT_ABLATE")) : 0;   // timing experiments only
 #define LAUNCH_EVAL(NBV, INLDS)                                                                    \
   if (pl->nq == 24 && NBV == 3)                                                                    \
     hipLaunchKernelGGL((fit_eval_kernel<3, 24, INLDS>), grid, block, L.total, ctx->stream, B, gm, L, dbg, ga, \
-                       pl->d_G, pl->d_Gp, pl->d_G32, pl->d_W32, pl->d_prep, q, flags, cost, g, H);  \
+                       pl->d_G, pl->d_pk, pl->d_G32, pl->d_W32, pl->d_prep, q, flags, cost, g, H);  \
   else                                                                                             \
   hipLaunchKernelGGL((fit_eval_kernel<NBV, 0, INLDS>), grid, block, L.total, ctx->stream, B, gm, L, dbg, ga, \
-                     pl->d_G, pl->d_Gp, pl->d_G32, pl->d_W32, pl->d_prep, q, flags, cost, g, H)
+                     pl->d_G, pl->d_pk, pl->d_G32, pl->d_W32, pl->d_prep, q, flags, cost, g, H)
   if (pl->g32_lds) {
     if (NB == 1) LAUNCH_EVAL(1, true);
     else if (NB == 2) LAUNCH_EVAL(2, true);
@@ -665,7 +695,7 @@ static int launch_step(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, double *q, c
   const dim3 grid((B + pl->wpb_step - 1) / pl->wpb_step), block(64 * pl->wpb_step);
 #define LAUNCH_STEP(NV)                                                                            \
   hipLaunchKernelGGL(fit_step_kernel<NV>, grid, block, L.total, ctx->stream, B, gm, L, o, ga, \
-                     pl->d_G, pl->d_Gp, pl->d_prep, q, pl->d_g, pl->d_H, pl->d_cost, pl->d_lm, pl->d_flags)
+                     pl->d_G, pl->d_pk, pl->d_W32, pl->d_prep, q, pl->d_g, pl->d_H, pl->d_cost, pl->d_lm, pl->d_flags)
   if (NB == 1) LAUNCH_STEP(16);
   else if (NB == 2) LAUNCH_STEP(32);
   else LAUNCH_STEP(48);
@@ -681,7 +711,7 @@ static int launch_lm(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, double *q, con
   int blocks = (B + pl->wpb_lm - 1) / pl->wpb_lm;
   if (blocks > pl->n_cu) blocks = pl->n_cu;           // persistent: one workgroup per CU pulls work
   hipLaunchKernelGGL((fit_lm_kernel<3, 24>), dim3(blocks), dim3(64 * pl->wpb_lm), L.total, ctx->stream, B, gm, L, o, budget,
-                     pl->d_G, pl->d_Gp, pl->d_G32, pl->d_W32, pl->d_prep, q, pl->d_cost, pl->d_g, pl->d_lm, pl->d_flags,
+                     pl->d_G, pl->d_pk, pl->d_G32, pl->d_W32, pl->d_prep, q, pl->d_cost, pl->d_g, pl->d_lm, pl->d_flags,
                      ctx->counter_dev + 4);
   D2D_LAUNCH_CHECK();
   return D2D_OK;
@@ -764,7 +794,7 @@ int d2d_fit_plan_destroy(d2d_fit_plan *pl) {
   hipSetDevice(pl->device);
   for (hipEvent_t e : pl->prof_ev) (void)hipEventDestroy(e);
   void *ptrs[] = {pl->d_G, pl->d_Gp, pl->d_G32, pl->d_W32, pl->d_Z, pl->d_Zp, pl->d_Pinit,
-                  pl->d_g, pl->d_H, pl->d_cost, pl->d_lm, pl->d_flags, pl->d_prep, pl->d_pos, pl->d_qprev};
+                  pl->d_g, pl->d_H, pl->d_cost, pl->d_lm, pl->d_flags, pl->d_prep, pl->d_pos, pl->d_qprev, pl->d_pk};
   for (void *p : ptrs)
     if (p) hipFree(p);
   delete pl;
@@ -810,7 +840,7 @@ int d2d_fit_eval(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, const double *scen
   if (int rc = launch_eval(ctx, pl, B, q, nullptr, cost, g, H ? plm->d_H : nullptr)) return rc;
   plm->prep_valid_for = nullptr;
   if (H) {
-    hipLaunchKernelGGL(untile_kernel, dim3(B), dim3(256), 0, ctx->stream, B, 2 * pl->nq, (2 * pl->nq + 15) / 16, plm->d_H, H);
+    hipLaunchKernelGGL(untile_kernel, dim3(B), dim3(256), 0, ctx->stream, B, 2 * pl->nq, (2 * pl->nq + 15) / 16, plm->d_H, pl->d_W32, pl->d_prep, H);
     D2D_LAUNCH_CHECK();
   }
   return D2D_OK;

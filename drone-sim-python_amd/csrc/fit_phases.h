@@ -8,7 +8,7 @@
 // qs: q of this trajectory in LDS; us [K][6] fp64 and cf [K+1][4] f32x4 are the wave's scratch.
 // Returns sum r^2; g_lane = (J^T r)[lane] for lane < 2nq.
 // cfd [K+1][nds] float2: row coefficients of the collision rows (only with a coupled group).
-__device__ __forceinline__ double eval_cost_grad(const FitGeom &g, const double *G64, const double *Gp64,
+__device__ __forceinline__ double eval_cost_grad(const FitGeom &g, const double *G64, const double *__restrict__ pkb,
                                                  const double *qs, double *us, f32x4 *cf, const ScenP &s,
                                                  int lane, int dbg, double &g_lane,
                                                  const GroupCtx &gc = GroupCtx{nullptr, 1, 0, 0, 0}, float2 *cfd = nullptr) {
@@ -18,11 +18,12 @@ __device__ __forceinline__ double eval_cost_grad(const FitGeom &g, const double 
   for (int k0 = 0; k0 < g.K; k0 += 64) {
     const int k = k0 + lane;
     if (k < g.K) {
-      double Y[6] = {1.0 + k, 2.0, 11.0, 3.0, 0.1, 0.2}, wpx, wpy, u[6] = {0, 0, 0, 0, 0, 0};
+      double Y[6] = {1.0 + k, 2.0, 11.0, 3.0, 0.1, 0.2}, u[6] = {0, 0, 0, 0, 0, 0}, pk[FIT_PK];
       f32x4 coef[4] = {f32x4{1.f, 0.f, 1.f, 0.f}, f32x4{1.f, 0.f, 1.f, 0.f}, f32x4{1.f, 0.f, 1.f, 0.f}, f32x4{1.f, 0.f, 1.f, 0.f}};
-      if (!(dbg & 8)) flat_outputs(g, G64, Gp64, qs, s, k, Y);
-      waypoint_at(s, g.K, k, wpx, wpy);
-      if (!(dbg & 1)) cacc += sample_terms<true>(s, Y, wpx, wpy, u, coef);
+#pragma unroll
+      for (int c = 0; c < FIT_PK; ++c) pk[c] = pkb[(size_t)c * g.K + k];
+      if (!(dbg & 8)) flat_outputs_pk(g, G64, qs, pk, k, Y);
+      if (!(dbg & 1)) cacc += sample_terms<true>(s, Y, pk[6], pk[7], u, coef);
       if (gc.nds) cacc += partner_terms<true>(s, gc, g.K, k, Y[0], Y[1], u, cfd + (size_t)k * gc.nds);
 #pragma unroll
       for (int c = 0; c < 6; ++c) us[k * 6 + c] = u[c];
@@ -56,72 +57,81 @@ __device__ __forceinline__ double eval_cost_grad(const FitGeom &g, const double 
 //   J = cA * TA[k][j] + cB * TB[k][j],  TA = G1 (v, phi) or G0 (obstacles), TB = G2 (phi only).
 // Operands of sample k+1 are fetched before the MFMAs of sample k are issued (the tables carry
 // one padded row).  acc: upper triangle of the NB x NB grid of 16x16 tiles.
-template <int NB, int NQ>
-__device__ __forceinline__ void jtj_mfma(const FitGeom &g, const float *T32, const f32x4 *cf, int lane,
-                                         int Kmf, f32x4 (&acc)[NB * (NB + 1) / 2],
-                                         const float2 *cfd = nullptr, int nds = 0) {
+template <int NB, int NQ, bool T_LDS>
+__device__ __forceinline__ void jtj_mfma(const FitGeom &g, const unsigned char *lds_base, int t32_off,
+                                         const float *T32g, int cf_off, int lane, int Kmf,
+                                         f32x4 (&acc)[NB * (NB + 1) / 2], int cfd_off = 0, int nds = 0) {
+  // All LDS operands are addressed as lds_base + integer byte offset so that the compiler keeps them
+  // in the LDS address space (ds_read with immediate offsets) through the unrolled loop.
   const int rho = lane >> 4, ci = lane & 15;
   const int nq = NQ ? NQ : g.nq;
   const int n = 2 * nq;
   const int plane = g.K * nq;
-  bool jok[NB];
-  const float *pc[NB], *pa[NB], *pb[NB];   // per-lane pointers: (cA,cB) pair, TA entry, TB entry
+  bool jok[NB], ayc[NB];
+  int oc[NB], oa[NB], ob[NB], jj[NB];     // byte offsets: (cA,cB) pair, TA entry, TB entry
 #pragma unroll
   for (int c = 0; c < NB; ++c) {
     const int col = 16 * c + ci;
     jok[c] = col < n;
-    const bool ay = col >= nq;
-    const int j = jok[c] ? col - (ay ? nq : 0) : 0;
-    pc[c] = reinterpret_cast<const float *>(cf + rho) + (ay ? 2 : 0);
-    pa[c] = T32 + ((rho < 2) ? plane : 0) + j;
-    pb[c] = T32 + 2 * plane + j;
+    ayc[c] = col >= nq;
+    jj[c] = jok[c] ? col - (ayc[c] ? nq : 0) : 0;
+    oc[c] = cf_off + rho * 16 + (ayc[c] ? 8 : 0);
+    oa[c] = 4 * (((rho < 2) ? plane : 0) + jj[c]);
+    ob[c] = 4 * (2 * plane + jj[c]);
   }
+#define LDS_F(off) (*reinterpret_cast<const float *>(lds_base + (off)))
+#define LDS_F2(off) (*reinterpret_cast<const float2 *>(lds_base + (off)))
+#define T32_AT(off) (T_LDS ? LDS_F(t32_off + (off)) : T32g[(off) >> 2])
 #pragma unroll
   for (int t = 0; t < NB * (NB + 1) / 2; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   float2 cc[NB];
   float ta[NB], tb[NB];
 #pragma unroll
   for (int c = 0; c < NB; ++c) {
-    cc[c] = *reinterpret_cast<const float2 *>(pc[c]);
-    ta[c] = *pa[c]; tb[c] = *pb[c];
+    cc[c] = LDS_F2(oc[c]);
+    ta[c] = T32_AT(oa[c]); tb[c] = T32_AT(ob[c]);
   }
-  for (int k = 0; k < Kmf; ++k) {
-    float v[NB];
-#pragma unroll
-    for (int c = 0; c < NB; ++c) {
-      const float val = fmaf(cc[c].y, tb[c], cc[c].x * ta[c]);
-      v[c] = (2 * nq == 16 * NB || jok[c]) ? val : 0.f;
-    }
-#pragma unroll
-    for (int c = 0; c < NB; ++c) {
-      cc[c] = *reinterpret_cast<const float2 *>(pc[c] + (k + 1) * 16);
-      ta[c] = pa[c][(k + 1) * nq]; tb[c] = pb[c][(k + 1) * nq];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    int t = 0;
-#pragma unroll
-    for (int I = 0; I < NB; ++I)
-#pragma unroll
-      for (int J = I; J < NB; ++J, ++t)
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[I], v[J], acc[t], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
+  // one k-step; KK is the compile-time offset from the running offsets so that every LDS read of
+  // the unrolled body carries an immediate offset (no per-sample address arithmetic).  Operands of
+  // sample k+1 are fetched before the MFMAs of sample k are issued.
+#define JTJ_KSTEP(KK)                                                                          \
+  {                                                                                            \
+    float v[NB];                                                                               \
+    _Pragma("unroll") for (int c = 0; c < NB; ++c) {                                           \
+      const float val = fmaf(cc[c].y, tb[c], cc[c].x * ta[c]);                                 \
+      v[c] = (2 * nq == 16 * NB || jok[c]) ? val : 0.f;                                        \
+    }                                                                                          \
+    _Pragma("unroll") for (int c = 0; c < NB; ++c) {                                           \
+      cc[c] = LDS_F2(oc[c] + ((KK) + 1) * 64);                                                 \
+      ta[c] = T32_AT(oa[c] + ((KK) + 1) * nq * 4); tb[c] = T32_AT(ob[c] + ((KK) + 1) * nq * 4); \
+    }                                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    int t = 0;                                                                                 \
+    _Pragma("unroll") for (int I = 0; I < NB; ++I)                                             \
+      _Pragma("unroll") for (int J = I; J < NB; ++J, ++t)                                      \
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[I], v[J], acc[t], 0, 0, 0);            \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
   }
+  int k = 0;
+  for (; k + 5 <= Kmf; k += 5) {
+    JTJ_KSTEP(0) JTJ_KSTEP(1) JTJ_KSTEP(2) JTJ_KSTEP(3) JTJ_KSTEP(4)
+#pragma unroll
+    for (int c = 0; c < NB; ++c) { oc[c] += 5 * 64; oa[c] += 5 * nq * 4; ob[c] += 5 * nq * 4; }
+  }
+  for (; k < Kmf; ++k) {
+    JTJ_KSTEP(0)
+#pragma unroll
+    for (int c = 0; c < NB; ++c) { oc[c] += 64; oa[c] += nq * 4; ob[c] += nq * 4; }
+  }
+#undef JTJ_KSTEP
   // collision rows of a coupled group: further k-steps of four rows each, all of the form c * G0[k][j]
   for (int grp = 0; grp * 4 < nds; ++grp) {
-    const float *p0[NB];
-    bool ayc[NB];
-#pragma unroll
-    for (int c = 0; c < NB; ++c) {
-      const int col = 16 * c + ci;
-      ayc[c] = col >= nq;
-      p0[c] = T32 + (jok[c] ? col - (ayc[c] ? nq : 0) : 0);
-    }
-    for (int k = 0; k < Kmf; ++k) {
-      const float2 c2 = cfd[(size_t)k * nds + grp * 4 + rho];
+    for (int kk = 0; kk < Kmf; ++kk) {
+      const float2 c2 = LDS_F2(cfd_off + (kk * nds + grp * 4 + rho) * 8);
       float v[NB];
 #pragma unroll
       for (int c = 0; c < NB; ++c) {
-        const float val = (ayc[c] ? c2.y : c2.x) * p0[c][k * nq];
+        const float val = (ayc[c] ? c2.y : c2.x) * T32_AT(4 * (kk * nq + jj[c]));
         v[c] = (2 * nq == 16 * NB || jok[c]) ? val : 0.f;
       }
       int t = 0;
@@ -132,6 +142,9 @@ __device__ __forceinline__ void jtj_mfma(const FitGeom &g, const float *T32, con
           acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[I], v[J], acc[t], 0, 0, 0);
     }
   }
+#undef LDS_F
+#undef LDS_F2
+#undef T32_AT
 }
 
 // Row `lane` of the symmetric matrix whose upper block triangle sits tile-major in `tiles`

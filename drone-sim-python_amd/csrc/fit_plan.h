@@ -27,6 +27,7 @@ struct d2d_fit_plan {
   double *d_lm = nullptr;    // [B][4] lambda, nu, gmax, pad
   int32_t *d_flags = nullptr;  // [B][4] status, iters, need_eval, nevals
   double *d_prep = nullptr;    // [B][FIT_PREP_STRIDE] derived scenario rows (fit_prep_kernel)
+  double *d_pk = nullptr;      // [B][FIT_PK][K] per-sample constants (fit_prepk_kernel)
   double *d_pos = nullptr;     // [B][2][K] sampled positions (coupled groups)
   double *d_qprev = nullptr;   // [B][2nq] unknowns at the start of a Gauss-Seidel sweep
   int n_group = 1, nds = 0;    // aircraft per coupled group and padded collision-row slots per sample
