@@ -207,7 +207,7 @@ static StepLds step_lds_layout(int K, int nq, int N, int wpb) {
   int w = 0;
   {
     const int nb = N / 16, tiles = nb * (nb + 1) / 2;
-    const int bytes = (N * (N + 1) > tiles * 256 ? N * (N + 1) : tiles * 256) * 4;
+    const int bytes = (N * (N + 4) > tiles * TILE_T ? N * (N + 4) : tiles * TILE_T) * 4;
     L.Lm = w; w = align16(w + bytes);
   }
   L.vec = w; w = align16(w + N * 4);
@@ -266,7 +266,7 @@ fit_step_kernel(int B, FitGeom g, StepLds L, d2d_fit_opts opts, GroupArgs ga,
     const double wwp = prep[(size_t)b * FIT_PREP_STRIDE + PR_WWP];
     const float ww = (float)(wwp * wwp);
 #pragma unroll
-    for (int i = 0; i < NT * 4; ++i) Lm[i * 64 + lane] = fmaf(ww, gWt[i * 64 + lane], Hb[i * 64 + lane]);
+    for (int i = 0; i < NT * 4; ++i) Lm[(i >> 2) * TILE_T + tile_slot(i & 3, lane)] = fmaf(ww, gWt[i * 64 + lane], Hb[i * 64 + lane]);
   }
   wave_lds_sync();
   float hrow[N];
@@ -310,7 +310,7 @@ fit_step_kernel(int B, FitGeom g, StepLds L, d2d_fit_opts opts, GroupArgs ga,
 // fp64 VALU phases, and trajectories that converge early free their wave for the tail.
 #define FIT_LM_WPB_MAX 8
 struct FusedLds {
-  int G64, Gp64, G32, wave0, wave_stride;
+  int G64, Gp64, G32, Wt, wave0, wave_stride;
   int qs, qt, big, cf;      // inside a wave's block; `big` holds us+cf, then the tiles, then the factor
   int total;
 };
@@ -321,6 +321,7 @@ static FusedLds fused_lds_layout(int K, int nq, int N, int wpb) {
   L.G64 = o; o = align16(o + 3 * K * gstr * 8);
   L.Gp64 = o;
   L.G32 = o; o = align16(o + (3 * K + 1) * nq * 4);
+  L.Wt = o; o = align16(o + (N / 16) * (N / 16 + 1) / 2 * 256 * 4);      // waypoint rows' constant block, tile-major
   L.wave0 = o;
   int w = 0;
   L.qs = w; w = align16(w + N * 8);
@@ -330,8 +331,8 @@ static FusedLds fused_lds_layout(int K, int nq, int N, int wpb) {
   L.cf = w + us_bytes;
   const int nb = N / 16, tiles = nb * (nb + 1) / 2;
   int big = us_bytes + cf_bytes;
-  if (tiles * 1024 > big) big = tiles * 1024;
-  if (N * (N + 1) * 4 > big) big = N * (N + 1) * 4;
+  if (tiles * TILE_T * 4 > big) big = tiles * TILE_T * 4;
+  if (N * (N + 4) * 4 > big) big = N * (N + 4) * 4;
   w = align16(w + big);
   L.wave_stride = w;
   L.total = o + wpb * w;
@@ -345,18 +346,28 @@ static bool pick_fused_layout(int K, int nq, int N, int *wpb) {
 
 template <int NB, int NQ>
 __global__ void __launch_bounds__(64 * FIT_LM_WPB_MAX)
-fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_budget,
+fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_budget, int getenv_rl,
               const double *__restrict__ gG64, const double *__restrict__ pk,
               const float *__restrict__ gG32, const float *__restrict__ gWt,
               const double *__restrict__ prep, double *__restrict__ q_io, double *__restrict__ cost_io,
               double *__restrict__ g_io, double *__restrict__ lm, int32_t *__restrict__ flags,
-              int32_t *__restrict__ work) {
+              unsigned long long *__restrict__ stamps) {
+  // stamps != NULL (D2D_LM_STAMPS=1, diagnostics only): per-phase wave-cycle totals, see launch_lm
+  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = 0;
+#define LM_STAMP(i)                                                     \
+  if (stamps) {                                                         \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();         \
+    st_acc[i] += t_ - st_last;                                          \
+    st_last = t_;                                                       \
+  }
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   constexpr int N = 16 * NB, NT = NB * (NB + 1) / 2;
   double *G64 = reinterpret_cast<double *>(lds + L.G64);
   stage(G64, gG64, 3 * g.K * g.gstr * 8);
   stage(lds + L.G32, gG32, (3 * g.K + 1) * g.nq * 4);
+  stage(lds + L.Wt, gWt, NT * 256 * 4);
   __syncthreads();
+  const float *Wt = reinterpret_cast<const float *>(lds + L.Wt);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   unsigned char *wl = lds + L.wave0 + wave * L.wave_stride;
   double *qs = reinterpret_cast<double *>(wl + L.qs);
@@ -368,8 +379,8 @@ fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_budget,
   const bool act = lane < n;
 
   // static striding over the batch: wave w of workgroup g takes trajectories g*wpb + w, + gridDim*wpb, ...
-  (void)work;
   const int stride = gridDim.x * (blockDim.x >> 6);
+  if (stamps) st_last = __builtin_amdgcn_s_memtime();
   for (int b = blockIdx.x * (blockDim.x >> 6) + wave; b < B; b += stride) {
     if (flags[4 * b + FL_STATUS] != D2D_ST_RUNNING) continue;
     const double *prow = prep + (size_t)b * FIT_PREP_STRIDE;
@@ -382,44 +393,58 @@ fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_budget,
     float hrow[N];
 #pragma unroll
     for (int j = 0; j < N; ++j) hrow[j] = 0.f;
-    bool need_eval = true;
-    // every value that steers the loop below is made scalar (uniform_*): the control flow is
-    // wave-uniform by construction and must compile to scalar branches
-    for (;;) {
-      if (need_eval) {
-        if (lane < N) qs[lane] = qi;
-        wave_lds_sync();
-        const ScenP s = load_scenp(prow);
-        c = uniform_d(eval_cost_grad(g, G64, pkb, qs, us, cf, s, lane, 0, gi));
-        ++nev;
-        if (!(fabs(c) <= 1.79e308)) { status = D2D_ST_NONFINITE; break; }
-        if (status != D2D_ST_RUNNING) break;             // accepted + converged: cost / J^T r refreshed
+    // Every value that steers the loop below is made scalar (uniform_*): the control flow is
+    // wave-uniform by construction and must compile to scalar branches.
+    // Invariant at the top of the loop: us / cf hold phase 1 at the point qs (= qi) whose cost is c;
+    // `fresh` says they still need phase 2 + MFMA (J^T r, J^T J) before the next damped solve.
+    if (lane < N) qs[lane] = qi;
+    wave_lds_sync();
+    LM_STAMP(0)
+    {
+      const ScenP s = load_scenp(prow);
+      c = uniform_d(eval_phase1(g, G64, pkb, qs, us, cf, s, lane, 0));
+    }
+    LM_STAMP(1)
+    bool fresh = true;
+    if (!(fabs(c) <= 1.79e308)) { status = D2D_ST_NONFINITE; fresh = false; }
+    while (status == D2D_ST_RUNNING || fresh) {
+      if (fresh) {
+        gi = eval_phase2(g, G64, us, lane, 0);
+        LM_STAMP(2)
+        fresh = false;
+        if (status != D2D_ST_RUNNING) break;             // accepted + converged: J^T r refreshed, done
         f32x4 acc[NT];
         jtj_mfma<NB, NQ, true>(g, lds, L.G32, gG32, L.wave0 + wave * L.wave_stride + L.cf, lane, g.K, acc);
-        wave_lds_sync();                                 // every lane is done with cf before it is overwritten
-        const float ww = (float)(s.wwp * s.wwp);
+        ++nev;                                           // counts J^T J evaluations (the roofline unit)
+        wave_lds_sync();                                 // every lane is done with us / cf before they are overwritten
+        LM_STAMP(3)
+        const float ww = (float)(prow[PR_WWP] * prow[PR_WWP]);
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) big[(t * 4 + r) * 64 + lane] = fmaf(ww, gWt[(t * 4 + r) * 64 + lane], acc[t][r]);
+          for (int r = 0; r < 4; ++r) big[t * TILE_T + tile_slot(r, lane)] = fmaf(ww, gWt[(t * 4 + r) * 64 + lane], acc[t][r]);
         wave_lds_sync();
         gather_row<N>(big, lane, n, act, hrow);
         wave_lds_sync();
-        need_eval = false;
+        LM_STAMP(4)
       }
       if (local >= iter_budget || iters >= opts.max_iter) break;
       const double gmax = uniform_d(wave_max(fabs(gi)));
       if (gmax <= opts.gtol) { status = D2D_ST_CONVERGED; break; }
       float dgi, dl;
-      const int ok = uniform_i(damped_solve<N>(hrow, lam, gi, act, lane, big, dgi, dl) ? 1 : 0);
+      LM_STAMP(6)
+      const int ok = uniform_i((getenv_rl ? damped_solve_rl<N>(hrow, lam, gi, act, lane, big, dgi, dl) : damped_solve<N>(hrow, lam, gi, act, lane, big, dgi, dl)) ? 1 : 0);
       const double delta = (double)dl;
-      if (lane < N) qt[lane] = qi + delta;
+      if (lane < N) qs[lane] = qi + delta;               // the trial point; restored below if rejected
       wave_lds_sync();
+      LM_STAMP(5)
       double ct;
       {
+        // full phase 1 at the trial point: if the step is accepted its rows are the next evaluation
         const ScenP s = load_scenp(prow);
-        ct = uniform_d(wave_cost(g, G64, pkb, qt, s, lane));
+        ct = uniform_d(eval_phase1(g, G64, pkb, qs, us, cf, s, lane, 0));
       }
+      LM_STAMP(1)
       const double pred = uniform_d(wave_sum(delta * (lam * (double)dgi * delta - gi)));
       const double dmax = uniform_d(wave_max(fabs(delta))), qmax = uniform_d(wave_max(fabs(qi)));
       const StepOutcome so = judge_step(ok != 0, c, ct, pred, dmax, qmax, lam, nu, opts);
@@ -427,10 +452,9 @@ fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_budget,
       lam = so.lam; nu = so.nu; status = so.status;
       if (so.accept) {
         qi += delta; c = ct;
-        need_eval = true;                                // also when converged: refresh cost / J^T r
-      } else if (status != D2D_ST_RUNNING) {
-        break;
+        fresh = true;                                    // also when converged: refresh J^T r
       }
+      LM_STAMP(6)
     }
     if (status == D2D_ST_RUNNING && iters >= opts.max_iter) status = D2D_ST_MAXITER;
     const double gmax = uniform_d(wave_max(fabs(gi)));
@@ -441,7 +465,11 @@ fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_budget,
       flags[4 * b + FL_STATUS] = status; flags[4 * b + FL_ITERS] = iters; flags[4 * b + FL_NEED] = 1;
       flags[4 * b + FL_NEVAL] += nev;
     }
+    LM_STAMP(0)
   }
+  if (stamps && lane == 0)
+    for (int i = 0; i < 8; ++i) atomicAdd(&stamps[i], st_acc[i]);
+#undef LM_STAMP
 }
 
 // ------------------------------------------------------------------------------------
@@ -707,13 +735,26 @@ static int launch_step(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, double *q, c
 static int launch_lm(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, double *q, const d2d_fit_opts &o, int budget) {
   const FitGeom gm = geom_of(pl);
   const FusedLds L = fused_lds_layout(pl->K, pl->nq, 48, pl->wpb_lm);
-  D2D_CHECK_HIP(hipMemsetAsync(ctx->counter_dev + 4, 0, sizeof(int32_t), ctx->stream));
+  static const bool want_stamps = getenv("D2D_LM_STAMPS") != nullptr;
+  unsigned long long *stamps = want_stamps ? reinterpret_cast<unsigned long long *>(ctx->stats_dev + 8) : nullptr;
+  if (want_stamps) D2D_CHECK_HIP(hipMemsetAsync(stamps, 0, 8 * sizeof(unsigned long long), ctx->stream));
   int blocks = (B + pl->wpb_lm - 1) / pl->wpb_lm;
   if (blocks > pl->n_cu) blocks = pl->n_cu;           // persistent: one workgroup per CU pulls work
-  hipLaunchKernelGGL((fit_lm_kernel<3, 24>), dim3(blocks), dim3(64 * pl->wpb_lm), L.total, ctx->stream, B, gm, L, o, budget,
+  hipLaunchKernelGGL((fit_lm_kernel<3, 24>), dim3(blocks), dim3(64 * pl->wpb_lm), L.total, ctx->stream, B, gm, L, o, budget, getenv("D2D_LM_RL") ? 1 : 0,
                      pl->d_G, pl->d_pk, pl->d_G32, pl->d_W32, pl->d_prep, q, pl->d_cost, pl->d_g, pl->d_lm, pl->d_flags,
-                     ctx->counter_dev + 4);
+                     stamps);
   D2D_LAUNCH_CHECK();
+  if (want_stamps) {
+    unsigned long long h[8];
+    D2D_CHECK_HIP(hipMemcpyAsync(h, stamps, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    D2D_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    static const char *nm[8] = {"io/loop", "phase1", "phase2", "mfma", "tiles+gather", "solve", "reduce+judge", "-"};
+    double tot = 0;
+    for (int i = 0; i < 7; ++i) tot += (double)h[i];
+    fprintf(stderr, "[fit_lm stamps] wave-cycles (s_memtime ticks), B=%d budget=%d:", B, budget);
+    for (int i = 0; i < 7; ++i) fprintf(stderr, " %s=%.1f%%", nm[i], 100.0 * (double)h[i] / tot);
+    fprintf(stderr, " total=%.3e\n", tot);
+  }
   return D2D_OK;
 }
 

@@ -8,12 +8,10 @@
 // qs: q of this trajectory in LDS; us [K][6] fp64 and cf [K+1][4] f32x4 are the wave's scratch.
 // Returns sum r^2; g_lane = (J^T r)[lane] for lane < 2nq.
 // cfd [K+1][nds] float2: row coefficients of the collision rows (only with a coupled group).
-__device__ __forceinline__ double eval_cost_grad(const FitGeom &g, const double *G64, const double *__restrict__ pkb,
-                                                 const double *qs, double *us, f32x4 *cf, const ScenP &s,
-                                                 int lane, int dbg, double &g_lane,
-                                                 const GroupCtx &gc = GroupCtx{nullptr, 1, 0, 0, 0}, float2 *cfd = nullptr) {
-  const int n = 2 * g.nq;
-  // phase 1: lane = sample
+// phase 1 (lane = sample): flat outputs, rows, u_k = D_k^T r_k -> us, fp32 row coefficients -> cf / cfd.
+__device__ __forceinline__ double eval_phase1(const FitGeom &g, const double *G64, const double *__restrict__ pkb,
+                                              const double *qs, double *us, f32x4 *cf, const ScenP &s, int lane, int dbg,
+                                              const GroupCtx &gc = GroupCtx{nullptr, 1, 0, 0, 0}, float2 *cfd = nullptr) {
   double cacc = 0.0;
   for (int k0 = 0; k0 < g.K; k0 += 64) {
     const int k = k0 + lane;
@@ -33,8 +31,13 @@ __device__ __forceinline__ double eval_cost_grad(const FitGeom &g, const double 
   }
   const double cost = wave_sum(cacc);
   wave_lds_sync();
-  // phase 2: lane = unknown, three independent fp64 accumulation chains
-  g_lane = 0.0;
+  return cost;
+}
+
+// phase 2 (lane = unknown): (J^T r)[lane] = sum_k G_k^T u_k, three independent fp64 accumulation chains
+__device__ __forceinline__ double eval_phase2(const FitGeom &g, const double *G64, const double *us, int lane, int dbg) {
+  const int n = 2 * g.nq;
+  double g_lane = 0.0;
   if (lane < n && !(dbg & 2)) {
     const int ax = lane >= g.nq ? 1 : 0, jj = lane - ax * g.nq;
     const double *g0 = G64 + jj, *g1 = g0 + (size_t)g.K * g.gstr, *g2 = g1 + (size_t)g.K * g.gstr;
@@ -48,7 +51,23 @@ __device__ __forceinline__ double eval_cost_grad(const FitGeom &g, const double 
     }
     g_lane = (a0 + a1) + a2;
   }
+  return g_lane;
+}
+
+__device__ __forceinline__ double eval_cost_grad(const FitGeom &g, const double *G64, const double *__restrict__ pkb,
+                                                 const double *qs, double *us, f32x4 *cf, const ScenP &s,
+                                                 int lane, int dbg, double &g_lane,
+                                                 const GroupCtx &gc = GroupCtx{nullptr, 1, 0, 0, 0}, float2 *cfd = nullptr) {
+  const double cost = eval_phase1(g, G64, pkb, qs, us, cf, s, lane, dbg, gc, cfd);
+  g_lane = eval_phase2(g, G64, us, lane, dbg);
   return cost;
+}
+
+template <typename T, int ALIGN>
+__device__ __forceinline__ T lds_load(const unsigned char *p) {
+  T v;
+  __builtin_memcpy(&v, __builtin_assume_aligned(p, ALIGN), sizeof(T));
+  return v;
 }
 
 // ---- phase 3: J^T J by v_mfma_f32_16x16x4_f32 ------------------------------------------------
@@ -79,8 +98,10 @@ __device__ __forceinline__ void jtj_mfma(const FitGeom &g, const unsigned char *
     oa[c] = 4 * (((rho < 2) ? plane : 0) + jj[c]);
     ob[c] = 4 * (2 * plane + jj[c]);
   }
-#define LDS_F(off) (*reinterpret_cast<const float *>(lds_base + (off)))
-#define LDS_F2(off) (*reinterpret_cast<const float2 *>(lds_base + (off)))
+  // (loads go through memcpy: the row coefficients are stored as f32x4 by other lanes, and a
+  // type-punned load would let type-based alias analysis reorder it against those stores)
+#define LDS_F(off) lds_load<float, 4>(lds_base + (off))
+#define LDS_F2(off) lds_load<float2, 8>(lds_base + (off))
 #define T32_AT(off) (T_LDS ? LDS_F(t32_off + (off)) : T32g[(off) >> 2])
 #pragma unroll
   for (int t = 0; t < NB * (NB + 1) / 2; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -147,8 +168,16 @@ __device__ __forceinline__ void jtj_mfma(const FitGeom &g, const unsigned char *
 #undef T32_AT
 }
 
-// Row `lane` of the symmetric matrix whose upper block triangle sits tile-major in `tiles`
-// ([tile][reg][lane], MFMA C/D map: row = 16I + 4(lane>>4) + reg, col = 16J + (lane&15)).
+// LDS image of the J^T J tiles used between the MFMA and the Cholesky: element (reg, lane=(rho,cc)) of tile t
+// sits at t*TILE_T + reg*TILE_S1 + rho*TILE_S2 + cc.  The strides are chosen so that the accumulator
+// stores (fixed reg, all lanes) and the row gather (fixed column, 16 rows of a tile) both spread over
+// the 32 LDS banks.
+#define TILE_S2 17
+#define TILE_S1 70
+#define TILE_T (4 * TILE_S1)
+__device__ __forceinline__ int tile_slot(int reg, int lane) { return reg * TILE_S1 + (lane >> 4) * TILE_S2 + (lane & 15); }
+
+// Row `lane` of the symmetric matrix whose upper block triangle sits in the padded tile image.
 template <int N>
 __device__ __forceinline__ void gather_row(const float *tiles, int lane, int n, bool act, float (&row)[N]) {
   constexpr int NBs = N / 16;
@@ -162,7 +191,7 @@ __device__ __forceinline__ void gather_row(const float *tiles, int lane, int n, 
       const int ti = r >> 4, tj = c >> 4;
       const int tile = ti * NBs - ti * (ti - 1) / 2 + (tj - ti);
       const int rr = r & 15;
-      v = tiles[(tile * 4 + (rr & 3)) * 64 + (rr >> 2) * 16 + (c & 15)];
+      v = tiles[tile * TILE_T + (rr & 3) * TILE_S1 + (rr >> 2) * TILE_S2 + (c & 15)];
     }
     row[j] = v;
   }
@@ -173,10 +202,11 @@ __device__ __forceinline__ void gather_row(const float *tiles, int lane, int n, 
 // left-looking Cholesky with the row owned by each lane in registers and row j broadcast by
 // v_readlane (all indices compile-time), forward substitution in registers, back substitution
 // through an LDS copy Lm [N][N+1] of the factor.  Returns false if a pivot is not positive.
+#define CHOL_LS (N + 4)      // row stride of the LDS factor image: multiple of 4 floats -> aligned ds_read_b128
 template <int N>
 __device__ __forceinline__ bool damped_solve(const float (&hrow)[N], double lam, double gi, bool act, int lane,
                                              float *Lm, float &dgi, float &delta) {
-  constexpr int LS = N + 1;
+  constexpr int LS = CHOL_LS;
   float row[N];
   float d = 1.f;
 #pragma unroll
@@ -190,47 +220,109 @@ __device__ __forceinline__ bool damped_solve(const float (&hrow)[N], double lam,
 #pragma unroll
   for (int j = 0; j < N; ++j)
     if (j == lane) row[j] = act ? (d + add) : 1.f;
+  // Left-looking Cholesky: lane i owns row i in registers; finished columns are mirrored into the LDS
+  // image Lm [N][LS] so that row j can be broadcast to every lane by a few ds_read_b128.
   bool ok = true;
+  float myinv = 1.f;                 // 1 / L[lane][lane]
+  const float *Lrow = Lm;
 #pragma unroll
   for (int j = 0; j < N; ++j) {
-    float sacc = row[j];
+    float s0 = row[j], s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (j > 0) wave_lds_sync();
 #pragma unroll
-    for (int k = 0; k < j; ++k) {
-      const float ljk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, row[k]), j));
-      sacc = fmaf(-row[k], ljk, sacc);
+    for (int k4 = 0; k4 < (j + 3) / 4; ++k4) {
+      f32x4 l;       // L[j][4k4 .. 4k4+3], same address in every lane (memcpy: no type-based aliasing assumptions)
+      __builtin_memcpy(&l, __builtin_assume_aligned(Lrow + j * LS + 4 * k4, 16), 16);
+      if (4 * k4 + 0 < j) s0 = fmaf(-row[4 * k4 + 0], l.x, s0);
+      if (4 * k4 + 1 < j) s1 = fmaf(-row[4 * k4 + 1], l.y, s1);
+      if (4 * k4 + 2 < j) s2 = fmaf(-row[4 * k4 + 2], l.z, s2);
+      if (4 * k4 + 3 < j) s3 = fmaf(-row[4 * k4 + 3], l.w, s3);
     }
+    const float sacc = (s0 + s1) + (s2 + s3);
     const float djj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sacc), j));
     ok = ok && (djj > 0.f);
     const float inv = rsqrtf(fmaxf(djj, 1e-30f));
     row[j] = (lane >= j) ? sacc * inv : 0.f;   // L[lane][j]; diagonal = sqrt(djj)
+    if (lane == j) myinv = inv;
+    if (lane < N) Lm[lane * LS + j] = row[j];
   }
   // forward substitution L y = -g (lane i keeps y_i)
   float y = (float)(-gi);
 #pragma unroll
   for (int j = 0; j < N; ++j) {
-    float ljj = 1.f;
-#pragma unroll
-    for (int t = 0; t < N; ++t)
-      if (t == j) ljj = row[t];
-    const float yj_own = y / ljj;                                  // valid on lane j
-    const float yj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, yj_own), j));
+    const float yj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, y * myinv), j));
     if (lane == j) y = yj;
     else if (lane > j) y = fmaf(-row[j], yj, y);
   }
-  // back substitution L^T delta = y: needs columns of L -> stage L in LDS
-#pragma unroll
-  for (int j = 0; j < N; ++j)
-    if (lane < N) Lm[lane * LS + j] = row[j];
+  // back substitution L^T delta = y through the columns of the LDS image
   wave_lds_sync();
   float dl = y;
 #pragma unroll
   for (int i = N - 1; i >= 0; --i) {
-    float lii = 1.f;
+    const float di = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dl * myinv), i));
+    if (lane == i) dl = di;
+    else if (lane < i) dl = fmaf(-Lm[i * LS + lane], di, dl);      // L[i][lane]
+  }
+  delta = act ? dl : 0.f;
+  return ok;
+}
+
+// register / v_readlane variant of damped_solve (row j broadcast lane by lane)
+template <int N>
+__device__ __forceinline__ bool damped_solve_rl(const float (&hrow)[N], double lam, double gi, bool act, int lane,
+                                             float *Lm, float &dgi, float &delta) {
+  constexpr int LS = CHOL_LS;
+  float row[N];
+  float d = 1.f;
 #pragma unroll
-    for (int t = 0; t < N; ++t)
-      if (t == i) lii = row[t];
-    const float di_own = dl / lii;                                 // valid on lane i
-    const float di = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, di_own), i));
+  for (int j = 0; j < N; ++j) {
+    row[j] = hrow[j];
+    if (j == lane) d = hrow[j];
+  }
+  if (!act) d = 1.f;
+  dgi = fmaxf(d, (float)D2D_LM_DIAG_FLOOR);
+  const float add = (float)(lam * (double)dgi);
+#pragma unroll
+  for (int j = 0; j < N; ++j)
+    if (j == lane) row[j] = act ? (d + add) : 1.f;
+  // Left-looking Cholesky: lane i owns row i in registers; finished columns are mirrored into the LDS
+  // image Lm [N][LS] so that row j can be broadcast to every lane by a few ds_read_b128.
+  bool ok = true;
+  float myinv = 1.f;                 // 1 / L[lane][lane]
+  const float *Lrow = Lm;
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    float s0 = row[j], s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+    for (int k = 0; k < j; ++k) {
+      const float ljk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, row[k]), j));
+      if ((k & 3) == 0) s0 = fmaf(-row[k], ljk, s0);
+      else if ((k & 3) == 1) s1 = fmaf(-row[k], ljk, s1);
+      else if ((k & 3) == 2) s2 = fmaf(-row[k], ljk, s2);
+      else s3 = fmaf(-row[k], ljk, s3);
+    }
+    const float sacc = (s0 + s1) + (s2 + s3);
+    const float djj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sacc), j));
+    ok = ok && (djj > 0.f);
+    const float inv = rsqrtf(fmaxf(djj, 1e-30f));
+    row[j] = (lane >= j) ? sacc * inv : 0.f;   // L[lane][j]; diagonal = sqrt(djj)
+    if (lane == j) myinv = inv;
+    if (lane < N) Lm[lane * LS + j] = row[j];
+  }
+  // forward substitution L y = -g (lane i keeps y_i)
+  float y = (float)(-gi);
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    const float yj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, y * myinv), j));
+    if (lane == j) y = yj;
+    else if (lane > j) y = fmaf(-row[j], yj, y);
+  }
+  // back substitution L^T delta = y through the columns of the LDS image
+  wave_lds_sync();
+  float dl = y;
+#pragma unroll
+  for (int i = N - 1; i >= 0; --i) {
+    const float di = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dl * myinv), i));
     if (lane == i) dl = di;
     else if (lane < i) dl = fmaf(-Lm[i * LS + lane], di, dl);      // L[i][lane]
   }
