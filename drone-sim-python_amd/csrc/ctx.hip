@@ -29,7 +29,7 @@ int d2d_ctx_create(int device, void *stream, d2d_ctx **out) {
   c->stream = static_cast<hipStream_t>(stream);
   D2D_CHECK_HIP(hipMalloc(&c->counter_dev, 16 * sizeof(int32_t)));
   D2D_CHECK_HIP(hipHostMalloc(&c->counter_host, 16 * sizeof(int32_t)));
-  D2D_CHECK_HIP(hipMalloc(&c->stats_dev, 16 * sizeof(double)));
+  D2D_CHECK_HIP(hipMalloc(&c->stats_dev, 32 * sizeof(double)));
   D2D_CHECK_HIP(hipHostMalloc(&c->stats_host, 16 * sizeof(double)));
   *out = c;
   return D2D_OK;

@@ -11,6 +11,7 @@
 #define FIT_OBS_K 2.0     // src/d2d/opty_utils.py:103
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // Compiler-level ordering of LDS traffic between the lanes of ONE wavefront (the LDS
 // itself executes a wave's DS instructions in order).
@@ -29,15 +30,36 @@ __device__ __forceinline__ double uniform_d(double v) {
 }
 __device__ __forceinline__ int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// Wave reductions on the DPP cross-lane path (no LDS round trips): xor-1 and xor-2 inside quads,
+// row_half_mirror, row_mirror -> every lane holds the total of its row of 16; the four row totals
+// are combined through scalar registers.  The result is wave-uniform.
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_value(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+#define DPP_QUAD_XOR1 0xB1        // quad_perm [1,0,3,2]
+#define DPP_QUAD_XOR2 0x4E        // quad_perm [2,3,0,1]
+#define DPP_ROW_HALF_MIRROR 0x141
+#define DPP_ROW_MIRROR 0x140
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_move<DPP_QUAD_XOR1>(v);
+  v += dpp_move<DPP_QUAD_XOR2>(v);
+  v += dpp_move<DPP_ROW_HALF_MIRROR>(v);
+  v += dpp_move<DPP_ROW_MIRROR>(v);
+  return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
 }
 __device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmax(v, dpp_move<DPP_QUAD_XOR1>(v));
+  v = fmax(v, dpp_move<DPP_QUAD_XOR2>(v));
+  v = fmax(v, dpp_move<DPP_ROW_HALF_MIRROR>(v));
+  v = fmax(v, dpp_move<DPP_ROW_MIRROR>(v));
+  return fmax(fmax(lane_value(v, 0), lane_value(v, 16)), fmax(lane_value(v, 32), lane_value(v, 48)));
 }
 
 // Geometry of the shared LDS image of the basis block.
@@ -201,16 +223,58 @@ __device__ __forceinline__ void prepk_entry(const double *__restrict__ pr, const
   }
 }
 
-// Flat outputs of sample k from the per-sample base pk[0..5] plus G_d[k] . q  (oracle/fit.py flat_outputs)
+// LDS copy of the unknowns of one trajectory: the two axes interleaved, q_lds[2j] = x-axis unknown j,
+// q_lds[2j+1] = y-axis unknown j (one 16-byte broadcast read per j).  q_slot: where unknown `lane` goes.
+__device__ __forceinline__ int q_slot(int lane, int nq) { return lane < nq ? 2 * lane : 2 * (lane - nq) + 1; }
+
+// Flat outputs of sample k from the per-sample base pk[0..5] plus G_d[k] . q  (oracle/fit.py flat_outputs).
+// NQ > 0: compile-time nq -- unrolled in groups of four unknowns, every LDS read with an immediate offset
+// and the 16 reads of a group requested before its 24 FMAs.
+template <int NQ>
 __device__ __forceinline__ void flat_outputs_pk(const FitGeom &g, const double *__restrict__ G64,
                                                 const double *__restrict__ q, const double pk[FIT_PK], int k, double Y[6]) {
+  typedef double __attribute__((ext_vector_type(2), may_alias)) f64x2a;
+  const int nq = NQ ? NQ : g.nq, gstr = NQ ? NQ + 1 : g.gstr;
 #pragma unroll
   for (int c = 0; c < 6; ++c) Y[c] = pk[c];
-  const double *g0 = G64 + (size_t)k * g.gstr;
-  const double *g1 = g0 + (size_t)g.K * g.gstr;
-  const double *g2 = g1 + (size_t)g.K * g.gstr;
-  for (int j = 0; j < g.nq; ++j) {
-    const double qx = q[j], qy = q[g.nq + j];
+  const double *g0 = G64 + (size_t)k * gstr;
+  const double *g1 = g0 + (size_t)g.K * gstr;
+  const double *g2 = g1 + (size_t)g.K * gstr;
+  int j = 0;
+  if (NQ) {
+    // two unknowns per stage, software-pipelined by hand: the 10 reads of stage s+1 are requested before
+    // the 12 FMAs of stage s run; the scheduling barriers keep the compiler from requesting everything
+    // at once (it would hold ~180 VGPRs of operands)
+    constexpr int NS = NQ / 2;
+    f64x2a qq[2][2];
+    double a0[2][2], a1[2][2], a2[2][2];
+#define FO_LOAD(S, B)                                                                      \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                          \
+    qq[B][i] = *reinterpret_cast<const f64x2a *>(q + 2 * (2 * (S) + i));                   \
+    a0[B][i] = g0[2 * (S) + i]; a1[B][i] = g1[2 * (S) + i]; a2[B][i] = g2[2 * (S) + i];    \
+  }
+    FO_LOAD(0, 0)
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+      const int cur = st & 1;
+      if (st + 1 < NS) { FO_LOAD(st + 1, cur ^ 1) }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        Y[0] = fma(a0[cur][i], qq[cur][i].x, Y[0]); Y[1] = fma(a0[cur][i], qq[cur][i].y, Y[1]);
+        Y[2] = fma(a1[cur][i], qq[cur][i].x, Y[2]); Y[3] = fma(a1[cur][i], qq[cur][i].y, Y[3]);
+        Y[4] = fma(a2[cur][i], qq[cur][i].x, Y[4]); Y[5] = fma(a2[cur][i], qq[cur][i].y, Y[5]);
+      }
+      // all six chains advance in every stage (without this the optimiser sinks four of them behind the
+      // loop and holds their 96 operands in registers)
+      asm volatile("" : "+v"(Y[0]), "+v"(Y[1]), "+v"(Y[2]), "+v"(Y[3]), "+v"(Y[4]), "+v"(Y[5]));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#undef FO_LOAD
+    j = 2 * NS;
+  }
+  for (; j < nq; ++j) {
+    const double qx = q[2 * j], qy = q[2 * j + 1];
     const double a0 = g0[j], a1 = g1[j], a2 = g2[j];
     Y[0] = fma(a0, qx, Y[0]); Y[1] = fma(a0, qy, Y[1]);
     Y[2] = fma(a1, qx, Y[2]); Y[3] = fma(a1, qy, Y[3]);
@@ -320,7 +384,7 @@ __device__ __forceinline__ double wave_cost(const FitGeom &g, const double *G64,
       double pk[FIT_PK], Y[6];
 #pragma unroll
       for (int c = 0; c < FIT_PK; ++c) pk[c] = pkb[(size_t)c * g.K + k];
-      flat_outputs_pk(g, G64, q, pk, k, Y);
+      flat_outputs_pk<0>(g, G64, q, pk, k, Y);
       acc += sample_terms<false>(s, Y, pk[6], pk[7], nullptr, nullptr);
       acc += partner_terms<false>(s, gc, g.K, k, Y[0], Y[1], nullptr, nullptr);
     }

@@ -5,6 +5,7 @@
 //                     trial cost (fp64), Nielsen gain-ratio update
 // One wavefront per trajectory; the basis block shared by the whole batch is staged in LDS
 // once per workgroup.  Restates oracle/fit.py (lm_solve, eval_normal).
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -142,12 +143,12 @@ fit_eval_kernel(int B, FitGeom g, FitLds L, int dbg, GroupArgs ga, const double 
   for (int bl = blockIdx.x * wpb + wave; bl < B; bl += stride_bl) {
     const int b = ga.off + bl * ga.stride;
     if (flags && !(flags[4 * b + FL_STATUS] == D2D_ST_RUNNING && flags[4 * b + FL_NEED] != 0)) continue;
-    if (lane < n) qs[lane] = q_in[(size_t)b * n + lane];
+    if (lane < n) qs[q_slot(lane, g.nq)] = q_in[(size_t)b * n + lane];
     const ScenP s = load_scenp(prep + (size_t)b * FIT_PREP_STRIDE);
     wave_lds_sync();
     double g_lane;
     const GroupCtx gc{ga.pos, ga.n_ac, ga.n_ac > 0 ? b % ga.n_ac : 0, ga.n_ac > 0 ? (b / ga.n_ac) * ga.n_ac : 0, ga.pos ? ga.nds : 0};
-    const double cost = eval_cost_grad(g, G64, pk + (size_t)b * FIT_PK * g.K, qs, us, cf, s, lane, dbg, g_lane, gc, cfd);
+    const double cost = eval_cost_grad<NQ>(g, G64, pk + (size_t)b * FIT_PK * g.K, qs, us, cf, s, lane, dbg, g_lane, gc, cfd);
     if (lane < n && g_out) g_out[(size_t)b * n + lane] = g_lane;
     if (lane == 0) {
       if (cost_out) cost_out[b] = cost;
@@ -206,9 +207,7 @@ static StepLds step_lds_layout(int K, int nq, int N, int wpb) {
   L.wave0 = o;
   int w = 0;
   {
-    const int nb = N / 16, tiles = nb * (nb + 1) / 2;
-    const int bytes = (N * (N + 4) > tiles * TILE_T ? N * (N + 4) : tiles * TILE_T) * 4;
-    L.Lm = w; w = align16(w + bytes);
+    L.Lm = w; w = align16(w + (N + 2) * (N + 4) * 4);     // image of J^T J, then of its Cholesky factor
   }
   L.vec = w; w = align16(w + N * 4);
   L.qt = w; w = align16(w + N * 8);
@@ -241,10 +240,9 @@ fit_step_kernel(int B, FitGeom g, StepLds L, d2d_fit_opts opts, GroupArgs ga,
   __syncthreads();
   if (!active) return;
   unsigned char *wl = lds + L.wave0 + wave * L.wave_stride;
-  float *Lm = reinterpret_cast<float *>(wl + L.Lm);       // [N][N+1]
+  float *Lm = reinterpret_cast<float *>(wl + L.Lm);       // [N][N+4]
   double *qt = reinterpret_cast<double *>(wl + L.qt);     // trial point
   const int n = 2 * g.nq;
-  const int LS = N + 1;
 
   const double lam = lm[4 * b + 0], nu = lm[4 * b + 1];
   const double c = cost_io[b];
@@ -258,25 +256,29 @@ fit_step_kernel(int B, FitGeom g, StepLds L, d2d_fit_opts opts, GroupArgs ga,
     if (lane == 0) flags[4 * b + FL_STATUS] = D2D_ST_CONVERGED;
     return;
   }
-  // H arrives tile-major (fit_eval_kernel): stage the wave's 16x16 tiles in LDS with coalesced
-  // loads, gather row `lane`, then reuse the LDS block for the Cholesky factor.
+  // H arrives tile-major (fit_eval_kernel: coalesced loads in the accumulator layout): add the waypoint
+  // block, write the row-major LDS image, read row `lane`; the image then becomes the Cholesky factor.
   constexpr int NBs = N / 16, NT = NBs * (NBs + 1) / 2;
+  f32x2 hrow[N / 2];
   {
     const float *Hb = H_in + (size_t)b * NT * 256;
     const double wwp = prep[(size_t)b * FIT_PREP_STRIDE + PR_WWP];
     const float ww = (float)(wwp * wwp);
+    f32x4 acc[NT];
 #pragma unroll
-    for (int i = 0; i < NT * 4; ++i) Lm[(i >> 2) * TILE_T + tile_slot(i & 3, lane)] = fmaf(ww, gWt[i * 64 + lane], Hb[i * 64 + lane]);
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[t][r] = fmaf(ww, gWt[(t * 4 + r) * 64 + lane], Hb[(t * 4 + r) * 64 + lane]);
+    tiles_to_image<N>(acc, Lm, lane);
   }
   wave_lds_sync();
-  float hrow[N];
-  gather_row<N>(Lm, lane, n, act, hrow);
+  image_row<N>(Lm, lane, hrow);
   wave_lds_sync();
   float dgi, dl;
   const bool ok = damped_solve<N>(hrow, lam, gi, act, lane, Lm, dgi, dl);
   const double delta = (double)dl;
   // ---- trial point, predicted and actual reduction ------------------------------------
-  if (lane < N) qt[lane] = qi + delta;
+  if (act) qt[q_slot(lane, g.nq)] = qi + delta;
   wave_lds_sync();
   const ScenP s = load_scenp(prep + (size_t)b * FIT_PREP_STRIDE);
   const GroupCtx gc{ga.pos, ga.n_ac, ga.n_ac > 0 ? b % ga.n_ac : 0, ga.n_ac > 0 ? (b / ga.n_ac) * ga.n_ac : 0, ga.pos ? ga.nds : 0};
@@ -311,7 +313,7 @@ fit_step_kernel(int B, FitGeom g, StepLds L, d2d_fit_opts opts, GroupArgs ga,
 #define FIT_LM_WPB_MAX 8
 struct FusedLds {
   int G64, Gp64, G32, Wt, wave0, wave_stride;
-  int qs, qt, big, cf;      // inside a wave's block; `big` holds us+cf, then the tiles, then the factor
+  int qs, sp, big, cf;      // inside a wave's block; `big` holds us+cf, then the image of J^T J / its factor
   int total;
 };
 static FusedLds fused_lds_layout(int K, int nq, int N, int wpb) {
@@ -325,37 +327,36 @@ static FusedLds fused_lds_layout(int K, int nq, int N, int wpb) {
   L.wave0 = o;
   int w = 0;
   L.qs = w; w = align16(w + N * 8);
-  L.qt = w; w = align16(w + N * 8);
+  L.sp = w; w = align16(w + FIT_PREP_STRIDE * 8);      // the scenario row (fit_device.h PR_*)
   L.big = w;
   const int us_bytes = align16(K * 6 * 8), cf_bytes = (K + 1) * 4 * 16;
   L.cf = w + us_bytes;
-  const int nb = N / 16, tiles = nb * (nb + 1) / 2;
   int big = us_bytes + cf_bytes;
-  if (tiles * TILE_T * 4 > big) big = tiles * TILE_T * 4;
-  if (N * (N + 4) * 4 > big) big = N * (N + 4) * 4;
+  if ((N + 2) * (N + 4) * 4 > big) big = (N + 2) * (N + 4) * 4;
   w = align16(w + big);
   L.wave_stride = w;
   L.total = o + wpb * w;
   return L;
 }
 static bool pick_fused_layout(int K, int nq, int N, int *wpb) {
+  if (K > 64) return false;      // the fused kernel keeps one sample per lane
   for (int w = FIT_LM_WPB_MAX; w >= 4; --w)
     if (fused_lds_layout(K, nq, N, w).total <= FIT_LDS_BYTES) { *wpb = w; return true; }
   return false;
 }
 
-template <int NB, int NQ>
+template <int NB, int NQ, bool STAMPS>
 __global__ void __launch_bounds__(64 * FIT_LM_WPB_MAX)
-fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_budget, int getenv_rl,
+fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_budget,
               const double *__restrict__ gG64, const double *__restrict__ pk,
               const float *__restrict__ gG32, const float *__restrict__ gWt,
               const double *__restrict__ prep, double *__restrict__ q_io, double *__restrict__ cost_io,
               double *__restrict__ g_io, double *__restrict__ lm, int32_t *__restrict__ flags,
               unsigned long long *__restrict__ stamps) {
   // stamps != NULL (D2D_LM_STAMPS=1, diagnostics only): per-phase wave-cycle totals, see launch_lm
-  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = 0;
+  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = 0, st_solve[5] = {0, 0, 0, 0, 0};
 #define LM_STAMP(i)                                                     \
-  if (stamps) {                                                         \
+  if (STAMPS) {                                                         \
     const unsigned long long t_ = __builtin_amdgcn_s_memtime();         \
     st_acc[i] += t_ - st_last;                                          \
     st_last = t_;                                                       \
@@ -371,16 +372,16 @@ fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_budget, 
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   unsigned char *wl = lds + L.wave0 + wave * L.wave_stride;
   double *qs = reinterpret_cast<double *>(wl + L.qs);
-  double *qt = reinterpret_cast<double *>(wl + L.qt);
+  double *sp = reinterpret_cast<double *>(wl + L.sp);
   double *us = reinterpret_cast<double *>(wl + L.big);
   f32x4 *cf = reinterpret_cast<f32x4 *>(wl + L.cf);
-  float *big = reinterpret_cast<float *>(wl + L.big);          // tiles, then the Cholesky factor
+  float *big = reinterpret_cast<float *>(wl + L.big);          // image of J^T J, then of its Cholesky factor
   const int n = 2 * g.nq;
   const bool act = lane < n;
 
   // static striding over the batch: wave w of workgroup g takes trajectories g*wpb + w, + gridDim*wpb, ...
   const int stride = gridDim.x * (blockDim.x >> 6);
-  if (stamps) st_last = __builtin_amdgcn_s_memtime();
+  if (STAMPS) st_last = __builtin_amdgcn_s_memtime();
   for (int b = blockIdx.x * (blockDim.x >> 6) + wave; b < B; b += stride) {
     if (flags[4 * b + FL_STATUS] != D2D_ST_RUNNING) continue;
     const double *prow = prep + (size_t)b * FIT_PREP_STRIDE;
@@ -390,26 +391,27 @@ fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_budget, 
     int iters = flags[4 * b + FL_ITERS];
     int nev = 0, local = 0, status = D2D_ST_RUNNING;
     double c = 0.0, gi = 0.0;
-    float hrow[N];
+    f32x2 hrow[N / 2];
 #pragma unroll
-    for (int j = 0; j < N; ++j) hrow[j] = 0.f;
+    for (int m = 0; m < N / 2; ++m) hrow[m] = f32x2{0.f, 0.f};
     // Every value that steers the loop below is made scalar (uniform_*): the control flow is
     // wave-uniform by construction and must compile to scalar branches.
     // Invariant at the top of the loop: us / cf hold phase 1 at the point qs (= qi) whose cost is c;
     // `fresh` says they still need phase 2 + MFMA (J^T r, J^T J) before the next damped solve.
-    if (lane < N) qs[lane] = qi;
+    if (act) qs[q_slot(lane, g.nq)] = qi;
+    if (lane < FIT_PREP_STRIDE) sp[lane] = prow[lane];
+    double pkr[FIT_PK];
+#pragma unroll
+    for (int cc = 0; cc < FIT_PK; ++cc) pkr[cc] = lane < g.K ? pkb[(size_t)cc * g.K + lane] : 0.0;
     wave_lds_sync();
     LM_STAMP(0)
-    {
-      const ScenP s = load_scenp(prow);
-      c = uniform_d(eval_phase1(g, G64, pkb, qs, us, cf, s, lane, 0));
-    }
+    c = uniform_d(eval_phase1_reg<NQ>(g, G64, pkr, sp, qs, us, cf, lane));
     LM_STAMP(1)
     bool fresh = true;
     if (!(fabs(c) <= 1.79e308)) { status = D2D_ST_NONFINITE; fresh = false; }
     while (status == D2D_ST_RUNNING || fresh) {
       if (fresh) {
-        gi = eval_phase2(g, G64, us, lane, 0);
+        gi = eval_phase2<NQ>(g, G64, us, lane, 0);
         LM_STAMP(2)
         fresh = false;
         if (status != D2D_ST_RUNNING) break;             // accepted + converged: J^T r refreshed, done
@@ -418,13 +420,14 @@ fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_budget, 
         ++nev;                                           // counts J^T J evaluations (the roofline unit)
         wave_lds_sync();                                 // every lane is done with us / cf before they are overwritten
         LM_STAMP(3)
-        const float ww = (float)(prow[PR_WWP] * prow[PR_WWP]);
+        const float ww = (float)(sp[PR_WWP] * sp[PR_WWP]);
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) big[t * TILE_T + tile_slot(r, lane)] = fmaf(ww, gWt[(t * 4 + r) * 64 + lane], acc[t][r]);
+          for (int r = 0; r < 4; ++r) acc[t][r] = fmaf(ww, Wt[(t * 4 + r) * 64 + lane], acc[t][r]);
+        tiles_to_image<N>(acc, big, lane);
         wave_lds_sync();
-        gather_row<N>(big, lane, n, act, hrow);
+        image_row<N>(big, lane, hrow);
         wave_lds_sync();
         LM_STAMP(4)
       }
@@ -433,17 +436,13 @@ fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_budget, 
       if (gmax <= opts.gtol) { status = D2D_ST_CONVERGED; break; }
       float dgi, dl;
       LM_STAMP(6)
-      const int ok = uniform_i((getenv_rl ? damped_solve_rl<N>(hrow, lam, gi, act, lane, big, dgi, dl) : damped_solve<N>(hrow, lam, gi, act, lane, big, dgi, dl)) ? 1 : 0);
+      const int ok = uniform_i(damped_solve<N>(hrow, lam, gi, act, lane, big, dgi, dl, STAMPS ? st_solve : nullptr) ? 1 : 0);
       const double delta = (double)dl;
-      if (lane < N) qs[lane] = qi + delta;               // the trial point; restored below if rejected
+      if (act) qs[q_slot(lane, g.nq)] = qi + delta;      // the trial point
       wave_lds_sync();
       LM_STAMP(5)
-      double ct;
-      {
-        // full phase 1 at the trial point: if the step is accepted its rows are the next evaluation
-        const ScenP s = load_scenp(prow);
-        ct = uniform_d(eval_phase1(g, G64, pkb, qs, us, cf, s, lane, 0));
-      }
+      // full phase 1 at the trial point: if the step is accepted its rows are the next evaluation
+      const double ct = uniform_d(eval_phase1_reg<NQ>(g, G64, pkr, sp, qs, us, cf, lane));
       LM_STAMP(1)
       const double pred = uniform_d(wave_sum(delta * (lam * (double)dgi * delta - gi)));
       const double dmax = uniform_d(wave_max(fabs(delta))), qmax = uniform_d(wave_max(fabs(qi)));
@@ -467,8 +466,10 @@ fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_budget, 
     }
     LM_STAMP(0)
   }
-  if (stamps && lane == 0)
+  if (STAMPS && lane == 0) {
     for (int i = 0; i < 8; ++i) atomicAdd(&stamps[i], st_acc[i]);
+    for (int i = 0; i < 5; ++i) atomicAdd(&stamps[8 + i], st_solve[i]);
+  }
 #undef LM_STAMP
 }
 
@@ -736,16 +737,27 @@ static int launch_lm(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, double *q, con
   const FitGeom gm = geom_of(pl);
   const FusedLds L = fused_lds_layout(pl->K, pl->nq, 48, pl->wpb_lm);
   static const bool want_stamps = getenv("D2D_LM_STAMPS") != nullptr;
+  static const bool want_times = getenv("D2D_LM_TIMES") != nullptr;      // diagnostics: wall time of every launch
+  std::chrono::steady_clock::time_point t0;
+  if (want_times) { D2D_CHECK_HIP(hipStreamSynchronize(ctx->stream)); t0 = std::chrono::steady_clock::now(); }
   unsigned long long *stamps = want_stamps ? reinterpret_cast<unsigned long long *>(ctx->stats_dev + 8) : nullptr;
-  if (want_stamps) D2D_CHECK_HIP(hipMemsetAsync(stamps, 0, 8 * sizeof(unsigned long long), ctx->stream));
+  if (want_stamps) D2D_CHECK_HIP(hipMemsetAsync(stamps, 0, 13 * sizeof(unsigned long long), ctx->stream));
   int blocks = (B + pl->wpb_lm - 1) / pl->wpb_lm;
   if (blocks > pl->n_cu) blocks = pl->n_cu;           // persistent: one workgroup per CU pulls work
-  hipLaunchKernelGGL((fit_lm_kernel<3, 24>), dim3(blocks), dim3(64 * pl->wpb_lm), L.total, ctx->stream, B, gm, L, o, budget, getenv("D2D_LM_RL") ? 1 : 0,
-                     pl->d_G, pl->d_pk, pl->d_G32, pl->d_W32, pl->d_prep, q, pl->d_cost, pl->d_g, pl->d_lm, pl->d_flags,
-                     stamps);
+  if (want_stamps)
+    hipLaunchKernelGGL((fit_lm_kernel<3, 24, true>), dim3(blocks), dim3(64 * pl->wpb_lm), L.total, ctx->stream, B, gm, L, o, budget,
+                       pl->d_G, pl->d_pk, pl->d_G32, pl->d_W32, pl->d_prep, q, pl->d_cost, pl->d_g, pl->d_lm, pl->d_flags, stamps);
+  else
+    hipLaunchKernelGGL((fit_lm_kernel<3, 24, false>), dim3(blocks), dim3(64 * pl->wpb_lm), L.total, ctx->stream, B, gm, L, o, budget,
+                       pl->d_G, pl->d_pk, pl->d_G32, pl->d_W32, pl->d_prep, q, pl->d_cost, pl->d_g, pl->d_lm, pl->d_flags, stamps);
   D2D_LAUNCH_CHECK();
+  if (want_times) {
+    D2D_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    fprintf(stderr, "[fit_lm launch] B=%d budget=%d blocks=%d wpb=%d: %.1f us\n", B, budget, blocks, pl->wpb_lm, us);
+  }
   if (want_stamps) {
-    unsigned long long h[8];
+    unsigned long long h[13];
     D2D_CHECK_HIP(hipMemcpyAsync(h, stamps, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
     D2D_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     static const char *nm[8] = {"io/loop", "phase1", "phase2", "mfma", "tiles+gather", "solve", "reduce+judge", "-"};
@@ -753,7 +765,8 @@ static int launch_lm(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, double *q, con
     for (int i = 0; i < 7; ++i) tot += (double)h[i];
     fprintf(stderr, "[fit_lm stamps] wave-cycles (s_memtime ticks), B=%d budget=%d:", B, budget);
     for (int i = 0; i < 7; ++i) fprintf(stderr, " %s=%.1f%%", nm[i], 100.0 * (double)h[i] / tot);
-    fprintf(stderr, " total=%.3e\n", tot);
+    fprintf(stderr, " total=%.3e | solve split: setup=%.1f%% steps0-15=%.1f%% 16-31=%.1f%% 32-47=%.1f%% subst=%.1f%%\n", tot,
+            100.0 * h[8] / tot, 100.0 * h[9] / tot, 100.0 * h[10] / tot, 100.0 * h[11] / tot, 100.0 * h[12] / tot);
   }
   return D2D_OK;
 }
@@ -823,7 +836,8 @@ int d2d_fit_plan_create(d2d_ctx *ctx, int S, int K, double duration, const doubl
   allow_big_lds(&fit_eval_kernel<1, 0, true>); allow_big_lds(&fit_eval_kernel<2, 0, true>); allow_big_lds(&fit_eval_kernel<3, 0, true>);
   allow_big_lds(&fit_eval_kernel<1, 0, false>); allow_big_lds(&fit_eval_kernel<2, 0, false>); allow_big_lds(&fit_eval_kernel<3, 0, false>);
   allow_big_lds(&fit_eval_kernel<3, 24, true>); allow_big_lds(&fit_eval_kernel<3, 24, false>);
-  allow_big_lds(&fit_lm_kernel<3, 24>);
+  allow_big_lds(&fit_lm_kernel<3, 24, false>);
+  allow_big_lds(&fit_lm_kernel<3, 24, true>);
   allow_big_lds(&fit_step_kernel<16>); allow_big_lds(&fit_step_kernel<32>); allow_big_lds(&fit_step_kernel<48>);
   (void)hipGetLastError();
   *out = pl;

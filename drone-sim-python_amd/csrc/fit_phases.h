@@ -4,15 +4,23 @@
 #pragma once
 #include "fit_device.h"
 
+// Opaque re-definition of a per-lane value (no instruction is emitted).
+#define LAUNDER(v) asm volatile("" : "+v"(v))
+
 // ---- phases 1+2: cost and J^T r ------------------------------------------------------------
 // qs: q of this trajectory in LDS; us [K][6] fp64 and cf [K+1][4] f32x4 are the wave's scratch.
 // Returns sum r^2; g_lane = (J^T r)[lane] for lane < 2nq.
 // cfd [K+1][nds] float2: row coefficients of the collision rows (only with a coupled group).
 // phase 1 (lane = sample): flat outputs, rows, u_k = D_k^T r_k -> us, fp32 row coefficients -> cf / cfd.
+// qs is the interleaved LDS copy of the unknowns (fit_device.h q_slot).
+template <int NQ = 0>
 __device__ __forceinline__ double eval_phase1(const FitGeom &g, const double *G64, const double *__restrict__ pkb,
                                               const double *qs, double *us, f32x4 *cf, const ScenP &s, int lane, int dbg,
                                               const GroupCtx &gc = GroupCtx{nullptr, 1, 0, 0, 0}, float2 *cfd = nullptr) {
   double cacc = 0.0;
+  // (LAUNDER: inside an iteration loop every address below is loop-invariant; re-defining the lane id
+  // keeps the compiler from hoisting dozens of them out of the loop and spilling them)
+  LAUNDER(lane);
   for (int k0 = 0; k0 < g.K; k0 += 64) {
     const int k = k0 + lane;
     if (k < g.K) {
@@ -20,7 +28,7 @@ __device__ __forceinline__ double eval_phase1(const FitGeom &g, const double *G6
       f32x4 coef[4] = {f32x4{1.f, 0.f, 1.f, 0.f}, f32x4{1.f, 0.f, 1.f, 0.f}, f32x4{1.f, 0.f, 1.f, 0.f}, f32x4{1.f, 0.f, 1.f, 0.f}};
 #pragma unroll
       for (int c = 0; c < FIT_PK; ++c) pk[c] = pkb[(size_t)c * g.K + k];
-      if (!(dbg & 8)) flat_outputs_pk(g, G64, qs, pk, k, Y);
+      if (!(dbg & 8)) flat_outputs_pk<NQ>(g, G64, qs, pk, k, Y);
       if (!(dbg & 1)) cacc += sample_terms<true>(s, Y, pk[6], pk[7], u, coef);
       if (gc.nds) cacc += partner_terms<true>(s, gc, g.K, k, Y[0], Y[1], u, cfd + (size_t)k * gc.nds);
 #pragma unroll
@@ -34,40 +42,93 @@ __device__ __forceinline__ double eval_phase1(const FitGeom &g, const double *G6
   return cost;
 }
 
-// phase 2 (lane = unknown): (J^T r)[lane] = sum_k G_k^T u_k, three independent fp64 accumulation chains
+// phase 1 of the fused kernel (K <= 64, no group coupling): the per-sample constants pkr live in registers
+// for the whole fit (lane = sample never changes) and the scenario row sp is the wave's LDS copy, read
+// where it is used instead of being held in ~44 registers across the flat-output loop.
+template <int NQ>
+__device__ __forceinline__ double eval_phase1_reg(const FitGeom &g, const double *G64, const double (&pkr)[FIT_PK],
+                                                  const double *sp, const double *qs, double *us, f32x4 *cf, int lane) {
+  double cacc = 0.0;
+  LAUNDER(lane);
+  const int k = lane;
+  if (k < g.K) {
+    double Y[6], u[6] = {0, 0, 0, 0, 0, 0};
+    f32x4 coef[4];
+    flat_outputs_pk<NQ>(g, G64, qs, pkr, k, Y);
+    const ScenP s = load_scenp(sp);
+    cacc = sample_terms<true>(s, Y, pkr[6], pkr[7], u, coef);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) us[k * 6 + c] = u[c];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cf[k * 4 + r] = coef[r];
+  }
+  const double cost = wave_sum(cacc);
+  wave_lds_sync();
+  return cost;
+}
+
+// phase 2 (lane = unknown): (J^T r)[lane] = sum_k G_k^T u_k, three independent fp64 accumulation chains.
+// NQ > 0: nq is a compile-time constant, so every LDS read of a chunk of five samples carries an
+// immediate offset and the whole chunk (15 basis values + 15 u's) is requested before its FMAs run.
+template <int NQ>
 __device__ __forceinline__ double eval_phase2(const FitGeom &g, const double *G64, const double *us, int lane, int dbg) {
-  const int n = 2 * g.nq;
+  const int nq = NQ ? NQ : g.nq, gstr = NQ ? NQ + 1 : g.gstr;
+  const int n = 2 * nq;
   double g_lane = 0.0;
+  LAUNDER(lane);
   if (lane < n && !(dbg & 2)) {
-    const int ax = lane >= g.nq ? 1 : 0, jj = lane - ax * g.nq;
-    const double *g0 = G64 + jj, *g1 = g0 + (size_t)g.K * g.gstr, *g2 = g1 + (size_t)g.K * g.gstr;
+    const int ax = lane >= nq ? 1 : 0, jj = lane - ax * nq;
+    const double *g0 = G64 + jj, *g1 = g0 + (size_t)g.K * gstr, *g2 = g1 + (size_t)g.K * gstr;
     const double *uk = us + ax;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-#pragma unroll 5
-    for (int k = 0; k < g.K; ++k) {
-      a0 = fma(uk[k * 6], g0[k * g.gstr], a0);
-      a1 = fma(uk[k * 6 + 2], g1[k * g.gstr], a1);
-      a2 = fma(uk[k * 6 + 4], g2[k * g.gstr], a2);
+    int k = 0;
+    for (; k + 5 <= g.K; k += 5) {
+      double gv[15], uv[15];
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        gv[3 * i] = g0[i * gstr]; gv[3 * i + 1] = g1[i * gstr]; gv[3 * i + 2] = g2[i * gstr];
+        uv[3 * i] = uk[i * 6]; uv[3 * i + 1] = uk[i * 6 + 2]; uv[3 * i + 2] = uk[i * 6 + 4];
+      }
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        a0 = fma(uv[3 * i], gv[3 * i], a0);
+        a1 = fma(uv[3 * i + 1], gv[3 * i + 1], a1);
+        a2 = fma(uv[3 * i + 2], gv[3 * i + 2], a2);
+      }
+      g0 += 5 * gstr; g1 += 5 * gstr; g2 += 5 * gstr; uk += 30;
+    }
+    for (; k < g.K; ++k) {
+      a0 = fma(uk[0], g0[0], a0);
+      a1 = fma(uk[2], g1[0], a1);
+      a2 = fma(uk[4], g2[0], a2);
+      g0 += gstr; g1 += gstr; g2 += gstr; uk += 6;
     }
     g_lane = (a0 + a1) + a2;
   }
   return g_lane;
 }
 
+template <int NQ = 0>
 __device__ __forceinline__ double eval_cost_grad(const FitGeom &g, const double *G64, const double *__restrict__ pkb,
                                                  const double *qs, double *us, f32x4 *cf, const ScenP &s,
                                                  int lane, int dbg, double &g_lane,
                                                  const GroupCtx &gc = GroupCtx{nullptr, 1, 0, 0, 0}, float2 *cfd = nullptr) {
-  const double cost = eval_phase1(g, G64, pkb, qs, us, cf, s, lane, dbg, gc, cfd);
-  g_lane = eval_phase2(g, G64, us, lane, dbg);
+  const double cost = eval_phase1<NQ>(g, G64, pkb, qs, us, cf, s, lane, dbg, gc, cfd);
+  g_lane = eval_phase2<NQ>(g, G64, us, lane, dbg);
   return cost;
 }
 
-template <typename T, int ALIGN>
-__device__ __forceinline__ T lds_load(const unsigned char *p) {
-  T v;
-  __builtin_memcpy(&v, __builtin_assume_aligned(p, ALIGN), sizeof(T));
-  return v;
+// (accesses whose type differs from the one the bytes were stored with go through may_alias types:
+// type-based alias analysis must not reorder them against those stores)
+template <typename T>
+__device__ __forceinline__ T lds_get(const void *p) {
+  typedef T __attribute__((may_alias)) Ta;
+  return *reinterpret_cast<const Ta *>(p);
+}
+template <typename T>
+__device__ __forceinline__ void lds_put(void *p, const T &v) {
+  typedef T __attribute__((may_alias)) Ta;
+  *reinterpret_cast<Ta *>(p) = v;
 }
 
 // ---- phase 3: J^T J by v_mfma_f32_16x16x4_f32 ------------------------------------------------
@@ -82,6 +143,7 @@ __device__ __forceinline__ void jtj_mfma(const FitGeom &g, const unsigned char *
                                          f32x4 (&acc)[NB * (NB + 1) / 2], int cfd_off = 0, int nds = 0) {
   // All LDS operands are addressed as lds_base + integer byte offset so that the compiler keeps them
   // in the LDS address space (ds_read with immediate offsets) through the unrolled loop.
+  LAUNDER(lane);
   const int rho = lane >> 4, ci = lane & 15;
   const int nq = NQ ? NQ : g.nq;
   const int n = 2 * nq;
@@ -98,10 +160,8 @@ __device__ __forceinline__ void jtj_mfma(const FitGeom &g, const unsigned char *
     oa[c] = 4 * (((rho < 2) ? plane : 0) + jj[c]);
     ob[c] = 4 * (2 * plane + jj[c]);
   }
-  // (loads go through memcpy: the row coefficients are stored as f32x4 by other lanes, and a
-  // type-punned load would let type-based alias analysis reorder it against those stores)
-#define LDS_F(off) lds_load<float, 4>(lds_base + (off))
-#define LDS_F2(off) lds_load<float2, 8>(lds_base + (off))
+#define LDS_F(off) lds_get<float>(lds_base + (off))
+#define LDS_F2(off) lds_get<float2>(lds_base + (off))
 #define T32_AT(off) (T_LDS ? LDS_F(t32_off + (off)) : T32g[(off) >> 2])
 #pragma unroll
   for (int t = 0; t < NB * (NB + 1) / 2; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -168,166 +228,149 @@ __device__ __forceinline__ void jtj_mfma(const FitGeom &g, const unsigned char *
 #undef T32_AT
 }
 
-// LDS image of the J^T J tiles used between the MFMA and the Cholesky: element (reg, lane=(rho,cc)) of tile t
-// sits at t*TILE_T + reg*TILE_S1 + rho*TILE_S2 + cc.  The strides are chosen so that the accumulator
-// stores (fixed reg, all lanes) and the row gather (fixed column, 16 rows of a tile) both spread over
-// the 32 LDS banks.
-#define TILE_S2 17
-#define TILE_S1 70
-#define TILE_T (4 * TILE_S1)
-__device__ __forceinline__ int tile_slot(int reg, int lane) { return reg * TILE_S1 + (lane >> 4) * TILE_S2 + (lane & 15); }
-
-// Row `lane` of the symmetric matrix whose upper block triangle sits in the padded tile image.
+// ---- J^T J: accumulator tiles -> row-owned registers ------------------------------------------
+// Row-major LDS image Hs [N+2][N+4] (last two rows: scratch of the solve) of the full symmetric matrix (later overwritten in place by the
+// Cholesky factor).  Lane l holds elements (16I + 4(l>>4) + r, 16J + (l&15)) of tile (I,J): stored
+// as they are (one address register + immediate offsets, conflict-free) and, for off-diagonal
+// tiles, mirrored with one 16-byte store (rows 16J + (l&15), columns 16I + 4(l>>4) .. +3).
+// The row stride N+4 floats (an odd number of 16-byte quads) makes the row reads conflict-free.
+#define CHOL_LS (N + 4)
 template <int N>
-__device__ __forceinline__ void gather_row(const float *tiles, int lane, int n, bool act, float (&row)[N]) {
-  constexpr int NBs = N / 16;
+__device__ __forceinline__ void tiles_to_image(const f32x4 (&acc)[(N / 16) * (N / 16 + 1) / 2], float *Hs, int lane) {
+  constexpr int NBs = N / 16, LS = CHOL_LS;
+  LAUNDER(lane);
+  float *wb = Hs + 4 * (lane >> 4) * LS + (lane & 15);
+  float *mb = Hs + (lane & 15) * LS + 4 * (lane >> 4);
+  int t = 0;
 #pragma unroll
-  for (int j = 0; j < N; ++j) {
-    float v = 0.f;
-    if (act && j < n) {
-      const int J = j >> 4, I = lane >> 4;
-      const bool up = I <= J;
-      const int r = up ? lane : j, c = up ? j : lane;
-      const int ti = r >> 4, tj = c >> 4;
-      const int tile = ti * NBs - ti * (ti - 1) / 2 + (tj - ti);
-      const int rr = r & 15;
-      v = tiles[tile * TILE_T + (rr & 3) * TILE_S1 + (rr >> 2) * TILE_S2 + (c & 15)];
+  for (int I = 0; I < NBs; ++I)
+#pragma unroll
+    for (int J = I; J < NBs; ++J, ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) wb[(16 * I + r) * LS + 16 * J] = acc[t][r];
+      if (J > I) lds_put<f32x4>(mb + 16 * J * LS + 16 * I, acc[t]);
     }
-    row[j] = v;
+}
+
+// row `lane` of the image (lanes >= N read row N-1; their values are not used)
+template <int N>
+__device__ __forceinline__ void image_row(const float *Hs, int lane, f32x2 (&hrow)[N / 2]) {
+  constexpr int LS = CHOL_LS;
+  LAUNDER(lane);
+  const float *src = Hs + (lane < N ? lane : N - 1) * LS;
+#pragma unroll
+  for (int m = 0; m < N / 4; ++m) {
+    const f32x4 v = lds_get<f32x4>(src + 4 * m);
+    hrow[2 * m] = f32x2{v.x, v.y};
+    hrow[2 * m + 1] = f32x2{v.z, v.w};
   }
+}
+
+__device__ __forceinline__ float lane_value(float v, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
 }
 
 // ---- damped normal-equation solve -----------------------------------------------------------
-// hrow = row `lane` of J^T J.  Solves (J^T J + lam*diag(max(J^T J_ii, floor))) delta = -g in fp32:
-// left-looking Cholesky with the row owned by each lane in registers and row j broadcast by
-// v_readlane (all indices compile-time), forward substitution in registers, back substitution
-// through an LDS copy Lm [N][N+1] of the factor.  Returns false if a pivot is not positive.
-#define CHOL_LS (N + 4)      // row stride of the LDS factor image: multiple of 4 floats -> aligned ds_read_b128
+// hrow = row `lane` of J^T J (pairs of columns).  Solves (J^T J + lam*diag(max(J^T J_ii, floor))) delta = -g
+// in fp32.  Left-looking Cholesky, lane i owns row i in registers.  Step j needs row j of the factor
+// in every lane: entries k <= j-2 come from the LDS image Lm [N+2][N+4] (each lane mirrors its
+// finished entries there; one address for the whole wave = a broadcast read), the newest entry
+// L[j][j-1] comes straight from lane j's register by v_readlane, so the LDS write -> read round trip
+// is off the critical path.  Dot products run as two packed (v_pk_fma_f32) chains.  The forward
+// substitution L y = -g rides along (y_j is final once column j is); the back substitution reads
+// the columns of Lm.  Returns false if a pivot is not positive.
 template <int N>
-__device__ __forceinline__ bool damped_solve(const float (&hrow)[N], double lam, double gi, bool act, int lane,
-                                             float *Lm, float &dgi, float &delta) {
+__device__ __forceinline__ bool damped_solve(const f32x2 (&hrow)[N / 2], double lam, double gi, bool act, int lane,
+                                             float *Lm, float &dgi, float &delta, unsigned long long *tt = nullptr) {
   constexpr int LS = CHOL_LS;
-  float row[N];
+  // tt (diagnostics, fused kernel with D2D_LM_STAMPS): cycles of setup, steps [0,N/3), [N/3,2N/3), [2N/3,N), substitution
+  unsigned long long tl = 0;
+#define DS_STAMP(i) if (tt) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tt[i] += t_ - tl; tl = t_; }
+  if (tt) tl = __builtin_amdgcn_s_memtime();
+  // (every `lane > j` mask below is loop-invariant in the caller's iteration loop: hoisted, they would
+  // need 2N scalar registers the wave does not have)
+  LAUNDER(lane);
+  f32x2 row[N / 2];
   float d = 1.f;
 #pragma unroll
-  for (int j = 0; j < N; ++j) {
-    row[j] = hrow[j];
-    if (j == lane) d = hrow[j];
+  for (int m = 0; m < N / 2; ++m) {
+    row[m] = act ? hrow[m] : f32x2{0.f, 0.f};
+    if (2 * m == lane) d = hrow[m].x;
+    if (2 * m + 1 == lane) d = hrow[m].y;
   }
   if (!act) d = 1.f;
   dgi = fmaxf(d, (float)D2D_LM_DIAG_FLOOR);
-  const float add = (float)(lam * (double)dgi);
+  const float dd = act ? d + (float)(lam * (double)dgi) : 1.f;
 #pragma unroll
-  for (int j = 0; j < N; ++j)
-    if (j == lane) row[j] = act ? (d + add) : 1.f;
-  // Left-looking Cholesky: lane i owns row i in registers; finished columns are mirrored into the LDS
-  // image Lm [N][LS] so that row j can be broadcast to every lane by a few ds_read_b128.
-  bool ok = true;
-  float myinv = 1.f;                 // 1 / L[lane][lane]
-  const float *Lrow = Lm;
+  for (int m = 0; m < N / 2; ++m) {
+    if (2 * m == lane) row[m].x = dd;
+    if (2 * m + 1 == lane) row[m].y = dd;
+  }
+#define ROW_EL(k) (((k) & 1) ? row[(k) >> 1].y : row[(k) >> 1].x)
+  // The factor is kept STRICTLY lower triangular, in registers and in the image (every lane stores
+  // its entry of column j at every step, zeros on and above the diagonal), and the reciprocal
+  // diagonal goes to the image's dummy row: no per-lane selects in either substitution.
+  int pivmin = 0x7f800000;           // min over the pivots' bit patterns: > 0 <=> every pivot positive (scalar unit)
+  float y = (float)(-gi);            // forward substitution rides along: lane i ends with y_i * L[i][i]
+  float *wrow = Lm + (lane < N ? lane : N) * LS;      // lanes >= N (all zeros) write the dummy row
+  float *dinv = Lm + (N + 1) * LS;                    // [N] reciprocal diagonal, one more row
+  // lq: the quads of row j of the factor, fetched one step ahead (row j+1 is requested while step j
+  // computes, so the LDS latency never sits on the chain); ljp = L[j][j-1] for the step to come.
+  f32x4 lq[N / 4];
+  float ljp = 0.f;
+  DS_STAMP(0)
 #pragma unroll
   for (int j = 0; j < N; ++j) {
-    float s0 = row[j], s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    if (j > 0) wave_lds_sync();
+    if (j == N / 3) { DS_STAMP(1) }
+    if (j == 2 * (N / 3)) { DS_STAMP(2) }
+    // t = sum_k L[lane][k] L[j][k] - A[lane][j]  (products accumulated with positive sign: a negated
+    // uniform operand would be moved to the scalar unit, four v_readlane per quad)
+    __builtin_amdgcn_sched_barrier(0);                   // (the next step's FMAs must not drift into this step's tail: they wait on LDS)
+    f32x2 d01 = {-ROW_EL(j), 0.f}, d23 = {0.f, 0.f};
+    const int nk = j - 1;            // entries 0 .. j-2 of row j come from the image
+    const float yraw = lane_value(y, j);                 // lane j's running y is final already
+    if (j >= 1) wave_lds_sync();                         // column j-1 is in the image
 #pragma unroll
-    for (int k4 = 0; k4 < (j + 3) / 4; ++k4) {
-      f32x4 l;       // L[j][4k4 .. 4k4+3], same address in every lane (memcpy: no type-based aliasing assumptions)
-      __builtin_memcpy(&l, __builtin_assume_aligned(Lrow + j * LS + 4 * k4, 16), 16);
-      if (4 * k4 + 0 < j) s0 = fmaf(-row[4 * k4 + 0], l.x, s0);
-      if (4 * k4 + 1 < j) s1 = fmaf(-row[4 * k4 + 1], l.y, s1);
-      if (4 * k4 + 2 < j) s2 = fmaf(-row[4 * k4 + 2], l.z, s2);
-      if (4 * k4 + 3 < j) s3 = fmaf(-row[4 * k4 + 3], l.w, s3);
+    for (int k4 = 0; 4 * k4 < nk; ++k4) {
+      const f32x4 l = lq[k4];
+      if (4 * k4 + 1 < nk) d01 = __builtin_elementwise_fma(row[2 * k4], f32x2{l.x, l.y}, d01);
+      else d01.x = fmaf(row[2 * k4].x, l.x, d01.x);
+      if (4 * k4 + 3 < nk) d23 = __builtin_elementwise_fma(row[2 * k4 + 1], f32x2{l.z, l.w}, d23);
+      else if (4 * k4 + 2 < nk) d23.x = fmaf(row[2 * k4 + 1].x, l.z, d23.x);
     }
-    const float sacc = (s0 + s1) + (s2 + s3);
-    const float djj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sacc), j));
-    ok = ok && (djj > 0.f);
-    const float inv = rsqrtf(fmaxf(djj, 1e-30f));
-    row[j] = (lane >= j) ? sacc * inv : 0.f;   // L[lane][j]; diagonal = sqrt(djj)
-    if (lane == j) myinv = inv;
-    if (lane < N) Lm[lane * LS + j] = row[j];
-  }
-  // forward substitution L y = -g (lane i keeps y_i)
-  float y = (float)(-gi);
+    // request row j+1 (entries <= j-1 are final) now: it lands while the dependent tail of this step runs
+    if (j + 1 < N) {
 #pragma unroll
-  for (int j = 0; j < N; ++j) {
-    const float yj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, y * myinv), j));
-    if (lane == j) y = yj;
-    else if (lane > j) y = fmaf(-row[j], yj, y);
-  }
-  // back substitution L^T delta = y through the columns of the LDS image
-  wave_lds_sync();
-  float dl = y;
-#pragma unroll
-  for (int i = N - 1; i >= 0; --i) {
-    const float di = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dl * myinv), i));
-    if (lane == i) dl = di;
-    else if (lane < i) dl = fmaf(-Lm[i * LS + lane], di, dl);      // L[i][lane]
-  }
-  delta = act ? dl : 0.f;
-  return ok;
-}
-
-// register / v_readlane variant of damped_solve (row j broadcast lane by lane)
-template <int N>
-__device__ __forceinline__ bool damped_solve_rl(const float (&hrow)[N], double lam, double gi, bool act, int lane,
-                                             float *Lm, float &dgi, float &delta) {
-  constexpr int LS = CHOL_LS;
-  float row[N];
-  float d = 1.f;
-#pragma unroll
-  for (int j = 0; j < N; ++j) {
-    row[j] = hrow[j];
-    if (j == lane) d = hrow[j];
-  }
-  if (!act) d = 1.f;
-  dgi = fmaxf(d, (float)D2D_LM_DIAG_FLOOR);
-  const float add = (float)(lam * (double)dgi);
-#pragma unroll
-  for (int j = 0; j < N; ++j)
-    if (j == lane) row[j] = act ? (d + add) : 1.f;
-  // Left-looking Cholesky: lane i owns row i in registers; finished columns are mirrored into the LDS
-  // image Lm [N][LS] so that row j can be broadcast to every lane by a few ds_read_b128.
-  bool ok = true;
-  float myinv = 1.f;                 // 1 / L[lane][lane]
-  const float *Lrow = Lm;
-#pragma unroll
-  for (int j = 0; j < N; ++j) {
-    float s0 = row[j], s1 = 0.f, s2 = 0.f, s3 = 0.f;
-#pragma unroll
-    for (int k = 0; k < j; ++k) {
-      const float ljk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, row[k]), j));
-      if ((k & 3) == 0) s0 = fmaf(-row[k], ljk, s0);
-      else if ((k & 3) == 1) s1 = fmaf(-row[k], ljk, s1);
-      else if ((k & 3) == 2) s2 = fmaf(-row[k], ljk, s2);
-      else s3 = fmaf(-row[k], ljk, s3);
+      for (int k4 = 0; 4 * k4 < j; ++k4) lq[k4] = lds_get<f32x4>(Lm + (j + 1) * LS + 4 * k4);
     }
-    const float sacc = (s0 + s1) + (s2 + s3);
-    const float djj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sacc), j));
-    ok = ok && (djj > 0.f);
-    const float inv = rsqrtf(fmaxf(djj, 1e-30f));
-    row[j] = (lane >= j) ? sacc * inv : 0.f;   // L[lane][j]; diagonal = sqrt(djj)
-    if (lane == j) myinv = inv;
-    if (lane < N) Lm[lane * LS + j] = row[j];
+    __builtin_amdgcn_sched_barrier(0);
+    const f32x2 dd2 = d01 + d23;
+    float t = dd2.x + dd2.y;
+    if (j >= 1) t = fmaf(ROW_EL(j - 1), ljp, t);
+    const float djj = -lane_value(t, j);
+    const float tnext = (j + 1 < N) ? lane_value(t, j + 1) : 0.f;
+    pivmin = min(pivmin, __builtin_bit_cast(int, djj));
+    const float inv = __builtin_amdgcn_rsqf(__builtin_amdgcn_fmed3f(djj, 1e-30f, 3.0e38f));
+    const float lij = (lane > j) ? -t * inv : 0.f;      // L[lane][j], strictly lower
+    ljp = -tnext * inv;                                  // L[j+1][j], uniform
+    if (j & 1) row[j >> 1].y = lij; else row[j >> 1].x = lij;
+    wrow[j] = lij;
+    dinv[j] = inv;                                      // uniform value, one address
+    y = fmaf(-lij, yraw * inv, y);                      // y_j = yraw / L[j][j]
   }
-  // forward substitution L y = -g (lane i keeps y_i)
-  float y = (float)(-gi);
-#pragma unroll
-  for (int j = 0; j < N; ++j) {
-    const float yj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, y * myinv), j));
-    if (lane == j) y = yj;
-    else if (lane > j) y = fmaf(-row[j], yj, y);
-  }
-  // back substitution L^T delta = y through the columns of the LDS image
+#undef ROW_EL
+  DS_STAMP(3)
+  // back substitution L^T delta = y through the columns of the image
   wave_lds_sync();
-  float dl = y;
+  const float myinv = dinv[lane < N ? lane : 0];        // 1 / L[lane][lane]
+  const float *col = Lm + (lane < N ? lane : 0);
+  float dl = y * myinv * myinv;                          // running (y_i - sum_{k>i} L[k][i] delta_k) / L[i][i]
 #pragma unroll
-  for (int i = N - 1; i >= 0; --i) {
-    const float di = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dl * myinv), i));
-    if (lane == i) dl = di;
-    else if (lane < i) dl = fmaf(-Lm[i * LS + lane], di, dl);      // L[i][lane]
-  }
+  for (int i = N - 1; i >= 1; --i) dl = fmaf(-col[i * LS] * myinv, lane_value(dl, i), dl);   // L[i][lane] = 0 for i <= lane
   delta = act ? dl : 0.f;
-  return ok;
+  DS_STAMP(4)
+#undef DS_STAMP
+  return pivmin > 0;
 }
 
 // Outcome of one damped step (Nielsen gain-ratio rule, oracle/fit.py lm_solve).  All values are

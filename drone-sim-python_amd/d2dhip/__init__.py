@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), 'lib', 'libd2dhip.so')
+LIB_PATH = os.environ.get('D2D_LIB') or os.path.join(os.path.dirname(_HERE), 'lib', 'libd2dhip.so')   # D2D_LIB: A/B builds
 
 SCEN_STRIDE = 32
 (SC_X0, SC_Y0, SC_PSI0, SC_X1, SC_Y1, SC_PSI1, SC_VREF, SC_VSP, SC_KV, SC_KPHI, SC_KOBS, SC_S,
