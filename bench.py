@@ -8,14 +8,16 @@ One "step" = one complete Levenberg-Marquardt solve of the per-GPU batch (BASELI
 configs[1]: 4096 independent single-drone fits, S=6, K=50) with the scenarios and the
 initial guesses already resident in HBM.  With N > 1 the batch shards by trajectory
 (4096 per rank, weak scaling); the only collective is the all-reduce of the convergence
-statistics [sum cost, max |J^T r|, trajectories still running] every `check_every`
-iterations (RCCL; `nccl` backend).  Rank 0 prints ONE JSON line.
+statistics [sum cost, max |J^T r|, trajectories still running] after every persistent launch
+of the LM kernel (`check_every` iterations; default = max_iter, i.e. one launch and one
+all-reduce per solve; RCCL, `nccl` backend).  Rank 0 prints ONE JSON line.
 
 Besides the contract fields the line carries
-  roofline      -- the fit_eval (J^T J, fp32 MFMA) kernel over an instrumented repeat of the
-                   timed region: algorithmic flop = 200*48*49 per trajectory evaluation
-                   (DESIGN.md "J^T J kernel") x evaluations / summed HIP-event kernel time
-  roofline_isolated -- the same kernel on the full resident batch (every trajectory active)
+  roofline      -- the dominant kernel (fit_lm_kernel: the whole LM loop, J^T J on the fp32 MFMA) over an
+                   instrumented repeat of the timed region: algorithmic flop = 200*48*49 per J^T J
+                   evaluation x evaluations / summed HIP-event kernel time
+  roofline_isolated -- the J^T J kernel of the split path (fit_eval_kernel) alone on the full resident
+                   batch (every trajectory active), HIP events around the kernel only
   cpu_baseline  -- scipy.optimize.least_squares (method 'lm', analytic Jacobian) on the
                    oracle's residual function over a process pool, bounded sample
 """
@@ -73,7 +75,7 @@ def _host_cores():
     return max(1, min(n, int(os.environ.get('D2D_BENCH_CORES', 16))))
 
 
-def cpu_baseline(n_sample=192):
+def cpu_baseline(n_sample=1024):
     import multiprocessing as mp
     from oracle import fit as F               # the oracle is the thing timed in this leg only
     from d2dhip import synth
@@ -99,10 +101,11 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--batch', type=int, default=4096, help='trajectories per GPU')
-    ap.add_argument('--check-every', type=int, default=50)
+    ap.add_argument('--check-every', type=int, default=200,
+                    help='LM iterations per persistent launch = interval of the global convergence check (all-reduce)')
     ap.add_argument('--max-iter', type=int, default=200)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample', type=int, default=192)
+    ap.add_argument('--cpu-sample', type=int, default=1024)
     a = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0)); world = int(os.environ.get('WORLD_SIZE', 1))
@@ -194,22 +197,23 @@ def main():
                     'alg_flop_per_unit': ALG_FLOP_PER_EVAL, 'units_per_launch_avg': n_evals / ev_n,
                     'avg_launch_us': 1e3 * ev_ms / ev_n, 'launches': int(ev_n),
                     'step_kernel_avg_launch_us': 1e3 * stp_ms / stp_n, 'eval_ms_total': ev_ms, 'step_ms_total': stp_ms}
-        # isolated: every trajectory active in one launch
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        # isolated: the J^T J kernel alone (fit_eval_kernel), every trajectory active in one launch, bracketed by
+        # HIP events on the library's stream (d2d_fit_profile); prep / untile launches of the public call excluded
         for _ in range(3):
             plan.eval(dsc, q0)
-        nit = 20
         torch.cuda.synchronize()
-        e0.record(ctx.stream)
+        plan.profile(True)
+        nit = 20
         for _ in range(nit):
             plan.eval(dsc, q0)
-        e1.record(ctx.stream)
-        torch.cuda.synchronize()
-        iso_ms = e0.elapsed_time(e1) / nit
+        iso_ms, iso_n = plan.profile_read()[:2]
+        plan.profile(False)
+        iso_ms /= iso_n
         ach_i = ALG_FLOP_PER_EVAL * B / (iso_ms * 1e-3) / 1e12
-        roof_iso = {'bound': 'mfma', 'achieved': ach_i, 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': ach_i / FP32_PEAK_TFLOPS, 'avg_launch_us': 1e3 * iso_ms, 'units_per_launch': B,
-                    'note': 'public d2d_fit_eval on the full batch = prep + fit_eval_kernel + untile launches (kernel-only time: profiles/)'}
+        roof_iso = {'bound': 'mfma', 'kernel': 'fit_eval_kernel<3,24,true> (fp64 residual / J^T r phases + J^T J on v_mfma_f32_16x16x4_f32)',
+                    'achieved': ach_i, 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': ach_i / FP32_PEAK_TFLOPS, 'avg_launch_us': 1e3 * iso_ms, 'units_per_launch': B, 'launches': int(iso_n),
+                    'note': 'the split-path J^T J kernel on the full resident batch (kernel only, HIP events; rocprofv3 summary in profiles/)'}
 
     if rank == 0:
         total = B * world * a.steps

@@ -15,7 +15,10 @@
 #include "fit_phases.h"
 #include "fit_plan.h"
 
-#define FIT_WPB_MAX 12       // wavefronts (= trajectories) per workgroup, fewer when K is large
+// wavefronts (= trajectories) per workgroup, fewer when K is large.  The launch bounds set the VGPR cap:
+// 16 waves -> 128 VGPRs (fit_eval_kernel needs ~85), 12 waves -> 168 (fit_step_kernel: ~135)
+#define FIT_EVAL_WPB_MAX 16
+#define FIT_WPB_MAX 12
 #define FIT_THREADS (64 * FIT_WPB_MAX)
 #define FIT_LDS_BYTES (160 * 1024)
 
@@ -60,7 +63,7 @@ static FitLds eval_lds_layout(int K, int nq, bool g32_lds, int wpb, int nds = 0)
 static bool pick_eval_layout(int K, int nq, bool *g32_lds, int *wpb, int nds = 0) {
   for (int pass = 0; pass < 2; ++pass) {
     const bool in_lds = pass == 0;
-    for (int w = FIT_WPB_MAX; w >= (in_lds ? 4 : 1); --w)
+    for (int w = FIT_EVAL_WPB_MAX; w >= (in_lds ? 4 : 1); --w)
       if (eval_lds_layout(K, nq, in_lds, w, nds).total <= FIT_LDS_BYTES) { *g32_lds = in_lds; *wpb = w; return true; }
   }
   return false;
@@ -98,7 +101,7 @@ fit_prepk_kernel(int B, int K, const double *__restrict__ prep, const double *__
 // K1 + K2: cost, J^T r, J^T J.   H is written as the upper block triangle of 16x16 tiles
 // of a [n][n] row-major matrix (n = 2nq); symmetrize_kernel mirrors it for the public API.
 template <int NB, int NQ, bool G32_LDS>   // NB = ceil(2nq/16) column blocks of the MFMA tiling; NQ = nq or 0 (runtime)
-__global__ void __launch_bounds__(FIT_THREADS)
+__global__ void __launch_bounds__(64 * FIT_EVAL_WPB_MAX)
 fit_eval_kernel(int B, FitGeom g, FitLds L, int dbg, GroupArgs ga, const double *__restrict__ gG64,
                 const double *__restrict__ pk, const float *__restrict__ gG32,
                 const float *__restrict__ gW32, const double *__restrict__ prep,
@@ -884,6 +887,9 @@ int d2d_fit_project(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, const double *s
   return D2D_OK;
 }
 
+static int prof_begin(d2d_ctx *ctx, d2d_fit_plan *pl, int kind);
+static int prof_end(d2d_ctx *ctx, d2d_fit_plan *pl);
+
 int d2d_fit_eval(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, const double *scen, const double *q,
                  double *cost, double *g, float *H) {
   D2D_REQUIRE(ctx && pl && scen && q, "d2d_fit_eval: null argument");
@@ -892,7 +898,9 @@ int d2d_fit_eval(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, const double *scen
   if (plm->active_B != 0 && B > plm->cap_B) { d2d_set_error("d2d_fit_eval: a solve of a smaller batch is in progress on this plan"); return D2D_ESTATE; }
   if (int rc = ensure_scratch(plm, B)) return rc;
   if (int rc = launch_prep(ctx, pl, B, scen)) return rc;
+  if (int rc = prof_begin(ctx, plm, 0)) return rc;       // (d2d_fit_profile: the J^T J kernel alone, every trajectory active)
   if (int rc = launch_eval(ctx, pl, B, q, nullptr, cost, g, H ? plm->d_H : nullptr)) return rc;
+  if (int rc = prof_end(ctx, plm)) return rc;
   plm->prep_valid_for = nullptr;
   if (H) {
     hipLaunchKernelGGL(untile_kernel, dim3(B), dim3(256), 0, ctx->stream, B, 2 * pl->nq, (2 * pl->nq + 15) / 16, plm->d_H, pl->d_W32, pl->d_prep, H);
@@ -1035,8 +1043,11 @@ int d2d_fit_solve(d2d_ctx *ctx, const d2d_fit_plan *plc, int B, const double *sc
   D2D_REQUIRE(o.max_iter >= 1 && o.check_every >= 1, "d2d_fit_solve: max_iter and check_every must be >= 1");
   if (int rc = d2d_fit_begin(ctx, pl, B)) return rc;
   int32_t running = B;
+  // the persistent LM kernel masks finished trajectories itself and ends when its last one stops: one
+  // launch for the whole solve; the split path counts the running trajectories every check_every iterations
+  const int per_call = (pl->use_lm && pl->n_group <= 1) ? o.max_iter : o.check_every;
   while (running > 0)
-    if (int rc = d2d_fit_iterate(ctx, pl, B, scen, q, &o, o.check_every, &running)) return rc;
+    if (int rc = d2d_fit_iterate(ctx, pl, B, scen, q, &o, per_call, &running)) return rc;
   return d2d_fit_finish(ctx, pl, B, scen, q, cost, iters, status, stats);
 }
 

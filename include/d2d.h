@@ -272,7 +272,8 @@ int d2d_fit_solve_groups(d2d_ctx *ctx, d2d_fit_plan *plan, int R, const double *
                          double *cost, int32_t *sweeps_done, double *stats);
 
 /* Per-launch timing of the LM loop with HIP events on the context's stream: enable = 1
- * starts a fresh recording, 0 stops.  d2d_fit_profile_read waits for the recorded events:
+ * starts a fresh recording, 0 stops (d2d_fit_eval's kernel launch is recorded too, as a fit_eval launch).
+ * d2d_fit_profile_read waits for the recorded events:
  * out[6]: [0] = sum of fit_eval (J^T J) kernel ms, [1] = its launches, [2] = sum of fit_step kernel
  * ms, [3] = its launches, [4] = sum of fit_lm (fused persistent LM loop) kernel ms, [5] = its launches. */
 int d2d_fit_profile(d2d_fit_plan *plan, int enable);
