@@ -172,6 +172,33 @@ ctrl_gain_kernel(d2d_track_params p, const double *__restrict__ X, const double 
   }
 }
 
+// DFFFController.get for n independent (state, reference sample) pairs
+__global__ void __launch_bounds__(64)
+dfff_kernel(d2d_track_params p, const double *__restrict__ X, const double *__restrict__ Yref,
+            double *__restrict__ Xr, double *__restrict__ U, double *__restrict__ Kg) {
+  const int n = p.n;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = i < n;
+  if (!live) i = n - 1;   // keep the whole wave converged in care_sda's __all()
+  const State5 s = {X[i], X[n + i], X[2 * n + i], X[3 * n + i], X[4 * n + i]};
+  double Y[6];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) Y[c] = Yref[(long)c * n + i];
+  const DfffOut o = dfff_gain(s, Y, p);
+  if (!live) return;
+  if (Xr) {
+#pragma unroll
+    for (int c = 0; c < 5; ++c) Xr[(long)c * n + i] = o.Xr[c];
+  }
+  if (U) { U[i] = o.U[0]; U[n + i] = o.U[1]; }
+  if (Kg) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) Kg[(long)(r * 3 + c) * n + i] = o.K[r][c];
+  }
+}
+
 // numpy.gradient(f, edge_order=2) with unit spacing at row i of a [n_rows][n] plane
 __device__ __forceinline__ double grad2(const double *__restrict__ f, int i, int T, long n, long d) {
   if (i == 0) return -1.5 * f[d] + 2.0 * f[n + d] - 0.5 * f[2 * n + d];
@@ -417,6 +444,15 @@ int d2d_ctrl_gain(d2d_ctx *ctx, const d2d_track_params *p, const double *X, cons
   D2D_REQUIRE(ctx && p && X && Yref, "d2d_ctrl_gain: null argument");
   if (int rc = check_track(p, "d2d_ctrl_gain")) return rc;
   hipLaunchKernelGGL(ctrl_gain_kernel, dim3((p->n + 63) / 64), dim3(64), 0, ctx->stream, *p, X, Yref, Xr, dX, U, Kgain);
+  D2D_LAUNCH_CHECK();
+  return D2D_OK;
+}
+
+int d2d_dfff_eval(d2d_ctx *ctx, const d2d_track_params *p, const double *X, const double *Yref,
+                  double *Xr, double *U, double *Kgain) {
+  D2D_REQUIRE(ctx && p && X && Yref, "d2d_dfff_eval: null argument");
+  if (int rc = check_track(p, "d2d_dfff_eval")) return rc;
+  hipLaunchKernelGGL(dfff_kernel, dim3((p->n + 63) / 64), dim3(64), 0, ctx->stream, *p, X, Yref, Xr, U, Kgain);
   D2D_LAUNCH_CHECK();
   return D2D_OK;
 }

@@ -1,7 +1,7 @@
 """Mirror of the guidance classes of src/d2d/guidance.py used by the full simulations:
-WindField, DiffFlatness, DCFController, CircleTraj, GVFcontroller.  Numerics run through
-libd2dhip.so.  (DFFFController and the pure-pursuit controllers of the reference are legacy
-paths outside this engine's scope)"""
+WindField, DiffFlatness, DFFFController, DCFController, CircleTraj, GVFcontroller.  Numerics run
+through libd2dhip.so.  (The pure-pursuit controllers of the reference are legacy paths outside this
+engine's scope)"""
 import numpy as np
 
 import d2dhip
@@ -33,6 +33,44 @@ class DiffFlatness:
             Y[2 * d, 0], Y[2 * d + 1, 0] = Ys[d, 0], Ys[d, 1]
         X, U, Xd = ctx.flatness(0, ctx.dev(Y), (float(W[0]), float(W[1])), ac.tau_phi, ac.tau_v)
         return X.cpu().numpy()[:, 0], U.cpu().numpy()[:, 0], Xd.cpu().numpy()[:, 0]
+
+
+class DFFFController:
+    """Differential-flatness feed-forward + 3-state LQR feedback (src/d2d/guidance.py:52-95).
+    `get(X, t)` is one d2d_dfff_eval call; `get_batch` evaluates many aircraft at once."""
+
+    def __init__(self, traj, ac, wind):
+        self.traj, self.ac, self.wind = traj, ac, wind
+        self.dt = 0.01
+        self.time = np.arange(0, traj.duration, self.dt)
+        self.carrot, self.ref_pos = [0, 0], [0, 0]
+        self.Xref = []
+        self.K = []
+
+    def get(self, X, t):
+        Yref = np.asarray(self.traj.get(t), dtype=np.float64)
+        W = self.wind.sample(t, Yref[0])
+        U, K, Xr = DFFFController.get_batch(np.asarray(X, float)[None], Yref[None], W, self.ac)
+        self.Xref.append(Xr[0])
+        self.K.append(K[0])
+        return U[0]
+
+    @staticmethod
+    def get_batch(X, Yref, W, ac):
+        """X (n,5), Yref (n,>=3,2) [derivative, axis], one wind W for the batch -> U (n,2), K (n,2,5), Xr (n,5)."""
+        ctx = d2dhip.default_context()
+        X = np.asarray(X, dtype=np.float64); Yref = np.asarray(Yref, dtype=np.float64)
+        n = X.shape[0]
+        Y = np.ascontiguousarray(Yref[:, :3, :].reshape(n, 6).T)          # rows x,y,xd,yd,xdd,ydd
+        Xr, U, K1 = ctx.dfff_eval(ctx.dev(np.ascontiguousarray(X.T)), ctx.dev(Y), (float(W[0]), float(W[1])),
+                                  ac.tau_phi, ac.tau_v)
+        K = np.zeros((n, 2, 5))
+        K[:, :, :3] = K1.cpu().numpy().T.reshape(n, 2, 3)
+        return U.cpu().numpy().T.copy(), K, Xr.cpu().numpy().T.copy()
+
+    def draw_debug(self, _f, _a, time):
+        Xref = np.array(self.Xref)
+        _a[0, 0].plot(time, Xref[:, 0])
 
 
 class DCFController:

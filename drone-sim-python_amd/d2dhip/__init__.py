@@ -53,6 +53,7 @@ _SIGS = {
     'd2d_step': (C.c_int, [_P, C.c_int, _P, _P, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _P]),
     'd2d_sim_gvf_run': (C.c_int, [_P, C.POINTER(GvfParams)] + [_P] * 12),
     'd2d_ctrl_gain': (C.c_int, [_P, C.POINTER(TrackParams)] + [_P] * 6),
+    'd2d_dfff_eval': (C.c_int, [_P, C.POINTER(TrackParams)] + [_P] * 5),
     'd2d_sim_track_run': (C.c_int, [_P, C.POINTER(TrackParams)] + [_P] * 10),
     'd2d_dcf_eval': (C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.c_double, _P, _P, _P, _P]),
     'd2d_gvf_eval': (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_double, C.c_double, _P]),
@@ -250,6 +251,16 @@ class Context:
         Xr, dX, U, K = self.empty(5, n), self.empty(5, n), self.empty(2, n), self.empty(10, n)
         _check(self.lib.d2d_ctrl_gain(self.h, C.byref(p), _ptr(X), _ptr(Yref), _ptr(Xr), _ptr(dX), _ptr(U), _ptr(K)))
         return Xr, dX, U, K
+
+    def dfff_eval(self, X, Yref, w=(0.0, 0.0), tau_phi=0.01, tau_v=1.0):
+        """DFFFController.get for n (state, reference sample) pairs: X dev [5][n], Yref dev [6][n]
+        (x,y,xd,yd,xdd,ydd) -> Xr [5][n], U [2][n], K1 [6][n] (row-major 2x3)."""
+        n = X.shape[1]
+        p = self.track_params(n, 1, 0.01, w=w, tau_phi=tau_phi, tau_v=tau_v, phi_lim=np.deg2rad(45),
+                              Q=(1, 1, 0.1, 0.0, 0.0), R=(8, 1))          # src/d2d/guidance.py:79,86
+        Xr, U, K = self.empty(5, n), self.empty(2, n), self.empty(6, n)
+        _check(self.lib.d2d_dfff_eval(self.h, C.byref(p), _ptr(X), _ptr(Yref), _ptr(Xr), _ptr(U), _ptr(K)))
+        return Xr, U, K
 
     def track_run(self, x_ref, y_ref, X0, dt, record=('X', 'U', 'Xr', 'dX', 'Yd', 'Ydd'), **kw):
         """x_ref, y_ref dev [T][n]; X0 dev [5][n] -> dict of device histories."""

@@ -5,7 +5,7 @@ import numpy as np
 
 from . import (SCEN_STRIDE, SC_X0, SC_Y0, SC_PSI0, SC_X1, SC_Y1, SC_PSI1, SC_VREF, SC_VSP, SC_KV, SC_KPHI,
                SC_KOBS, SC_S, SC_WWP, SC_GOLEFT, SC_O0X, SC_O0Y, SC_O0R, SC_O1X, SC_O1Y, SC_O1R, SC_WBND,
-               SC_PHIMAX, SC_VMIN, SC_VMAX)
+               SC_PHIMAX, SC_VMIN, SC_VMAX, SC_KCOL, SC_RCOL, SC_SCOL, SC_PMASK)
 
 G_ACC = 9.81
 
@@ -48,4 +48,29 @@ def synth_scenarios(B, seed=20241008, rank=0, n_obs=2, wbnd=1.0, wwp=0.02, obj_s
         sc[:, ox], sc[:, oy] = c[:, 0], c[:, 1]
         sc[:, orr] = rad[:, i] if i < n_obs else 0.0
     sc[:, SC_S] = obj_scale / K
+    return sc
+
+
+def circle_group_scenarios(n_ac, R, duration, K=50, seed=0, sigma=2.0, pair01_only=False, obj_scale=1.0):
+    """BASELINE configs[2]: R replicas of n_ac aircraft on a circle of radius t1*vref/2/1.5 heading to their
+    antipodes (generalises exp_2, src/07_multioptyplan.py:251-260), collision rows kcol = rcol = 10 (:403);
+    replicas differ by a sigma-metre perturbation of the start / end points.  Rows [R][n_ac][32]: the
+    aircraft of one scenario are consecutive, as d2d_fit_solve_groups expects."""
+    rng = np.random.default_rng(seed)
+    rad = duration * 12.0 / 2 / 1.5
+    s = obj_scale / K
+    sc = np.zeros((R, n_ac, SCEN_STRIDE))
+    for i in range(n_ac):
+        a = 2 * np.pi * i / n_ac
+        sc[:, i, SC_X0], sc[:, i, SC_Y0], sc[:, i, SC_PSI0] = rad * np.cos(a), rad * np.sin(a), a + np.pi
+        sc[:, i, SC_X1], sc[:, i, SC_Y1], sc[:, i, SC_PSI1] = -rad * np.cos(a), -rad * np.sin(a), a + np.pi
+    sc[..., [SC_X0, SC_Y0, SC_X1, SC_Y1]] += rng.normal(0, sigma, (R, n_ac, 4))
+    sc[..., SC_VREF] = 12; sc[..., SC_VSP] = 12; sc[..., SC_KV] = 5; sc[..., SC_KPHI] = 1
+    sc[..., SC_S] = s / n_ac; sc[..., SC_WWP] = 0.02; sc[..., SC_GOLEFT] = -1; sc[..., SC_WBND] = 1
+    sc[..., SC_PHIMAX] = np.deg2rad(40.0); sc[..., SC_VMIN] = 9; sc[..., SC_VMAX] = 15
+    sc[..., SC_KCOL] = 10; sc[..., SC_RCOL] = 10; sc[..., SC_SCOL] = s
+    if pair01_only:
+        sc[:, 0, SC_PMASK] = 0b10; sc[:, 1, SC_PMASK] = 0b01
+    else:
+        sc[..., SC_PMASK] = (1 << n_ac) - 1
     return sc

@@ -125,6 +125,17 @@ typedef struct {
 int d2d_ctrl_gain(d2d_ctx *ctx, const d2d_track_params *p, const double *X, const double *Yref,
                   double *Xr, double *dX, double *U, double *Kgain);
 
+/* One batched evaluation of the legacy DFFFController.get(X, t) (src/d2d/guidance.py:62-91):
+ * DiffFlatness.state_and_input_from_output (:22-47) of the reference sample, error wrap (psi) and clip
+ * (:70-72), Aircraft.cont_jac, control.lqr on the 3-state sub-system A[:3,:3], A[:3,3:] (:78-81; 3x3
+ * Riccati equation solved on the device), U = clip(Ur - K dX) (:85-88).  Of d2d_track_params it reads n,
+ * tau_phi, tau_v, wx, wy, err_sats, q_diag[0..2], r_diag, phi_lim, v_min, v_max.
+ *   X dev [5][n]; Yref dev [6][n] = x,y,xd,yd,xdd,ydd (the sample traj.get(t) of every drone)
+ *   outputs (dev, any may be NULL): Xr [5][n], U [2][n], Kgain [6][n] (K1 row-major 2x3; the phi and v
+ *   columns of the reference's 2x5 K are zero). */
+int d2d_dfff_eval(d2d_ctx *ctx, const d2d_track_params *p, const double *X, const double *Yref,
+                  double *Xr, double *U, double *Kgain);
+
 /* Trajectory-tracking phase, whole time loop on the device.  Replaces
  * implement_controller(n_ac, time, x_ref, y_ref, v, w, X0s)
  * (src/11_full_sim_case1.py:241-291) including ComputeDerivatives (:197-204; two passes

@@ -357,7 +357,41 @@ def fx_tracking_trace():
              tau_phi=acs[0].tau_phi, tau_v=acs[0].tau_v)
 
 
+def fx_dfff():
+    """DFFFController.get (src/d2d/guidance.py:62-91; 3-state LQR through the CARE stand-in) on seeded
+    reference samples and perturbed states, with and without wind."""
+    r = np.random.default_rng(7)
+    n = 48
+    Y = r.uniform(-80, 80, (n, 2)); psi = r.uniform(-np.pi, np.pi, n); sp = r.uniform(9, 15, n)
+    Yd = np.stack([sp * np.cos(psi), sp * np.sin(psi)], 1)
+    Ydd = r.uniform(-4, 4, (n, 2)); Yddd = r.uniform(-1, 1, (n, 2))
+    W = np.stack([r.uniform(-2, 2, n), r.uniform(-2, 2, n)], 1); W[: n // 2] = 0.0
+    ac = ddyn.Aircraft()
+
+    class _Traj:                                   # the controller only needs .duration and .get(t)
+        duration = 10.0
+
+        def __init__(self, Ys): self.Ys = Ys
+        def get(self, t): return self.Ys
+
+    X = np.zeros((n, 5)); U = np.zeros((n, 2)); K = np.zeros((n, 2, 5)); Xr = np.zeros((n, 5))
+    for i in range(n):
+        Ys = np.array([Y[i], Yd[i], Ydd[i], Yddd[i]])
+        ctl = ddg.DFFFController(_Traj(Ys), ac, ddg.WindField(list(W[i])))
+        xr = ddg.DiffFlatness.state_and_input_from_output(Ys, W[i], ac)[0]
+        X[i] = xr + np.array([r.uniform(-25, 25), r.uniform(-25, 25), r.uniform(-1.5, 1.5), r.uniform(-1.0, 1.0), r.uniform(-2, 2)])
+        if i == 0:
+            X[i, 2] = xr[2] + 2 * np.pi - 0.2     # wrap of dpsi
+        U[i] = ctl.get(X[i].copy(), 0.5)
+        K[i] = ctl.K[-1]; Xr[i] = ctl.Xref[-1]
+    np.savez(os.path.join(OUT, 'dfff_carestandin.npz'), Y=Y, Yd=Yd, Ydd=Ydd, Yddd=Yddd, W=W, X=X, U=U, K=K, Xr=Xr,
+             tau_phi=ac.tau_phi, tau_v=ac.tau_v)
+
+
 if __name__ == '__main__':
+    only = sys.argv[1:]
     for f in (fx_plant, fx_flatness_ctrl, fx_guidance, fx_states_over_time, fx_costs, fx_guess_poly,
-              fx_fit_cost, fx_planner_goldens, fx_tracking_trace):
+              fx_fit_cost, fx_planner_goldens, fx_tracking_trace, fx_dfff):
+        if only and f.__name__ not in only:
+            continue
         f(); print('wrote', f.__name__)

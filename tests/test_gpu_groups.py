@@ -11,26 +11,9 @@ DUR = F.planner_timing(0, 4.9, 10)[2]
 
 
 def circle_scenarios(n_ac, R, seed=0, sigma=2.0, pair01_only=False):
-    """n_ac aircraft on a circle of radius t1*vref/2/1.5 heading to their antipodes (generalises exp_2 of
-    src/07_multioptyplan.py:251-260); replicas differ by a sigma-metre perturbation of the start/end points."""
-    rng = np.random.default_rng(seed)
-    rad = DUR * 12.0 / 2 / 1.5
-    s = 1.0 / K
-    sc = np.zeros((R, n_ac, F.SCEN_STRIDE))
-    for i in range(n_ac):
-        a = 2 * np.pi * i / n_ac
-        sc[:, i, F.SC_X0], sc[:, i, F.SC_Y0], sc[:, i, F.SC_PSI0] = rad * np.cos(a), rad * np.sin(a), a + np.pi
-        sc[:, i, F.SC_X1], sc[:, i, F.SC_Y1], sc[:, i, F.SC_PSI1] = -rad * np.cos(a), -rad * np.sin(a), a + np.pi
-    sc[..., [F.SC_X0, F.SC_Y0, F.SC_X1, F.SC_Y1]] += rng.normal(0, sigma, (R, n_ac, 4))
-    sc[..., F.SC_VREF] = 12; sc[..., F.SC_VSP] = 12; sc[..., F.SC_KV] = 5; sc[..., F.SC_KPHI] = 1
-    sc[..., F.SC_S] = s / n_ac; sc[..., F.SC_WWP] = 0.02; sc[..., F.SC_GOLEFT] = -1; sc[..., F.SC_WBND] = 1
-    sc[..., F.SC_PHIMAX] = F.PHI_MAX; sc[..., F.SC_VMIN] = 9; sc[..., F.SC_VMAX] = 15
-    sc[..., F.SC_KCOL] = 10; sc[..., F.SC_RCOL] = 10; sc[..., F.SC_SCOL] = s
-    if pair01_only:
-        sc[:, 0, F.SC_PMASK] = 0b10; sc[:, 1, F.SC_PMASK] = 0b01
-    else:
-        sc[..., F.SC_PMASK] = (1 << n_ac) - 1
-    return sc
+    """BASELINE configs[2] scenario rows (d2dhip.synth.circle_group_scenarios, obj_scale = 1)."""
+    from d2dhip import synth
+    return synth.circle_group_scenarios(n_ac, R, DUR, K, seed=seed, sigma=sigma, pair01_only=pair01_only, obj_scale=1.0)
 
 
 @pytest.fixture(scope='module')

@@ -59,6 +59,27 @@ def test_compute_gain_like_the_reference_loop(gold):
         np.testing.assert_allclose(ctrl.K[-1], g['gain_K_carestandin'][i], rtol=1e-8, atol=1e-9)
 
 
+def test_dfff_controller_class(gold):
+    """ddg.DFFFController(traj, ac, wind).get(X, t) as 05_test_simulation.py / compare.py call it."""
+    import d2d.dynamic as ddyn
+    import d2d.guidance as ddg
+    g = gold('dfff_carestandin')
+
+    class Traj:
+        duration = 10.0
+
+        def __init__(self, Ys): self.Ys = Ys
+        def get(self, t): return self.Ys
+
+    ac = ddyn.Aircraft()
+    for i in (0, 5, 30, 47):
+        ctl = ddg.DFFFController(Traj(np.array([g['Y'][i], g['Yd'][i], g['Ydd'][i], g['Yddd'][i]])), ac, ddg.WindField(list(g['W'][i])))
+        U = ctl.get(g['X'][i].copy(), 0.5)
+        np.testing.assert_allclose(U, g['U'][i], rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(ctl.K[-1], g['K'][i], rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(ctl.Xref[-1], g['Xr'][i], rtol=1e-12, atol=1e-12)
+
+
 def test_lqr_vs_scipy_care():
     """control.lqr replacement on random stabilisable 5x5 / 2-input systems."""
     import scipy.linalg

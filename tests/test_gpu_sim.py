@@ -133,6 +133,30 @@ def test_ctrl_gain_vs_golden_and_oracle(ctx, gold):
         np.testing.assert_allclose(U, g['gain_U_carestandin'][i], rtol=1e-8, atol=1e-9)
 
 
+def test_dfff_vs_golden_and_oracle(ctx, gold):
+    """d2d_dfff_eval (legacy DFFFController: flatness feed-forward + 3x3 Riccati feedback on the device)."""
+    g = gold('dfff_carestandin')
+    n = len(g['X'])
+    Yref = np.concatenate([g['Y'], g['Yd'], g['Ydd']], 1)                    # (n, 6)
+    tau_phi, tau_v = float(g['tau_phi']), float(g['tau_v'])
+    for i in range(n):        # wind differs per row
+        Xr, U, K = ctx.dfff_eval(ctx.dev(_planes(g['X'][i:i + 1])), ctx.dev(_planes(Yref[i:i + 1])), tuple(g['W'][i]), tau_phi, tau_v)
+        Xr, U, K = (t.cpu().numpy()[:, 0] for t in (Xr, U, K))
+        np.testing.assert_allclose(Xr, g['Xr'][i], rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(K.reshape(2, 3), g['K'][i][:, :3], rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(U, g['U'][i], rtol=1e-8, atol=1e-9)
+    # one batched call (rows without wind) and another lag constant against the oracle
+    idx = np.where(np.abs(g['W']).sum(1) == 0)[0]
+    for tau in (0.01, 0.9667):
+        Xr, U, K = ctx.dfff_eval(ctx.dev(_planes(g['X'][idx])), ctx.dev(_planes(Yref[idx])), (0.0, 0.0), tau, 1.0)
+        U = U.cpu().numpy().T; K = K.cpu().numpy().T.reshape(len(idx), 2, 3)
+        for j, i in enumerate(idx):
+            Ys = np.array([g['Y'][i], g['Yd'][i], g['Ydd'][i]])
+            Uo, Ko, _ = S.dfff_get(g['X'][i], Ys, (0, 0), tau, 1.0)
+            np.testing.assert_allclose(K[j], Ko[:, :3], rtol=1e-8, atol=1e-9)
+            np.testing.assert_allclose(U[j], Uo, rtol=1e-8, atol=1e-9)
+
+
 def test_ctrl_gain_batch_and_tau(ctx):
     rng = np.random.default_rng(11)
     n = 777
