@@ -382,10 +382,12 @@ fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_budget,
   const int n = 2 * g.nq;
   const bool act = lane < n;
 
-  // static striding over the batch: wave w of workgroup g takes trajectories g*wpb + w, + gridDim*wpb, ...
+  // static striding over the batch, workgroup-major: wave w of workgroup g takes trajectories
+  // g + gridDim*w, + gridDim*wpb, ...  -- a batch smaller than the grid's wave count spreads over all CUs
+  // (and over the four SIMDs of a CU: consecutive waves of a workgroup sit on different SIMDs)
   const int stride = gridDim.x * (blockDim.x >> 6);
   if (STAMPS) st_last = __builtin_amdgcn_s_memtime();
-  for (int b = blockIdx.x * (blockDim.x >> 6) + wave; b < B; b += stride) {
+  for (int b = blockIdx.x + gridDim.x * wave; b < B; b += stride) {
     if (flags[4 * b + FL_STATUS] != D2D_ST_RUNNING) continue;
     const double *prow = prep + (size_t)b * FIT_PREP_STRIDE;
     const double *pkb = pk + (size_t)b * FIT_PK * g.K;
@@ -745,8 +747,7 @@ static int launch_lm(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, double *q, con
   if (want_times) { D2D_CHECK_HIP(hipStreamSynchronize(ctx->stream)); t0 = std::chrono::steady_clock::now(); }
   unsigned long long *stamps = want_stamps ? reinterpret_cast<unsigned long long *>(ctx->stats_dev + 8) : nullptr;
   if (want_stamps) D2D_CHECK_HIP(hipMemsetAsync(stamps, 0, 13 * sizeof(unsigned long long), ctx->stream));
-  int blocks = (B + pl->wpb_lm - 1) / pl->wpb_lm;
-  if (blocks > pl->n_cu) blocks = pl->n_cu;           // persistent: one workgroup per CU pulls work
+  const int blocks = B < pl->n_cu ? B : pl->n_cu;     // persistent: one workgroup per CU
   if (want_stamps)
     hipLaunchKernelGGL((fit_lm_kernel<3, 24, true>), dim3(blocks), dim3(64 * pl->wpb_lm), L.total, ctx->stream, B, gm, L, o, budget,
                        pl->d_G, pl->d_pk, pl->d_G32, pl->d_W32, pl->d_prep, q, pl->d_cost, pl->d_g, pl->d_lm, pl->d_flags, stamps);

@@ -185,6 +185,31 @@ def test_solve_full_batch_properties(ctx, plan, obasis):
     np.testing.assert_array_equal(qp.cpu().numpy(), q.cpu().numpy()[perm])
 
 
+def test_fused_and_split_paths_agree(ctx, plan, obasis, monkeypatch):
+    """d2d_fit_solve runs the persistent fit_lm_kernel; D2D_FIT_SPLIT=1 at plan creation selects the
+    eval/step launch pairs (same building blocks): same fixed points, same iteration counts."""
+    import d2dhip
+    B = 300
+    sc = F.set_scale(F.synth_scenarios(B, seed=5), 0.1, K)
+    dsc = ctx.dev(sc)
+    qa = plan.init(dsc); ca, ia, sa, _ = plan.solve(dsc, qa)
+    monkeypatch.setenv('D2D_FIT_SPLIT', '1')
+    plan2 = d2dhip.FitPlan(ctx, S_, K, DUR, WREF)
+    monkeypatch.delenv('D2D_FIT_SPLIT')
+    try:
+        qb = plan2.init(dsc); cb, ib, sb, _ = plan2.solve(dsc, qb)
+    finally:
+        plan2.close()
+    ia, ib, sa, sb = (t.cpu().numpy() for t in (ia, ib, sa, sb))
+    ca, cb, qa, qb = (t.cpu().numpy() for t in (ca, cb, qa, qb))
+    same = ia == ib
+    assert same.mean() > 0.9, same.mean()            # (an fp32-rounding tie in a gain ratio may shift a path)
+    np.testing.assert_allclose(qa[same], qb[same], rtol=0, atol=1e-6 * np.abs(qb).max())
+    np.testing.assert_allclose(ca[same], cb[same], rtol=1e-9)
+    assert (sa[same] == sb[same]).all()
+    assert np.abs(ca - cb).max() <= 1e-6 * np.abs(cb).max() or (np.abs(ca - cb) > 1e-6 * np.abs(cb)).mean() < 0.05
+
+
 def test_small_and_other_shapes(ctx):
     """B = 1, and a plan with another horizon / segment count (K = 71, S = 4)."""
     import d2dhip
