@@ -1,10 +1,13 @@
 // Polynomial trajectory fit: kernels and C-ABI entry points (include/d2d.h).
 //
+//   fit_lm_kernel   : the whole Levenberg-Marquardt loop of a trajectory in one persistent launch
+//                     (hot path of d2d_fit_solve for 6-segment plans)
 //   fit_eval_kernel : flat outputs + residuals (fp64), J^T r (fp64), J^T J (fp32 MFMA)
-//   fit_step_kernel : damped Cholesky solve (fp32, registers + cross-lane broadcast),
-//                     trial cost (fp64), Nielsen gain-ratio update
+//   fit_step_kernel : damped Cholesky solve (fp32), trial cost (fp64), Nielsen gain-ratio update
+//                     (one LM iteration per launch pair: d2d_fit_eval, coupled groups, other plans)
 // One wavefront per trajectory; the basis block shared by the whole batch is staged in LDS
-// once per workgroup.  Restates oracle/fit.py (lm_solve, eval_normal).
+// once per workgroup; the phases themselves live in fit_phases.h.  Restates oracle/fit.py
+// (lm_solve, eval_normal, bgs_solve).
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -27,7 +30,7 @@ enum { FL_STATUS = 0, FL_ITERS = 1, FL_NEED = 2, FL_NEVAL = 3 };
 
 struct FitLds {
   // byte offsets into dynamic LDS
-  int G64, Gp64, G32, wave0, wave_stride;
+  int G64, G32, wave0, wave_stride;
   int q, u, coef, cfd;     // offsets inside a wave's private block
   int total;
 };
@@ -47,7 +50,6 @@ static FitLds eval_lds_layout(int K, int nq, bool g32_lds, int wpb, int nds = 0)
   const int gstr = nq + 1;
   int o = 0;
   L.G64 = o; o = align16(o + 3 * K * gstr * 8);
-  L.Gp64 = o;                                       // (end-condition part now comes from the pk table)
   L.G32 = o; o = align16(o + (g32_lds ? (3 * K + 1) * nq * 4 : 0));   // + one padded sample row
   L.wave0 = o;
   int w = 0;
@@ -99,7 +101,7 @@ fit_prepk_kernel(int B, int K, const double *__restrict__ prep, const double *__
 
 // ------------------------------------------------------------------------------------
 // K1 + K2: cost, J^T r, J^T J.   H is written as the upper block triangle of 16x16 tiles
-// of a [n][n] row-major matrix (n = 2nq); symmetrize_kernel mirrors it for the public API.
+// of a [n][n] row-major matrix (n = 2nq), in the accumulator layout; untile_kernel expands it for the public API.
 template <int NB, int NQ, bool G32_LDS>   // NB = ceil(2nq/16) column blocks of the MFMA tiling; NQ = nq or 0 (runtime)
 __global__ void __launch_bounds__(64 * FIT_EVAL_WPB_MAX)
 fit_eval_kernel(int B, FitGeom g, FitLds L, int dbg, GroupArgs ga, const double *__restrict__ gG64,
@@ -199,14 +201,13 @@ untile_kernel(int B, int n, int NB, const float *__restrict__ Ht, const float *_
 // ------------------------------------------------------------------------------------
 // K3: one damped solve + trial + accept/reject.  N = padded system size (16*NB).
 struct StepLds {
-  int G64, Gp64, wave0, wave_stride, Lm, vec, qt, total;
+  int G64, wave0, wave_stride, Lm, vec, qt, total;
 };
 static StepLds step_lds_layout(int K, int nq, int N, int wpb) {
   StepLds L;
   const int gstr = nq + 1;
   int o = 0;
   L.G64 = o; o = align16(o + 3 * K * gstr * 8);
-  L.Gp64 = o;
   L.wave0 = o;
   int w = 0;
   {
@@ -315,7 +316,7 @@ fit_step_kernel(int B, FitGeom g, StepLds L, d2d_fit_opts opts, GroupArgs ga,
 // fp64 VALU phases, and trajectories that converge early free their wave for the tail.
 #define FIT_LM_WPB_MAX 8
 struct FusedLds {
-  int G64, Gp64, G32, Wt, wave0, wave_stride;
+  int G64, G32, Wt, wave0, wave_stride;
   int qs, sp, big, cf;      // inside a wave's block; `big` holds us+cf, then the image of J^T J / its factor
   int total;
 };
@@ -324,7 +325,6 @@ static FusedLds fused_lds_layout(int K, int nq, int N, int wpb) {
   const int gstr = nq + 1;
   int o = 0;
   L.G64 = o; o = align16(o + 3 * K * gstr * 8);
-  L.Gp64 = o;
   L.G32 = o; o = align16(o + (3 * K + 1) * nq * 4);
   L.Wt = o; o = align16(o + (N / 16) * (N / 16 + 1) / 2 * 256 * 4);      // waypoint rows' constant block, tile-major
   L.wave0 = o;
@@ -764,7 +764,7 @@ static int launch_lm(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, double *q, con
     unsigned long long h[13];
     D2D_CHECK_HIP(hipMemcpyAsync(h, stamps, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
     D2D_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-    static const char *nm[8] = {"io/loop", "phase1", "phase2", "mfma", "tiles+gather", "solve", "reduce+judge", "-"};
+    static const char *nm[8] = {"io/loop", "phase1", "phase2", "mfma", "image", "solve", "reduce+judge", "-"};
     double tot = 0;
     for (int i = 0; i < 7; ++i) tot += (double)h[i];
     fprintf(stderr, "[fit_lm stamps] wave-cycles (s_memtime ticks), B=%d budget=%d:", B, budget);
