@@ -106,6 +106,7 @@ def main():
     ap.add_argument('--max-iter', type=int, default=200)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=1024)
+    ap.add_argument('--large-batch', type=int, default=32768, help='extra single solve at this batch size (0: skip)')
     a = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0)); world = int(os.environ.get('WORLD_SIZE', 1))
@@ -215,6 +216,24 @@ def main():
                     'frac': ach_i / FP32_PEAK_TFLOPS, 'avg_launch_us': 1e3 * iso_ms, 'units_per_launch': B, 'launches': int(iso_n),
                     'note': 'the split-path J^T J kernel on the full resident batch (kernel only, HIP events; rocprofv3 summary in profiles/)'}
 
+    # ---- the same solve on a larger resident batch (rank 0, N = 1 only): 4096 fits on 2048 wave slots are
+    # bound by the last 1 % of the fits (110..200 iterations); this shows the throughput-bound regime
+    large = None
+    if rank == 0 and world == 1 and a.large_batch > B:
+        Bl = a.large_batch
+        dscl = ctx.dev(synth.synth_scenarios(Bl, seed=20241008, rank=0, obj_scale=OBJ_SCALE, K=K))
+        q0l = plan.init(dscl)
+        plan.solve(dscl, q0l.clone(), max_iter=a.max_iter, check_every=a.max_iter)
+        torch.cuda.synchronize()
+        tl = time.perf_counter()
+        _c, _i, _s, stl = plan.solve(dscl, q0l.clone(), max_iter=a.max_iter, check_every=a.max_iter)
+        torch.cuda.synchronize()
+        tl = time.perf_counter() - tl
+        large = {'batch': Bl, 'value': Bl / tl, 'unit': 'trajectory-optimisations/s', 'ms_per_step': 1e3 * tl,
+                 'jtj_frac_of_fp32_mfma_peak': ALG_FLOP_PER_EVAL * float(stl[3]) / tl / 1e12 / FP32_PEAK_TFLOPS,
+                 'note': 'one solve, wall clock around d2d_fit_solve; not the headline configuration'}
+        del dscl, q0l
+
     if rank == 0:
         total = B * world * a.steps
         line = {
@@ -227,7 +246,7 @@ def main():
                        'check_every': a.check_every, 'parallelism': f'trajectory-sharded x{world}'},
             'converged_frac': conv, 'mean_iters': float(iters.double().mean().item()),
             'evals_per_fit': float(stats[3] / B), 'mean_cost': float(stats[0] / B),
-            'roofline': roof, 'roofline_isolated': roof_iso, 'cpu_baseline': cpu,
+            'roofline': roof, 'roofline_isolated': roof_iso, 'large_batch': large, 'cpu_baseline': cpu,
         }
         print(json.dumps(line))
     if dist is not None:
