@@ -211,7 +211,7 @@ static StepLds step_lds_layout(int K, int nq, int N, int wpb) {
   L.wave0 = o;
   int w = 0;
   {
-    L.Lm = w; w = align16(w + (N + 2) * (N + 4) * 4);     // image of J^T J, then of its Cholesky factor
+    L.Lm = w; w = align16(w + (N + 3) * (N + 4) * 4);     // image of J^T J, then of its Cholesky factor
   }
   L.vec = w; w = align16(w + N * 4);
   L.qt = w; w = align16(w + N * 8);
@@ -274,12 +274,13 @@ fit_step_kernel(int B, FitGeom g, StepLds L, d2d_fit_opts opts, GroupArgs ga,
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[t][r] = fmaf(ww, gWt[(t * 4 + r) * 64 + lane], Hb[(t * 4 + r) * 64 + lane]);
     tiles_to_image<N>(acc, Lm, lane);
+    image_put_rhs<N>(Lm, lane, gi);
   }
   wave_lds_sync();
   image_row<N>(Lm, lane, hrow);
   wave_lds_sync();
   float dgi, dl;
-  const bool ok = damped_solve<N>(hrow, lam, gi, act, lane, Lm, dgi, dl);
+  const bool ok = damped_solve<N>(hrow, lam, act, lane, Lm, dgi, dl);
   const double delta = (double)dl;
   // ---- trial point, predicted and actual reduction ------------------------------------
   if (act) qt[q_slot(lane, g.nq)] = qi + delta;
@@ -335,7 +336,7 @@ static FusedLds fused_lds_layout(int K, int nq, int N, int wpb) {
   const int us_bytes = align16(K * 6 * 8), cf_bytes = (K + 1) * 4 * 16;
   L.cf = w + us_bytes;
   int big = us_bytes + cf_bytes;
-  if ((N + 2) * (N + 4) * 4 > big) big = (N + 2) * (N + 4) * 4;
+  if ((N + 3) * (N + 4) * 4 > big) big = (N + 3) * (N + 4) * 4;
   w = align16(w + big);
   L.wave_stride = w;
   L.total = o + wpb * w;
@@ -431,6 +432,7 @@ fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_budget,
 #pragma unroll
           for (int r = 0; r < 4; ++r) acc[t][r] = fmaf(ww, Wt[(t * 4 + r) * 64 + lane], acc[t][r]);
         tiles_to_image<N>(acc, big, lane);
+        image_put_rhs<N>(big, lane, gi);
         wave_lds_sync();
         image_row<N>(big, lane, hrow);
         wave_lds_sync();
@@ -441,7 +443,7 @@ fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_budget,
       if (gmax <= opts.gtol) { status = D2D_ST_CONVERGED; break; }
       float dgi, dl;
       LM_STAMP(6)
-      const int ok = uniform_i(damped_solve<N>(hrow, lam, gi, act, lane, big, dgi, dl, STAMPS ? st_solve : nullptr) ? 1 : 0);
+      const int ok = uniform_i(damped_solve<N>(hrow, lam, act, lane, big, dgi, dl, STAMPS ? st_solve : nullptr) ? 1 : 0);
       const double delta = (double)dl;
       if (act) qs[q_slot(lane, g.nq)] = qi + delta;      // the trial point
       wave_lds_sync();

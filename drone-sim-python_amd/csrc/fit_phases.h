@@ -229,7 +229,7 @@ __device__ __forceinline__ void jtj_mfma(const FitGeom &g, const unsigned char *
 }
 
 // ---- J^T J: accumulator tiles -> row-owned registers ------------------------------------------
-// Row-major LDS image Hs [N+2][N+4] (last two rows: scratch of the solve) of the full symmetric matrix (later overwritten in place by the
+// Row-major LDS image Hs [N+3][N+4] (row N: right-hand side, then two scratch rows of the solve) of the full symmetric matrix (later overwritten in place by the
 // Cholesky factor).  Lane l holds elements (16I + 4(l>>4) + r, 16J + (l&15)) of tile (I,J): stored
 // as they are (one address register + immediate offsets, conflict-free) and, for off-diagonal
 // tiles, mirrored with one 16-byte store (rows 16J + (l&15), columns 16I + 4(l>>4) .. +3).
@@ -252,12 +252,20 @@ __device__ __forceinline__ void tiles_to_image(const f32x4 (&acc)[(N / 16) * (N 
     }
 }
 
-// row `lane` of the image (lanes >= N read row N-1; their values are not used)
+// The right-hand side -g of the damped system becomes row N of the image: lane N then owns it like any
+// other row and the factorisation itself performs the forward substitution (row N of the factor of
+// [[A, b], [b^T, .]] is y^T with L y = b).
+template <int N>
+__device__ __forceinline__ void image_put_rhs(float *Hs, int lane, double gi) {
+  if (lane < N) Hs[N * CHOL_LS + lane] = (float)(-gi);
+}
+
+// row `lane` of the image (lane N: the right-hand side; lanes > N read it too, their values are not used)
 template <int N>
 __device__ __forceinline__ void image_row(const float *Hs, int lane, f32x2 (&hrow)[N / 2]) {
   constexpr int LS = CHOL_LS;
   LAUNDER(lane);
-  const float *src = Hs + (lane < N ? lane : N - 1) * LS;
+  const float *src = Hs + (lane < N ? lane : N) * LS;
 #pragma unroll
   for (int m = 0; m < N / 4; ++m) {
     const f32x4 v = lds_get<f32x4>(src + 4 * m);
@@ -271,16 +279,18 @@ __device__ __forceinline__ float lane_value(float v, int l) {
 }
 
 // ---- damped normal-equation solve -----------------------------------------------------------
-// hrow = row `lane` of J^T J (pairs of columns).  Solves (J^T J + lam*diag(max(J^T J_ii, floor))) delta = -g
-// in fp32.  Left-looking Cholesky, lane i owns row i in registers.  Step j needs row j of the factor
-// in every lane: entries k <= j-2 come from the LDS image Lm [N+2][N+4] (each lane mirrors its
-// finished entries there; one address for the whole wave = a broadcast read), the newest entry
-// L[j][j-1] comes straight from lane j's register by v_readlane, so the LDS write -> read round trip
-// is off the critical path.  Dot products run as two packed (v_pk_fma_f32) chains.  The forward
-// substitution L y = -g rides along (y_j is final once column j is); the back substitution reads
-// the columns of Lm.  Returns false if a pivot is not positive.
+// hrow = row `lane` of J^T J (pairs of columns); lane N holds the right-hand side b = -g (image_put_rhs).
+// Solves (J^T J + lam*diag(max(J^T J_ii, floor))) delta = b in fp32.  Left-looking Cholesky, lane i owns
+// row i in registers.  Step j needs row j of the factor in every lane: entries k <= j-2 come from the LDS
+// image Lm [N+3][N+4] (each lane mirrors its finished entries there; one address for the whole wave = a
+// broadcast read, requested a whole step ahead), the newest entry L[j][j-1] comes straight from lane j's
+// register by v_readlane, so the LDS write -> read round trip is off the critical path.  Dot products
+// run as two packed (v_pk_fma_f32) chains.  Lane N rides along as row N of the augmented matrix, which
+// makes its entries the forward substitution L y = b; the back substitution reads the columns of Lm.
+// A non-positive pivot is not clamped: it turns the step into NaN, which the gain-ratio test rejects
+// like any failed step.  Returns false if a pivot is not positive.
 template <int N>
-__device__ __forceinline__ bool damped_solve(const f32x2 (&hrow)[N / 2], double lam, double gi, bool act, int lane,
+__device__ __forceinline__ bool damped_solve(const f32x2 (&hrow)[N / 2], double lam, bool act, int lane,
                                              float *Lm, float &dgi, float &delta, unsigned long long *tt = nullptr) {
   constexpr int LS = CHOL_LS;
   // tt (diagnostics, fused kernel with D2D_LM_STAMPS): cycles of setup, steps [0,N/3), [N/3,2N/3), [2N/3,N), substitution
@@ -290,11 +300,12 @@ __device__ __forceinline__ bool damped_solve(const f32x2 (&hrow)[N / 2], double 
   // (every `lane > j` mask below is loop-invariant in the caller's iteration loop: hoisted, they would
   // need 2N scalar registers the wave does not have)
   LAUNDER(lane);
+  const bool live = act || lane == N;           // rows of the system + the right-hand side row
   f32x2 row[N / 2];
   float d = 1.f;
 #pragma unroll
   for (int m = 0; m < N / 2; ++m) {
-    row[m] = act ? hrow[m] : f32x2{0.f, 0.f};
+    row[m] = live ? hrow[m] : f32x2{0.f, 0.f};
     if (2 * m == lane) d = hrow[m].x;
     if (2 * m + 1 == lane) d = hrow[m].y;
   }
@@ -309,62 +320,60 @@ __device__ __forceinline__ bool damped_solve(const f32x2 (&hrow)[N / 2], double 
 #define ROW_EL(k) (((k) & 1) ? row[(k) >> 1].y : row[(k) >> 1].x)
   // The factor is kept STRICTLY lower triangular, in registers and in the image (every lane stores
   // its entry of column j at every step, zeros on and above the diagonal), and the reciprocal
-  // diagonal goes to the image's dummy row: no per-lane selects in either substitution.
+  // diagonal goes to a side row of the image: no per-lane selects in the substitutions.
   int pivmin = 0x7f800000;           // min over the pivots' bit patterns: > 0 <=> every pivot positive (scalar unit)
-  float y = (float)(-gi);            // forward substitution rides along: lane i ends with y_i * L[i][i]
-  float *wrow = Lm + (lane < N ? lane : N) * LS;      // lanes >= N (all zeros) write the dummy row
-  float *dinv = Lm + (N + 1) * LS;                    // [N] reciprocal diagonal, one more row
-  // lq: the quads of row j of the factor, fetched one step ahead (row j+1 is requested while step j
-  // computes, so the LDS latency never sits on the chain); ljp = L[j][j-1] for the step to come.
-  f32x4 lq[N / 4];
+  float *wrow = Lm + (lane <= N ? lane : N + 1) * LS;  // lanes > N (all zeros) write a dummy row
+  float *dinv = Lm + (N + 2) * LS;                     // [N] reciprocal diagonal
+  // lq[j&1]: the quads of row j of the factor, requested a whole step ahead (double-buffered: row j+1 is
+  // requested at the top of step j, before step j's own FMAs, so the LDS latency never sits on the
+  // chain); ljp = L[j][j-1] for the step to come.
+  f32x4 lq[2][N / 4];
   float ljp = 0.f;
   DS_STAMP(0)
 #pragma unroll
   for (int j = 0; j < N; ++j) {
     if (j == N / 3) { DS_STAMP(1) }
     if (j == 2 * (N / 3)) { DS_STAMP(2) }
-    // t = sum_k L[lane][k] L[j][k] - A[lane][j]  (products accumulated with positive sign: a negated
-    // uniform operand would be moved to the scalar unit, four v_readlane per quad)
     __builtin_amdgcn_sched_barrier(0);                   // (the next step's FMAs must not drift into this step's tail: they wait on LDS)
-    f32x2 d01 = {-ROW_EL(j), 0.f}, d23 = {0.f, 0.f};
     const int nk = j - 1;            // entries 0 .. j-2 of row j come from the image
-    const float yraw = lane_value(y, j);                 // lane j's running y is final already
     if (j >= 1) wave_lds_sync();                         // column j-1 is in the image
+    if (j + 1 < N) {                                     // row j+1: its entries <= j-1 are final
+#pragma unroll
+      for (int k4 = 0; 4 * k4 < j; ++k4) lq[(j + 1) & 1][k4] = lds_get<f32x4>(Lm + (j + 1) * LS + 4 * k4);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // dot = sum_k L[lane][k] L[j][k]
+    f32x2 d01 = {0.f, 0.f}, d23 = {0.f, 0.f};
 #pragma unroll
     for (int k4 = 0; 4 * k4 < nk; ++k4) {
-      const f32x4 l = lq[k4];
+      const f32x4 l = lq[j & 1][k4];
       if (4 * k4 + 1 < nk) d01 = __builtin_elementwise_fma(row[2 * k4], f32x2{l.x, l.y}, d01);
       else d01.x = fmaf(row[2 * k4].x, l.x, d01.x);
       if (4 * k4 + 3 < nk) d23 = __builtin_elementwise_fma(row[2 * k4 + 1], f32x2{l.z, l.w}, d23);
       else if (4 * k4 + 2 < nk) d23.x = fmaf(row[2 * k4 + 1].x, l.z, d23.x);
     }
-    // request row j+1 (entries <= j-1 are final) now: it lands while the dependent tail of this step runs
-    if (j + 1 < N) {
-#pragma unroll
-      for (int k4 = 0; 4 * k4 < j; ++k4) lq[k4] = lds_get<f32x4>(Lm + (j + 1) * LS + 4 * k4);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    const f32x2 dd2 = d01 + d23;
-    float t = dd2.x + dd2.y;
-    if (j >= 1) t = fmaf(ROW_EL(j - 1), ljp, t);
-    const float djj = -lane_value(t, j);
-    const float tnext = (j + 1 < N) ? lane_value(t, j + 1) : 0.f;
+    float sres = ROW_EL(j);
+    if (j >= 2) { const f32x2 dd2 = d01 + d23; sres -= dd2.x + dd2.y; }
+    if (j >= 1) sres = fmaf(-ROW_EL(j - 1), ljp, sres);
+    const float djj = lane_value(sres, j);
+    const float snext = (j + 1 < N) ? lane_value(sres, j + 1) : 0.f;
     pivmin = min(pivmin, __builtin_bit_cast(int, djj));
-    const float inv = __builtin_amdgcn_rsqf(__builtin_amdgcn_fmed3f(djj, 1e-30f, 3.0e38f));
-    const float lij = (lane > j) ? -t * inv : 0.f;      // L[lane][j], strictly lower
-    ljp = -tnext * inv;                                  // L[j+1][j], uniform
+    const float inv = __builtin_amdgcn_rsqf(djj);
+    const float lij = (lane > j) ? sres * inv : 0.f;    // L[lane][j], strictly lower
+    ljp = snext * inv;                                   // L[j+1][j], uniform
     if (j & 1) row[j >> 1].y = lij; else row[j >> 1].x = lij;
     wrow[j] = lij;
     dinv[j] = inv;                                      // uniform value, one address
-    y = fmaf(-lij, yraw * inv, y);                      // y_j = yraw / L[j][j]
   }
 #undef ROW_EL
   DS_STAMP(3)
-  // back substitution L^T delta = y through the columns of the image
+  // back substitution L^T delta = y through the columns of the image; y = row N of the factor
   wave_lds_sync();
-  const float myinv = dinv[lane < N ? lane : 0];        // 1 / L[lane][lane]
-  const float *col = Lm + (lane < N ? lane : 0);
-  float dl = y * myinv * myinv;                          // running (y_i - sum_{k>i} L[k][i] delta_k) / L[i][i]
+  LAUNDER(lane);
+  const int li = lane < N ? lane : 0;
+  const float myinv = dinv[li];                          // 1 / L[lane][lane]
+  const float *col = Lm + li;
+  float dl = col[N * LS] * myinv;                        // running (y_i - sum_{k>i} L[k][i] delta_k) / L[i][i]
 #pragma unroll
   for (int i = N - 1; i >= 1; --i) dl = fmaf(-col[i * LS] * myinv, lane_value(dl, i), dl);   // L[i][lane] = 0 for i <= lane
   delta = act ? dl : 0.f;

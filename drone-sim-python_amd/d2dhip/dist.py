@@ -22,15 +22,19 @@ class StatsReducer:
         if dist is not None:
             import torch
             self.sum_buf = torch.zeros(2, dtype=torch.float64, device=device)
-            self.max_buf = torch.zeros(1, dtype=torch.float64, device=device)
+            self.mine = torch.zeros(3, dtype=torch.float64, device=device)
+            self.all = [torch.zeros(3, dtype=torch.float64, device=device) for _ in range(dist.get_world_size())]
 
     def __call__(self, cost_sum, gmax, running):
+        """(sum of costs, max |J^T r|, trajectories not converged) over all ranks: ONE collective (an
+        all-gather of the three scalars; sum and max are then taken locally)."""
         if self.dist is None:
             return float(cost_sum), float(gmax), int(running)
-        self.sum_buf[0] = float(cost_sum); self.sum_buf[1] = float(running); self.max_buf[0] = float(gmax)
-        self.dist.all_reduce(self.sum_buf, op=self.dist.ReduceOp.SUM)
-        self.dist.all_reduce(self.max_buf, op=self.dist.ReduceOp.MAX)
-        return float(self.sum_buf[0].item()), float(self.max_buf[0].item()), int(round(self.sum_buf[1].item()))
+        import torch
+        self.mine.copy_(torch.tensor([float(cost_sum), float(gmax), float(running)], dtype=torch.float64))
+        self.dist.all_gather(self.all, self.mine)
+        t = torch.stack(self.all).cpu()
+        return float(t[:, 0].sum()), float(t[:, 1].max()), int(round(float(t[:, 2].sum())))
 
     def running_only(self, running):
         """The per-check exchange inside the iteration loop (one all-reduce)."""
