@@ -1020,7 +1020,9 @@ int d2d_fit_finish(d2d_ctx *ctx, d2d_fit_plan *pl, int B, const double *scen, co
     if (int rc = launch_prep(ctx, pl, B, scen)) return rc;
     pl->prep_valid_for = scen;
   }
-  if (int rc = launch_eval(ctx, pl, B, q, nullptr, pl->d_cost, pl->d_g, nullptr)) return rc;
+  // (the persistent LM kernel leaves cost and J^T r of every trajectory evaluated at its final point)
+  if (!(pl->use_lm && pl->n_group <= 1 && pl->it_done > 0))
+    if (int rc = launch_eval(ctx, pl, B, q, nullptr, pl->d_cost, pl->d_g, nullptr)) return rc;
   if (cost) D2D_CHECK_HIP(hipMemcpyAsync(cost, pl->d_cost, (size_t)B * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
   hipLaunchKernelGGL(fit_export_kernel, g1, b1, 0, ctx->stream, B, pl->d_flags, iters, status);
   D2D_LAUNCH_CHECK();
