@@ -9,6 +9,7 @@
 
 #define FIT_G 9.81        // src/d2d/guidance.py:39
 #define FIT_OBS_K 2.0     // src/d2d/opty_utils.py:103
+#define FIT_OBS_ARGMAX 3.4538776394910684   // 0.5 * ln(1e3): the clip of kind-0 obstacles, :111
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -151,13 +152,16 @@ __device__ __forceinline__ void flat_outputs(const FitGeom &g, const double *__r
 #define FIT_PREP_STRIDE 48
 enum { PR_DX = 0, PR_DY = 4, PR_P2X = 8, PR_P2Y, PR_SAX, PR_SAY, PR_SBX, PR_SBY, PR_CV, PR_CPHI, PR_COBS,
        PR_K0, PR_K1, PR_CV2, PR_CPHI2, PR_WB2, PR_WWP, PR_WBND, PR_VSP, PR_WX, PR_WY, PR_PHIMAX, PR_VMIN,
-       PR_VMAX, PR_O0X, PR_O0Y, PR_O1X, PR_O1Y, PR_X0, PR_Y0, PR_X1, PR_Y1, PR_CCOL, PR_KC, PR_PMASK };
+       PR_VMAX, PR_O0X, PR_O0Y, PR_O1X, PR_O1Y, PR_X0, PR_Y0, PR_X1, PR_Y1, PR_CCOL, PR_KC, PR_PMASK,
+       PR_C0, PR_C1, PR_CPHIMAX };
 
 struct ScenP {
   double cv, cphi, cobs, k0, k1, cv2, cphi2, wb2, wwp, wbnd, vsp, wx, wy, phimax, vmin, vmax;
   double o0x, o0y, o1x, o1y;
   double ccol, kc;      // collision rows: sqrt(s_col*kcol), k / rcol
   int pmask;            // bit j: coupled with aircraft j of the group
+  double c0, c1;        // obstacle rows: exponent offset (r^2 for kind 0, 0 for kind 1)
+  double cphimax;       // CostBank max mode: weight sqrt(obj_scale*kphi) of the one selected phi row, 0 = mean mode
 };
 
 // Group coupling context of one trajectory (collision rows against the other aircraft of its
@@ -177,7 +181,13 @@ __device__ __forceinline__ void prep_row(const double *__restrict__ sc, double d
   o[PR_SBX] = n2 > 1 ? (s.x1 - s.p2x) / (n2 - 1) : 0.0; o[PR_SBY] = n2 > 1 ? (s.y1 - s.p2y) / (n2 - 1) : 0.0;
   o[PR_CV2] = s.s * s.kv; o[PR_CPHI2] = s.s * s.kphi;
   o[PR_CV] = sqrt(s.s * s.kv); o[PR_CPHI] = sqrt(s.s * s.kphi); o[PR_COBS] = sqrt(s.s * s.kobs);
-  o[PR_K0] = s.o0r > 0.0 ? FIT_OBS_K / s.o0r : 0.0; o[PR_K1] = s.o1r > 0.0 ? FIT_OBS_K / s.o1r : 0.0;
+  // obstacle row h = cobs * exp(min(0.5 * (c - |k (p - o)|^2), FIT_OBS_ARGMAX)): kind 1 (CostObstacle, e =
+  // exp(-|2 (p-o)/r|^2)): k = 2/r, c = 0; kind 0 (e = clip(exp(r^2 - |p-o|^2), 0, 1e3)): k = 1, c = r^2
+  const int okind = (int)sc[D2D_SC_OKIND];
+  o[PR_K0] = s.o0r > 0.0 ? ((okind & 1) ? 1.0 : FIT_OBS_K / s.o0r) : 0.0;
+  o[PR_K1] = s.o1r > 0.0 ? ((okind & 2) ? 1.0 : FIT_OBS_K / s.o1r) : 0.0;
+  o[PR_C0] = (okind & 1) ? s.o0r * s.o0r : 0.0; o[PR_C1] = (okind & 2) ? s.o1r * s.o1r : 0.0;
+  o[PR_CPHIMAX] = sc[D2D_SC_BANKMAX] != 0.0 ? sqrt(s.s * K * s.kphi) : 0.0;
   o[PR_WB2] = s.wbnd * s.wbnd; o[PR_WWP] = s.wwp; o[PR_WBND] = s.wbnd; o[PR_VSP] = s.vsp;
   o[PR_WX] = s.wx; o[PR_WY] = s.wy; o[PR_PHIMAX] = s.phimax; o[PR_VMIN] = s.vmin; o[PR_VMAX] = s.vmax;
   o[PR_O0X] = s.o0x; o[PR_O0Y] = s.o0y; o[PR_O1X] = s.o1x; o[PR_O1Y] = s.o1y;
@@ -195,6 +205,7 @@ __device__ __forceinline__ ScenP load_scenp(const double *__restrict__ p) {
   s.vsp = p[PR_VSP]; s.wx = p[PR_WX]; s.wy = p[PR_WY]; s.phimax = p[PR_PHIMAX]; s.vmin = p[PR_VMIN]; s.vmax = p[PR_VMAX];
   s.o0x = p[PR_O0X]; s.o0y = p[PR_O0Y]; s.o1x = p[PR_O1X]; s.o1y = p[PR_O1Y];
   s.ccol = p[PR_CCOL]; s.kc = p[PR_KC]; s.pmask = (int)p[PR_PMASK];
+  s.c0 = p[PR_C0]; s.c1 = p[PR_C1]; s.cphimax = p[PR_CPHIMAX];
   return s;
 }
 
@@ -288,9 +299,18 @@ __device__ __forceinline__ void flat_outputs_pk(const FitGeom &g, const double *
 // for unknown j of axis a is  cA[rho][a]*TA_rho[k][j] + cB[rho][a]*TB_rho[k][j]  with
 // (TA,TB) = (G1,-) for v, (G1,G2) for phi, (G0,-) for the obstacles:
 //   coef[rho] = {cA_x, cB_x, cA_y, cB_y}
+// |w| = |tan(phi)| of one sample: what CostBank's max mode ranks the samples by (phi = atan(w) is monotone)
+__device__ __forceinline__ double sample_absw(const ScenP &s, const double Y[6]) {
+  const double a = Y[2] - s.wx, b = Y[3] - s.wy;
+  return fabs(Y[5] * a - Y[4] * b) / (sqrt(a * a + b * b) * FIT_G);
+}
+
+// bank_sel: CostBank max mode only -- true for the one sample whose phi row is kept (weight s.cphimax).
 template <bool WANT_JAC>
 __device__ __forceinline__ double sample_terms(const ScenP &s, const double Y[6], double wpx,
-                                               double wpy, double u[6], f32x4 coef[4]) {
+                                               double wpy, double u[6], f32x4 coef[4], bool bank_sel = false) {
+  const double cphi = s.cphimax > 0.0 ? (bank_sel ? s.cphimax : 0.0) : s.cphi;
+  const double cphi2 = s.cphimax > 0.0 ? cphi * cphi : s.cphi2;
   const double x = Y[0], y = Y[1];
   const double a = Y[2] - s.wx, b = Y[3] - s.wy, c = Y[4], d = Y[5];
   const double va2 = a * a + b * b, va = sqrt(va2);
@@ -299,16 +319,21 @@ __device__ __forceinline__ double sample_terms(const ScenP &s, const double Y[6]
   const double w = n * ivg;
   const double phi = atan(w);                       // src/d2d/guidance.py:40
   const double r0 = s.cv * (va - s.vsp);            // CostInput, src/d2d/opty_utils.py:85-97
-  const double r1 = s.cphi * phi;
+  const double r1 = cphi * phi;
   const double r2 = s.wwp * (x - wpx), r3 = s.wwp * (y - wpy);
   double h0 = 0.0, h1 = 0.0, e0x = 0.0, e0y = 0.0, e1x = 0.0, e1y = 0.0;
-  if (s.k0 > 0.0) {                                 // CostObstacle kind 1, :99-134
+  bool clip0 = false, clip1 = false;                // kind 0 only: the row sits on its clip (zero slope)
+  if (s.k0 > 0.0) {                                 // CostObstacle, :99-134 (both kinds, see prep_row)
     e0x = (x - s.o0x) * s.k0; e0y = (y - s.o0y) * s.k0;
-    h0 = s.cobs * exp(-0.5 * (e0x * e0x + e0y * e0y));
+    const double arg = 0.5 * (s.c0 - (e0x * e0x + e0y * e0y));
+    clip0 = arg > FIT_OBS_ARGMAX;
+    h0 = s.cobs * exp(clip0 ? FIT_OBS_ARGMAX : arg);
   }
   if (s.k1 > 0.0) {
     e1x = (x - s.o1x) * s.k1; e1y = (y - s.o1y) * s.k1;
-    h1 = s.cobs * exp(-0.5 * (e1x * e1x + e1y * e1y));
+    const double arg = 0.5 * (s.c1 - (e1x * e1x + e1y * e1y));
+    clip1 = arg > FIT_OBS_ARGMAX;
+    h1 = s.cobs * exp(clip1 ? FIT_OBS_ARGMAX : arg);
   }
   const double hphi = fmax(fabs(phi) - s.phimax, 0.0);
   const double hv = fmax(va - s.vmax, 0.0) + fmin(va - s.vmin, 0.0);
@@ -323,11 +348,11 @@ __device__ __forceinline__ double sample_terms(const ScenP &s, const double Y[6]
     const double dp_c = -b * ivg * f, dp_d = a * ivg * f;
     const double actp = (hphi > 0.0) ? ((phi > 0.0) ? 1.0 : -1.0) : 0.0;
     const double actv = (va > s.vmax || va < s.vmin) ? 1.0 : 0.0;
-    const double o0x = -h0 * e0x * s.k0, o0y = -h0 * e0y * s.k0;
-    const double o1x = -h1 * e1x * s.k1, o1y = -h1 * e1y * s.k1;
+    const double o0x = clip0 ? 0.0 : -h0 * e0x * s.k0, o0y = clip0 ? 0.0 : -h0 * e0y * s.k0;
+    const double o1x = clip1 ? 0.0 : -h1 * e1x * s.k1, o1y = clip1 ? 0.0 : -h1 * e1y * s.k1;
     // u = D^T r over all eight rows
     const double tv = s.cv * r0 + s.wbnd * actv * r7;               // multiplies d va
-    const double tp = s.cphi * r1 + s.wbnd * actp * r6;             // multiplies d phi
+    const double tp = cphi * r1 + s.wbnd * actp * r6;               // multiplies d phi
     u[0] = s.wwp * r2 + o0x * h0 + o1x * h1;
     u[1] = s.wwp * r3 + o0y * h0 + o1y * h1;
     u[2] = tv * dva_a + tp * dp_a;
@@ -336,7 +361,7 @@ __device__ __forceinline__ double sample_terms(const ScenP &s, const double Y[6]
     u[5] = tp * dp_d;
     // merged row weights for J^T J: (cv^2 + wb^2 actv) dva dva^T, (cphi^2 + wb^2 |actp|) dphi dphi^T
     const double mv = sqrt(s.cv2 + s.wb2 * actv);
-    const double mp = sqrt(s.cphi2 + s.wb2 * actp * actp);
+    const double mp = sqrt(cphi2 + s.wb2 * actp * actp);
     coef[0] = f32x4{(float)(mv * dva_a), 0.f, (float)(mv * dva_b), 0.f};
     coef[1] = f32x4{(float)(mp * dp_a), (float)(mp * dp_c), (float)(mp * dp_b), (float)(mp * dp_d)};
     coef[2] = f32x4{(float)o0x, 0.f, (float)o0y, 0.f};
@@ -373,11 +398,39 @@ __device__ __forceinline__ double partner_terms(const ScenP &s, const GroupCtx &
   return cost;
 }
 
+// CostBank max mode: index of the sample with the largest |phi| (the first one on ties, as numpy.argmax,
+// src/d2d/opty_utils.py:80); -1 in mean mode.  Wave-cooperative, the result is wave-uniform.
+template <int NQ>
+__device__ __forceinline__ int bank_argmax(const FitGeom &g, const double *G64, const double *__restrict__ pkb,
+                                           const double *q, const ScenP &s, int lane) {
+  if (!(s.cphimax > 0.0)) return -1;
+  double best = -1.0;
+  int kstar = 0;
+  for (int k0 = 0; k0 < g.K; k0 += 64) {
+    const int k = k0 + lane;
+    double aw = -1.0;
+    if (k < g.K) {
+      double pk[FIT_PK], Y[6];
+#pragma unroll
+      for (int c = 0; c < FIT_PK; ++c) pk[c] = pkb[(size_t)c * g.K + k];
+      flat_outputs_pk<NQ>(g, G64, q, pk, k, Y);
+      aw = sample_absw(s, Y);
+    }
+    const double m = wave_max(aw);
+    if (m > best) {
+      best = m;
+      kstar = k0 + (int)__builtin_ctzll(__ballot(aw == m));
+    }
+  }
+  return __builtin_amdgcn_readfirstlane(kstar);
+}
+
 // Cost at q (wave-cooperative): sum over samples of sum r^2.  pkb = this trajectory's [FIT_PK][K] block.
 __device__ __forceinline__ double wave_cost(const FitGeom &g, const double *G64, const double *__restrict__ pkb,
                                             const double *q, const ScenP &s, int lane,
                                             const GroupCtx &gc = GroupCtx{nullptr, 1, 0, 0, 0}) {
   double acc = 0.0;
+  const int kbank = bank_argmax<0>(g, G64, pkb, q, s, lane);
   for (int k0 = 0; k0 < g.K; k0 += 64) {
     const int k = k0 + lane;
     if (k < g.K) {
@@ -385,7 +438,7 @@ __device__ __forceinline__ double wave_cost(const FitGeom &g, const double *G64,
 #pragma unroll
       for (int c = 0; c < FIT_PK; ++c) pk[c] = pkb[(size_t)c * g.K + k];
       flat_outputs_pk<0>(g, G64, q, pk, k, Y);
-      acc += sample_terms<false>(s, Y, pk[6], pk[7], nullptr, nullptr);
+      acc += sample_terms<false>(s, Y, pk[6], pk[7], nullptr, nullptr, k == kbank);
       acc += partner_terms<false>(s, gc, g.K, k, Y[0], Y[1], nullptr, nullptr);
     }
   }

@@ -411,7 +411,7 @@ fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_budget,
     for (int cc = 0; cc < FIT_PK; ++cc) pkr[cc] = lane < g.K ? pkb[(size_t)cc * g.K + lane] : 0.0;
     wave_lds_sync();
     LM_STAMP(0)
-    c = uniform_d(eval_phase1_reg<NQ>(g, G64, pkr, sp, qs, us, cf, lane));
+    c = uniform_d(eval_phase1_reg<NQ>(g, G64, pkr, pkb, sp, qs, us, cf, lane));
     LM_STAMP(1)
     bool fresh = true;
     if (!(fabs(c) <= 1.79e308)) { status = D2D_ST_NONFINITE; fresh = false; }
@@ -449,7 +449,7 @@ fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_budget,
       wave_lds_sync();
       LM_STAMP(5)
       // full phase 1 at the trial point: if the step is accepted its rows are the next evaluation
-      const double ct = uniform_d(eval_phase1_reg<NQ>(g, G64, pkr, sp, qs, us, cf, lane));
+      const double ct = uniform_d(eval_phase1_reg<NQ>(g, G64, pkr, pkb, sp, qs, us, cf, lane));
       LM_STAMP(1)
       const double pred = uniform_d(wave_sum(delta * (lam * (double)dgi * delta - gi)));
       const double dmax = uniform_d(wave_max(fabs(delta))), qmax = uniform_d(wave_max(fabs(qi)));

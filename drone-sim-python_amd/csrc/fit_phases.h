@@ -21,6 +21,7 @@ __device__ __forceinline__ double eval_phase1(const FitGeom &g, const double *G6
   // (LAUNDER: inside an iteration loop every address below is loop-invariant; re-defining the lane id
   // keeps the compiler from hoisting dozens of them out of the loop and spilling them)
   LAUNDER(lane);
+  const int kbank = bank_argmax<NQ>(g, G64, pkb, qs, s, lane);
   for (int k0 = 0; k0 < g.K; k0 += 64) {
     const int k = k0 + lane;
     if (k < g.K) {
@@ -29,7 +30,7 @@ __device__ __forceinline__ double eval_phase1(const FitGeom &g, const double *G6
 #pragma unroll
       for (int c = 0; c < FIT_PK; ++c) pk[c] = pkb[(size_t)c * g.K + k];
       if (!(dbg & 8)) flat_outputs_pk<NQ>(g, G64, qs, pk, k, Y);
-      if (!(dbg & 1)) cacc += sample_terms<true>(s, Y, pk[6], pk[7], u, coef);
+      if (!(dbg & 1)) cacc += sample_terms<true>(s, Y, pk[6], pk[7], u, coef, k == kbank);
       if (gc.nds) cacc += partner_terms<true>(s, gc, g.K, k, Y[0], Y[1], u, cfd + (size_t)k * gc.nds);
 #pragma unroll
       for (int c = 0; c < 6; ++c) us[k * 6 + c] = u[c];
@@ -47,16 +48,19 @@ __device__ __forceinline__ double eval_phase1(const FitGeom &g, const double *G6
 // where it is used instead of being held in ~44 registers across the flat-output loop.
 template <int NQ>
 __device__ __forceinline__ double eval_phase1_reg(const FitGeom &g, const double *G64, const double (&pkr)[FIT_PK],
-                                                  const double *sp, const double *qs, double *us, f32x4 *cf, int lane) {
+                                                  const double *__restrict__ pkb, const double *sp, const double *qs,
+                                                  double *us, f32x4 *cf, int lane) {
   double cacc = 0.0;
   LAUNDER(lane);
   const int k = lane;
+  int kbank = -1;
+  if (sp[PR_CPHIMAX] > 0.0) kbank = bank_argmax<NQ>(g, G64, pkb, qs, load_scenp(sp), lane);   // (rare mode: extra pass)
   if (k < g.K) {
     double Y[6], u[6] = {0, 0, 0, 0, 0, 0};
     f32x4 coef[4];
     flat_outputs_pk<NQ>(g, G64, qs, pkr, k, Y);
     const ScenP s = load_scenp(sp);
-    cacc = sample_terms<true>(s, Y, pkr[6], pkr[7], u, coef);
+    cacc = sample_terms<true>(s, Y, pkr[6], pkr[7], u, coef, k == kbank);
 #pragma unroll
     for (int c = 0; c < 6; ++c) us[k * 6 + c] = u[c];
 #pragma unroll

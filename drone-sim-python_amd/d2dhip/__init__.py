@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get('D2D_LIB') or os.path.join(os.path.dirname(_HERE), 'li
 SCEN_STRIDE = 32
 (SC_X0, SC_Y0, SC_PSI0, SC_X1, SC_Y1, SC_PSI1, SC_VREF, SC_VSP, SC_KV, SC_KPHI, SC_KOBS, SC_S,
  SC_WWP, SC_WX, SC_WY, SC_GOLEFT, SC_O0X, SC_O0Y, SC_O0R, SC_O1X, SC_O1Y, SC_O1R, SC_WBND,
- SC_PHIMAX, SC_VMIN, SC_VMAX, SC_KCOL, SC_RCOL, SC_SCOL, SC_PMASK) = range(30)
+ SC_PHIMAX, SC_VMIN, SC_VMAX, SC_KCOL, SC_RCOL, SC_SCOL, SC_PMASK, SC_OKIND, SC_BANKMAX) = range(32)
 ST_RUNNING, ST_CONVERGED, ST_MAXITER, ST_NONFINITE, ST_STALLED = range(5)
 
 

@@ -32,33 +32,31 @@ def get_plan(K, duration, obj_scale_over_n, kv=5., kphi=1.):
 
 
 def lower_cost(cost):
-    """Recognise the reference's cost plug-ins structurally -> (vsp, kv, kphi, kobs, obstacles,
-    kcol, rcol).  Anything else has no kernel and raises (there is no CPU solver to fall back to)."""
+    """Recognise the reference's cost plug-ins structurally -> (vsp, kv, kphi, kobs, obstacles, kcol, rcol,
+    okind, bankmax): okind = bit mask of the obstacles of CostObstacle kind 0, bankmax = CostBank max mode.
+    Anything else has no kernel and raises (there is no CPU solver to fall back to)."""
     nan = float('nan')
     if isinstance(cost, d2ou.CostAirVel):
-        return cost.vsp, 1., 0., 0., (), nan, 0.
+        return cost.vsp, 1., 0., 0., (), nan, 0., 0, 0
     if isinstance(cost, d2ou.CostBank):
-        if not cost.use_mean:
-            raise NotImplementedError('CostBank(use_mean=False): the max-bank objective is not a sum of squares')
-        return 0., 0., 1., 0., (), nan, 0.
+        return 0., 0., 1., 0., (), nan, 0., 0, 0 if cost.use_mean else 1
     if isinstance(cost, (d2ou.CostInput, d2mou.CostInput)):
-        return cost.vsp, cost.kv, cost.kphi, 0., (), nan, 0.
+        return cost.vsp, cost.kv, cost.kphi, 0., (), nan, 0., 0, 0
     if isinstance(cost, d2mou.CostNull):
-        return 0., 0., 0., 0., (), nan, 0.
+        return 0., 0., 0., 0., (), nan, 0., 0, 0
     if isinstance(cost, d2ou.CostComposit):
         obss = [(o.c[0], o.c[1], o.r) for o in cost.cobs.obss] if hasattr(cost, 'cobs') else []
-        if obss and cost.cobs.obss[0].kind != 1:
-            raise NotImplementedError('CostObstacle kind 0 (clipped exp(r^2-d^2)) is not contracted by the HIP fit; use obs_kind=1')
-        return cost.cvel.vsp, cost.kvel, cost.kbank, cost.kobs, tuple(obss), nan, 0.
+        okind = sum(1 << i for i, o in enumerate(cost.cobs.obss) if o.kind == 0) if obss else 0
+        return cost.cvel.vsp, cost.kvel, cost.kbank, cost.kobs, tuple(obss), nan, 0., okind, 0 if cost.cbank.use_mean else 1
     if isinstance(cost, d2mou.CostComposit):
         obss = ()
         kobs = 0.
+        okind = 0
         if not np.isnan(cost.kobs):
             obss = tuple((o[0], o[1], o[2]) for o in cost.obss)
             kobs = cost.kobs
-            if obss and cost.obs_kind != 1:
-                raise NotImplementedError('CostObstacle kind 0 is not contracted by the HIP fit; use obs_kind=1')
-        return cost.vsp, cost.kvel, cost.kbank, kobs, obss, cost.kcol, cost.rcol
+            okind = ((1 << len(obss)) - 1) if cost.obs_kind == 0 else 0
+        return cost.vsp, cost.kvel, cost.kbank, kobs, obss, cost.kcol, cost.rcol, okind, 0
     raise NotImplementedError(f'cost plug-in {type(cost).__name__} has no HIP lowering')
 
 
@@ -66,7 +64,8 @@ def scen_row(p0, p1, vref, lowered, s, wind, phi_c, v_c, go_left=-1.):
     """One d2dhip scenario row.  The reference's symbolic model adds the wind with the opposite
     sign to the plant (src/d2d/opty_utils.py:42-44 vs src/d2d/dynamic.py:18-19); the planner keeps
     that convention, hence -w."""
-    vsp, kv, kphi, kobs, obss, _, _ = lowered
+    vsp, kv, kphi, kobs, obss = lowered[:5]
+    okind, bankmax = lowered[7], lowered[8]
     if len(obss) > 2:
         raise NotImplementedError('at most two static obstacles per trajectory in this build')
     r = np.zeros(d2dhip.SCEN_STRIDE)
@@ -80,6 +79,7 @@ def scen_row(p0, p1, vref, lowered, s, wind, phi_c, v_c, go_left=-1.):
         r[d2dhip.SC_O0X + 3 * i:d2dhip.SC_O0X + 3 * i + 3] = o
     r[d2dhip.SC_PHIMAX] = max(abs(phi_c[0]), abs(phi_c[1]))
     r[d2dhip.SC_VMIN], r[d2dhip.SC_VMAX] = v_c
+    r[d2dhip.SC_OKIND], r[d2dhip.SC_BANKMAX] = okind, bankmax
     return r
 
 

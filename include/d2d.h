@@ -204,7 +204,9 @@ enum {
   D2D_SC_KCOL, D2D_SC_RCOL,  /* collision rows between the aircraft of one group: weight, radius */
   D2D_SC_SCOL,  /* their scale, obj_scale / K (src/d2d/multiopty_utils.py:132: no 1/n_ac)  */
   D2D_SC_PMASK, /* bit j set: coupled with aircraft j of the same group (stored as a double) */
-  D2D_SC_SPARE0 /* .. D2D_SCEN_STRIDE-1 unused, must be 0                               */
+  D2D_SC_OKIND, /* bit i set: obstacle i is CostObstacle kind 0, e = clip(exp(r^2 - d^2), 0, 1e3)
+                   (src/d2d/opty_utils.py:108-111); clear: kind 1 (stored as a double)          */
+  D2D_SC_BANKMAX /* != 0: CostBank(use_mean=False): obj_scale*max(phi^2) instead of the mean (:72-73) */
 };
 #define D2D_FIT_NROW 8        /* residual rows per sample */
 #define D2D_FIT_MAX_S 6

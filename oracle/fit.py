@@ -190,9 +190,12 @@ SCEN_STRIDE = 32
 (SC_X0, SC_Y0, SC_PSI0, SC_X1, SC_Y1, SC_PSI1, SC_VREF, SC_VSP, SC_KV, SC_KPHI,
  SC_KOBS, SC_S, SC_WWP, SC_WX, SC_WY, SC_GOLEFT,
  SC_O0X, SC_O0Y, SC_O0R, SC_O1X, SC_O1Y, SC_O1R, SC_WBND, SC_PHIMAX, SC_VMIN, SC_VMAX,
- SC_KCOL, SC_RCOL, SC_SCOL, SC_PMASK) = range(30)
+ SC_KCOL, SC_RCOL, SC_SCOL, SC_PMASK, SC_OKIND, SC_BANKMAX) = range(32)
 # SC_KCOL/RCOL/SCOL: collision weight, radius and scale (obj_scale/N, src/d2d/multiopty_utils.py:132);
-# SC_PMASK: bit j set <=> coupled with aircraft j of the same group (CostCollision pairs)
+# SC_PMASK: bit j set <=> coupled with aircraft j of the same group (CostCollision pairs);
+# SC_OKIND: bit i set <=> obstacle i is CostObstacle kind 0 (src/d2d/opty_utils.py:108-111);
+# SC_BANKMAX != 0 <=> CostBank(use_mean=False) (:72-73, :80-81)
+OBS_CLIP = 1e3                                   # np.clip(errs, 0., 1e3), src/d2d/opty_utils.py:111
 # default bounds of the soft bound rows (phi in +-40 deg, v in [9,15]: src/multi_opt_planner.py:192-193)
 PHI_MAX = math.radians(40.0)
 V_MIN, V_MAX = 9.0, 15.0
@@ -273,17 +276,30 @@ def residuals(basis, sc, q, wp=None, want_jac=False, others=None):
     cv = math.sqrt(s * sc[SC_KV]); cphi = math.sqrt(s * sc[SC_KPHI]); cobs = math.sqrt(s * sc[SC_KOBS])
     r = np.zeros((K, NROW + n_oth))
     r[:, 0] = cv * (va - sc[SC_VSP])
-    r[:, 1] = cphi * phi
+    wphi = np.full(K, cphi)                      # weight of the phi row of every sample
+    if sc[SC_BANKMAX] != 0:                      # CostBank max mode: obj_scale*max(phi^2) = one row, at argmax
+        wphi = np.zeros(K)
+        wphi[int(np.argmax(np.square(phi)))] = math.sqrt(s * K * sc[SC_KPHI])
+    r[:, 1] = wphi * phi
     r[:, 2] = sc[SC_WWP] * (x - wp[0])
     r[:, 3] = sc[SC_WWP] * (y - wp[1])
     obs = []
     for i, (ox, oy, orr) in enumerate(((SC_O0X, SC_O0Y, SC_O0R), (SC_O1X, SC_O1Y, SC_O1R))):
         rr = sc[orr]
         if rr > 0:
-            ddx = (x - sc[ox]) * (OBS_K / rr); ddy = (y - sc[oy]) * (OBS_K / rr)
-            h = cobs * np.exp(-0.5 * (ddx * ddx + ddy * ddy))     # sqrt(s*kobs*e)
+            if (int(sc[SC_OKIND]) >> i) & 1:     # kind 0: e = clip(exp(r^2 - d^2), 0, 1e3); the row sqrt(s*kobs*e) is flat on the clip
+                kk = 1.0
+                ddx = x - sc[ox]; ddy = y - sc[oy]
+                e = np.exp(rr * rr - (ddx * ddx + ddy * ddy))
+                live = (e <= OBS_CLIP).astype(float)
+                h = cobs * np.sqrt(np.clip(e, 0.0, OBS_CLIP))
+            else:                                # kind 1: e = exp(-|k (p - o) / r|^2)
+                kk = OBS_K / rr
+                ddx = (x - sc[ox]) * kk; ddy = (y - sc[oy]) * kk
+                h = cobs * np.exp(-0.5 * (ddx * ddx + ddy * ddy))     # sqrt(s*kobs*e)
+                live = 1.0
             r[:, 4 + i] = h
-            obs.append((i, ddx, ddy, h, rr))
+            obs.append((i, ddx, ddy, h * live, kk))
     wb = sc[SC_WBND]
     hphi = np.maximum(np.abs(phi) - sc[SC_PHIMAX], 0.0)
     hv = np.maximum(va - sc[SC_VMAX], 0.0) + np.minimum(va - sc[SC_VMIN], 0.0)
@@ -309,12 +325,12 @@ def residuals(basis, sc, q, wp=None, want_jac=False, others=None):
     dw_c = -b * ivg
     dw_d = a * ivg
     dphi = np.stack([dw_a, dw_b, dw_c, dw_d], axis=1) * f[:, None]      # wrt a,b,c,d
-    D[:, 1, 2:6] = cphi * dphi
+    D[:, 1, 2:6] = wphi[:, None] * dphi
     D[:, 2, 0] = sc[SC_WWP]
     D[:, 3, 1] = sc[SC_WWP]
-    for (i, ddx, ddy, h, rr) in obs:
-        D[:, 4 + i, 0] = -h * ddx * (OBS_K / rr)
-        D[:, 4 + i, 1] = -h * ddy * (OBS_K / rr)
+    for (i, ddx, ddy, h, kk) in obs:
+        D[:, 4 + i, 0] = -h * ddx * kk
+        D[:, 4 + i, 1] = -h * ddy * kk
     act = (hphi > 0) * np.sign(phi)
     D[:, 6, 2:6] = wb * act[:, None] * dphi
     actv = ((va > sc[SC_VMAX]) | (va < sc[SC_VMIN])).astype(float)

@@ -1,6 +1,9 @@
 """GPU parity: polynomial trajectory fit kernels (through the C-ABI) against the oracle
 (oracle/fit.py), the golden vectors computed by the reference's own classes, and the CPU
 arbiter scipy.optimize.least_squares."""
+import math
+import os
+
 import numpy as np
 import pytest
 
@@ -81,6 +84,61 @@ def test_init_eval_vs_oracle(ctx, plan, obasis):
         # fp32 MFMA J^T J: relative to the largest entry
         assert np.abs(H[i] - Ho).max() <= 2e-5 * np.abs(Ho).max(), (i, np.abs(H[i] - Ho).max() / np.abs(Ho).max())
         assert np.array_equal(H[i], H[i].T)
+
+
+def test_obstacle_kind0_and_bank_max_rows(ctx, plan, obasis):
+    """CostObstacle kind 0 (clipped exp(r^2 - d^2)) and CostBank max mode through every kernel that forms the
+    rows: the J^T J kernel (cost, J^T r, J^T J), the fused LM kernel and the split step kernel (trial cost)."""
+    import d2dhip
+    B = 29
+    sc = F.set_scale(F.synth_scenarios(B, seed=17), 0.1, K)
+    rng = np.random.default_rng(2)
+    q0 = np.array([F.initial_guess(obasis, sc[i]) for i in range(B)])
+    qh = q0 + rng.normal(0, 0.3, q0.shape)
+    for i in range(B):                               # obstacles onto the path: clipped, active and far samples
+        Y = F.flat_outputs(obasis, sc[i], qh[i])
+        sc[i, F.SC_O0X], sc[i, F.SC_O0Y], sc[i, F.SC_O0R] = Y[0, 0, 20] + 0.6, Y[0, 1, 20] - 0.5, 3.0
+        sc[i, F.SC_OKIND] = (1, 3, 1, 0)[i % 4]      # kind 0 for obstacle 0 / both / ... / none
+        if i % 4 == 1:
+            sc[i, F.SC_O1X], sc[i, F.SC_O1Y], sc[i, F.SC_O1R] = Y[0, 0, 35] - 0.3, Y[0, 1, 35] + 0.4, 2.8
+        sc[i, F.SC_BANKMAX] = 1.0 if i % 3 else 0.0
+    dsc = ctx.dev(sc)
+    cost, g, H = plan.eval(dsc, ctx.dev(qh))
+    cost, g, H = cost.cpu().numpy(), g.cpu().numpy(), H.cpu().numpy()
+    n_clip = 0
+    for i in range(B):
+        co, go, Ho = F.eval_normal(obasis, sc[i], qh[i])
+        assert abs(cost[i] - co) <= 1e-11 * co, (i, cost[i], co)
+        assert np.abs(g[i] - go).max() <= 1e-10 * max(1.0, np.abs(go).max())
+        assert np.abs(H[i] - Ho).max() <= 2e-5 * np.abs(Ho).max()
+        n_clip += int((F.residuals(obasis, sc[i], qh[i])[:, 4] >= math.sqrt(sc[i, F.SC_S] * 1e3) * (1 - 1e-12)).any())
+    assert n_clip >= B // 2                          # the clip is really exercised
+    # solves: fused kernel, and the split path (eval + step kernels) on the same scenarios
+    from scipy.optimize import least_squares
+    for split in (False, True):
+        p2 = plan
+        if split:
+            os.environ['D2D_FIT_SPLIT'] = '1'
+            try:
+                p2 = d2dhip.FitPlan(ctx, S_, K, DUR, WREF)
+            finally:
+                del os.environ['D2D_FIT_SPLIT']
+        q = ctx.dev(q0.copy())
+        cst, iters, status, stats = p2.solve(dsc, q)
+        qs, cst = q.cpu().numpy(), cst.cpu().numpy()
+        if split:
+            p2.close()
+        n_ok = 0
+        for i in range(0, B, 3):
+            co = F.cost(obasis, sc[i], qs[i])
+            assert abs(cst[i] - co) <= 1e-10 * co
+            assert co <= F.cost(obasis, sc[i], q0[i]) * (1 + 1e-12)            # descent
+            # scipy polish from the GPU point: these objectives are only piecewise smooth (clip, argmax), so the
+            # polish may slide to a neighbouring piece; it must not find a lower cost on the GPU's own piece
+            fun = lambda qq: F.residuals(obasis, sc[i], qq).reshape(-1)           # noqa: E731
+            pol = least_squares(fun, qs[i], method='lm', xtol=1e-13, ftol=1e-13, gtol=1e-13)
+            n_ok += int(2 * pol.cost >= co * (1 - 1e-6))
+        assert n_ok >= len(range(0, B, 3)) - 2, n_ok
 
 
 def test_cost_vs_reference_classes_golden(ctx, plan, obasis, gold):

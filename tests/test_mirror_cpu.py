@@ -126,9 +126,12 @@ def test_cost_lowering_and_scenarios():
     low = sop.lower_cost(d2mou.CostComposit(kvel=70., kbank=1., kobs=nan, kcol=10., vsp=12., rcol=10.))
     assert low[:3] == (12., 70., 1.) and low[5] == 10. and low[6] == 10.
     bmax = d2ou.CostBank(); bmax.use_mean = False
-    for bad in (bmax, d2ou.CostComposit([(1, 2, 3)], obs_kind=0), object()):
-        with pytest.raises(NotImplementedError):
-            sop.lower_cost(bad)
+    assert sop.lower_cost(bmax)[7:] == (0, 1) and sop.lower_cost(d2ou.CostBank())[7:] == (0, 0)
+    low = sop.lower_cost(d2ou.CostComposit([(1, 2, 3), (4, 5, 6)], obs_kind=0))
+    assert low[7:] == (0b11, 0) and low[4] == ((1, 2, 3), (4, 5, 6))
+    assert sop.lower_cost(d2mou.CostComposit(kobs=1., obss=[(1, 2, 3)], obs_kind=0))[7] == 1
+    with pytest.raises(NotImplementedError):
+        sop.lower_cost(object())
     # scenario protocol
     for s in d2oscen.scens:
         for attr in ('name', 'desc', 't0', 't1', 'hz', 'p0', 'p1', 'wind', 'cost', 'obj_scale', 'x_constraint',
@@ -144,3 +147,6 @@ def test_cost_lowering_and_scenarios():
     import d2dhip
     assert row[d2dhip.SC_WX] == -1.0 and row[d2dhip.SC_WY] == 2.0 and row[d2dhip.SC_PHIMAX] == 0.5
     assert row[d2dhip.SC_VMIN] == 9. and row[d2dhip.SC_VMAX] == 14. and row.shape == (32,)
+    row = sop.scen_row((0, 0, 0, 0, 10), (0, 30, np.pi, 0, 10), 12., sop.lower_cost(d2ou.CostComposit([(1, 2, 3)], obs_kind=0)),
+                       0.01, [0., 0.], (-0.5, 0.5), (9., 14.))
+    assert row[d2dhip.SC_OKIND] == 1 and row[d2dhip.SC_BANKMAX] == 0 and row[d2dhip.SC_O0R] == 3
