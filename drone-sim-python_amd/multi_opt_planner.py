@@ -84,6 +84,7 @@ class Planner:
             cost, iters, status, stats = plan.solve(dsc, q, max_iter=max_iter)
         _, Xs = plan.sample(dsc, q)
         Xs = Xs.cpu().numpy()                        # (n, 5, N)
+        sop.check_boxes(Xs[:, 0], Xs[:, 1], self.scen.x_constraint, self.scen.y_constraint)
         self.fit_q, self.fit_plan, self.fit_scen = q, plan, dsc
         self.fit_coefs = plan.coeffs(dsc, q).cpu().numpy()
         sol = np.zeros(self.prob.num_free)

@@ -83,6 +83,15 @@ def scen_row(p0, p1, vref, lowered, s, wind, phi_c, v_c, go_left=-1.):
     return r
 
 
+def check_boxes(x, y, x_constraint, y_constraint):
+    """x/y_constraint boxes are not rows of the fit: a solution that stays inside them is also the solution
+    of the boxed problem; one that leaves them is refused instead of being returned as if the box held."""
+    for name, v, box in (('x', x, x_constraint), ('y', y, y_constraint)):
+        if box is not None and (np.min(v) < box[0] - 1e-9 or np.max(v) > box[1] + 1e-9):
+            raise NotImplementedError(f'the plan leaves the {name}_constraint box {tuple(box)} '
+                                      f'([{np.min(v):.3f}, {np.max(v):.3f}]): binding position boxes have no kernel')
+
+
 class _FitProblem:
     """Stands where the reference keeps its opty Problem (`Planner.prob`): num_free, the two
     option spellings the reference uses, and solve(x0) -> (solution, info)."""
@@ -151,6 +160,8 @@ class Planner:
         max_iter = int(min(max(self.prob.options.get('max_iter', 200), 1), 2000))
         cost, iters, status, stats = plan.solve(dsc, q, max_iter=max_iter)
         _, Xs = plan.sample(dsc, q)
+        Xh = Xs.cpu().numpy()[0]
+        check_boxes(Xh[0], Xh[1], self.exp.x_constraint, self.exp.y_constraint)
         self.fit_q, self.fit_plan, self.fit_scen = q, plan, dsc
         self.fit_coefs = plan.coeffs(dsc, q).cpu().numpy()[0]
         info = {'status': int(status.cpu().numpy()[0]), 'iters': int(iters.cpu().numpy()[0]),

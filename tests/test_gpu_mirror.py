@@ -228,6 +228,39 @@ def test_single_planner_exp14_and_wind():
     assert _kinematic_residual(pw.sol_x, pw.sol_y, pw.sol_psi, pw.sol_phi, pw.sol_v, pw.fit_coefs, pw.duration, wind=(2., 0.)) < 1e-8
 
 
+def test_planner_cost_variants_and_boxes():
+    """CostComposit with kind-0 obstacles, CostBank max mode, and the x/y box policy (verified or refused)."""
+    import d2d.opty_utils as d2ou
+    import d2d.optyplan_scenarios as d2oscen
+    import single_opt_planner as sop
+
+    class kind0(d2oscen.exp_14):
+        obstacles = [(30., 2., 4.)]
+        cost = d2ou.CostComposit([(30., 2., 4.)], vsp=12., kobs=1., kvel=5., kbank=1., obs_kind=0)
+    p = sop.Planner(kind0, initialize=True)
+    p.run()
+    d = np.hypot(p.sol_x - 30., p.sol_y - 2.)
+    assert np.isfinite(p.solution).all() and p.info['obj_val'] > 0
+    # the reported objective is the mirrored reference cost (+ waypoint / bound regularisers >= 0)
+    assert kind0.cost.cost(p.solution, p) <= p.info['obj_val'] * (1 + 1e-9) + 1e-12, (kind0.cost.cost(p.solution, p), p.info, d.min())
+
+    class bankmax(d2oscen.exp_14):
+        cost = d2ou.CostBank()
+    bankmax.cost.use_mean = False
+    pb = sop.Planner(bankmax, initialize=True)
+    pb.run()
+    assert bankmax.cost.cost(pb.solution, pb) <= pb.info['obj_val'] * (1 + 1e-9) + 1e-12
+
+    class boxed(d2oscen.exp_14):
+        y_constraint = (-1., 1.)                       # the dog-leg of this scenario needs more room
+    with pytest.raises(NotImplementedError, match='y_constraint'):
+        sop.Planner(boxed, initialize=True).run()
+
+    class roomy(d2oscen.exp_14):
+        x_constraint, y_constraint = (-500., 500.), (-500., 500.)
+    sop.Planner(roomy, initialize=True).run()
+
+
 def test_multi_planner_like_11_full_sim():
     import multi_opt_planner as mop
     import d2d.multiopty_utils as d2mou
