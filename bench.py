@@ -106,7 +106,9 @@ def main():
     ap.add_argument('--max-iter', type=int, default=200)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=1024)
-    ap.add_argument('--large-batch', type=int, default=32768, help='extra single solve at this batch size (0: skip)')
+    ap.add_argument('--large-batch', type=int, default=0,
+                    help='extra single solve at this batch size, reported as large_batch (off by default: its launches '
+                         'would mix into the kernel statistics of the headline configuration)')
     a = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0)); world = int(os.environ.get('WORLD_SIZE', 1))
