@@ -247,7 +247,8 @@ def main():
                        'segments': S_, 'samples': K, 'unknowns_reduced': NQ2, 'max_iter': a.max_iter,
                        'check_every': a.check_every, 'parallelism': f'trajectory-sharded x{world}'},
             'converged_frac': conv, 'mean_iters': float(iters.double().mean().item()),
-            'evals_per_fit': float(stats[3] / B), 'mean_cost': float(stats[0] / B),
+            'evals_per_fit': float(stats[3] / B),          # in Gauss-Newton units (200 rows); second-order evaluations count 1.5
+             'mean_cost': float(stats[0] / B),
             'roofline': roof, 'roofline_isolated': roof_iso, 'large_batch': large, 'cpu_baseline': cpu,
         }
         print(json.dumps(line))

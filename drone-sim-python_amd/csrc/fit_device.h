@@ -306,9 +306,14 @@ __device__ __forceinline__ double sample_absw(const ScenP &s, const double Y[6])
 }
 
 // bank_sel: CostBank max mode only -- true for the one sample whose phi row is kept (weight s.cphimax).
+// so != nullptr (second-order mode): instead of the four Gauss-Newton row coefficient sets, coef[m] receives row m
+// of the 4x4 block M_vel = sum_rows (grad r grad r^T + r Hess r) over (a,b,c,d) = (xd-wx, yd-wy, xdd, ydd), laid
+// out as (M[m][a], M[m][c], M[m][b], M[m][d]) (x-axis G1/G2 pair, y-axis G1/G2 pair), and so[m] row m of the 2x2
+// position block M_pos of the obstacle rows (oracle/fit.py curvature_blocks + the Gauss-Newton part).
 template <bool WANT_JAC>
 __device__ __forceinline__ double sample_terms(const ScenP &s, const double Y[6], double wpx,
-                                               double wpy, double u[6], f32x4 coef[4], bool bank_sel = false) {
+                                               double wpy, double u[6], f32x4 coef[4], bool bank_sel = false,
+                                               float2 *so = nullptr) {
   const double cphi = s.cphimax > 0.0 ? (bank_sel ? s.cphimax : 0.0) : s.cphi;
   const double cphi2 = s.cphimax > 0.0 ? cphi * cphi : s.cphi2;
   const double x = Y[0], y = Y[1];
@@ -359,13 +364,43 @@ __device__ __forceinline__ double sample_terms(const ScenP &s, const double Y[6]
     u[3] = tv * dva_b + tp * dp_b;
     u[4] = tp * dp_c;
     u[5] = tp * dp_d;
-    // merged row weights for J^T J: (cv^2 + wb^2 actv) dva dva^T, (cphi^2 + wb^2 |actp|) dphi dphi^T
-    const double mv = sqrt(s.cv2 + s.wb2 * actv);
-    const double mp = sqrt(cphi2 + s.wb2 * actp * actp);
-    coef[0] = f32x4{(float)(mv * dva_a), 0.f, (float)(mv * dva_b), 0.f};
-    coef[1] = f32x4{(float)(mp * dp_a), (float)(mp * dp_c), (float)(mp * dp_b), (float)(mp * dp_d)};
-    coef[2] = f32x4{(float)o0x, 0.f, (float)o0y, 0.f};
-    coef[3] = f32x4{(float)o1x, 0.f, (float)o1y, 0.f};
+    if (so == nullptr) {
+      // merged row weights for J^T J: (cv^2 + wb^2 actv) dva dva^T, (cphi^2 + wb^2 |actp|) dphi dphi^T
+      const double mv = sqrt(s.cv2 + s.wb2 * actv);
+      const double mp = sqrt(cphi2 + s.wb2 * actp * actp);
+      coef[0] = f32x4{(float)(mv * dva_a), 0.f, (float)(mv * dva_b), 0.f};
+      coef[1] = f32x4{(float)(mp * dp_a), (float)(mp * dp_c), (float)(mp * dp_b), (float)(mp * dp_d)};
+      coef[2] = f32x4{(float)o0x, 0.f, (float)o0y, 0.f};
+      coef[3] = f32x4{(float)o1x, 0.f, (float)o1y, 0.f};
+    } else {
+      // ---- velocity block: mv2 t t^T + kv (I - t t^T)  +  (mp2 - 2 w tp) dphi dphi^T  +  tp f Hess(w)
+      const double mv2 = s.cv2 + s.wb2 * actv, mp2 = cphi2 + s.wb2 * actp * actp;
+      const double kv = (s.cv * r0 + s.wbnd * actv * r7) * iva;
+      const double e1 = mv2 - kv;                               // coefficient of t t^T on top of kv I
+      const double e2 = mp2 - 2.0 * w * tp;
+      const double i2 = iva * iva, q1 = ivg * i2, tf = tp * f, wi2 = w * i2;
+      const double hw_aa = -2.0 * q1 * d * a + wi2 * (3.0 * a * a * i2 - 1.0);
+      const double hw_ab = -q1 * (d * b - a * c) + 3.0 * wi2 * i2 * a * b;
+      const double hw_bb = 2.0 * q1 * c * b + wi2 * (3.0 * b * b * i2 - 1.0);
+      const double hw_ac = q1 * a * b, hw_ad = ivg - q1 * a * a, hw_bc = -ivg + q1 * b * b, hw_bd = -q1 * a * b;
+      const double m_aa = kv + e1 * dva_a * dva_a + e2 * dp_a * dp_a + tf * hw_aa;
+      const double m_ab = e1 * dva_a * dva_b + e2 * dp_a * dp_b + tf * hw_ab;
+      const double m_bb = kv + e1 * dva_b * dva_b + e2 * dp_b * dp_b + tf * hw_bb;
+      const double m_ac = e2 * dp_a * dp_c + tf * hw_ac, m_ad = e2 * dp_a * dp_d + tf * hw_ad;
+      const double m_bc = e2 * dp_b * dp_c + tf * hw_bc, m_bd = e2 * dp_b * dp_d + tf * hw_bd;
+      const double m_cc = e2 * dp_c * dp_c, m_cd = e2 * dp_c * dp_d, m_dd = e2 * dp_d * dp_d;
+      coef[0] = f32x4{(float)m_aa, (float)m_ac, (float)m_ab, (float)m_ad};     // row a: (a, c | b, d)
+      coef[1] = f32x4{(float)m_ab, (float)m_bc, (float)m_bb, (float)m_bd};     // row b
+      coef[2] = f32x4{(float)m_ac, (float)m_cc, (float)m_bc, (float)m_cd};     // row c
+      coef[3] = f32x4{(float)m_ad, (float)m_cd, (float)m_bd, (float)m_dd};     // row d
+      // ---- position block: sum over the unclipped obstacles of h^2 k^2 (2 e e^T - I)
+      const double g0 = clip0 ? 0.0 : h0 * h0 * s.k0 * s.k0, g1 = clip1 ? 0.0 : h1 * h1 * s.k1 * s.k1;
+      const double p_xx = g0 * (2.0 * e0x * e0x - 1.0) + g1 * (2.0 * e1x * e1x - 1.0);
+      const double p_xy = 2.0 * (g0 * e0x * e0y + g1 * e1x * e1y);
+      const double p_yy = g0 * (2.0 * e0y * e0y - 1.0) + g1 * (2.0 * e1y * e1y - 1.0);
+      so[0] = float2{(float)p_xx, (float)p_xy};
+      so[1] = float2{(float)p_xy, (float)p_yy};
+    }
   }
   return cost;
 }

@@ -25,7 +25,7 @@
 #define FIT_THREADS (64 * FIT_WPB_MAX)
 #define FIT_LDS_BYTES (160 * 1024)
 
-// flags[b][4] = status, iters, need_eval, nevals ; lm[b][4] = lambda, nu, gmax, cost_prev
+// flags[b][4] = status, iters, need_eval, evaluations (half-units: 2 per Gauss-Newton, 3 per second-order one); lm[b][4] = lambda, nu, gmax, second-order mode of the pending evaluation
 enum { FL_STATUS = 0, FL_ITERS = 1, FL_NEED = 2, FL_NEVAL = 3 };
 
 struct FitLds {
@@ -159,7 +159,7 @@ fit_eval_kernel(int B, FitGeom g, FitLds L, int dbg, GroupArgs ga, const double 
       if (cost_out) cost_out[b] = cost;
       if (flags) {
         flags[4 * b + FL_NEED] = 0;
-        flags[4 * b + FL_NEVAL] += 1;
+        flags[4 * b + FL_NEVAL] += 2;      // half-units: see fit_stats_kernel
         if (!(fabs(cost) <= 1.79e308)) flags[4 * b + FL_STATUS] = D2D_ST_NONFINITE;
       }
     }
@@ -318,7 +318,7 @@ fit_step_kernel(int B, FitGeom g, StepLds L, d2d_fit_opts opts, GroupArgs ga,
 #define FIT_LM_WPB_MAX 8
 struct FusedLds {
   int G64, G32, Wt, wave0, wave_stride;
-  int qs, sp, big, cf;      // inside a wave's block; `big` holds us+cf, then the image of J^T J / its factor
+  int qs, sp, big, cf, cfp; // inside a wave's block; `big` holds us + cf + cfp, then the image of J^T J / its factor
   int total;
 };
 static FusedLds fused_lds_layout(int K, int nq, int N, int wpb) {
@@ -335,7 +335,8 @@ static FusedLds fused_lds_layout(int K, int nq, int N, int wpb) {
   L.big = w;
   const int us_bytes = align16(K * 6 * 8), cf_bytes = (K + 1) * 4 * 16;
   L.cf = w + us_bytes;
-  int big = us_bytes + cf_bytes;
+  L.cfp = L.cf + cf_bytes;                      // second-order mode: position-block records [K+1][2] float2
+  int big = us_bytes + cf_bytes + align16((K + 1) * 2 * 8);
   if ((N + 3) * (N + 4) * 4 > big) big = (N + 3) * (N + 4) * 4;
   w = align16(w + big);
   L.wave_stride = w;
@@ -379,6 +380,7 @@ fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_budget,
   double *sp = reinterpret_cast<double *>(wl + L.sp);
   double *us = reinterpret_cast<double *>(wl + L.big);
   f32x4 *cf = reinterpret_cast<f32x4 *>(wl + L.cf);
+  float2 *cfp = reinterpret_cast<float2 *>(wl + L.cfp);
   float *big = reinterpret_cast<float *>(wl + L.big);          // image of J^T J, then of its Cholesky factor
   const int n = 2 * g.nq;
   const bool act = lane < n;
@@ -411,7 +413,9 @@ fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_budget,
     for (int cc = 0; cc < FIT_PK; ++cc) pkr[cc] = lane < g.K ? pkb[(size_t)cc * g.K + lane] : 0.0;
     wave_lds_sync();
     LM_STAMP(0)
-    c = uniform_d(eval_phase1_reg<NQ>(g, G64, pkr, pkb, sp, qs, us, cf, lane));
+    // mode of the rows in us / cf (and of hrow after the MFMA pass); kept in lm[.][3] between launches
+    bool so_rows = uniform_i(lm[4 * b + 3] != 0.0 ? 1 : 0) != 0;
+    c = uniform_d(eval_phase1_reg<NQ>(g, G64, pkr, pkb, sp, qs, us, cf, cfp, so_rows, lane));
     LM_STAMP(1)
     bool fresh = true;
     if (!(fabs(c) <= 1.79e308)) { status = D2D_ST_NONFINITE; fresh = false; }
@@ -422,8 +426,9 @@ fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_budget,
         fresh = false;
         if (status != D2D_ST_RUNNING) break;             // accepted + converged: J^T r refreshed, done
         f32x4 acc[NT];
-        jtj_mfma<NB, NQ, true>(g, lds, L.G32, gG32, L.wave0 + wave * L.wave_stride + L.cf, lane, g.K, acc);
-        ++nev;                                           // counts J^T J evaluations (the roofline unit)
+        if (so_rows) jtj_mfma_so<NB, NQ>(g, lds, L.G32, L.wave0 + wave * L.wave_stride + L.cf, L.wave0 + wave * L.wave_stride + L.cfp, lane, acc);
+        else jtj_mfma<NB, NQ, true>(g, lds, L.G32, gG32, L.wave0 + wave * L.wave_stride + L.cf, lane, g.K, acc);
+        nev += so_rows ? 3 : 2;                          // contracted rows in units of 100 (the roofline unit is 200 rows)
         wave_lds_sync();                                 // every lane is done with us / cf before they are overwritten
         LM_STAMP(3)
         const float ww = (float)(sp[PR_WWP] * sp[PR_WWP]);
@@ -448,8 +453,10 @@ fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_budget,
       if (act) qs[q_slot(lane, g.nq)] = qi + delta;      // the trial point
       wave_lds_sync();
       LM_STAMP(5)
-      // full phase 1 at the trial point: if the step is accepted its rows are the next evaluation
-      const double ct = uniform_d(eval_phase1_reg<NQ>(g, G64, pkr, pkb, sp, qs, us, cf, lane));
+      // full phase 1 at the trial point: if the step is accepted its rows are the next evaluation -- with the
+      // second-order blocks once the damping (before this step's update) has fallen to so_lambda
+      const bool so_next = opts.so_lambda > 0.0 && lam <= opts.so_lambda;
+      const double ct = uniform_d(eval_phase1_reg<NQ>(g, G64, pkr, pkb, sp, qs, us, cf, cfp, so_next, lane));
       LM_STAMP(1)
       const double pred = uniform_d(wave_sum(delta * (lam * (double)dgi * delta - gi)));
       const double dmax = uniform_d(wave_max(fabs(delta))), qmax = uniform_d(wave_max(fabs(qi)));
@@ -459,6 +466,7 @@ fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_budget,
       if (so.accept) {
         qi += delta; c = ct;
         fresh = true;                                    // also when converged: refresh J^T r
+        so_rows = so_next;
       }
       LM_STAMP(6)
     }
@@ -467,7 +475,7 @@ fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_budget,
     if (act) { q_io[(size_t)b * n + lane] = qi; g_io[(size_t)b * n + lane] = gi; }
     if (lane == 0) {
       cost_io[b] = c;
-      lm[4 * b + 0] = lam; lm[4 * b + 1] = nu; lm[4 * b + 2] = gmax;
+      lm[4 * b + 0] = lam; lm[4 * b + 1] = nu; lm[4 * b + 2] = gmax; lm[4 * b + 3] = so_rows ? 1.0 : 0.0;
       flags[4 * b + FL_STATUS] = status; flags[4 * b + FL_ITERS] = iters; flags[4 * b + FL_NEED] = 1;
       flags[4 * b + FL_NEVAL] += nev;
     }
@@ -542,7 +550,7 @@ fit_stats_kernel(int B, int n, const double *__restrict__ cost, const double *__
     for (int j = 0; j < n; ++j) gm = fmax(gm, fabs(g[(size_t)b * n + j]));
     const int st = flags[4 * b + FL_STATUS];
     nr = (st == D2D_ST_CONVERGED || st == D2D_ST_STALLED) ? 0.0 : 1.0;
-    ne = flags[4 * b + FL_NEVAL];
+    ne = 0.5 * flags[4 * b + FL_NEVAL];            // evaluations in units of a Gauss-Newton one (200 rows; second-order: 1.5)
   }
   c = wave_sum(c); gm = wave_max(gm); nr = wave_sum(nr); ne = wave_sum(ne);
   if ((threadIdx.x & 63) == 0) {
@@ -953,7 +961,7 @@ int d2d_fit_profile_read(d2d_fit_plan *pl, double *out) {
 }
 
 static d2d_fit_opts opts_or_default(const d2d_fit_opts *opts) {
-  d2d_fit_opts o = {200, 8, 1e-14, 1e-9, 1e-11};
+  d2d_fit_opts o = {200, 8, 1e-14, 1e-9, 1e-11, D2D_LM_SO_LAMBDA};
   if (opts) o = *opts;
   return o;
 }

@@ -49,7 +49,9 @@ __device__ __forceinline__ double eval_phase1(const FitGeom &g, const double *G6
 template <int NQ>
 __device__ __forceinline__ double eval_phase1_reg(const FitGeom &g, const double *G64, const double (&pkr)[FIT_PK],
                                                   const double *__restrict__ pkb, const double *sp, const double *qs,
-                                                  double *us, f32x4 *cf, int lane) {
+                                                  double *us, f32x4 *cf, float2 *cfp, bool so, int lane) {
+  // so (wave-uniform): write the second-order block records (cf [K+1][4] rows of M_vel, cfp [K+1][2] rows of
+  // M_pos, fit_device.h sample_terms) instead of the four Gauss-Newton row coefficient sets
   double cacc = 0.0;
   LAUNDER(lane);
   const int k = lane;
@@ -60,11 +62,21 @@ __device__ __forceinline__ double eval_phase1_reg(const FitGeom &g, const double
     f32x4 coef[4];
     flat_outputs_pk<NQ>(g, G64, qs, pkr, k, Y);
     const ScenP s = load_scenp(sp);
-    cacc = sample_terms<true>(s, Y, pkr[6], pkr[7], u, coef, k == kbank);
+    if (so) {
+      float2 pos[2];
+      cacc = sample_terms<true>(s, Y, pkr[6], pkr[7], u, coef, k == kbank, pos);
+      cfp[k * 2] = pos[0]; cfp[k * 2 + 1] = pos[1];
+    } else {
+      cacc = sample_terms<true>(s, Y, pkr[6], pkr[7], u, coef, k == kbank);
+    }
 #pragma unroll
     for (int c = 0; c < 6; ++c) us[k * 6 + c] = u[c];
 #pragma unroll
     for (int r = 0; r < 4; ++r) cf[k * 4 + r] = coef[r];
+  } else if (so && k == g.K) {       // the padded sample of an odd K: zero records
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cf[k * 4 + r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    cfp[k * 2] = float2{0.f, 0.f}; cfp[k * 2 + 1] = float2{0.f, 0.f};
   }
   const double cost = wave_sum(cacc);
   wave_lds_sync();
@@ -232,6 +244,72 @@ __device__ __forceinline__ void jtj_mfma(const FitGeom &g, const unsigned char *
 #undef T32_AT
 }
 
+// ---- phase 3, second-order mode: H = sum_k G_k^T M_k G_k with the per-sample blocks of sample_terms -------
+// A-operand = the plain basis rows G_k (component m of sample k: a -> G1 on the x columns, b -> G1 on the y
+// columns, c -> G2 on x, d -> G2 on y; position rows: G0 on x / on y), B-operand = M_k G_k (rows with the
+// coefficient records).  One velocity k-step per sample (its four rows) and one position k-step per PAIR of
+// samples (two rows each): 1.5 k-steps per sample.  Only the upper block triangle is accumulated; M_k is
+// symmetric, so A^T B is (to fp32 rounding).
+template <int NB, int NQ>
+__device__ __forceinline__ void jtj_mfma_so(const FitGeom &g, const unsigned char *lds_base, int t32_off, int cf_off,
+                                            int cfp_off, int lane, f32x4 (&acc)[NB * (NB + 1) / 2]) {
+  LAUNDER(lane);
+  const int rho = lane >> 4, ci = lane & 15;
+  const int nq = NQ ? NQ : g.nq;
+  const int plane = g.K * nq;
+  bool ayc[NB];
+  int jj[NB];
+#pragma unroll
+  for (int c = 0; c < NB; ++c) {
+    const int col = 16 * c + ci;
+    ayc[c] = col >= nq;
+    jj[c] = col < 2 * nq ? col - (ayc[c] ? nq : 0) : 0;
+  }
+#pragma unroll
+  for (int t = 0; t < NB * (NB + 1) / 2; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool row_y = (rho & 1) != 0;          // velocity rows: a, c act on the x columns, b, d on the y columns
+  const bool row_2 = rho >= 2;                // velocity rows c, d use G2; position rows 2, 3 belong to the next sample
+#define SO_T(pl, kk, j) lds_get<float>(lds_base + t32_off + 4 * ((pl) * plane + (kk) * nq + (j)))
+#define SO_MFMAS                                                                              \
+  {                                                                                           \
+    int t = 0;                                                                                \
+    _Pragma("unroll") for (int I = 0; I < NB; ++I)                                            \
+      _Pragma("unroll") for (int J = I; J < NB; ++J, ++t)                                     \
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(va_[I], vb_[J], acc[t], 0, 0, 0);       \
+  }
+  for (int k = 0; k < g.K; k += 2) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {                  // velocity k-steps of samples k and k+1
+      const int ks = k + half;
+      const f32x4 rec = lds_get<f32x4>(lds_base + cf_off + (ks * 4 + rho) * 16);
+      float va_[NB], vb_[NB];
+#pragma unroll
+      for (int c = 0; c < NB; ++c) {
+        const float g1 = SO_T(1, ks, jj[c]), g2 = SO_T(2, ks, jj[c]);
+        const float cx = ayc[c] ? rec.z : rec.x, cy = ayc[c] ? rec.w : rec.y;
+        const bool live = 16 * c + ci < 2 * nq;
+        vb_[c] = live ? fmaf(cy, g2, cx * g1) : 0.f;
+        va_[c] = (live && row_y == ayc[c]) ? (row_2 ? g2 : g1) : 0.f;
+      }
+      SO_MFMAS
+      if (half == 0) {                                      // position k-step of the pair (k, k+1)
+        const int kp = k + (row_2 ? 1 : 0);
+        const float2 rp = lds_get<float2>(lds_base + cfp_off + (kp * 2 + (rho & 1)) * 8);
+#pragma unroll
+        for (int c = 0; c < NB; ++c) {
+          const float g0 = SO_T(0, kp, jj[c]);
+          const bool live = 16 * c + ci < 2 * nq;
+          vb_[c] = live ? (ayc[c] ? rp.y : rp.x) * g0 : 0.f;
+          va_[c] = (live && row_y == ayc[c]) ? g0 : 0.f;
+        }
+        SO_MFMAS
+      }
+    }
+  }
+#undef SO_T
+#undef SO_MFMAS
+}
+
 // ---- J^T J: accumulator tiles -> row-owned registers ------------------------------------------
 // Row-major LDS image Hs [N+3][N+4] (row N: right-hand side, then two scratch rows of the solve) of the full symmetric matrix (later overwritten in place by the
 // Cholesky factor).  Lane l holds elements (16I + 4(l>>4) + r, 16J + (l&15)) of tile (I,J): stored
@@ -314,7 +392,7 @@ __device__ __forceinline__ bool damped_solve(const f32x2 (&hrow)[N / 2], double 
     if (2 * m + 1 == lane) d = hrow[m].y;
   }
   if (!act) d = 1.f;
-  dgi = fmaxf(d, (float)D2D_LM_DIAG_FLOOR);
+  dgi = fmaxf(fabsf(d), (float)D2D_LM_DIAG_FLOOR);      // (|.|: the second-order Hessian may have a negative diagonal)
   const float dd = act ? d + (float)(lam * (double)dgi) : 1.f;
 #pragma unroll
   for (int m = 0; m < N / 2; ++m) {
@@ -412,6 +490,9 @@ __device__ __forceinline__ StepOutcome judge_step(bool ok, double c, double ct, 
     r.lam = lam * nu;
     r.nu = nu * 2.0;
     if (r.lam > D2D_LM_LAMBDA_MAX) r.status = D2D_ST_STALLED;
+    // a rejected step whose predicted reduction is already below ftol: the iterate sits on the rounding
+    // floor of the cost (typical after the quadratic phase of the second-order mode) -- converged
+    if (fin && pred <= o.ftol * c) r.status = D2D_ST_CONVERGED;
   }
   return r;
 }

@@ -40,7 +40,10 @@ class TrackParams(C.Structure):
 
 class FitOpts(C.Structure):
     _fields_ = [('max_iter', C.c_int32), ('check_every', C.c_int32), ('ftol', C.c_double),
-                ('gtol', C.c_double), ('xtol', C.c_double)]
+                ('gtol', C.c_double), ('xtol', C.c_double), ('so_lambda', C.c_double)]
+
+
+SO_LAMBDA = 1e-4          # D2D_LM_SO_LAMBDA: damping below which the evaluations carry the second-order term
 
 
 _P = C.c_void_p
@@ -333,7 +336,7 @@ class FitPlan:
         _check(self.ctx.lib.d2d_fit_eval(self.ctx.h, self.h, B, _ptr(scen), _ptr(q), _ptr(cost), _ptr(g), _ptr(H)))
         return cost, g, H
 
-    def solve(self, scen, q, max_iter=200, check_every=8, ftol=1e-14, gtol=1e-9, xtol=1e-11):
+    def solve(self, scen, q, max_iter=200, check_every=8, ftol=1e-14, gtol=1e-9, xtol=1e-11, so_lambda=SO_LAMBDA):
         """In-place LM solve of q.  Returns cost, iters, status (device) and stats (numpy[4])."""
         torch = _torch()
         B = scen.shape[0]
@@ -341,7 +344,7 @@ class FitPlan:
         iters = torch.empty(B, dtype=torch.int32, device=self.ctx.device)
         status = torch.empty(B, dtype=torch.int32, device=self.ctx.device)
         stats = np.zeros(4)
-        o = FitOpts(max_iter, check_every, ftol, gtol, xtol)
+        o = FitOpts(max_iter, check_every, ftol, gtol, xtol, so_lambda)
         _check(self.ctx.lib.d2d_fit_solve(self.ctx.h, self.h, B, _ptr(scen), _ptr(q), C.byref(o), _ptr(cost),
                                           _ptr(iters), _ptr(status), _hptr(stats)))
         return cost, iters, status, stats
@@ -350,9 +353,9 @@ class FitPlan:
     def begin(self, B):
         _check(self.ctx.lib.d2d_fit_begin(self.ctx.h, self.h, B))
 
-    def iterate(self, scen, q, n_iters, max_iter=200, ftol=1e-14, gtol=1e-9, xtol=1e-11):
+    def iterate(self, scen, q, n_iters, max_iter=200, ftol=1e-14, gtol=1e-9, xtol=1e-11, so_lambda=SO_LAMBDA):
         """Run n_iters more damped solves; returns the number of trajectories still running."""
-        o = FitOpts(max_iter, n_iters, ftol, gtol, xtol)
+        o = FitOpts(max_iter, n_iters, ftol, gtol, xtol, so_lambda)
         running = C.c_int32(0)
         _check(self.ctx.lib.d2d_fit_iterate(self.ctx.h, self.h, scen.shape[0], _ptr(scen), _ptr(q), C.byref(o), n_iters,
                                             C.byref(running)))
@@ -381,7 +384,7 @@ class FitPlan:
         B = scen.shape[0]
         assert B % n_ac == 0
         cost = self.ctx.empty(B)
-        o = FitOpts(inner_iters, 1, ftol, gtol, xtol)
+        o = FitOpts(inner_iters, 1, ftol, gtol, xtol, 0.0)
         sw = C.c_int32(0)
         stats = np.zeros(4)
         _check(self.ctx.lib.d2d_fit_solve_groups(self.ctx.h, self.h, B // n_ac, _ptr(scen), _ptr(q), C.byref(o), max_sweeps,

@@ -217,12 +217,18 @@ enum {
 #define D2D_LM_LAMBDA_MIN 1e-12
 #define D2D_LM_LAMBDA_MAX 1e12
 #define D2D_LM_DIAG_FLOOR 1e-30
+#define D2D_LM_SO_LAMBDA 1e-4     /* default of d2d_fit_opts.so_lambda */
 enum { D2D_ST_RUNNING = 0, D2D_ST_CONVERGED = 1, D2D_ST_MAXITER = 2, D2D_ST_NONFINITE = 3, D2D_ST_STALLED = 4 };
 
 typedef struct {
   int32_t max_iter;     /* damped solves per trajectory (default 200)                  */
   int32_t check_every;  /* host convergence poll period in iterations (default 8)      */
   double ftol, gtol, xtol;   /* defaults 1e-14, 1e-9, 1e-11                            */
+  double so_lambda;     /* once the damping has fallen to this value the next evaluation carries the
+                           second-order term sum_i r_i Hessian(r_i) (exact Hessian of 0.5 sum r^2) beside
+                           J^T J: Gauss-Newton's linear rate on these large-residual fits becomes
+                           quadratic.  0 = Gauss-Newton only; default D2D_LM_SO_LAMBDA.  Persistent LM
+                           kernel only (6-segment plans); the launch-pair path ignores it.            */
 } d2d_fit_opts;
 
 /* Build the shared basis block on the host (fp64) and upload it.  wref[3] = weights of the
@@ -251,8 +257,9 @@ int d2d_fit_eval(d2d_ctx *ctx, const d2d_fit_plan *plan, int B, const double *sc
 
 /* Full Levenberg-Marquardt solve from q (in/out).  cost dev [B], iters / status dev int32 [B]
  * (any may be NULL).  stats host double[4] (may be NULL): sum cost, max |J^T r|_inf,
- * trajectories still running, evaluations performed -- the local contribution to the
- * cross-GPU convergence all-reduce.  Synchronises the stream before returning. */
+ * trajectories still running, evaluations performed (in units of one Gauss-Newton evaluation = 200
+ * contracted rows at K = 50; an evaluation with the second-order blocks contracts 1.5 times as many and counts
+ * 1.5) -- the local contribution to the cross-GPU convergence all-reduce.  Synchronises the stream before returning. */
 int d2d_fit_solve(d2d_ctx *ctx, const d2d_fit_plan *plan, int B, const double *scen, double *q,
                   const d2d_fit_opts *opts, double *cost, int32_t *iters, int32_t *status,
                   double *stats);

@@ -359,12 +359,85 @@ def cost(basis, sc, q, wp=None, others=None):
     return float(np.sum(r * r))
 
 
-def eval_normal(basis, sc, q, wp=None, others=None):
-    """cost = sum r^2, g = J^T r, H = J^T J (all fp64)."""
+def curvature_blocks(basis, sc, q, wp=None):
+    """W (K,6,6) = sum over the rows of sample k of r_i * Hessian_Y(r_i), Y = (x,y,xd,yd,xdd,ydd): the
+    second-order part of the Hessian of 0.5*sum r^2 is sum_k G_k^T W_k G_k (the flat outputs are linear in q).
+    Rows: speed row and its hinge (curvature of |v_a|), bank row and its hinge (curvature of atan(w)),
+    obstacle rows (curvature of the Gaussian bump; none on the clip of kind 0); waypoint rows are linear."""
+    K = basis.K
+    if wp is None:
+        wp = waypoints(sc, K, basis.duration)
+    r = residuals(basis, sc, q, wp)
+    Y = flat_outputs(basis, sc, q)
+    x, y = Y[0]; a = Y[1, 0] - sc[SC_WX]; b = Y[1, 1] - sc[SC_WY]; c, d = Y[2]
+    va2 = a * a + b * b; va = np.sqrt(va2)
+    n = d * a - c * b
+    ivg = 1.0 / (va * G_ACC)
+    w = n * ivg
+    phi = np.arctan(w)
+    f = 1.0 / (1.0 + w * w)
+    s = sc[SC_S]
+    W = np.zeros((K, 6, 6))
+    # |v_a|: Hessian (I - t t^T)/va on (xd, yd); rows 0 (weight cv) and 7 (weight wb where the bound is active)
+    cv = math.sqrt(s * sc[SC_KV]); wb = sc[SC_WBND]
+    actv = ((va > sc[SC_VMAX]) | (va < sc[SC_VMIN])).astype(float)
+    kv = (cv * r[:, 0] + wb * actv * r[:, 7]) / va
+    t = np.stack([a, b], 1) / va[:, None]
+    Pn = np.eye(2)[None] - t[:, :, None] * t[:, None, :]
+    W[:, 2:4, 2:4] += kv[:, None, None] * Pn
+    # phi = atan(w): Hessian f*Hess(w) - 2 w f^2 grad(w) grad(w)^T on (a,b,c,d); rows 1 and 6
+    gn = np.stack([d, -c, -b, a], 1)                       # grad n
+    p4 = np.stack([a, b, np.zeros(K), np.zeros(K)], 1)
+    gw = ivg[:, None] * gn - (w / va2)[:, None] * p4       # grad w
+    Hn = np.zeros((4, 4)); Hn[0, 3] = Hn[3, 0] = 1.0; Hn[1, 2] = Hn[2, 1] = -1.0
+    P2 = np.diag([1.0, 1.0, 0.0, 0.0])
+    Hw = (ivg[:, None, None] * Hn[None]
+          - (ivg / va2)[:, None, None] * (gn[:, :, None] * p4[:, None, :] + p4[:, :, None] * gn[:, None, :])
+          + w[:, None, None] * (3.0 * p4[:, :, None] * p4[:, None, :] / (va2 * va2)[:, None, None] - P2[None] / va2[:, None, None]))
+    Hphi = f[:, None, None] * Hw - (2.0 * w * f * f)[:, None, None] * gw[:, :, None] * gw[:, None, :]
+    wphi = np.full(K, math.sqrt(s * sc[SC_KPHI]))
+    if sc[SC_BANKMAX] != 0:
+        wphi = np.zeros(K); wphi[int(np.argmax(np.square(phi)))] = math.sqrt(s * K * sc[SC_KPHI])
+    hphi = np.maximum(np.abs(phi) - sc[SC_PHIMAX], 0.0)
+    act = (hphi > 0) * np.sign(phi)
+    kphi = wphi * r[:, 1] + wb * act * r[:, 6]
+    W[:, 2:6, 2:6] += kphi[:, None, None] * Hphi
+    # obstacles: h = cobs*exp(0.5*(c0 - |e|^2)), e = kk*(p - o): Hessian h*kk^2*(e e^T - I) on (x, y)
+    for i, (ox, oy, orr) in enumerate(((SC_O0X, SC_O0Y, SC_O0R), (SC_O1X, SC_O1Y, SC_O1R))):
+        rr = sc[orr]
+        if rr > 0:
+            kind0 = (int(sc[SC_OKIND]) >> i) & 1
+            kk = 1.0 if kind0 else OBS_K / rr
+            e = np.stack([(x - sc[ox]) * kk, (y - sc[oy]) * kk], 1)
+            h = r[:, 4 + i]
+            live = np.ones(K)
+            if kind0:
+                live = (np.exp(rr * rr - np.sum(e * e, 1)) <= OBS_CLIP).astype(float)
+            W[:, 0:2, 0:2] += (h * h * live * kk * kk)[:, None, None] * (e[:, :, None] * e[:, None, :] - np.eye(2)[None])
+    return W
+
+
+def second_order_term(basis, sc, q, wp=None):
+    """S = sum_i r_i Hessian_q(r_i) = sum_k G_k^T W_k G_k (2nq x 2nq)."""
+    K, nq = basis.K, basis.nq
+    W = curvature_blocks(basis, sc, q, wp)
+    Gk = np.zeros((K, 6, 2 * nq))
+    for der in range(3):
+        Gk[:, 2 * der, :nq] = basis.G[der]
+        Gk[:, 2 * der + 1, nq:] = basis.G[der]
+    return np.einsum('kia,kij,kjb->ab', Gk, W, Gk)
+
+
+def eval_normal(basis, sc, q, wp=None, others=None, second_order=False):
+    """cost = sum r^2, g = J^T r, H = J^T J (all fp64); second_order adds sum_i r_i Hessian(r_i) to H."""
     r, D = residuals(basis, sc, q, wp, want_jac=True, others=others)
     J = jacobian(basis, D)
     rv = r.reshape(-1)
-    return float(rv @ rv), J.T @ rv, J.T @ J
+    H = J.T @ J
+    if second_order:
+        assert others is None
+        H = H + second_order_term(basis, sc, q, wp)
+    return float(rv @ rv), J.T @ rv, H
 
 
 def initial_guess(basis, sc, wp=None):
@@ -386,17 +459,23 @@ def initial_guess(basis, sc, wp=None):
 LM_LAMBDA0 = 1e-3
 LM_LAMBDA_MIN, LM_LAMBDA_MAX = 1e-12, 1e12
 LM_DIAG_FLOOR = 1e-30
+LM_SO_LAMBDA = 1e-4     # below this damping the next evaluation carries the second-order term (include/d2d.h D2D_LM_SO_LAMBDA)
 ST_RUNNING, ST_CONVERGED, ST_MAXITER, ST_NONFINITE, ST_STALLED = 0, 1, 2, 3, 4
 
 
 def lm_solve(basis, sc, q0=None, max_iter=200, ftol=1e-14, gtol=1e-9, xtol=1e-11,
-             hess_dtype=np.float64, chol_dtype=np.float64, others=None):
-    """(J^T J + lam*diag(J^T J)) delta = -J^T r with Nielsen's gain-ratio damping.
+             hess_dtype=np.float64, chol_dtype=np.float64, others=None, so_lambda=None):
+    """(H + lam*diag|H|) delta = -J^T r with Nielsen's gain-ratio damping, H = J^T J (Gauss-Newton) or, once the
+    damping has fallen to so_lambda, J^T J + sum_i r_i Hessian(r_i) (the exact Hessian of 0.5*sum r^2).
 
-    One "iteration" = one damped solve + one trial cost; J^T J is re-evaluated only
-    after an accepted step.  hess_dtype / chol_dtype = np.float32 mimic the HIP path's
-    fp32 MFMA J^T J and fp32 Cholesky (residuals, cost and J^T r stay fp64).
+    One "iteration" = one damped solve + one trial cost; H is re-evaluated only after an accepted step, in the
+    mode decided by the damping BEFORE that step (the kernel computes the rows of the trial point
+    speculatively, before it knows the gain ratio).  so_lambda: None = LM_SO_LAMBDA for single trajectories and
+    off for coupled groups; 0 = Gauss-Newton only.  hess_dtype / chol_dtype = np.float32 mimic the HIP path's
+    fp32 MFMA Hessian and fp32 Cholesky (residuals, cost and J^T r stay fp64).
     Returns q, cost, iters, status."""
+    if so_lambda is None:
+        so_lambda = LM_SO_LAMBDA if others is None else 0.0
     wp = waypoints(sc, basis.K, basis.duration)
     q = initial_guess(basis, sc, wp) if q0 is None else np.array(q0, float)
     lam, nu = LM_LAMBDA0, 2.0
@@ -410,7 +489,8 @@ def lm_solve(basis, sc, q0=None, max_iter=200, ftol=1e-14, gtol=1e-9, xtol=1e-11
         if np.max(np.abs(g)) <= gtol:
             status = ST_CONVERGED
             break
-        dg = np.maximum(np.diag(H), LM_DIAG_FLOOR)
+        so_next = so_lambda > 0 and lam <= so_lambda
+        dg = np.maximum(np.abs(np.diag(H)), LM_DIAG_FLOOR)
         A = (H + lam * np.diag(dg)).astype(chol_dtype)
         ok = True
         try:
@@ -429,13 +509,16 @@ def lm_solve(basis, sc, q0=None, max_iter=200, ftol=1e-14, gtol=1e-9, xtol=1e-11
             q = q + delta
             lam = max(lam * max(1.0 / 3.0, 1.0 - (2.0 * rho - 1.0) ** 3), LM_LAMBDA_MIN); nu = 2.0
             small_f = (c - ct) <= ftol * c and pred <= ftol * c
-            c, g, H = eval_normal(basis, sc, q, wp, others)
+            c, g, H = eval_normal(basis, sc, q, wp, others, second_order=so_next)
             H = H.astype(hess_dtype).astype(np.float64)
             if small_f or small_x:
                 status = ST_CONVERGED
                 break
         else:
             lam *= nu; nu *= 2.0
+            if ok and np.isfinite(ct) and 0 < pred <= ftol * c:     # rejected on the rounding floor of the cost: converged
+                status = ST_CONVERGED
+                break
             if lam > LM_LAMBDA_MAX:
                 status = ST_STALLED
                 break
