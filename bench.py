@@ -104,6 +104,8 @@ def main():
     ap.add_argument('--check-every', type=int, default=200,
                     help='LM iterations per persistent launch = interval of the global convergence check (all-reduce)')
     ap.add_argument('--max-iter', type=int, default=200)
+    ap.add_argument('--so-lambda', type=float, default=None,
+                    help='damping below which the evaluations carry the second-order term (default: library default; 0 = Gauss-Newton)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=1024)
     ap.add_argument('--large-batch', type=int, default=0,
@@ -145,10 +147,12 @@ def main():
     from d2dhip.dist import StatsReducer, solve_sharded
     reducer = StatsReducer(dist, ctx.device if backend == 'nccl' else 'cpu')
 
+    tolkw = {} if a.so_lambda is None else {'so_lambda': a.so_lambda}
+
     def one_step():
         """Full LM solve of the resident shard with the global convergence check."""
         q = q0.clone()
-        cost, iters, status, stats, glob, checks = solve_sharded(plan, dsc, q, reducer, a.check_every, a.max_iter)
+        cost, iters, status, stats, glob, checks = solve_sharded(plan, dsc, q, reducer, a.check_every, a.max_iter, **tolkw)
         return (cost, iters, status, stats), q
 
     def barrier():
@@ -225,10 +229,10 @@ def main():
         Bl = a.large_batch
         dscl = ctx.dev(synth.synth_scenarios(Bl, seed=20241008, rank=0, obj_scale=OBJ_SCALE, K=K))
         q0l = plan.init(dscl)
-        plan.solve(dscl, q0l.clone(), max_iter=a.max_iter, check_every=a.max_iter)
+        plan.solve(dscl, q0l.clone(), max_iter=a.max_iter, check_every=a.max_iter, **tolkw)
         torch.cuda.synchronize()
         tl = time.perf_counter()
-        _c, _i, _s, stl = plan.solve(dscl, q0l.clone(), max_iter=a.max_iter, check_every=a.max_iter)
+        _c, _i, _s, stl = plan.solve(dscl, q0l.clone(), max_iter=a.max_iter, check_every=a.max_iter, **tolkw)
         torch.cuda.synchronize()
         tl = time.perf_counter() - tl
         large = {'batch': Bl, 'value': Bl / tl, 'unit': 'trajectory-optimisations/s', 'ms_per_step': 1e3 * tl,
@@ -245,7 +249,8 @@ def main():
             'dtype': 'f64 residual/gradient + f32 MFMA J^T J', 'data': 'synthetic',
             'config': {'workload': f'batch={B} per GPU independent single-drone 6-seg poly fits, 50 waypoints (BASELINE configs[1])',
                        'segments': S_, 'samples': K, 'unknowns_reduced': NQ2, 'max_iter': a.max_iter,
-                       'check_every': a.check_every, 'parallelism': f'trajectory-sharded x{world}'},
+                       'check_every': a.check_every, 'so_lambda': d2dhip.SO_LAMBDA if a.so_lambda is None else a.so_lambda,
+                       'parallelism': f'trajectory-sharded x{world}'},
             'converged_frac': conv, 'mean_iters': float(iters.double().mean().item()),
             'evals_per_fit': float(stats[3] / B),          # in Gauss-Newton units (200 rows); second-order evaluations count 1.5
              'mean_cost': float(stats[0] / B),
