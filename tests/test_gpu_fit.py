@@ -302,6 +302,25 @@ def test_small_and_other_shapes(ctx):
             qo, co, ito, sto = F.lm_solve(ob, sc[i])
             assert abs(cost.cpu().numpy()[i] - co) <= 1e-6 * co
     p.close()
+    # an odd sample count on the persistent kernel (6 segments): the second-order pass pairs the samples
+    K3 = 51
+    dur3 = F.planner_timing(0, 5.0, 10)[2]
+    s3 = 0.1 / K3
+    wref3 = (0.02 ** 2, s3 * 5.0, s3 / F.G_ACC ** 2)
+    p3 = d2dhip.FitPlan(ctx, 6, K3, dur3, wref3)
+    ob3 = F.FitBasis.from_arrays(6, K3, dur3, *p3.basis())
+    sc3 = F.set_scale(F.synth_scenarios(12, seed=8), 0.1, K3)
+    dsc3 = ctx.dev(sc3)
+    q3 = p3.init(dsc3)
+    cost3, it3, st3, _ = p3.solve(dsc3, q3)
+    n_same = 0
+    for i in range(12):
+        qo, co, ito, sto = F.lm_solve(ob3, sc3[i])
+        n_same += int(abs(cost3.cpu().numpy()[i] - co) <= 1e-6 * co)
+        assert F.cost(ob3, sc3[i], q3.cpu().numpy()[i]) == pytest.approx(cost3.cpu().numpy()[i], rel=1e-10)
+    assert n_same >= 11 and (st3.cpu().numpy() == F.ST_CONVERGED).all(), (n_same, st3)
+    assert it3.double().mean().item() < 60
+    p3.close()
     with pytest.raises(d2dhip.D2DError):
         d2dhip.FitPlan(ctx, 7, 50, 4.9, wref)          # S > 6
     with pytest.raises(d2dhip.D2DError):
