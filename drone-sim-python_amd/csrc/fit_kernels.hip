@@ -1008,12 +1008,16 @@ int d2d_fit_iterate(d2d_ctx *ctx, d2d_fit_plan *pl, int B, const double *scen, d
     if (int rc = prof_end(ctx, pl)) return rc;
   }
   if (n_running) {
-    D2D_CHECK_HIP(hipMemsetAsync(ctx->counter_dev, 0, sizeof(int32_t), ctx->stream));
-    hipLaunchKernelGGL(fit_count_kernel, g1, b1, 0, ctx->stream, B, pl->d_flags, ctx->counter_dev);
-    D2D_LAUNCH_CHECK();
-    D2D_CHECK_HIP(hipMemcpyAsync(ctx->counter_host, ctx->counter_dev, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    D2D_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-    *n_running = (pl->it_done >= o.max_iter) ? 0 : ctx->counter_host[0];
+    if (pl->it_done >= o.max_iter) {
+      *n_running = 0;                    // the iteration budget is spent: nothing to count (d2d_fit_finish synchronises)
+    } else {
+      D2D_CHECK_HIP(hipMemsetAsync(ctx->counter_dev, 0, sizeof(int32_t), ctx->stream));
+      hipLaunchKernelGGL(fit_count_kernel, g1, b1, 0, ctx->stream, B, pl->d_flags, ctx->counter_dev);
+      D2D_LAUNCH_CHECK();
+      D2D_CHECK_HIP(hipMemcpyAsync(ctx->counter_host, ctx->counter_dev, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+      D2D_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+      *n_running = ctx->counter_host[0];
+    }
   }
   return D2D_OK;
 }

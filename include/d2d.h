@@ -267,8 +267,8 @@ int d2d_fit_solve(d2d_ctx *ctx, const d2d_fit_plan *plan, int B, const double *s
 /* The same loop in three parts, for callers that interleave their own convergence check
  * (the cross-GPU all-reduce of the statistics): begin resets the per-trajectory LM state;
  * iterate runs up to n_iters more damped solves (never beyond opts->max_iter in total) and,
- * if n_running != NULL, synchronises and returns how many trajectories are still running
- * (0 once max_iter is reached); finish refreshes cost / J^T r and exports as d2d_fit_solve. */
+ * if n_running != NULL, synchronises and returns how many trajectories are still running (once max_iter is
+ * reached it returns 0 without synchronising); finish refreshes cost / J^T r and exports as d2d_fit_solve. */
 int d2d_fit_begin(d2d_ctx *ctx, d2d_fit_plan *plan, int B);
 int d2d_fit_iterate(d2d_ctx *ctx, d2d_fit_plan *plan, int B, const double *scen, double *q,
                     const d2d_fit_opts *opts, int n_iters, int32_t *n_running);
