@@ -357,7 +357,7 @@ fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_budget,
               const float *__restrict__ gG32, const float *__restrict__ gWt,
               const double *__restrict__ prep, double *__restrict__ q_io, double *__restrict__ cost_io,
               double *__restrict__ g_io, double *__restrict__ lm, int32_t *__restrict__ flags,
-              unsigned long long *__restrict__ stamps) {
+              int32_t *__restrict__ queue, unsigned long long *__restrict__ stamps) {
   // stamps != NULL (D2D_LM_STAMPS=1, diagnostics only): per-phase wave-cycle totals, see launch_lm
   unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = 0, st_solve[5] = {0, 0, 0, 0, 0};
 #define LM_STAMP(i)                                                     \
@@ -385,12 +385,20 @@ fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_budget,
   const int n = 2 * g.nq;
   const bool act = lane < n;
 
-  // static striding over the batch, workgroup-major: wave w of workgroup g takes trajectories
-  // g + gridDim*w, + gridDim*wpb, ...  -- a batch smaller than the grid's wave count spreads over all CUs
-  // (and over the four SIMDs of a CU: consecutive waves of a workgroup sit on different SIMDs)
+  // Work distribution: the first trajectory of a wave is static and workgroup-major (wave w of workgroup g
+  // takes g + gridDim*w: a batch smaller than the grid's wave count spreads over all CUs, and over the four
+  // SIMDs of a CU -- consecutive waves of a workgroup sit on different SIMDs); every further one is pulled
+  // from a device-wide counter (`queue`, set to the number of wave slots by the host), so that a wave that
+  // drew short fits takes more of them (iteration counts range from 20 to 150).  queue == NULL: static striding.
   const int stride = gridDim.x * (blockDim.x >> 6);
+  auto next_index = [&](int b) -> int {
+    if (queue == nullptr) return b + stride;
+    int t = 0;
+    if (lane == 0) t = atomicAdd(queue, 1);
+    return __builtin_amdgcn_readfirstlane(t);
+  };
   if (STAMPS) st_last = __builtin_amdgcn_s_memtime();
-  for (int b = blockIdx.x + gridDim.x * wave; b < B; b += stride) {
+  for (int b = blockIdx.x + gridDim.x * wave; (unsigned)b < (unsigned)B; b = next_index(b)) {
     if (flags[4 * b + FL_STATUS] != D2D_ST_RUNNING) continue;
     const double *prow = prep + (size_t)b * FIT_PREP_STRIDE;
     const double *pkb = pk + (size_t)b * FIT_PK * g.K;
@@ -758,12 +766,17 @@ static int launch_lm(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, double *q, con
   unsigned long long *stamps = want_stamps ? reinterpret_cast<unsigned long long *>(ctx->stats_dev + 8) : nullptr;
   if (want_stamps) D2D_CHECK_HIP(hipMemsetAsync(stamps, 0, 13 * sizeof(unsigned long long), ctx->stream));
   const int blocks = B < pl->n_cu ? B : pl->n_cu;     // persistent: one workgroup per CU
+  static const bool no_queue = getenv("D2D_LM_STATIC") != nullptr;      // A/B switch: static striding instead of the work queue
+  int32_t *queue = no_queue ? nullptr : ctx->counter_dev + 8;
+  if (queue) {
+    D2D_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(queue), blocks * pl->wpb_lm, 1, ctx->stream));
+  }
   if (want_stamps)
     hipLaunchKernelGGL((fit_lm_kernel<3, 24, true>), dim3(blocks), dim3(64 * pl->wpb_lm), L.total, ctx->stream, B, gm, L, o, budget,
-                       pl->d_G, pl->d_pk, pl->d_G32, pl->d_W32, pl->d_prep, q, pl->d_cost, pl->d_g, pl->d_lm, pl->d_flags, stamps);
+                       pl->d_G, pl->d_pk, pl->d_G32, pl->d_W32, pl->d_prep, q, pl->d_cost, pl->d_g, pl->d_lm, pl->d_flags, queue, stamps);
   else
     hipLaunchKernelGGL((fit_lm_kernel<3, 24, false>), dim3(blocks), dim3(64 * pl->wpb_lm), L.total, ctx->stream, B, gm, L, o, budget,
-                       pl->d_G, pl->d_pk, pl->d_G32, pl->d_W32, pl->d_prep, q, pl->d_cost, pl->d_g, pl->d_lm, pl->d_flags, stamps);
+                       pl->d_G, pl->d_pk, pl->d_G32, pl->d_W32, pl->d_prep, q, pl->d_cost, pl->d_g, pl->d_lm, pl->d_flags, queue, stamps);
   D2D_LAUNCH_CHECK();
   if (want_times) {
     D2D_CHECK_HIP(hipStreamSynchronize(ctx->stream));
