@@ -388,13 +388,14 @@ fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_budget,
   // Work distribution: the first trajectory of a wave is static and workgroup-major (wave w of workgroup g
   // takes g + gridDim*w: a batch smaller than the grid's wave count spreads over all CUs, and over the four
   // SIMDs of a CU -- consecutive waves of a workgroup sit on different SIMDs); every further one is pulled
-  // from a device-wide counter (`queue`, set to the number of wave slots by the host), so that a wave that
-  // drew short fits takes more of them (iteration counts range from 20 to 150).  queue == NULL: static striding.
+  // from a device-wide counter (queue[0], zero at launch), so that a wave that drew short fits takes more of
+  // them (iteration counts range from 20 to 150).  queue[1] counts the waves that have left the loop: the last
+  // one zeroes both for the next launch (d2d_fit_begin zeroes them too).  queue == NULL: static striding.
   const int stride = gridDim.x * (blockDim.x >> 6);
   auto next_index = [&](int b) -> int {
     if (queue == nullptr) return b + stride;
     int t = 0;
-    if (lane == 0) t = atomicAdd(queue, 1);
+    if (lane == 0) t = stride + atomicAdd(queue, 1);
     return __builtin_amdgcn_readfirstlane(t);
   };
   if (STAMPS) st_last = __builtin_amdgcn_s_memtime();
@@ -489,6 +490,9 @@ fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_budget,
     }
     LM_STAMP(0)
   }
+  if (queue != nullptr && lane == 0) {
+    if (atomicAdd(queue + 1, 1) == stride - 1) { queue[0] = 0; queue[1] = 0; }     // every wave has stopped pulling
+  }
   if (STAMPS && lane == 0) {
     for (int i = 0; i < 8; ++i) atomicAdd(&stamps[i], st_acc[i]);
     for (int i = 0; i < 5; ++i) atomicAdd(&stamps[8 + i], st_solve[i]);
@@ -498,8 +502,10 @@ fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_budget,
 
 // ------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-fit_state_init_kernel(int B, int off, int stride, double *__restrict__ lm, int32_t *__restrict__ flags) {
+fit_state_init_kernel(int B, int off, int stride, double *__restrict__ lm, int32_t *__restrict__ flags,
+                      int32_t *__restrict__ queue) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0 && queue) { queue[0] = 0; queue[1] = 0; }     // work queue of the persistent LM kernel (fit_lm_kernel)
   if (i >= B) return;
   const int b = off + i * stride;
   lm[4 * b + 0] = D2D_LM_LAMBDA0; lm[4 * b + 1] = 2.0; lm[4 * b + 2] = 0.0; lm[4 * b + 3] = 0.0;
@@ -768,9 +774,6 @@ static int launch_lm(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, double *q, con
   const int blocks = B < pl->n_cu ? B : pl->n_cu;     // persistent: one workgroup per CU
   static const bool no_queue = getenv("D2D_LM_STATIC") != nullptr;      // A/B switch: static striding instead of the work queue
   int32_t *queue = no_queue ? nullptr : ctx->counter_dev + 8;
-  if (queue) {
-    D2D_CHECK_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(queue), blocks * pl->wpb_lm, 1, ctx->stream));
-  }
   if (want_stamps)
     hipLaunchKernelGGL((fit_lm_kernel<3, 24, true>), dim3(blocks), dim3(64 * pl->wpb_lm), L.total, ctx->stream, B, gm, L, o, budget,
                        pl->d_G, pl->d_pk, pl->d_G32, pl->d_W32, pl->d_prep, q, pl->d_cost, pl->d_g, pl->d_lm, pl->d_flags, queue, stamps);
@@ -983,7 +986,7 @@ int d2d_fit_begin(d2d_ctx *ctx, d2d_fit_plan *pl, int B) {
   D2D_REQUIRE(ctx && pl, "d2d_fit_begin: null argument");
   D2D_REQUIRE(B >= 1, "d2d_fit_begin: B must be >= 1");
   if (int rc = ensure_scratch(pl, B)) return rc;
-  hipLaunchKernelGGL(fit_state_init_kernel, dim3((B + 255) / 256), dim3(256), 0, ctx->stream, B, 0, 1, pl->d_lm, pl->d_flags);
+  hipLaunchKernelGGL(fit_state_init_kernel, dim3((B + 255) / 256), dim3(256), 0, ctx->stream, B, 0, 1, pl->d_lm, pl->d_flags, ctx->counter_dev + 8);
   D2D_LAUNCH_CHECK();
   pl->it_done = 0;
   pl->active_B = B;
@@ -1111,7 +1114,7 @@ int d2d_fit_solve_groups(d2d_ctx *ctx, d2d_fit_plan *pl, int R, const double *sc
   pl->active_B = 0;
   const FitGeom gm = geom_of(pl);
   const dim3 gB((B + 255) / 256), b1(256), gR((R + 255) / 256);
-  hipLaunchKernelGGL(fit_state_init_kernel, gB, b1, 0, ctx->stream, B, 0, 1, pl->d_lm, pl->d_flags);
+  hipLaunchKernelGGL(fit_state_init_kernel, gB, b1, 0, ctx->stream, B, 0, 1, pl->d_lm, pl->d_flags, (int32_t *)nullptr);
   D2D_LAUNCH_CHECK();
   int sw = 0;
   for (sw = 1; sw <= max_sweeps; ++sw) {
@@ -1119,7 +1122,7 @@ int d2d_fit_solve_groups(d2d_ctx *ctx, d2d_fit_plan *pl, int R, const double *sc
     for (int i = 0; i < n_ac; ++i) {
       // freeze the others where they are now
       hipLaunchKernelGGL(fit_pos_kernel, dim3(((long)B * pl->K + 255) / 256), b1, 0, ctx->stream, B, gm, pl->d_G, pl->d_Gp, pl->d_prep, q, pl->d_pos);
-      hipLaunchKernelGGL(fit_state_init_kernel, gR, b1, 0, ctx->stream, R, i, n_ac, pl->d_lm, pl->d_flags);
+      hipLaunchKernelGGL(fit_state_init_kernel, gR, b1, 0, ctx->stream, R, i, n_ac, pl->d_lm, pl->d_flags, (int32_t *)nullptr);
       D2D_LAUNCH_CHECK();
       const GroupArgs ga{pl->d_pos, n_ac, i, n_ac, pl->nds};
       for (int it = 0; it < inner_iters; ++it) {
