@@ -13,8 +13,8 @@ of the LM kernel (`check_every` iterations; default = max_iter, i.e. one launch 
 all-reduce per solve; RCCL, `nccl` backend).  Rank 0 prints ONE JSON line.
 
 Besides the contract fields the line carries
-  roofline      -- the dominant kernel (fit_lm_kernel: the whole LM loop, J^T J on the fp32 MFMA) over an
-                   instrumented repeat of the timed region: algorithmic flop = 200*48*49 per J^T J
+  roofline      -- the dominant kernel (fit_lm_kernel: the whole LM loop, J^T J on the fp32 MFMA), HIP events
+                   around each of its launches inside the timed region: algorithmic flop = 200*48*49 per J^T J
                    evaluation x evaluations / summed HIP-event kernel time
   roofline_isolated -- the J^T J kernel of the split path (fit_eval_kernel) alone on the full resident
                    batch (every trajectory active), HIP events around the kernel only
@@ -165,10 +165,15 @@ def main():
 
     for _ in range(a.warmup):
         one_step()
+    # per-kernel HIP events over the timed region itself (d2d_fit_profile: two event records on the library's stream
+    # around each hot-path launch, no synchronisation until they are read back after the closing barrier)
+    plan.profile(True)
+    n_evals = 0.0
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         (cost, iters, status, stats), q = one_step()
+        n_evals += stats[3]                # evaluation units of this solve (host copy already made by the solve)
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -178,18 +183,11 @@ def main():
     st = status.cpu().numpy()
     conv = float(np.isin(st, (d2dhip.ST_CONVERGED, d2dhip.ST_STALLED)).mean())
 
-    # ---- instrumented repeat (same workload) for the per-kernel roofline -------------
+    # ---- per-kernel roofline from the events of the timed region -------------
     roof = roof_iso = None
+    ev_ms, ev_n, stp_ms, stp_n, lm_ms, lm_n = plan.profile_read()
+    plan.profile(False)
     if rank == 0:
-        plan.profile(True)
-    nrep = max(1, min(a.steps, 3))
-    n_evals = 0.0
-    for _ in range(nrep):                  # every rank runs it (the loop holds a collective)
-        (c_, i_, s_, stt), _q = one_step()
-        n_evals += stt[3]                  # gated evaluations only (finish()'s refresh is not counted)
-    if rank == 0:
-        ev_ms, ev_n, stp_ms, stp_n, lm_ms, lm_n = plan.profile_read()
-        plan.profile(False)
         if lm_n > 0:
             # the whole LM loop runs in one persistent kernel per convergence check: it IS the hot path
             ach = ALG_FLOP_PER_EVAL * n_evals / (lm_ms * 1e-3) / 1e12

@@ -6,12 +6,13 @@ from d2dhip import synth
 ctx = d2dhip.Context(0); K = 50
 plan = d2dhip.FitPlan(ctx, 6, K, synth.planner_timing(0, 4.9, 10)[2], synth.default_wref(0.1, K))
 B = 4096
+MAX_ITER = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 for rank in range(8):
     sc = ctx.dev(synth.synth_scenarios(B, seed=20241008, rank=rank, obj_scale=0.1, K=K)); q0 = plan.init(sc)
-    plan.solve(sc, q0.clone(), check_every=200)
+    plan.solve(sc, q0.clone(), check_every=200, max_iter=MAX_ITER)
     torch.cuda.synchronize(); t0 = time.perf_counter(); n = 5
     for _ in range(n):
-        cost, iters, status, stats = plan.solve(sc, q0.clone(), check_every=200)
+        cost, iters, status, stats = plan.solve(sc, q0.clone(), check_every=200, max_iter=MAX_ITER)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
     it = iters.cpu().numpy(); st = status.cpu().numpy()
     print(json.dumps({'rank': rank, 'ms': round(1e3 * dt, 3), 'mean_iters': round(float(it.mean()), 2), 'p99': int(np.percentile(it, 99)),
