@@ -149,11 +149,17 @@ __device__ __forceinline__ void flat_outputs(const FitGeom &g, const double *__r
 // Hot-path scenario row: everything that is uniform per trajectory is derived once by
 // fit_prep_kernel (double[FIT_PREP_STRIDE] per trajectory) so that the eval / step kernels
 // fetch it with scalar loads instead of recomputing sincos / sqrt / divisions in all 64 lanes.
-#define FIT_PREP_STRIDE 48
+#define FIT_PREP_STRIDE 112
 enum { PR_DX = 0, PR_DY = 4, PR_P2X = 8, PR_P2Y, PR_SAX, PR_SAY, PR_SBX, PR_SBY, PR_CV, PR_CPHI, PR_COBS,
        PR_K0, PR_K1, PR_CV2, PR_CPHI2, PR_WB2, PR_WWP, PR_WBND, PR_VSP, PR_WX, PR_WY, PR_PHIMAX, PR_VMIN,
        PR_VMAX, PR_O0X, PR_O0Y, PR_O1X, PR_O1Y, PR_X0, PR_Y0, PR_X1, PR_Y1, PR_CCOL, PR_KC, PR_PMASK,
-       PR_C0, PR_C1, PR_CPHIMAX };
+       PR_C0, PR_C1, PR_CPHIMAX,
+       PR_EXT,                           // obstacles 2.. : {x, y, k, c} each (k = 0: absent), D2D_MAX_OBS - 2 of them
+       PR_BOX = PR_EXT + 4 * (D2D_MAX_OBS - 2),      // xmin, xmax, ymin, ymax of the soft position box (+-1e300: open)
+       PR_NEXT = PR_BOX + 4 };   // index of the last present extra obstacle + 1, + FIT_XBOX if there is a position box
+                                 // (0: a trajectory with at most two obstacles and no box -- the fast path)
+#define FIT_XBOX 64
+static_assert(PR_NEXT < FIT_PREP_STRIDE, "prep row overflow");
 
 struct ScenP {
   double cv, cphi, cobs, k0, k1, cv2, cphi2, wb2, wwp, wbnd, vsp, wx, wy, phimax, vmin, vmax;
@@ -162,6 +168,8 @@ struct ScenP {
   int pmask;            // bit j: coupled with aircraft j of the group
   double c0, c1;        // obstacle rows: exponent offset (r^2 for kind 0, 0 for kind 1)
   double cphimax;       // CostBank max mode: weight sqrt(obj_scale*kphi) of the one selected phi row, 0 = mean mode
+  const double *ext;    // the prep row's PR_EXT block (obstacles 2..), read where it is used: it costs the common
+                        // trajectory (<= 2 obstacles) one load of the count per sample and no registers
 };
 
 // Group coupling context of one trajectory (collision rows against the other aircraft of its
@@ -188,6 +196,20 @@ __device__ __forceinline__ void prep_row(const double *__restrict__ sc, double d
   o[PR_K1] = s.o1r > 0.0 ? ((okind & 2) ? 1.0 : FIT_OBS_K / s.o1r) : 0.0;
   o[PR_C0] = (okind & 1) ? s.o0r * s.o0r : 0.0; o[PR_C1] = (okind & 2) ? s.o1r * s.o1r : 0.0;
   o[PR_CPHIMAX] = sc[D2D_SC_BANKMAX] != 0.0 ? sqrt(s.s * K * s.kphi) : 0.0;
+  int next = 0;
+  for (int i = 2; i < D2D_MAX_OBS; ++i) {
+    const double *ob = sc + D2D_SC_OEXT + 3 * (i - 2);
+    double *e = o + PR_EXT + 4 * (i - 2);
+    const bool kind0 = (okind >> i) & 1;
+    e[0] = ob[0]; e[1] = ob[1];
+    e[2] = ob[2] > 0.0 ? (kind0 ? 1.0 : FIT_OBS_K / ob[2]) : 0.0;
+    e[3] = kind0 ? ob[2] * ob[2] : 0.0;
+    if (ob[2] > 0.0) next = i - 1;
+  }
+  const bool bx = sc[D2D_SC_XMIN] < sc[D2D_SC_XMAX], by = sc[D2D_SC_YMIN] < sc[D2D_SC_YMAX];
+  o[PR_BOX + 0] = bx ? sc[D2D_SC_XMIN] : -1e300; o[PR_BOX + 1] = bx ? sc[D2D_SC_XMAX] : 1e300;
+  o[PR_BOX + 2] = by ? sc[D2D_SC_YMIN] : -1e300; o[PR_BOX + 3] = by ? sc[D2D_SC_YMAX] : 1e300;
+  o[PR_NEXT] = (double)(next + ((bx || by) ? FIT_XBOX : 0));
   o[PR_WB2] = s.wbnd * s.wbnd; o[PR_WWP] = s.wwp; o[PR_WBND] = s.wbnd; o[PR_VSP] = s.vsp;
   o[PR_WX] = s.wx; o[PR_WY] = s.wy; o[PR_PHIMAX] = s.phimax; o[PR_VMIN] = s.vmin; o[PR_VMAX] = s.vmax;
   o[PR_O0X] = s.o0x; o[PR_O0Y] = s.o0y; o[PR_O1X] = s.o1x; o[PR_O1Y] = s.o1y;
@@ -206,6 +228,7 @@ __device__ __forceinline__ ScenP load_scenp(const double *__restrict__ p) {
   s.o0x = p[PR_O0X]; s.o0y = p[PR_O0Y]; s.o1x = p[PR_O1X]; s.o1y = p[PR_O1Y];
   s.ccol = p[PR_CCOL]; s.kc = p[PR_KC]; s.pmask = (int)p[PR_PMASK];
   s.c0 = p[PR_C0]; s.c1 = p[PR_C1]; s.cphimax = p[PR_CPHIMAX];
+  s.ext = p + PR_EXT;
   return s;
 }
 
@@ -340,10 +363,47 @@ __device__ __forceinline__ double sample_terms(const ScenP &s, const double Y[6]
     clip1 = arg > FIT_OBS_ARGMAX;
     h1 = s.cobs * exp(clip1 ? FIT_OBS_ARGMAX : arg);
   }
+  // obstacles 2.. and the position box (rare): their rows only enter through sums -- cost, D^T r and the 2x2
+  // position block
+  double xh2 = 0.0, xux = 0.0, xuy = 0.0, xpxx = 0.0, xpxy = 0.0, xpyy = 0.0;
+  const int xcode = (int)s.ext[PR_NEXT - PR_EXT];
+  const int next = xcode & (FIT_XBOX - 1);
+  if (xcode & FIT_XBOX) {                             // rows w_b*dist(x, [xmin, xmax]), w_b*dist(y, [ymin, ymax])
+    const double *bx = s.ext + (PR_BOX - PR_EXT);
+    const double hx = fmax(x - bx[1], 0.0) + fmin(x - bx[0], 0.0);
+    const double hy = fmax(y - bx[3], 0.0) + fmin(y - bx[2], 0.0);
+    xh2 = s.wb2 * (hx * hx + hy * hy);
+    if (WANT_JAC) {                                   // piecewise linear: no curvature, the same block in both modes
+      xux = s.wb2 * hx; xuy = s.wb2 * hy;
+      xpxx = hx != 0.0 ? s.wb2 : 0.0; xpyy = hy != 0.0 ? s.wb2 : 0.0;
+    }
+  }
+  for (int i = 0; i < next; ++i) {
+    const double *ob = s.ext + 4 * i;
+    const double ki = ob[2];
+    if (ki > 0.0) {
+      const double ex = (x - ob[0]) * ki, ey = (y - ob[1]) * ki;
+      const double arg = 0.5 * (ob[3] - (ex * ex + ey * ey));
+      const bool clip = arg > FIT_OBS_ARGMAX;
+      const double h = s.cobs * exp(clip ? FIT_OBS_ARGMAX : arg);
+      xh2 = fma(h, h, xh2);
+      if (WANT_JAC && !clip) {
+        const double ox = -h * ex * ki, oy = -h * ey * ki;
+        xux = fma(ox, h, xux); xuy = fma(oy, h, xuy);
+        if (so == nullptr) {                          // Gauss-Newton: sum of o o^T
+          xpxx = fma(ox, ox, xpxx); xpxy = fma(ox, oy, xpxy); xpyy = fma(oy, oy, xpyy);
+        } else {                                      // second order: h^2 k^2 (2 e e^T - I)
+          const double gi = h * h * ki * ki;
+          xpxx = fma(gi, 2.0 * ex * ex - 1.0, xpxx); xpxy = fma(2.0 * gi * ex, ey, xpxy);
+          xpyy = fma(gi, 2.0 * ey * ey - 1.0, xpyy);
+        }
+      }
+    }
+  }
   const double hphi = fmax(fabs(phi) - s.phimax, 0.0);
   const double hv = fmax(va - s.vmax, 0.0) + fmin(va - s.vmin, 0.0);
   const double r6 = s.wbnd * hphi, r7 = s.wbnd * hv;
-  const double cost = r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3 + h0 * h0 + h1 * h1 + r6 * r6 + r7 * r7;
+  const double cost = r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3 + h0 * h0 + h1 * h1 + r6 * r6 + r7 * r7 + xh2;
   if (WANT_JAC) {
     const double iva = 1.0 / va;
     const double dva_a = a * iva, dva_b = b * iva;
@@ -358,8 +418,8 @@ __device__ __forceinline__ double sample_terms(const ScenP &s, const double Y[6]
     // u = D^T r over all eight rows
     const double tv = s.cv * r0 + s.wbnd * actv * r7;               // multiplies d va
     const double tp = cphi * r1 + s.wbnd * actp * r6;               // multiplies d phi
-    u[0] = s.wwp * r2 + o0x * h0 + o1x * h1;
-    u[1] = s.wwp * r3 + o0y * h0 + o1y * h1;
+    u[0] = s.wwp * r2 + o0x * h0 + o1x * h1 + xux;
+    u[1] = s.wwp * r3 + o0y * h0 + o1y * h1 + xuy;
     u[2] = tv * dva_a + tp * dp_a;
     u[3] = tv * dva_b + tp * dp_b;
     u[4] = tp * dp_c;
@@ -370,8 +430,20 @@ __device__ __forceinline__ double sample_terms(const ScenP &s, const double Y[6]
       const double mp = sqrt(cphi2 + s.wb2 * actp * actp);
       coef[0] = f32x4{(float)(mv * dva_a), 0.f, (float)(mv * dva_b), 0.f};
       coef[1] = f32x4{(float)(mp * dp_a), (float)(mp * dp_c), (float)(mp * dp_b), (float)(mp * dp_d)};
-      coef[2] = f32x4{(float)o0x, 0.f, (float)o0y, 0.f};
-      coef[3] = f32x4{(float)o1x, 0.f, (float)o1y, 0.f};
+      if (xcode == 0) {
+        coef[2] = f32x4{(float)o0x, 0.f, (float)o0y, 0.f};
+        coef[3] = f32x4{(float)o1x, 0.f, (float)o1y, 0.f};
+      } else {
+        // more than two position rows (obstacles, box): their J^T J part at this sample is G0^T P G0 with the 2x2
+        // P = sum o o^T, so two rows carry it whatever their number: the rows of the Cholesky factor of P,
+        // (l11, l21) and (0, l22)
+        const double pxx = o0x * o0x + o1x * o1x + xpxx, pxy = o0x * o0y + o1x * o1y + xpxy;
+        const double pyy = o0y * o0y + o1y * o1y + xpyy;
+        const double l11 = sqrt(pxx), l21 = pxx > 0.0 ? pxy / l11 : 0.0;
+        const double l22 = sqrt(fmax(pyy - l21 * l21, 0.0));
+        coef[2] = f32x4{(float)l11, 0.f, (float)l21, 0.f};
+        coef[3] = f32x4{0.f, 0.f, (float)l22, 0.f};
+      }
     } else {
       // ---- velocity block: mv2 t t^T + kv (I - t t^T)  +  (mp2 - 2 w tp) dphi dphi^T  +  tp f Hess(w)
       const double mv2 = s.cv2 + s.wb2 * actv, mp2 = cphi2 + s.wb2 * actp * actp;
@@ -395,9 +467,9 @@ __device__ __forceinline__ double sample_terms(const ScenP &s, const double Y[6]
       coef[3] = f32x4{(float)m_ad, (float)m_cd, (float)m_bd, (float)m_dd};     // row d
       // ---- position block: sum over the unclipped obstacles of h^2 k^2 (2 e e^T - I)
       const double g0 = clip0 ? 0.0 : h0 * h0 * s.k0 * s.k0, g1 = clip1 ? 0.0 : h1 * h1 * s.k1 * s.k1;
-      const double p_xx = g0 * (2.0 * e0x * e0x - 1.0) + g1 * (2.0 * e1x * e1x - 1.0);
-      const double p_xy = 2.0 * (g0 * e0x * e0y + g1 * e1x * e1y);
-      const double p_yy = g0 * (2.0 * e0y * e0y - 1.0) + g1 * (2.0 * e1y * e1y - 1.0);
+      const double p_xx = g0 * (2.0 * e0x * e0x - 1.0) + g1 * (2.0 * e1x * e1x - 1.0) + xpxx;
+      const double p_xy = 2.0 * (g0 * e0x * e0y + g1 * e1x * e1y) + xpxy;
+      const double p_yy = g0 * (2.0 * e0y * e0y - 1.0) + g1 * (2.0 * e1y * e1y - 1.0) + xpyy;
       so[0] = float2{(float)p_xx, (float)p_xy};
       so[1] = float2{(float)p_xy, (float)p_yy};
     }

@@ -416,7 +416,7 @@ fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_budget,
     // Invariant at the top of the loop: us / cf hold phase 1 at the point qs (= qi) whose cost is c;
     // `fresh` says they still need phase 2 + MFMA (J^T r, J^T J) before the next damped solve.
     if (act) qs[q_slot(lane, g.nq)] = qi;
-    if (lane < FIT_PREP_STRIDE) sp[lane] = prow[lane];
+    for (int i = lane; i < FIT_PREP_STRIDE; i += 64) sp[i] = prow[i];
     double pkr[FIT_PK];
 #pragma unroll
     for (int cc = 0; cc < FIT_PK; ++cc) pkr[cc] = lane < g.K ? pkb[(size_t)cc * g.K + lane] : 0.0;

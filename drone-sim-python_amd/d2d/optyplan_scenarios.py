@@ -1,8 +1,10 @@
 """Planner scenario catalogue in the reference's scenario protocol (src/d2d/optyplan_scenarios.py:
 classes with class attributes name, desc, t0/t1/hz, p0/p1, wind, cost, obj_scale, bounds,
 obstacles, vref, tol, max_iter, ncases, set_case(idx), label(idx)).  Scenario parameters are
-the reference's; kinds of cost the HIP fit does not contract (sharp obstacles `kind 0`, max-bank)
-are listed in single_opt_planner.lower_cost."""
+the reference's; what the HIP fit can and cannot lower is decided in single_opt_planner.lower_cost /
+scen_row (up to d2dhip.MAX_OBS static obstacles of either kind; x/y boxes are verified, not enforced).
+A subset of the reference's catalogue: the cases its planners and the full simulation drive, one per
+kind of cost / obstacle count."""
 import numpy as np
 
 import d2d.opty_utils as d2ou
@@ -56,6 +58,30 @@ class exp_1(exp_0):
     cost, obj_scale = d2ou.CostComposit(obstacles, vsp=exp_0.vref, kobs=1., kvel=1., kbank=1., obs_kind=1), 1.
 
 
+def _maze(vsp, **kw):
+    discs = ((25, 0, 15), (55, 7.5, 12), (80, -10, 12))
+    return discs, d2ou.CostComposit(discs, vsp=vsp, **kw)
+
+
+class exp_4_2(exp_0):
+    name, desc = 'exp4', 'obstacles - maze'
+    t1, p1 = 15., (100., 0., 0, 0., 10.)
+    obstacles, cost = _maze(15., kobs=0.5, kvel=0.5, kbank=1.)
+    obj_scale = 1.e-2
+    x_constraint, y_constraint = (-5., 105.), (-15., 35.)
+    phi_constraint = (-np.deg2rad(40.), np.deg2rad(40.))
+    v_constraint = (9., 15.)
+
+
+class exp_5(exp_0):
+    name = 'exp5'
+    t0, p0 = 0., (0., 40., 0, 0., 10.)
+    t1, p1 = 12., (100., 40., 0, 0., 10.)
+    obstacles = [(20. * i, 20. * j, 10.) for i in range(5) for j in range(5) if (i + j) % 2]     # 12 discs, checkerboard
+    cost = d2ou.CostComposit(obstacles, vsp=15., kobs=0.5, kvel=10., kbank=1.)
+    phi_constraint = (-np.deg2rad(40.), np.deg2rad(40.))
+
+
 class exp_13:
     name, desc = 'exp13 - some traj', 'just going'
     ncases = 1
@@ -96,7 +122,7 @@ class exp_14(exp_0):
     def label(idx): return ''
 
 
-scens = [exp_0, exp_0_1, exp_0_2, exp_1, exp_13, exp_14]
+scens = [exp_0, exp_0_1, exp_0_2, exp_1, exp_4_2, exp_5, exp_13, exp_14]
 
 
 def desc_all():

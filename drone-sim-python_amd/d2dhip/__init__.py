@@ -12,10 +12,19 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('D2D_LIB') or os.path.join(os.path.dirname(_HERE), 'lib', 'libd2dhip.so')   # D2D_LIB: A/B builds
 
-SCEN_STRIDE = 32
+SCEN_STRIDE = 80
+MAX_OBS = 16
 (SC_X0, SC_Y0, SC_PSI0, SC_X1, SC_Y1, SC_PSI1, SC_VREF, SC_VSP, SC_KV, SC_KPHI, SC_KOBS, SC_S,
  SC_WWP, SC_WX, SC_WY, SC_GOLEFT, SC_O0X, SC_O0Y, SC_O0R, SC_O1X, SC_O1Y, SC_O1R, SC_WBND,
- SC_PHIMAX, SC_VMIN, SC_VMAX, SC_KCOL, SC_RCOL, SC_SCOL, SC_PMASK, SC_OKIND, SC_BANKMAX) = range(32)
+ SC_PHIMAX, SC_VMIN, SC_VMAX, SC_KCOL, SC_RCOL, SC_SCOL, SC_PMASK, SC_OKIND, SC_BANKMAX, SC_OEXT) = range(33)
+SC_XMIN, SC_XMAX, SC_YMIN, SC_YMAX = range(SC_OEXT + 3 * (MAX_OBS - 2), SC_OEXT + 3 * (MAX_OBS - 2) + 4)   # soft position box
+
+
+def obs_col(i):
+    """First of the three columns (x, y, r) of static obstacle i in a scenario row (include/d2d.h D2D_SC_OEXT)."""
+    return SC_O0X + 3 * i if i < 2 else SC_OEXT + 3 * (i - 2)
+
+
 ST_RUNNING, ST_CONVERGED, ST_MAXITER, ST_NONFINITE, ST_STALLED = range(5)
 
 

@@ -114,7 +114,7 @@ def implement_controller(n_ac, time, x_ref, y_ref, v, w, X0s):
 
 
 def plan_batch(scen_rows, K, duration, obj_scale_over_n, q0=None, **solve_kw):
-    """Batched planning entry point: scen_rows (B, 32) in the d2dhip layout -> dict with device
+    """Batched planning entry point: scen_rows (B, d2dhip.SCEN_STRIDE) in the d2dhip layout -> dict with device
     tensors q, cost, iters, status and host stats."""
     import single_opt_planner as sop
     ctx = d2dhip.default_context()

@@ -61,7 +61,8 @@ class Planner:
         s = self.obj_scale / N / n                   # src/d2d/multiopty_utils.py:62
         plan = sop.get_plan(N, self.duration, s, low[1], low[2])
         rows = np.stack([sop.scen_row(p0, p1, self.scen.vref, low if i == 0 else low[:4] + ((),) + low[5:], s,
-                                      self.wind.w, self.scen.phi_constraint, self.scen.v_constraint)
+                                      self.wind.w, self.scen.phi_constraint, self.scen.v_constraint,
+                                      x_c=self.scen.x_constraint, y_c=self.scen.y_constraint)
                          for i, (p0, p1) in enumerate(zip(self.scen.p0s, self.scen.p1s))])
         # (static obstacles act on aircraft 0 only, src/d2d/multiopty_utils.py:74)
         if low[4]:
@@ -84,7 +85,7 @@ class Planner:
             cost, iters, status, stats = plan.solve(dsc, q, max_iter=max_iter)
         _, Xs = plan.sample(dsc, q)
         Xs = Xs.cpu().numpy()                        # (n, 5, N)
-        sop.check_boxes(Xs[:, 0], Xs[:, 1], self.scen.x_constraint, self.scen.y_constraint)
+        viol = sop.box_violation(Xs[:, 0], Xs[:, 1], self.scen.x_constraint, self.scen.y_constraint)
         self.fit_q, self.fit_plan, self.fit_scen = q, plan, dsc
         self.fit_coefs = plan.coeffs(dsc, q).cpu().numpy()
         sol = np.zeros(self.prob.num_free)
@@ -92,7 +93,8 @@ class Planner:
             sol[self._slice_x[i]], sol[self._slice_y[i]], sol[self._slice_psi[i]] = Xs[i, 0], Xs[i, 1], Xs[i, 2]
             sol[self._slice_phi[i]], sol[self._slice_v[i]] = Xs[i, 3], Xs[i, 4]
         st = status.cpu().numpy()
-        info = {'status': st.tolist(), 'iters': iters.cpu().numpy().tolist(), 'obj_val': float(cost.sum().item())}
+        info = {'status': st.tolist(), 'iters': iters.cpu().numpy().tolist(), 'obj_val': float(cost.sum().item()),
+                'box_violation': viol}
         return sol, info
 
     def run(self, initial_guess=None, tol=1e-8, max_iter=500):

@@ -60,14 +60,14 @@ def lower_cost(cost):
     raise NotImplementedError(f'cost plug-in {type(cost).__name__} has no HIP lowering')
 
 
-def scen_row(p0, p1, vref, lowered, s, wind, phi_c, v_c, go_left=-1.):
+def scen_row(p0, p1, vref, lowered, s, wind, phi_c, v_c, go_left=-1., x_c=None, y_c=None):
     """One d2dhip scenario row.  The reference's symbolic model adds the wind with the opposite
     sign to the plant (src/d2d/opty_utils.py:42-44 vs src/d2d/dynamic.py:18-19); the planner keeps
     that convention, hence -w."""
     vsp, kv, kphi, kobs, obss = lowered[:5]
     okind, bankmax = lowered[7], lowered[8]
-    if len(obss) > 2:
-        raise NotImplementedError('at most two static obstacles per trajectory in this build')
+    if len(obss) > d2dhip.MAX_OBS:
+        raise NotImplementedError(f'at most {d2dhip.MAX_OBS} static obstacles per trajectory in this build')
     r = np.zeros(d2dhip.SCEN_STRIDE)
     r[d2dhip.SC_X0], r[d2dhip.SC_Y0], r[d2dhip.SC_PSI0] = p0[0], p0[1], p0[2]
     r[d2dhip.SC_X1], r[d2dhip.SC_Y1], r[d2dhip.SC_PSI1] = p1[0], p1[1], p1[2]
@@ -76,20 +76,28 @@ def scen_row(p0, p1, vref, lowered, s, wind, phi_c, v_c, go_left=-1.):
     r[d2dhip.SC_WWP], r[d2dhip.SC_WBND], r[d2dhip.SC_GOLEFT] = W_WAYPOINT, W_BOUND, go_left
     r[d2dhip.SC_WX], r[d2dhip.SC_WY] = -wind[0], -wind[1]
     for i, o in enumerate(obss):
-        r[d2dhip.SC_O0X + 3 * i:d2dhip.SC_O0X + 3 * i + 3] = o
+        c = d2dhip.obs_col(i)
+        r[c:c + 3] = o
     r[d2dhip.SC_PHIMAX] = max(abs(phi_c[0]), abs(phi_c[1]))
     r[d2dhip.SC_VMIN], r[d2dhip.SC_VMAX] = v_c
     r[d2dhip.SC_OKIND], r[d2dhip.SC_BANKMAX] = okind, bankmax
+    # x/y_constraint boxes (src/single_opt_planner.py:56-57): soft bound rows like phi / v
+    if x_c is not None:
+        r[d2dhip.SC_XMIN], r[d2dhip.SC_XMAX] = x_c
+    if y_c is not None:
+        r[d2dhip.SC_YMIN], r[d2dhip.SC_YMAX] = y_c
     return r
 
 
-def check_boxes(x, y, x_constraint, y_constraint):
-    """x/y_constraint boxes are not rows of the fit: a solution that stays inside them is also the solution
-    of the boxed problem; one that leaves them is refused instead of being returned as if the box held."""
-    for name, v, box in (('x', x, x_constraint), ('y', y, y_constraint)):
-        if box is not None and (np.min(v) < box[0] - 1e-9 or np.max(v) > box[1] + 1e-9):
-            raise NotImplementedError(f'the plan leaves the {name}_constraint box {tuple(box)} '
-                                      f'([{np.min(v):.3f}, {np.max(v):.3f}]): binding position boxes have no kernel')
+def box_violation(x, y, x_constraint, y_constraint):
+    """Largest distance (m) by which the sampled plan leaves the x/y_constraint boxes.  The boxes are soft bound
+    rows of the fit (weight W_BOUND, like phi / v), so a binding box is honoured up to a small overshoot that
+    the planners report as info['box_violation'] instead of hiding it."""
+    v = 0.0
+    for val, box in ((x, x_constraint), (y, y_constraint)):
+        if box is not None:
+            v = max(v, float(box[0] - np.min(val)), float(np.max(val) - box[1]))
+    return max(v, 0.0)
 
 
 class _FitProblem:
@@ -153,7 +161,7 @@ class Planner:
         s = self.obj_scale / N
         plan = get_plan(N, self.duration, s, low[1], low[2])
         row = scen_row(self.exp.p0, self.exp.p1, self.exp.vref, low, s, self.wind.w, self.exp.phi_constraint,
-                       self.exp.v_constraint)
+                       self.exp.v_constraint, x_c=self.exp.x_constraint, y_c=self.exp.y_constraint)
         dsc = ctx.dev(row[None, :])
         xy = np.stack([x0[self._slice_x], x0[self._slice_y]])[None]
         q = plan.project(dsc, ctx.dev(xy))
@@ -161,11 +169,11 @@ class Planner:
         cost, iters, status, stats = plan.solve(dsc, q, max_iter=max_iter)
         _, Xs = plan.sample(dsc, q)
         Xh = Xs.cpu().numpy()[0]
-        check_boxes(Xh[0], Xh[1], self.exp.x_constraint, self.exp.y_constraint)
         self.fit_q, self.fit_plan, self.fit_scen = q, plan, dsc
         self.fit_coefs = plan.coeffs(dsc, q).cpu().numpy()[0]
         info = {'status': int(status.cpu().numpy()[0]), 'iters': int(iters.cpu().numpy()[0]),
-                'obj_val': float(cost.cpu().numpy()[0]), 'status_msg': ('running', 'converged', 'max_iter', 'non-finite', 'stalled')[int(status.cpu().numpy()[0])]}
+                'obj_val': float(cost.cpu().numpy()[0]),
+                'box_violation': box_violation(Xh[0], Xh[1], self.exp.x_constraint, self.exp.y_constraint), 'status_msg': ('running', 'converged', 'max_iter', 'non-finite', 'stalled')[int(status.cpu().numpy()[0])]}
         return Xs.cpu().numpy()[0].reshape(-1), info
 
     def run(self, initial_guess=None):

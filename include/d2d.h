@@ -186,7 +186,9 @@ int d2d_lqr(d2d_ctx *ctx, int n, const double *A, const double *B, const double 
  * ------------------------------------------------------------------------------------ */
 
 /* one scenario row: double[D2D_SCEN_STRIDE] per trajectory (dev [B][D2D_SCEN_STRIDE]) */
-#define D2D_SCEN_STRIDE 32
+#define D2D_SCEN_STRIDE 80
+#define D2D_MAX_OBS 16         /* static obstacles per trajectory (CostObstacles, src/d2d/opty_utils.py:136-147;
+                                 the reference's largest scenario list, exp_5, holds 12)                   */
 enum {
   D2D_SC_X0 = 0, D2D_SC_Y0, D2D_SC_PSI0, D2D_SC_X1, D2D_SC_Y1, D2D_SC_PSI1,
   D2D_SC_VREF,  /* end-condition speed and 'tri' waypoint speed                */
@@ -206,7 +208,15 @@ enum {
   D2D_SC_PMASK, /* bit j set: coupled with aircraft j of the same group (stored as a double) */
   D2D_SC_OKIND, /* bit i set: obstacle i is CostObstacle kind 0, e = clip(exp(r^2 - d^2), 0, 1e3)
                    (src/d2d/opty_utils.py:108-111); clear: kind 1 (stored as a double)          */
-  D2D_SC_BANKMAX /* != 0: CostBank(use_mean=False): obj_scale*max(phi^2) instead of the mean (:72-73) */
+  D2D_SC_BANKMAX, /* != 0: CostBank(use_mean=False): obj_scale*max(phi^2) instead of the mean (:72-73) */
+  D2D_SC_OEXT,    /* obstacles 2 .. D2D_MAX_OBS-1: (x, y, r) of obstacle i at D2D_SC_OEXT + 3*(i-2) (r<=0: absent;
+                     D2D_SC_OKIND bit i)                                                                        */
+  D2D_SC_XMIN = D2D_SC_OEXT + 3 * (D2D_MAX_OBS - 2),
+  D2D_SC_XMAX, D2D_SC_YMIN, D2D_SC_YMAX
+                  /* x_constraint / y_constraint boxes of the scenario (src/single_opt_planner.py:56-57, src/multi_opt_planner.py:63-64): soft bound
+                     rows w_b*dist(x, [XMIN, XMAX]), w_b*dist(y, [YMIN, YMAX]) with the weight D2D_SC_WBND of the
+                     phi / v rows; an axis with MIN >= MAX (e.g. both zero) has no box.  The last two columns of
+                     the row are reserved (zero).                                                                */
 };
 #define D2D_FIT_NROW 8        /* residual rows per sample */
 #define D2D_FIT_MAX_S 6

@@ -186,11 +186,19 @@ class FitBasis:
 # scenario parameters of one trajectory
 # ----------------------------------------------------------------------------------
 # scen row layout (float64[SCEN_STRIDE]); identical to include/d2d.h D2D_SCEN_*
-SCEN_STRIDE = 32
+SCEN_STRIDE = 80
+MAX_OBS = 16
 (SC_X0, SC_Y0, SC_PSI0, SC_X1, SC_Y1, SC_PSI1, SC_VREF, SC_VSP, SC_KV, SC_KPHI,
  SC_KOBS, SC_S, SC_WWP, SC_WX, SC_WY, SC_GOLEFT,
  SC_O0X, SC_O0Y, SC_O0R, SC_O1X, SC_O1Y, SC_O1R, SC_WBND, SC_PHIMAX, SC_VMIN, SC_VMAX,
- SC_KCOL, SC_RCOL, SC_SCOL, SC_PMASK, SC_OKIND, SC_BANKMAX) = range(32)
+ SC_KCOL, SC_RCOL, SC_SCOL, SC_PMASK, SC_OKIND, SC_BANKMAX, SC_OEXT) = range(33)
+# (x, y, r) columns of obstacle i: the first two sit at SC_O0X.., obstacles 2.. at SC_OEXT + 3*(i-2)
+SC_OBS = tuple((c, c + 1, c + 2) for c in [SC_O0X, SC_O1X] + [SC_OEXT + 3 * j for j in range(MAX_OBS - 2)])
+SC_XMIN, SC_XMAX, SC_YMIN, SC_YMAX = range(SC_OEXT + 3 * (MAX_OBS - 2), SC_OEXT + 3 * (MAX_OBS - 2) + 4)
+# x_constraint / y_constraint boxes (src/single_opt_planner.py:56-57) as soft rows w_b*dist(x,[XMIN,XMAX]), w_b*dist(y,..):
+# an axis with MIN >= MAX has none
+SC_O2X, SC_O2Y, SC_O2R = SC_OBS[2]
+SC_O3X, SC_O3Y, SC_O3R = SC_OBS[3]
 # SC_KCOL/RCOL/SCOL: collision weight, radius and scale (obj_scale/N, src/d2d/multiopty_utils.py:132);
 # SC_PMASK: bit j set <=> coupled with aircraft j of the same group (CostCollision pairs);
 # SC_OKIND: bit i set <=> obstacle i is CostObstacle kind 0 (src/d2d/opty_utils.py:108-111);
@@ -233,7 +241,25 @@ def waypoints(sc, K, duration):
 # ----------------------------------------------------------------------------------
 # residuals / Jacobian in reduced coordinates q = [q_x(24), q_y(24)]
 # ----------------------------------------------------------------------------------
-NROW = 8   # rows per sample: v, phi, wp_x, wp_y, obs0, obs1, hinge_phi, hinge_v
+NROW = 8   # rows per sample: v, phi, wp_x, wp_y, obs0, obs1, hinge_phi, hinge_v; obstacles 2.. (rare) follow at NROW..,
+           # then the collision rows of a coupled group
+
+
+def n_extra_obs(sc):
+    """Number of extra obstacle rows: index of the last present obstacle beyond the first two, + 1 - 2."""
+    n = 0
+    for i in range(2, MAX_OBS):
+        if sc[SC_OBS[i][2]] > 0:
+            n = i - 1
+    return n
+
+
+def obs_row(i):
+    return 4 + i if i < 2 else NROW + (i - 2)
+
+
+def has_box(sc):
+    return bool(sc[SC_XMIN] < sc[SC_XMAX] or sc[SC_YMIN] < sc[SC_YMAX])
 
 
 def flat_outputs(basis, sc, q):
@@ -258,7 +284,7 @@ def flatness(Y, sc):
 
 
 def residuals(basis, sc, q, wp=None, want_jac=False, others=None):
-    """r (K,NROW+n_others) and optionally the partials D (K,rows,6) wrt (x,y,xd,yd,xdd,ydd).
+    """r (K,NROW+n_extra_obs+(2 if box)+n_others) and optionally the partials D (K,rows,6) wrt (x,y,xd,yd,xdd,ydd).
 
     others (n_others,2,K): sampled positions of the coupled aircraft (held fixed): one extra row
     sqrt(s_col*kcol*e) each, e as CostCollision (src/d2d/multiopty_utils.py:120-153)."""
@@ -274,7 +300,10 @@ def residuals(basis, sc, q, wp=None, want_jac=False, others=None):
     phi = np.arctan(w)
     s = sc[SC_S]
     cv = math.sqrt(s * sc[SC_KV]); cphi = math.sqrt(s * sc[SC_KPHI]); cobs = math.sqrt(s * sc[SC_KOBS])
-    r = np.zeros((K, NROW + n_oth))
+    n_x = n_extra_obs(sc)
+    BROW = NROW + n_x                            # the two position-box rows (when the scenario has a box)
+    CROW = BROW + (2 if has_box(sc) else 0)      # first collision row
+    r = np.zeros((K, CROW + n_oth))
     r[:, 0] = cv * (va - sc[SC_VSP])
     wphi = np.full(K, cphi)                      # weight of the phi row of every sample
     if sc[SC_BANKMAX] != 0:                      # CostBank max mode: obj_scale*max(phi^2) = one row, at argmax
@@ -284,7 +313,7 @@ def residuals(basis, sc, q, wp=None, want_jac=False, others=None):
     r[:, 2] = sc[SC_WWP] * (x - wp[0])
     r[:, 3] = sc[SC_WWP] * (y - wp[1])
     obs = []
-    for i, (ox, oy, orr) in enumerate(((SC_O0X, SC_O0Y, SC_O0R), (SC_O1X, SC_O1Y, SC_O1R))):
+    for i, (ox, oy, orr) in enumerate(SC_OBS):
         rr = sc[orr]
         if rr > 0:
             if (int(sc[SC_OKIND]) >> i) & 1:     # kind 0: e = clip(exp(r^2 - d^2), 0, 1e3); the row sqrt(s*kobs*e) is flat on the clip
@@ -298,24 +327,31 @@ def residuals(basis, sc, q, wp=None, want_jac=False, others=None):
                 ddx = (x - sc[ox]) * kk; ddy = (y - sc[oy]) * kk
                 h = cobs * np.exp(-0.5 * (ddx * ddx + ddy * ddy))     # sqrt(s*kobs*e)
                 live = 1.0
-            r[:, 4 + i] = h
+            r[:, obs_row(i)] = h
             obs.append((i, ddx, ddy, h * live, kk))
     wb = sc[SC_WBND]
     hphi = np.maximum(np.abs(phi) - sc[SC_PHIMAX], 0.0)
     hv = np.maximum(va - sc[SC_VMAX], 0.0) + np.minimum(va - sc[SC_VMIN], 0.0)
     r[:, 6] = wb * hphi
     r[:, 7] = wb * hv
+    if has_box(sc):
+        xlo, xhi = (sc[SC_XMIN], sc[SC_XMAX]) if sc[SC_XMIN] < sc[SC_XMAX] else (-np.inf, np.inf)
+        ylo, yhi = (sc[SC_YMIN], sc[SC_YMAX]) if sc[SC_YMIN] < sc[SC_YMAX] else (-np.inf, np.inf)
+        hx = np.maximum(x - xhi, 0.0) + np.minimum(x - xlo, 0.0)
+        hy = np.maximum(y - yhi, 0.0) + np.minimum(y - ylo, 0.0)
+        r[:, BROW] = wb * hx
+        r[:, BROW + 1] = wb * hy
     col = []
     if n_oth:
         ccol = math.sqrt(sc[SC_SCOL] * sc[SC_KCOL]); kc = OBS_K / sc[SC_RCOL]
         for m in range(n_oth):
             ex = (x - others[m][0]) * kc; ey = (y - others[m][1]) * kc
             h = ccol * np.exp(-0.5 * (ex * ex + ey * ey))
-            r[:, NROW + m] = h
+            r[:, CROW + m] = h
             col.append((ex, ey, h, kc))
     if not want_jac:
         return r
-    D = np.zeros((K, NROW + n_oth, 6))
+    D = np.zeros((K, CROW + n_oth, 6))
     dva_a = a / va; dva_b = b / va
     D[:, 0, 2] = cv * dva_a; D[:, 0, 3] = cv * dva_b
     f = 1.0 / (1.0 + w * w)
@@ -329,15 +365,17 @@ def residuals(basis, sc, q, wp=None, want_jac=False, others=None):
     D[:, 2, 0] = sc[SC_WWP]
     D[:, 3, 1] = sc[SC_WWP]
     for (i, ddx, ddy, h, kk) in obs:
-        D[:, 4 + i, 0] = -h * ddx * kk
-        D[:, 4 + i, 1] = -h * ddy * kk
+        D[:, obs_row(i), 0] = -h * ddx * kk
+        D[:, obs_row(i), 1] = -h * ddy * kk
     act = (hphi > 0) * np.sign(phi)
     D[:, 6, 2:6] = wb * act[:, None] * dphi
     actv = ((va > sc[SC_VMAX]) | (va < sc[SC_VMIN])).astype(float)
     D[:, 7, 2] = wb * actv * dva_a; D[:, 7, 3] = wb * actv * dva_b
+    if has_box(sc):
+        D[:, BROW, 0] = wb * (hx != 0); D[:, BROW + 1, 1] = wb * (hy != 0)
     for m, (ex, ey, h, kc) in enumerate(col):
-        D[:, NROW + m, 0] = -h * ex * kc
-        D[:, NROW + m, 1] = -h * ey * kc
+        D[:, CROW + m, 0] = -h * ex * kc
+        D[:, CROW + m, 1] = -h * ey * kc
     return r, D
 
 
@@ -403,13 +441,13 @@ def curvature_blocks(basis, sc, q, wp=None):
     kphi = wphi * r[:, 1] + wb * act * r[:, 6]
     W[:, 2:6, 2:6] += kphi[:, None, None] * Hphi
     # obstacles: h = cobs*exp(0.5*(c0 - |e|^2)), e = kk*(p - o): Hessian h*kk^2*(e e^T - I) on (x, y)
-    for i, (ox, oy, orr) in enumerate(((SC_O0X, SC_O0Y, SC_O0R), (SC_O1X, SC_O1Y, SC_O1R))):
+    for i, (ox, oy, orr) in enumerate(SC_OBS):
         rr = sc[orr]
         if rr > 0:
             kind0 = (int(sc[SC_OKIND]) >> i) & 1
             kk = 1.0 if kind0 else OBS_K / rr
             e = np.stack([(x - sc[ox]) * kk, (y - sc[oy]) * kk], 1)
-            h = r[:, 4 + i]
+            h = r[:, obs_row(i)]
             live = np.ones(K)
             if kind0:
                 live = (np.exp(rr * rr - np.sum(e * e, 1)) <= OBS_CLIP).astype(float)
@@ -628,7 +666,7 @@ def synth_scenarios(B, seed=20241008, rank=0, n_obs=2, wbnd=1.0, wwp=0.02):
     along = rng.uniform(0.2, 0.8, (B, 2)); lat = rng.uniform(5, 15, (B, 2)) * rng.choice([-1.0, 1.0], (B, 2))
     rad = rng.uniform(5, 15, (B, 2))
     u = (p1 - p0) / dist[:, None]; nrm = np.stack([-u[:, 1], u[:, 0]], 1)
-    for i, (ox, oy, orr) in enumerate(((SC_O0X, SC_O0Y, SC_O0R), (SC_O1X, SC_O1Y, SC_O1R))):
+    for i, (ox, oy, orr) in enumerate(SC_OBS[:2]):
         c = p0 + along[:, i, None] * (p1 - p0) + lat[:, i, None] * nrm
         sc[:, ox], sc[:, oy] = c[:, 0], c[:, 1]
         sc[:, orr] = rad[:, i] if i < n_obs else 0.0

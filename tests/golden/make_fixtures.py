@@ -229,6 +229,24 @@ def fx_costs():
     np.savez(os.path.join(OUT, 'costs.npz'), **out)
 
 
+def fx_costs3():
+    """Three static obstacles (the list of the reference's exp_6 / exp_7 scenarios, d2d/optyplan_scenarios.py) through the
+    reference's CostObstacles / CostComposit, both obstacle kinds.  Own generator: the other fixtures stay byte-identical."""
+    r3 = np.random.default_rng(33)
+    N = 50
+    p = _FakeSingle(N, 0.7)
+    obss = [(25.0, 0.0, 15.0), (55.0, 7.5, 12.0), (80.0, -10.0, 12.0)]
+    free = np.concatenate([r3.uniform(0, 100, N), r3.uniform(-30, 30, N), r3.uniform(-3, 3, N),
+                           r3.uniform(-0.7, 0.7, N), r3.uniform(9, 15, N)])
+    out = dict(free=free, obj_scale=0.7, N=N, obss=np.array(obss))
+    cases = {'obsts_k1': d2ou.CostObstacles(obss, 1), 'obsts_k0': d2ou.CostObstacles(obss, 0),
+             'composit_k1': d2ou.CostComposit(obss, 12.0, kobs=0.5, kvel=10.0, kbank=1.0, obs_kind=1),
+             'composit_k0': d2ou.CostComposit(obss, 12.0, kobs=0.5, kvel=10.0, kbank=1.0, obs_kind=0)}
+    for k, cobj in cases.items():
+        out[k + '_cost'] = cobj.cost(free, p); out[k + '_grad'] = cobj.cost_grad(free, p)
+    np.savez(os.path.join(OUT, 'costs_obs3.npz'), **out)
+
+
 def fx_guess_poly():
     out = {}
     out['timing_in'] = np.array([[0, 10, 10], [0, 4.9, 10], [0, 7, 10], [0, 3, 10], [0, 12, 10], [0, 10, 50], [0.5, 6.0, 10]], float)
@@ -391,7 +409,7 @@ def fx_dfff():
 if __name__ == '__main__':
     only = sys.argv[1:]
     for f in (fx_plant, fx_flatness_ctrl, fx_guidance, fx_states_over_time, fx_costs, fx_guess_poly,
-              fx_fit_cost, fx_planner_goldens, fx_tracking_trace, fx_dfff):
+              fx_fit_cost, fx_planner_goldens, fx_tracking_trace, fx_dfff, fx_costs3):
         if only and f.__name__ not in only:
             continue
         f(); print('wrote', f.__name__)

@@ -297,6 +297,72 @@ def test_second_order_mode_follows_the_oracle(ctx, plan, obasis):
     assert n_same_it >= int(0.7 * B), n_same_it                           # (rounding ties in a gain ratio shift a path)
 
 
+def test_more_than_two_obstacles(ctx, plan, obasis, monkeypatch):
+    """Obstacles 2.. (scenario columns 32..; the reference's exp_4_2 carries three discs, exp_5 twelve): cost, J^T r and
+    J^T J (their rows contracted into two through the 2x2 Cholesky factor) against the oracle, then the fused solve in
+    both modes against the oracle's LM and the split path."""
+    import d2dhip
+    B = 24
+    sc = F.set_scale(F.synth_scenarios(B, seed=91), 0.1, K)
+    rng = np.random.default_rng(4)
+    q0 = np.array([F.initial_guess(obasis, sc[i]) for i in range(B)])
+    qh = q0 + rng.normal(0, 0.3, q0.shape)
+    for i in range(B):
+        Y = F.flat_outputs(obasis, sc[i], qh[i])
+        if i % 6 != 5:                                # obstacle 2: kind 1 disc near the path
+            sc[i, F.SC_O2X], sc[i, F.SC_O2Y], sc[i, F.SC_O2R] = Y[0, 0, 12] + 3.0, Y[0, 1, 12] - 2.0, 7.0
+        if i % 2 and i % 6 != 5:                      # obstacle 3: every other row, kind 0 on the path for i % 4 == 3
+            k0 = i % 4 == 3
+            sc[i, F.SC_O3X], sc[i, F.SC_O3Y], sc[i, F.SC_O3R] = Y[0, 0, 33] + 0.6, Y[0, 1, 33] - 0.5, (3.0 if k0 else 6.0)
+            sc[i, F.SC_OKIND] = 0b1000 if k0 else 0
+        if i % 6 == 4:                                # only obstacle 2: the first two absent
+            sc[i, F.SC_O0R] = sc[i, F.SC_O1R] = 0.0
+        if i % 6 == 2:                                # a dozen discs (checkerboard around the path, like exp_5)
+            for j in range(4, 12):
+                ox, oy, orr = F.SC_OBS[j]
+                k = 4 + 5 * (j - 4)
+                sc[i, ox], sc[i, oy], sc[i, orr] = Y[0, 0, k] + (6.0 if j % 2 else -6.0), Y[0, 1, k] + 5.0, 8.0
+        if i % 4 == 0 or i % 6 == 5:                  # soft position box that binds on part of the path
+            sc[i, F.SC_XMIN], sc[i, F.SC_XMAX] = np.quantile(Y[0, 0], 0.15), np.quantile(Y[0, 0], 0.9)
+            if i % 8 == 0:
+                sc[i, F.SC_YMIN], sc[i, F.SC_YMAX] = np.quantile(Y[0, 1], 0.25), Y[0, 1].max() + 4.0
+    assert {F.n_extra_obs(r) for r in sc} == {0, 1, 2, 10}
+    assert sum(F.has_box(r) for r in sc) >= B // 4 and any(F.has_box(r) and F.n_extra_obs(r) == 0 for r in sc)
+    dsc = ctx.dev(sc)
+    cost, g, H = plan.eval(dsc, ctx.dev(qh))
+    cost, g, H = cost.cpu().numpy(), g.cpu().numpy(), H.cpu().numpy()
+    for i in range(B):
+        co, go, Ho = F.eval_normal(obasis, sc[i], qh[i])
+        assert abs(cost[i] - co) <= 1e-11 * co, (i, cost[i], co)
+        assert np.abs(g[i] - go).max() <= 1e-10 * max(1.0, np.abs(go).max()), i
+        assert np.abs(H[i] - Ho).max() <= 2e-5 * np.abs(Ho).max(), (i, np.abs(H[i] - Ho).max() / np.abs(Ho).max())
+        assert np.array_equal(H[i], H[i].T)
+    # solves: Gauss-Newton fused vs split; default (second-order switch) vs the oracle's LM
+    qa = ctx.dev(q0.copy()); ca, ia, sa, _ = plan.solve(dsc, qa, so_lambda=0.0)
+    monkeypatch.setenv('D2D_FIT_SPLIT', '1')
+    plan2 = d2dhip.FitPlan(ctx, S_, K, DUR, WREF)
+    monkeypatch.delenv('D2D_FIT_SPLIT')
+    try:
+        qb = ctx.dev(q0.copy()); cb, ib, sb, _ = plan2.solve(dsc, qb)
+    finally:
+        plan2.close()
+    ca, cb, ia, ib = (t.cpu().numpy() for t in (ca, cb, ia, ib))
+    same = ia == ib
+    assert same.mean() >= 0.8, same.mean()
+    np.testing.assert_allclose(ca[same], cb[same], rtol=1e-9)
+    qc = ctx.dev(q0.copy()); cc, ic, sc_, stats = plan.solve(dsc, qc)
+    cc, ic, qc = cc.cpu().numpy(), ic.cpu().numpy(), qc.cpu().numpy()
+    assert stats[3] > 0
+    n_same_cost = n_same_it = 0
+    for i in range(B):
+        assert abs(cc[i] - F.cost(obasis, sc[i], qc[i])) <= 1e-10 * cc[i]
+        qo, co, ito, sto = F.lm_solve(obasis, sc[i], hess_dtype=np.float32, chol_dtype=np.float32)
+        n_same_cost += int(abs(cc[i] - co) <= 1e-6 * co)
+        n_same_it += int(abs(int(ic[i]) - ito) <= 2)
+    assert n_same_cost >= B - 3, n_same_cost
+    assert n_same_it >= int(0.7 * B), n_same_it
+
+
 def test_small_and_other_shapes(ctx):
     """B = 1, and a plan with another horizon / segment count (K = 71, S = 4)."""
     import d2dhip

@@ -229,7 +229,7 @@ def test_single_planner_exp14_and_wind():
 
 
 def test_planner_cost_variants_and_boxes():
-    """CostComposit with kind-0 obstacles, CostBank max mode, and the x/y box policy (verified or refused)."""
+    """CostComposit with kind-0 obstacles, CostBank max mode, and the x/y boxes (soft bound rows)."""
     import d2d.opty_utils as d2ou
     import d2d.optyplan_scenarios as d2oscen
     import single_opt_planner as sop
@@ -251,14 +251,57 @@ def test_planner_cost_variants_and_boxes():
     pb.run()
     assert bankmax.cost.cost(pb.solution, pb) <= pb.info['obj_val'] * (1 + 1e-9) + 1e-12
 
-    class boxed(d2oscen.exp_14):
-        y_constraint = (-1., 1.)                       # the dog-leg of this scenario needs more room
-    with pytest.raises(NotImplementedError, match='y_constraint'):
-        sop.Planner(boxed, initialize=True).run()
+    # x/y boxes are soft bound rows of the fit: a binding one bends the plan, a roomy one changes nothing
+    # (exp_0, the U-turn, swings 50 m out in +x; the box allows half of that)
+    free = sop.Planner(d2oscen.exp_0, initialize=True); free.run()
+    assert free.info['box_violation'] == 0.0 and np.max(free.sol_x) > 30.0
+    lim = float(np.max(free.sol_x)) / 2
 
-    class roomy(d2oscen.exp_14):
+    class boxed(d2oscen.exp_0):
+        x_constraint = (-1e3, lim)
+    pbx = sop.Planner(boxed, initialize=True); pbx.run()
+    assert lim - 1.0 < np.max(pbx.sol_x) < lim + 0.6 and 0.0 < pbx.info['box_violation'] < 0.6, (np.max(pbx.sol_x), lim, pbx.info)
+    assert pbx.info['obj_val'] > free.info['obj_val']             # the constrained optimum costs more
+
+    class roomy(d2oscen.exp_0):
         x_constraint, y_constraint = (-500., 500.), (-500., 500.)
-    sop.Planner(roomy, initialize=True).run()
+    pr = sop.Planner(roomy, initialize=True); pr.run()
+    np.testing.assert_allclose(pr.solution, free.solution, rtol=0, atol=1e-9)
+
+
+def test_planner_three_and_twelve_obstacles():
+    """The reference's three-disc 'maze' (exp_4_2, flown in 9 s: its 15 s make the box and the bank limit conflict) and
+    the twelve-disc checkerboard (exp_5) through the single planner: the obstacle rows beyond the first two and the
+    y box of the maze are lowered into the scenario row's extension columns; the fixed point the kernel reaches is a
+    stationary point of the oracle's objective for that row (every row is in), and the maze plan leans on its box."""
+    import d2d.optyplan_scenarios as d2oscen
+    import single_opt_planner as sop
+    from oracle import fit as F
+
+    class maze9(d2oscen.exp_4_2):
+        t1 = 9.
+    for scen, n_obs in ((maze9, 3), (d2oscen.exp_5, 12)):
+        assert len(scen.obstacles) == n_obs
+        for pl in sop._plans.values():             # plans are cached per (K, duration) with the whitening weights of their
+            pl.close()                             # first user: rebuild, so that the oracle basis below is this plan's
+        sop._plans.clear()
+        p = sop.Planner(scen, initialize=True)
+        p.run(initial_guess=p.get_initial_guess('tri'))
+        assert np.isfinite(p.solution).all() and p.info['obj_val'] > 0 and p.info['status_msg'] in ('converged', 'stalled'), p.info
+        assert scen.cost.cost(p.solution, p) <= p.info['obj_val'] * (1 + 1e-9) + 1e-12
+        full = scen.cost.cobs.cost(p.solution, p)
+        assert abs(sum(o.cost(p.solution, p) for o in scen.cost.cobs.obss) - full) <= 1e-12 * max(full, 1e-300)
+        row = p.fit_scen.cpu().numpy()[0]
+        q = p.fit_q.cpu().numpy()[0]
+        assert F.n_extra_obs(row) == n_obs - 2 and F.has_box(row) == (scen.y_constraint is not None)
+        low = sop.lower_cost(scen.cost)
+        s = scen.obj_scale / p.num_nodes
+        b = F.FitBasis(sop.N_SEG, p.num_nodes, p.duration, (sop.W_WAYPOINT ** 2, s * max(low[1], 1e-3), s * max(low[2], 1e-3) / 9.81 ** 2))
+        c, g, H = F.eval_normal(b, row, q)
+        assert abs(c - p.info['obj_val']) <= 1e-9 * c, (c, p.info)
+        assert np.abs(g).max() <= 1e-6 * max(1.0, c), (scen.name, np.abs(g).max(), c)
+        if scen is maze9:
+            assert p.info['box_violation'] < 0.05 and np.min(p.sol_y) < scen.y_constraint[0] + 0.5, (p.info, np.min(p.sol_y))
 
 
 def test_multi_planner_like_11_full_sim():

@@ -48,6 +48,29 @@ def test_single_cost_plugins(gold):
         np.testing.assert_allclose(c.cost_grad(f, p), g[k + '_grad'], rtol=1e-13, atol=1e-15, err_msg=k)
 
 
+def test_three_obstacle_costs(gold):
+    """The obstacle list of the reference's exp_6 / exp_7 (three discs) through the mirror's plug-ins, both kinds."""
+    g = gold('costs_obs3')
+    N = int(g['N']); p = FakeSingle(N, float(g['obj_scale'])); f = g['free']; obss = [tuple(o) for o in g['obss']]
+    assert len(obss) == 3
+    cases = {'obsts_k1': d2ou.CostObstacles(obss, 1), 'obsts_k0': d2ou.CostObstacles(obss, 0),
+             'composit_k1': d2ou.CostComposit(obss, 12.0, kobs=0.5, kvel=10.0, kbank=1.0, obs_kind=1),
+             'composit_k0': d2ou.CostComposit(obss, 12.0, kobs=0.5, kvel=10.0, kbank=1.0, obs_kind=0)}
+    for k, c in cases.items():
+        np.testing.assert_allclose(c.cost(f, p), g[k + '_cost'], rtol=1e-13, atol=1e-15, err_msg=k)
+        np.testing.assert_allclose(c.cost_grad(f, p), g[k + '_grad'], rtol=1e-13, atol=1e-15, err_msg=k)
+    # lowering: three and four obstacles land in the extension columns with their kind bits
+    import d2dhip
+    low = sop.lower_cost(cases['composit_k0'])
+    row = sop.scen_row((0, 0, 0, 0, 12), (100, 0, 0, 0, 12), 12., low, 0.01, [0., 0.], (-0.6, 0.6), (9., 15.))
+    assert tuple(row[d2dhip.SC_O0X:d2dhip.SC_O0X + 3]) == obss[0] and tuple(row[d2dhip.SC_O1X:d2dhip.SC_O1X + 3]) == obss[1]
+    c2 = d2dhip.obs_col(2)
+    assert c2 == d2dhip.SC_OEXT and tuple(row[c2:c2 + 3]) == obss[2] and not row[c2 + 3:].any() and row[d2dhip.SC_OKIND] == 0b111
+    many = d2ou.CostComposit([(float(i), 2., 3.) for i in range(d2dhip.MAX_OBS + 1)], 12.0, kobs=0.5, kvel=10.0, kbank=1.0, obs_kind=1)
+    with pytest.raises(NotImplementedError):
+        sop.scen_row((0, 0, 0, 0, 12), (100, 0, 0, 0, 12), 12., sop.lower_cost(many), 0.01, [0., 0.], (-0.6, 0.6), (9., 15.))
+
+
 def test_multi_cost_plugins(gold):
     g = gold('costs')
     N = int(g['s_N']); n = int(g['m_n']); p = FakeMulti(N, n, float(g['m_obj_scale'])); f = g['m_free']
@@ -146,7 +169,7 @@ def test_cost_lowering_and_scenarios():
                        [1.0, -2.0], (-0.5, 0.5), (9., 14.))
     import d2dhip
     assert row[d2dhip.SC_WX] == -1.0 and row[d2dhip.SC_WY] == 2.0 and row[d2dhip.SC_PHIMAX] == 0.5
-    assert row[d2dhip.SC_VMIN] == 9. and row[d2dhip.SC_VMAX] == 14. and row.shape == (32,)
+    assert row[d2dhip.SC_VMIN] == 9. and row[d2dhip.SC_VMAX] == 14. and row.shape == (d2dhip.SCEN_STRIDE,)
     row = sop.scen_row((0, 0, 0, 0, 10), (0, 30, np.pi, 0, 10), 12., sop.lower_cost(d2ou.CostComposit([(1, 2, 3)], obs_kind=0)),
                        0.01, [0., 0.], (-0.5, 0.5), (9., 14.))
     assert row[d2dhip.SC_OKIND] == 1 and row[d2dhip.SC_BANKMAX] == 0 and row[d2dhip.SC_O0R] == 3
