@@ -37,7 +37,7 @@ import numpy as np   # noqa: E402
 K, S_ = 50, 6
 OBJ_SCALE = 0.1
 FP32_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: f32-input MFMA peak
-ROWS_CONTRACTED = 200             # v, phi, obs0, obs1 rows of the 50 samples
+ROWS_CONTRACTED = 200             # v, phi and the two position rows of the 50 samples
 NQ2 = 48
 ALG_FLOP_PER_EVAL = ROWS_CONTRACTED * NQ2 * (NQ2 + 1)      # M*P*(P+1), SURVEY.md 8d
 
@@ -216,11 +216,25 @@ def main():
         iso_ms, iso_n = plan.profile_read()[:2]
         plan.profile(False)
         iso_ms /= iso_n
+        # the same kernel without its MFMA section (no J^T J requested): the difference is the time of the contraction
+        for _ in range(3):
+            plan.eval(dsc, q0, want_H=False)
+        torch.cuda.synchronize()
+        plan.profile(True)
+        for _ in range(nit):
+            plan.eval(dsc, q0, want_H=False)
+        noh_ms, noh_n = plan.profile_read()[:2]
+        plan.profile(False)
+        noh_ms /= noh_n
         ach_i = ALG_FLOP_PER_EVAL * B / (iso_ms * 1e-3) / 1e12
         roof_iso = {'bound': 'mfma', 'kernel': 'fit_eval_kernel<3,24,true> (fp64 residual / J^T r phases + J^T J on v_mfma_f32_16x16x4_f32)',
                     'achieved': ach_i, 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': ach_i / FP32_PEAK_TFLOPS, 'avg_launch_us': 1e3 * iso_ms, 'units_per_launch': B, 'launches': int(iso_n),
-                    'note': 'the split-path J^T J kernel on the full resident batch (kernel only, HIP events; rocprofv3 summary in profiles/)'}
+                    'avg_launch_us_without_jtj': 1e3 * noh_ms, 'jtj_section_us': 1e3 * (iso_ms - noh_ms),
+                    'jtj_section_frac': ALG_FLOP_PER_EVAL * B / ((iso_ms - noh_ms) * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
+                    'note': 'the split-path J^T J kernel on the full resident batch (kernel only, HIP events; rocprofv3 summary in profiles/); '
+                            'frac is over the whole kernel (fp64 row phases + contraction), jtj_section_* is the contraction alone, by difference '
+                            'against the same kernel launched without it'}
 
     # ---- the same solve on a larger resident batch (rank 0, N = 1 only): 4096 fits on 2048 wave slots are
     # bound by the last 1 % of the fits (110..200 iterations); this shows the throughput-bound regime

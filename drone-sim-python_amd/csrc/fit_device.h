@@ -169,7 +169,7 @@ struct ScenP {
   double c0, c1;        // obstacle rows: exponent offset (r^2 for kind 0, 0 for kind 1)
   double cphimax;       // CostBank max mode: weight sqrt(obj_scale*kphi) of the one selected phi row, 0 = mean mode
   const double *ext;    // the prep row's PR_EXT block (obstacles 2..), read where it is used: it costs the common
-                        // trajectory (<= 2 obstacles) one load of the count per sample and no registers
+                        // trajectory (<= 2 obstacles, no box) one load of the code per sample and no registers
 };
 
 // Group coupling context of one trajectory (collision rows against the other aircraft of its
@@ -318,7 +318,8 @@ __device__ __forceinline__ void flat_outputs_pk(const FitGeom &g, const double *
 
 // Residual rows of one sample (oracle/fit.py residuals).  Returns sum r^2.
 // With WANT_JAC: u[6] = D^T r (for J^T r, fp64) and the fp32 coefficients of the four rows the
-// MFMA contracts -- v, phi (bound rows merged into their weights), obs0, obs1.  Row rho's entry
+// MFMA contracts -- v, phi (bound rows merged into their weights), and two position rows (obs0, obs1, or
+// the contraction of all position rows when there are more: see below).  Row rho's entry
 // for unknown j of axis a is  cA[rho][a]*TA_rho[k][j] + cB[rho][a]*TB_rho[k][j]  with
 // (TA,TB) = (G1,-) for v, (G1,G2) for phi, (G0,-) for the obstacles:
 //   coef[rho] = {cA_x, cB_x, cA_y, cB_y}

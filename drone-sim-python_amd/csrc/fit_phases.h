@@ -148,7 +148,8 @@ __device__ __forceinline__ void lds_put(void *p, const T &v) {
 }
 
 // ---- phase 3: J^T J by v_mfma_f32_16x16x4_f32 ------------------------------------------------
-// One MFMA k-step = the four contracted rows (v, phi, obs0, obs1) of one sample.  Lane l supplies
+// One MFMA k-step = the four contracted rows (v, phi, and the two position rows: obs0, obs1 or, with more
+// obstacles / a position box, the two rows of the Cholesky factor of their 2x2 block) of one sample.  Lane l supplies
 // J[row rho = l>>4][col 16c + (l&15)] as A- and as B-operand alike:
 //   J = cA * TA[k][j] + cB * TB[k][j],  TA = G1 (v, phi) or G0 (obstacles), TB = G2 (phi only).
 // Operands of sample k+1 are fetched before the MFMAs of sample k are issued (the tables carry
