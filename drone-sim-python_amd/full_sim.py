@@ -123,3 +123,64 @@ def plan_batch(scen_rows, K, duration, obj_scale_over_n, q0=None, **solve_kw):
     q = plan.init(dsc) if q0 is None else q0
     cost, iters, status, stats = plan.solve(dsc, q, **solve_kw)
     return dict(plan=plan, scen=dsc, q=q, cost=cost, iters=iters, status=status, stats=stats)
+
+
+def full_sim_phases_batch(c, r, v, n_ac, X1_f, scen, X2_f, t_opt, ref3=None, t_sim_end=200., w=(0., 0.), t_step=0.05,
+                          t_end_1=1000., X0=None, max_sweeps=250, record2=('X', 'U'), record3=('X', 'U')):
+    """The three phases of src/11_full_sim_case1.py main() (:406-478) for many independent formations, chained ON THE
+    DEVICE: the circular-formation phase hands its final states to the planner as a device tensor, the planner's sampled
+    plan is the tracking reference of phase 2 without leaving HBM, and phase 3 restarts from phase 2's final states.
+
+      c (n_form, n_ac, 2) centres, r radius, v flight speed, X1_f (n_ac, >=3) or (n_form, n_ac, >=3) the formation
+      that ends phase 1 (:421)
+      scen        multi_opt_planner scenario class (trap_4, :444); its p0s come from phase 1, p1s = X2_f ((n_ac, >=3) or
+                  (n_form, n_ac, >=3)), t1 = t_opt
+      ref3        (time_3, x_ref_3, y_ref_3) of phase 3 -- e.g. ExtendTraj_symm(ExtractTrajData(csv)) -- or None
+    Returns a dict of device tensors (plane-major, drone index = formation * n_ac + aircraft):
+      phase1 (gvf_run dict), plan (q, cost, Xs [N][5][K]), phase2 (track_run dict), phase3 (list of track_run dicts)."""
+    import multi_opt_planner as mop
+    import d2d.opty_utils as d2ou
+    ctx = d2dhip.default_context()
+    torch = d2dhip._torch()
+    c = np.asarray(c, dtype=np.float64).reshape(-1, n_ac, 2)
+    n_form = c.shape[0]
+    X1f = np.broadcast_to(np.asarray(X1_f, dtype=np.float64).reshape(-1, n_ac, np.shape(X1_f)[-1])[:, :, :3], (n_form, n_ac, 3))
+    X2f = np.broadcast_to(np.asarray(X2_f, dtype=np.float64).reshape(-1, n_ac, np.shape(X2_f)[-1])[:, :, :3], (n_form, n_ac, 3))
+    ph1 = CircularFormationGVF_batch(c, r, v, n_ac, X0f=X1f, t_step=t_step, t_end=t_end_1, X0=X0, record=())
+    Xs1 = ph1['X_final']                                            # dev [5][N]: state at each formation's stop row
+    # ---- phase 2: plan from where phase 1 ended (scenario rows finished on the device) ----
+    scen.t1 = t_opt
+    N2, dt2, dur2 = d2ou.planner_timing(scen.t0, scen.t1, scen.hz)
+    rows, plan, coupled = mop.scenario_rows(scen, [(0., 0., 0., 0., 0.)] * n_ac, X2f[0], N2, dur2, scen.obj_scale, scen.wind.w)
+    rows = np.tile(rows, (n_form, 1))
+    rows[:, [d2dhip.SC_X1, d2dhip.SC_Y1, d2dhip.SC_PSI1]] = X2f.reshape(-1, 3)
+    dsc = ctx.dev(rows)
+    dsc[:, d2dhip.SC_X0], dsc[:, d2dhip.SC_Y0], dsc[:, d2dhip.SC_PSI0] = Xs1[0], Xs1[1], Xs1[2]
+    q = plan.init(dsc)
+    if coupled:
+        cost, sweeps, stats = plan.solve_groups(dsc, q, n_ac, max_sweeps=max_sweeps, inner_iters=8)
+        plan.set_groups(1)
+    else:
+        cost, iters, status, stats = plan.solve(dsc, q)
+    _, Xs = plan.sample(dsc, q)                                     # dev [N][5][K]
+    x_ref2 = Xs[:, 0, :].t().contiguous(); y_ref2 = Xs[:, 1, :].t().contiguous()     # dev [K][N]
+    ac = ddyn.Aircraft()
+    kw = dict(w=(float(w[0]), float(w[1])), tau_phi=ac.tau_phi, tau_v=ac.tau_v)
+    ph2 = ctx.track_run(x_ref2, y_ref2, Xs1, float(dt2), record=record2, **kw)
+    out = dict(phase1=ph1, plan=dict(q=q, cost=cost, Xs=Xs, scen=dsc, stats=stats), phase2=ph2, phase3=[])
+    # ---- phase 3: the periodic formation-flight reference, restarted from the last state until t_sim_end (:466-474) ----
+    if ref3 is not None:
+        time_3, x3, y3 = ref3
+        x3 = ctx.dev(np.tile(np.ascontiguousarray(x3, dtype=np.float64), (1, n_form)))
+        y3 = ctx.dev(np.tile(np.ascontiguousarray(y3, dtype=np.float64), (1, n_form)))
+        dt3 = float(time_3[1] - time_3[0])
+        # elapsed time: phase 1 ends per formation at its own stop row; the loop count follows the slowest formation
+        stop = ph1['stop_row'].cpu().numpy()
+        t_final = float((np.max(np.minimum(stop, len(ph1['time']))) - 1) * t_step + dur2)
+        X_last = ph2['X_final']
+        while t_final <= t_sim_end:
+            ph3 = ctx.track_run(x3, y3, X_last, dt3, record=record3, **kw)
+            out['phase3'].append(ph3)
+            X_last = ph3['X_final']
+            t_final += float(time_3[-1])
+    return out

@@ -11,6 +11,31 @@ import single_opt_planner as sop
 seed = None
 
 
+def scenario_rows(scen, p0s, p1s, N, duration, obj_scale, wind):
+    """d2dhip scenario rows (n_ac, SCEN_STRIDE) of one multi-aircraft scenario, its fit plan and whether the aircraft
+    are coupled by collision rows -- the lowering shared by Planner._solve and full_sim's on-device phase chain."""
+    n = len(p0s)
+    low = sop.lower_cost(scen.cost)
+    coupled = not np.isnan(low[5]) and n >= 2
+    if coupled and n > 8:
+        raise NotImplementedError('collision coupling is built for groups of at most 8 aircraft')
+    s = obj_scale / N / n                        # src/d2d/multiopty_utils.py:62
+    plan = sop.get_plan(N, duration, s, low[1], low[2])
+    rows = np.stack([sop.scen_row(p0, p1, scen.vref, low if i == 0 else low[:4] + ((),) + low[5:], s,
+                                  wind, scen.phi_constraint, scen.v_constraint,
+                                  x_c=scen.x_constraint, y_c=scen.y_constraint)
+                     for i, (p0, p1) in enumerate(zip(p0s, p1s))])
+    # (static obstacles act on aircraft 0 only, src/d2d/multiopty_utils.py:74)
+    if low[4]:
+        rows[:, d2dhip.SC_KOBS] *= n             # obstacle scale has no 1/n_ac (:91)
+    if coupled:
+        # CostCollision acts on the pair (aircraft 0, aircraft 1) only (src/d2d/multiopty_utils.py:124-125);
+        # scale obj_scale/N without 1/n_ac (:132)
+        rows[:, d2dhip.SC_KCOL], rows[:, d2dhip.SC_RCOL], rows[:, d2dhip.SC_SCOL] = low[5], low[6], obj_scale / N
+        rows[0, d2dhip.SC_PMASK], rows[1, d2dhip.SC_PMASK] = 0b10, 0b01
+    return rows, plan, coupled
+
+
 class Planner:
     def __init__(self, scen, initialize=True):
         self.scen = scen
@@ -54,24 +79,7 @@ class Planner:
     def _solve(self, x0):
         ctx = d2dhip.default_context()
         N, n = self.num_nodes, self.acs.nb_aicraft
-        low = sop.lower_cost(self.scen.cost)
-        coupled = not np.isnan(low[5]) and n >= 2
-        if coupled and n > 8:
-            raise NotImplementedError('collision coupling is built for groups of at most 8 aircraft')
-        s = self.obj_scale / N / n                   # src/d2d/multiopty_utils.py:62
-        plan = sop.get_plan(N, self.duration, s, low[1], low[2])
-        rows = np.stack([sop.scen_row(p0, p1, self.scen.vref, low if i == 0 else low[:4] + ((),) + low[5:], s,
-                                      self.wind.w, self.scen.phi_constraint, self.scen.v_constraint,
-                                      x_c=self.scen.x_constraint, y_c=self.scen.y_constraint)
-                         for i, (p0, p1) in enumerate(zip(self.scen.p0s, self.scen.p1s))])
-        # (static obstacles act on aircraft 0 only, src/d2d/multiopty_utils.py:74)
-        if low[4]:
-            rows[:, d2dhip.SC_KOBS] *= n             # obstacle scale has no 1/n_ac (:91)
-        if coupled:
-            # CostCollision acts on the pair (aircraft 0, aircraft 1) only (src/d2d/multiopty_utils.py:124-125);
-            # scale obj_scale/N without 1/n_ac (:132)
-            rows[:, d2dhip.SC_KCOL], rows[:, d2dhip.SC_RCOL], rows[:, d2dhip.SC_SCOL] = low[5], low[6], self.obj_scale / N
-            rows[0, d2dhip.SC_PMASK], rows[1, d2dhip.SC_PMASK] = 0b10, 0b01
+        rows, plan, coupled = scenario_rows(self.scen, self.scen.p0s, self.scen.p1s, N, self.duration, self.obj_scale, self.wind.w)
         dsc = ctx.dev(rows)
         xy = np.stack([np.stack([x0[self._slice_x[i]], x0[self._slice_y[i]]]) for i in range(n)])
         q = plan.project(dsc, ctx.dev(xy))

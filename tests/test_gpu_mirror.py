@@ -341,3 +341,59 @@ def test_multi_planner_like_11_full_sim():
     x_ref = np.array(_p.sol_x).T; y_ref = np.array(_p.sol_y).T
     X, U, Xr, Yd, Ydd, dX = full_sim.implement_controller(4, np.array(_p.sol_time), x_ref, y_ref, 15, [0, 0], scen.p0s)
     assert X.shape == (61, 4, 5) and np.abs(X[-1, :, 0] - x_ref[-1]).max() < 3.0
+
+
+def test_three_phase_chain_on_device():
+    """full_sim.full_sim_phases_batch chains the phases of src/11_full_sim_case1.py main() on the device for many
+    formations: formation 0 against the same phases driven one by one through the reference-named API (host hand-offs),
+    an identical formation bit for bit, and a translated one (the whole problem is translation-equivariant)."""
+    import full_sim as fs
+    import multi_opt_planner as mop
+    n_ac, r, v, w = 4, 60, 15, [0, 0]
+    c = np.array([[0, -20], [25, -20], [25, -100], [0, -100]], float)
+    X1_f = np.array(((0, 40, 0, 0, 12), (25, 40, 0, 0, 12), (25, -40, 0, 0, 12), (0, -40, 0, 0, 12)), float)
+    X2_f = np.array(((75, 40, 0, 0, 12), (100, 40, 0, 0, 12), (100, -40, 0, 0, 12), (75, -40, 0, 0, 12)), float)
+    t_opt = 6
+    # one by one, as main() does it (:433-457)
+    X1, U1, _, _, _, _, time1, t1_f = fs.CircularFormationGVF(c, r, v, n_ac, X1_f, 0, 0.05, 1000)
+    X2_i = tuple(map(tuple, X1[-1]))
+    scen = mop.trap_4
+    scen.t1, scen.p0s, scen.p1s = t_opt, X2_i, tuple(map(tuple, X2_f))
+    _p = mop.Planner(scen, initialize=True)
+    _p.run(initial_guess=_p.get_initial_guess(scen.initial_guess), tol=scen.tol, max_iter=scen.max_iter)
+    _p.interpret_solution()
+    x_ref_2, y_ref_2 = np.array(_p.sol_x).T, np.array(_p.sol_y).T
+    Xa2, Ua2, *_ = fs.implement_controller(n_ac, np.array(_p.sol_time), x_ref_2, y_ref_2, v, w, X2_i)
+    # phase 3 reference: a closed loop flown twice (stands for the csv of :430)
+    T3 = 120
+    th = np.linspace(0, 2 * np.pi, T3)
+    time_3 = np.arange(T3) * 0.1
+    x3 = X2_f[None, :, 0] + 30 * np.sin(th)[:, None]; y3 = X2_f[None, :, 1] + 30 * (1 - np.cos(th))[:, None]
+    Xa3, *_ = fs.implement_controller(n_ac, time_3, x3, y3, v, w, tuple(map(tuple, Xa2[-1])))
+    # the chain, three formations
+    off = np.array([40., 50.])                            # (stays inside the x/y boxes of trap_4, which are rows of the fit)
+    cB = np.stack([c, c, c + off])
+    X1B = np.stack([X1_f, X1_f, X1_f + np.r_[off, 0, 0, 0]]); X2B = np.stack([X2_f, X2_f, X2_f + np.r_[off, 0, 0, 0]])
+    t_end = t1_f + t_opt + 2 * time_3[-1] - 1e-6          # room for exactly two passes of phase 3
+    X0B = np.tile(fs.X1_START, (3, n_ac, 1)); X0B[2, :, :2] += off        # (every aircraft starts at the reference's X1, :113)
+    out = fs.full_sim_phases_batch(cB, r, v, n_ac, X1B, mop.trap_4, X2B, t_opt, ref3=(time_3, x3, y3), t_sim_end=t_end,
+                                   X0=X0B, record2=('X', 'U'), record3=('X',))
+    fs.d2dhip.default_context().sync()
+    N = 3 * n_ac
+    Xf1 = out['phase1']['X_final'].cpu().numpy().T.reshape(3, n_ac, 5)
+    np.testing.assert_array_equal(Xf1[0], X1[-1])
+    np.testing.assert_array_equal(Xf1[1], Xf1[0])
+    Xs = out['plan']['Xs'].cpu().numpy().reshape(3, n_ac, 5, -1)
+    np.testing.assert_allclose(Xs[0, :, 0].T, x_ref_2, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(Xs[0, :, 1].T, y_ref_2, rtol=0, atol=1e-6)
+    X2b = out['phase2']['X'].cpu().numpy().transpose(0, 2, 1).reshape(-1, 3, n_ac, 5)
+    np.testing.assert_allclose(X2b[:, 0], Xa2, rtol=0, atol=1e-5)
+    np.testing.assert_array_equal(X2b[:, 1], X2b[:, 0])
+    shift = np.r_[off, 0, 0, 0]
+    np.testing.assert_allclose(X2b[:, 2] - shift, X2b[:, 0], rtol=0, atol=1e-5)
+    assert len(out['phase3']) == 2
+    X3b = out['phase3'][0]['X'].cpu().numpy().transpose(0, 2, 1).reshape(-1, 3, n_ac, 5)
+    np.testing.assert_allclose(X3b[:, 0], Xa3, rtol=0, atol=1e-4)
+    # x3 / y3 are shared by the formations: the translated one chases the untranslated reference, so only 0 == 1 here
+    np.testing.assert_array_equal(X3b[:, 1], X3b[:, 0])
+    assert np.isfinite(out['phase3'][1]['X_final'].cpu().numpy()).all()
