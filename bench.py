@@ -94,6 +94,30 @@ def cpu_baseline(n_sample=1024):
             'mean_cost': float(np.mean(costs))}
 
 
+def cpu_baseline_sim_gvf(n_steps=300):
+    """cpu_baseline leg of the simulation bench (tools/bench_sim.py, BASELINE configs[4]): the oracle's restatement of
+    the reference's phase-1 loop body (DCF + GVF + scipy odeint) on one core."""
+    from oracle import sim as S               # the oracle is the thing timed in this leg only
+    c = np.array([[0, -20], [25, -20], [25, -100], [0, -100.0]])
+    X0 = np.tile([20, 30, -np.pi / 2, 0, 10.0], (4, 1))
+    t0 = time.perf_counter()
+    S.formation_gvf_run(c, 60.0, 15.0, X0, n_steps, 0.05, integrator='odeint')
+    dt = time.perf_counter() - t0
+    return {'value': 4 * (n_steps - 1) / dt, 'unit': 'drone-steps/s', 'cores': 1, 'kind': 'port',
+            'sample': f'{n_steps - 1} steps x 4 aircraft, oracle/sim.py loop with scipy.integrate.odeint as src/d2d/dynamic.py:26'}
+
+
+def cpu_baseline_sim_track(n_steps=60):
+    """cpu_baseline leg of the tracking bench: flatness + scipy CARE + odeint (oracle/sim.py track_run) on one core."""
+    from oracle import sim as S
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'tracking_trace_carestandin.npz'))
+    t0 = time.perf_counter()
+    S.track_run(g['time'][:n_steps], g['x_ref'][:n_steps], g['y_ref'][:n_steps], g['X'][0], integrator='odeint')
+    dt = time.perf_counter() - t0
+    return {'value': 4 * (n_steps - 1) / dt, 'unit': 'drone-steps/s', 'cores': 1, 'kind': 'port',
+            'sample': f'{n_steps - 1} steps x 4 aircraft, flatness + scipy CARE + odeint (oracle/sim.py track_run)'}
+
+
 # ---------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()

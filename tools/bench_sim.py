@@ -20,26 +20,8 @@ import numpy as np   # noqa: E402
 HBM_PEAK_GBS = 8000.0
 
 
-def cpu_gvf_baseline(n_steps=300):
-    """Oracle restatement of the reference loop body (DCF + GVF + scipy odeint) on one core."""
-    from oracle import sim as S
-    c = np.array([[0, -20], [25, -20], [25, -100], [0, -100.0]])
-    X0 = np.tile([20, 30, -np.pi / 2, 0, 10.0], (4, 1))
-    t0 = time.perf_counter()
-    S.formation_gvf_run(c, 60.0, 15.0, X0, n_steps, 0.05, integrator='odeint')
-    dt = time.perf_counter() - t0
-    return {'value': 4 * (n_steps - 1) / dt, 'unit': 'drone-steps/s', 'cores': 1, 'kind': 'port',
-            'sample': f'{n_steps - 1} steps x 4 aircraft, oracle/sim.py loop with scipy.integrate.odeint as src/d2d/dynamic.py:26'}
-
-
-def cpu_track_baseline(n_steps=60):
-    from oracle import sim as S
-    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'tracking_trace_carestandin.npz'))
-    t0 = time.perf_counter()
-    S.track_run(g['time'][:n_steps], g['x_ref'][:n_steps], g['y_ref'][:n_steps], g['X'][0], integrator='odeint')
-    dt = time.perf_counter() - t0
-    return {'value': 4 * (n_steps - 1) / dt, 'unit': 'drone-steps/s', 'cores': 1, 'kind': 'port',
-            'sample': f'{n_steps - 1} steps x 4 aircraft, flatness + scipy CARE + odeint (oracle/sim.py track_run)'}
+import bench                                   # noqa: E402  (the cpu_baseline legs live in bench.py: only it may run the oracle)
+cpu_gvf_baseline, cpu_track_baseline = bench.cpu_baseline_sim_gvf, bench.cpu_baseline_sim_track
 
 
 def main():
