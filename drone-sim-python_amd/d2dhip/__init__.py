@@ -184,9 +184,12 @@ class Context:
 
     def gvf_run(self, X0, centres, radius, n_ac, n_rows, dt, v_c, ke=4e-4, kd=25.0, kr=20.0,
                 B=None, z_des=None, tau_phi=0.01, tau_v=1.0, W=(0.0, 0.0), X0f=None,
-                stop_tol=(3.0, 3.0, np.deg2rad(0.5)), rec_stride=1, record=('X', 'U', 'Rr', 'eth')):
+                stop_tol=(3.0, 3.0, np.deg2rad(0.5)), rec_stride=1, record=('X', 'U', 'Rr', 'eth'), out=None):
         """Circular-formation phase for N = n_form*n_ac drones.  X0 dev [5][N], centres dev
-        [2][N], radius dev [N].  Returns dict of device tensors (plane-major)."""
+        [2][N], radius dev [N].  Returns dict of device tensors (plane-major).  out: the dictionary of an earlier
+        call with the same shapes and `record` -- its buffers are written again instead of allocating new ones
+        (without the stop rule every recorded row is rewritten; with it, rows behind the stop row keep their old
+        content)."""
         torch = _torch()
         N = X0.shape[1]
         assert N % n_ac == 0
@@ -200,13 +203,16 @@ class Context:
         p = GvfParams(n_form, n_ac, n_rows, rec_stride, dt, tau_phi, tau_v, ke, kd, kr, v_c, W[0], W[1],
                       1 if X0f is not None else 0, 0, (C.c_double * 3)(*stop_tol))
         n_rec = (n_rows + rec_stride - 1) // rec_stride
-        out = {}
-        out['X'] = self.zeros(n_rec, 5, N) if 'X' in record else None
-        out['U'] = self.zeros(n_rec, 2, N) if 'U' in record else None
-        out['Rr'] = self.zeros(n_rec, N) if 'Rr' in record else None
-        out['eth'] = self.zeros(n_rec, n_form * max(n_ac - 1, 0)) if ('eth' in record and n_ac > 1) else None
-        out['X_final'] = self.empty(5, N)
-        out['stop_row'] = torch.empty(n_form, dtype=torch.int32, device=self.device)
+        if out is None:
+            out = {}
+            out['X'] = self.zeros(n_rec, 5, N) if 'X' in record else None
+            out['U'] = self.zeros(n_rec, 2, N) if 'U' in record else None
+            out['Rr'] = self.zeros(n_rec, N) if 'Rr' in record else None
+            out['eth'] = self.zeros(n_rec, n_form * max(n_ac - 1, 0)) if ('eth' in record and n_ac > 1) else None
+            out['X_final'] = self.empty(5, N)
+            out['stop_row'] = torch.empty(n_form, dtype=torch.int32, device=self.device)
+        else:
+            assert out['X_final'].shape == (5, N) and all(out[k] is None or out[k].shape[0] == n_rec for k in ('X', 'U', 'Rr', 'eth'))
         _check(self.lib.d2d_sim_gvf_run(self.h, C.byref(p), _ptr(X0), _ptr(centres), _ptr(radius), _hptr(B), _hptr(z_des),
                                         _ptr(X0f), _ptr(out['X']), _ptr(out['U']), _ptr(out['Rr']), _ptr(out['eth']),
                                         _ptr(out['X_final']), _ptr(out['stop_row'])))
@@ -274,13 +280,17 @@ class Context:
         _check(self.lib.d2d_dfff_eval(self.h, C.byref(p), _ptr(X), _ptr(Yref), _ptr(Xr), _ptr(U), _ptr(K)))
         return Xr, U, K
 
-    def track_run(self, x_ref, y_ref, X0, dt, record=('X', 'U', 'Xr', 'dX', 'Yd', 'Ydd'), **kw):
-        """x_ref, y_ref dev [T][n]; X0 dev [5][n] -> dict of device histories."""
+    def track_run(self, x_ref, y_ref, X0, dt, record=('X', 'U', 'Xr', 'dX', 'Yd', 'Ydd'), out=None, **kw):
+        """x_ref, y_ref dev [T][n]; X0 dev [5][n] -> dict of device histories (out: reuse the buffers of an earlier
+        call with the same shapes and `record`)."""
         T, n = x_ref.shape
         p = self.track_params(n, T, dt, **kw)
-        out = {k: (self.zeros(T, c, n) if k in record else None)
-               for k, c in (('X', 5), ('U', 2), ('Xr', 5), ('dX', 5), ('Yd', 2), ('Ydd', 2))}
-        out['X_final'] = self.empty(5, n)
+        if out is None:
+            out = {k: (self.zeros(T, c, n) if k in record else None)
+                   for k, c in (('X', 5), ('U', 2), ('Xr', 5), ('dX', 5), ('Yd', 2), ('Ydd', 2))}
+            out['X_final'] = self.empty(5, n)
+        else:
+            assert out['X_final'].shape == (5, n) and all(out[k] is None or out[k].shape[0] == T for k in ('X', 'U', 'Xr', 'dX', 'Yd', 'Ydd'))
         _check(self.lib.d2d_sim_track_run(self.h, C.byref(p), _ptr(x_ref), _ptr(y_ref), _ptr(X0), _ptr(out['X']),
                                           _ptr(out['U']), _ptr(out['Xr']), _ptr(out['dX']), _ptr(out['Yd']),
                                           _ptr(out['Ydd']), _ptr(out['X_final'])))
