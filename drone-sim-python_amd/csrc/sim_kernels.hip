@@ -105,8 +105,10 @@ gvf_run_kernel(d2d_gvf_params p, GlMesh mesh, int fpb, const double *__restrict_
     for (int m = 0; m < nm; ++m) Ur += sh_B[a * nm + m] * sh_e[base + m];
     Ur *= -p.kr;
     const double Rr = Ur + R;
-    const double phi_c = gvf_bank_cmd(s, cx, cy, Rr, p.ke, p.kd, nullptr, nullptr);
-    State5 sn = plant_step(s, phi_c, p.v_c, p.wx, p.wy, mesh);
+    double sin_psi, cos_psi;                               // one sincos per step, shared by the guidance law and the plant
+    sincos(s.psi, &sin_psi, &cos_psi);
+    const double phi_c = gvf_bank_cmd(s, sin_psi, cos_psi, cx, cy, Rr, p.ke, p.kd, nullptr, nullptr);
+    State5 sn = plant_step(s, phi_c, p.v_c, p.wx, p.wy, mesh, sin_psi, cos_psi);
     if (run) {
       if (U_hist && ((i - 1) % rs == 0)) {
         const long r = (long)((i - 1) / rs) * 2 * N;
@@ -302,7 +304,9 @@ gvf_eval_kernel(int n, double ke, double kd, const double *__restrict__ X, const
   const State5 s = {X[i], X[n + i], X[2 * n + i], X[3 * n + i], X[4 * n + i]};
   const double Hm[4] = {H[i], H[n + i], H[2 * n + i], H[3 * n + i]};
   double U1, U2;
-  const double Ut = gvf_control(s, e[i], nv[i], nv[n + i], Hm, ke, kd, &U1, &U2);
+  double sin_psi, cos_psi;
+  sincos(s.psi, &sin_psi, &cos_psi);
+  const double Ut = gvf_control(s, sin_psi, cos_psi, e[i], nv[i], nv[n + i], Hm, ke, kd, &U1, &U2);
   U[i] = Ut; U[n + i] = U1; U[2 * n + i] = U2;
 }
 
