@@ -201,6 +201,50 @@ dfff_kernel(d2d_track_params p, const double *__restrict__ X, const double *__re
   }
 }
 
+// run_simulation of src/05_test_simulation.py:21-34 with the legacy DFFFController (src/d2d/guidance.py:52-91):
+//   U[i-1] = ctl.get(X[i-1], t[i-1]);  X[i] = disc_dyn(X[i-1], U[i-1]) + perts[i];  U[T-1] = ctl.get(X[T-1], t[T-1])
+// Yref [n_rows][6][n] = the trajectory's flat outputs at the sample times (x, y, xd, yd, xdd, ydd).
+__global__ void __launch_bounds__(64)
+dfff_run_kernel(d2d_track_params p, GlMesh mesh, const double *__restrict__ Yref, const double *__restrict__ perts,
+                const double *__restrict__ X0, double *__restrict__ X_hist, double *__restrict__ U_hist,
+                double *__restrict__ Xr_hist, double *__restrict__ X_final) {
+  const long n = p.n;
+  long d = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  const bool live = d < n;
+  if (!live) d = n - 1;                               // (keeps the wave converged in care_sda's __all())
+  State5 s = {X0[d], X0[n + d], X0[2 * n + d], X0[3 * n + d], X0[4 * n + d]};
+  if (live && X_hist) {
+    X_hist[d] = s.x; X_hist[n + d] = s.y; X_hist[2 * n + d] = s.psi; X_hist[3 * n + d] = s.phi; X_hist[4 * n + d] = s.v;
+  }
+  for (int i = 1; i <= p.n_rows; ++i) {
+    const long q = i - 1;                             // the row the controller acts on
+    double Y[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) Y[c] = Yref[(q * 6 + c) * n + d];
+    const DfffOut o = dfff_gain(s, Y, p);
+    if (live) {
+      if (U_hist) { U_hist[q * 2 * n + d] = o.U[0]; U_hist[q * 2 * n + n + d] = o.U[1]; }
+      if (Xr_hist) {
+#pragma unroll
+        for (int c = 0; c < 5; ++c) Xr_hist[(q * 5 + c) * n + d] = o.Xr[c];
+      }
+    }
+    if (i == p.n_rows) break;                         // the last row only gets its command (:33)
+    s = plant_step(s, o.U[0], o.U[1], p.wx, p.wy, mesh);
+    if (perts) {
+      const double *pr = perts + (long)i * 5 * n + d;
+      s.x += pr[0]; s.y += pr[n]; s.psi += pr[2 * n]; s.phi += pr[3 * n]; s.v += pr[4 * n];
+    }
+    if (live && X_hist) {
+      double *o5 = X_hist + (long)i * 5 * n;
+      o5[d] = s.x; o5[n + d] = s.y; o5[2 * n + d] = s.psi; o5[3 * n + d] = s.phi; o5[4 * n + d] = s.v;
+    }
+  }
+  if (live && X_final) {
+    X_final[d] = s.x; X_final[n + d] = s.y; X_final[2 * n + d] = s.psi; X_final[3 * n + d] = s.phi; X_final[4 * n + d] = s.v;
+  }
+}
+
 // numpy.gradient(f, edge_order=2) with unit spacing at row i of a [n_rows][n] plane
 __device__ __forceinline__ double grad2(const double *__restrict__ f, int i, int T, long n, long d) {
   if (i == 0) return -1.5 * f[d] + 2.0 * f[n + d] - 0.5 * f[2 * n + d];
@@ -457,6 +501,17 @@ int d2d_dfff_eval(d2d_ctx *ctx, const d2d_track_params *p, const double *X, cons
   D2D_REQUIRE(ctx && p && X && Yref, "d2d_dfff_eval: null argument");
   if (int rc = check_track(p, "d2d_dfff_eval")) return rc;
   hipLaunchKernelGGL(dfff_kernel, dim3((p->n + 63) / 64), dim3(64), 0, ctx->stream, *p, X, Yref, Xr, U, Kgain);
+  D2D_LAUNCH_CHECK();
+  return D2D_OK;
+}
+
+int d2d_sim_dfff_run(d2d_ctx *ctx, const d2d_track_params *p, const double *Yref, const double *perts,
+                     const double *X0, double *X_hist, double *U_hist, double *Xr_hist, double *X_final) {
+  D2D_REQUIRE(ctx && p && Yref && X0, "d2d_sim_dfff_run: null argument");
+  if (int rc = check_track(p, "d2d_sim_dfff_run")) return rc;
+  const GlMesh mesh = make_mesh(p->dt, p->tau_phi, p->tau_v);
+  hipLaunchKernelGGL(dfff_run_kernel, dim3((p->n + 63) / 64), dim3(64), 0, ctx->stream, *p, mesh, Yref, perts, X0, X_hist,
+                     U_hist, Xr_hist, X_final);
   D2D_LAUNCH_CHECK();
   return D2D_OK;
 }

@@ -66,6 +66,7 @@ _SIGS = {
     'd2d_sim_gvf_run': (C.c_int, [_P, C.POINTER(GvfParams)] + [_P] * 12),
     'd2d_ctrl_gain': (C.c_int, [_P, C.POINTER(TrackParams)] + [_P] * 6),
     'd2d_dfff_eval': (C.c_int, [_P, C.POINTER(TrackParams)] + [_P] * 5),
+    'd2d_sim_dfff_run': (C.c_int, [_P, C.POINTER(TrackParams)] + [_P] * 7),
     'd2d_sim_track_run': (C.c_int, [_P, C.POINTER(TrackParams)] + [_P] * 10),
     'd2d_dcf_eval': (C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.c_double, _P, _P, _P, _P]),
     'd2d_gvf_eval': (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_double, C.c_double, _P]),
@@ -279,6 +280,20 @@ class Context:
         Xr, U, K = self.empty(5, n), self.empty(2, n), self.empty(6, n)
         _check(self.lib.d2d_dfff_eval(self.h, C.byref(p), _ptr(X), _ptr(Yref), _ptr(Xr), _ptr(U), _ptr(K)))
         return Xr, U, K
+
+    def dfff_run(self, Yref, X0, dt, perts=None, record=('X', 'U', 'Xr'), w=(0.0, 0.0), tau_phi=0.01, tau_v=1.0, out=None):
+        """run_simulation of src/05_test_simulation.py with the legacy DFFFController for n aircraft: Yref dev [T][6][n]
+        (x,y,xd,yd,xdd,ydd at the sample times), X0 dev [5][n], perts dev [T][5][n] or None -> dict of device histories
+        X [T][5][n], U [T][2][n], Xr [T][5][n] and X_final."""
+        T, _, n = Yref.shape
+        p = self.track_params(n, T, dt, w=w, tau_phi=tau_phi, tau_v=tau_v, phi_lim=np.deg2rad(45),
+                              Q=(1, 1, 0.1, 0.0, 0.0), R=(8, 1))          # src/d2d/guidance.py:79,86
+        if out is None:
+            out = {k: (self.zeros(T, c, n) if k in record else None) for k, c in (('X', 5), ('U', 2), ('Xr', 5))}
+            out['X_final'] = self.empty(5, n)
+        _check(self.lib.d2d_sim_dfff_run(self.h, C.byref(p), _ptr(Yref), _ptr(perts), _ptr(X0), _ptr(out['X']), _ptr(out['U']),
+                                         _ptr(out['Xr']), _ptr(out['X_final'])))
+        return out
 
     def track_run(self, x_ref, y_ref, X0, dt, record=('X', 'U', 'Xr', 'dX', 'Yd', 'Ydd'), out=None, **kw):
         """x_ref, y_ref dev [T][n]; X0 dev [5][n] -> dict of device histories (out: reuse the buffers of an earlier

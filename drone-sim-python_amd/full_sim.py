@@ -5,6 +5,7 @@ GPU, plus batched variants over many independent formations.
   CircularFormationGVF(c, r, v, n_ac, X0f, ...)      src/11_full_sim_case1.py:93-177
   implement_controller(n_ac, time, x_ref, y_ref, ..)  :241-291
   ConstructBMatrix, ComputeDerivatives, ExtractTrajData, ExtendTraj_symm   :81-91, :197-239
+  run_simulation(time, aircraft, windfield, ctl, X0, perts)                src/05_test_simulation.py:21-34 (legacy DFFF loop)
 """
 import numpy as np
 
@@ -184,3 +185,27 @@ def full_sim_phases_batch(c, r, v, n_ac, X1_f, scen, X2_f, t_opt, ref3=None, t_s
             X_last = ph3['X_final']
             t_final += float(time_3[-1])
     return out
+
+
+def run_simulation_batch(time, Yrefs, X0s, perts=None, w=(0., 0.), record=('X', 'U', 'Xr')):
+    """The legacy DFFFController loop for n independent aircraft.  Yrefs (T, n, >=3, 2): each trajectory's traj.get(t) at
+    the sample times; X0s (n, 5); perts (T, n, 5) or None.  Device dictionary out (plane-major [T][.][n])."""
+    ctx = d2dhip.default_context()
+    ac = ddyn.Aircraft()
+    Y = np.asarray(Yrefs, dtype=np.float64)
+    T, n = Y.shape[:2]
+    Yd = np.ascontiguousarray(Y[:, :, :3, :].transpose(0, 2, 3, 1).reshape(T, 6, n))      # rows x, y, xd, yd, xdd, ydd
+    dP = None if perts is None else ctx.dev(np.ascontiguousarray(np.asarray(perts, dtype=np.float64).transpose(0, 2, 1)))
+    return ctx.dfff_run(ctx.dev(Yd), ctx.dev(_planes(np.asarray(X0s, dtype=np.float64))), float(time[1] - time[0]), perts=dP,
+                        record=record, w=(float(w[0]), float(w[1])), tau_phi=ac.tau_phi, tau_v=ac.tau_v)
+
+
+def run_simulation(time, aircraft, windfield, ctl, X0, perts):
+    """One aircraft, the reference's triple X (T,5), U (T,2), Yref (T,4,2) (src/05_test_simulation.py:21-34); ctl is a
+    d2d.guidance.DFFFController (its trajectory is sampled on the host, the time loop runs on the GPU)."""
+    Yref = np.array([ctl.traj.get(t) for t in time])
+    w = windfield.sample(time[0], Yref[0, 0])
+    out = run_simulation_batch(time, Yref[:, None], np.asarray(X0, dtype=np.float64)[None], None if perts is None else np.asarray(perts)[:, None],
+                               w=w, record=('X', 'U'))
+    d2dhip.default_context().sync()
+    return out['X'].cpu().numpy()[:, :, 0], out['U'].cpu().numpy()[:, :, 0], Yref

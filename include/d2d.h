@@ -150,6 +150,16 @@ int d2d_sim_track_run(d2d_ctx *ctx, const d2d_track_params *p, const double *x_r
                       double *Xr_hist, double *dX_hist, double *Yd_hist, double *Ydd_hist,
                       double *X_final);
 
+/* The legacy simulation loop run_simulation(time, aircraft, windfield, ctl, X0, perts)
+ * (src/05_test_simulation.py:21-34) with DFFFController (src/d2d/guidance.py:52-91) for n independent aircraft:
+ *   U[i-1] = ctl.get(X[i-1], t[i-1]); X[i] = disc_dyn(X[i-1], U[i-1], w, t[i-1], dt) + perts[i]; U[T-1] = ctl.get(X[T-1]).
+ *   Yref dev [n_rows][6][n]: the trajectory's flat outputs at the sample times (x, y, xd, yd, xdd, ydd: what
+ *   traj.get(t) returns, without the jerk the controller never reads); perts dev [n_rows][5][n] or NULL;
+ *   X0 dev [5][n]; X_hist dev [n_rows][5][n], U_hist [n_rows][2][n], Xr_hist [n_rows][5][n] (any may be NULL);
+ *   X_final dev [5][n] or NULL.  Controller constants as d2d_dfff_eval (p->q_diag[0..2], r_diag, err_sats, limits). */
+int d2d_sim_dfff_run(d2d_ctx *ctx, const d2d_track_params *p, const double *Yref, const double *perts,
+                     const double *X0, double *X_hist, double *U_hist, double *Xr_hist, double *X_final);
+
 /* Single batched evaluations behind the reference's per-call helper methods (the time
  * loops above fuse them; these exist so that host code written against the reference's
  * classes reaches the same device functions).

@@ -247,6 +247,36 @@ def fx_costs3():
     np.savez(os.path.join(OUT, 'costs_obs3.npz'), **out)
 
 
+def fx_dfff_run():
+    """The legacy simulation loop (run_simulation, src/05_test_simulation.py:21-34) with DFFFController on a composite
+    minimum-snap trajectory of the reference's own classes, with a perturbation row, 3-state LQR through the CARE stand-in."""
+    r = np.random.default_rng(21)
+    ac = ddyn.Aircraft()
+    wind = ddg.WindField([0.5, -0.3])
+    J = [np.array([[0., 0.], [12., 0.], [0., 0.], [0., 0.]]).T]              # (axis, deriv) junction data
+    for j in range(1, 4):
+        p = np.array([40. * j, 12. * (-1) ** j]); v = np.array([12., 2. * (-1) ** (j + 1)])
+        J.append(np.stack([p, v, r.normal(0, 0.5, 2), r.normal(0, 0.2, 2)], 1))
+    T = 3.5
+    steps = [ddt.MinSnapPoly(J[j], J[j + 1], T) for j in range(3)]
+    traj = ddt.CompositeTraj(steps)
+    dt = 0.05
+    time = np.arange(0, 3 * T - 1e-9, dt)
+    ctl = ddg.DFFFController(traj, ac, wind)
+    n = len(time)
+    perts = np.zeros((n, 5)); perts[40] = [0.8, -0.5, 0.05, 0.0, 0.3]
+    X = np.zeros((n, 5)); U = np.zeros((n, 2))
+    Yref = np.array([traj.get(t) for t in time])
+    X[0] = [1.0, -2.0, 0.1, 0.0, 11.0]
+    for i in range(1, n):
+        U[i - 1] = ctl.get(X[i - 1].copy(), time[i - 1])
+        X[i] = ac.disc_dyn(X[i - 1], U[i - 1], wind, time[i - 1], time[i] - time[i - 1])
+        X[i] += perts[i]
+    U[-1] = ctl.get(X[-1].copy(), time[-1])
+    np.savez(os.path.join(OUT, 'dfff_run_carestandin.npz'), time=time, Yref=Yref, X=X, U=U, Xr=np.array(ctl.Xref), K=np.array(ctl.K),
+             perts=perts, W=np.array(wind.w if hasattr(wind, 'w') else [0.5, -0.3]), tau_phi=ac.tau_phi, tau_v=ac.tau_v)
+
+
 def fx_guess_poly():
     out = {}
     out['timing_in'] = np.array([[0, 10, 10], [0, 4.9, 10], [0, 7, 10], [0, 3, 10], [0, 12, 10], [0, 10, 50], [0.5, 6.0, 10]], float)
@@ -409,7 +439,7 @@ def fx_dfff():
 if __name__ == '__main__':
     only = sys.argv[1:]
     for f in (fx_plant, fx_flatness_ctrl, fx_guidance, fx_states_over_time, fx_costs, fx_guess_poly,
-              fx_fit_cost, fx_planner_goldens, fx_tracking_trace, fx_dfff, fx_costs3):
+              fx_fit_cost, fx_planner_goldens, fx_tracking_trace, fx_dfff, fx_costs3, fx_dfff_run):
         if only and f.__name__ not in only:
             continue
         f(); print('wrote', f.__name__)

@@ -397,3 +397,31 @@ def test_three_phase_chain_on_device():
     # x3 / y3 are shared by the formations: the translated one chases the untranslated reference, so only 0 == 1 here
     np.testing.assert_array_equal(X3b[:, 1], X3b[:, 0])
     assert np.isfinite(out['phase3'][1]['X_final'].cpu().numpy()).all()
+
+
+def test_run_simulation_like_05_test_simulation():
+    """full_sim.run_simulation (the legacy DFFF loop of src/05_test_simulation.py:21-34, time loop on the GPU) against the
+    same loop driven call by call through the mirror's DFFFController.get and Aircraft.disc_dyn."""
+    import full_sim as fs
+    import d2d.dynamic as ddyn
+    import d2d.guidance as ddg
+    import d2d.trajectory as ddt
+    J = [np.array([[0., 0.], [12., 0.], [0., 0.], [0., 0.]]).T,
+         np.array([[40., 10.], [12., 1.], [0.2, -0.1], [0., 0.]]).T,
+         np.array([[80., -5.], [12., -1.], [0., 0.3], [0., 0.]]).T]
+    traj = ddt.CompositeTraj([ddt.MinSnapPoly(J[j], J[j + 1], 3.5) for j in range(2)])
+    ac, wind = ddyn.Aircraft(), ddg.WindField([0.4, 0.2])
+    time = np.arange(0, 7.0 - 1e-9, 0.05)
+    perts = np.zeros((len(time), 5)); perts[30] = [0.5, -0.4, 0.03, 0.0, 0.2]
+    X0 = np.array([0.5, -1.0, 0.05, 0.0, 11.5])
+    X, U, Yref = fs.run_simulation(time, ac, wind, ddg.DFFFController(traj, ac, wind), X0, perts)
+    ctl = ddg.DFFFController(traj, ac, wind)
+    Xh = np.zeros_like(X); Uh = np.zeros_like(U); Xh[0] = X0
+    for i in range(1, len(time)):
+        Uh[i - 1] = ctl.get(Xh[i - 1].copy(), time[i - 1])
+        Xh[i] = ac.disc_dyn(Xh[i - 1], Uh[i - 1], wind, time[i - 1], time[i] - time[i - 1]) + perts[i]
+    Uh[-1] = ctl.get(Xh[-1].copy(), time[-1])
+    assert Yref.shape == (len(time), 4, 2)
+    np.testing.assert_allclose(X, Xh, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(U, Uh, rtol=0, atol=1e-9)
+    assert np.hypot(X[-1, 0] - Yref[-1, 0, 0], X[-1, 1] - Yref[-1, 0, 1]) < 2.0          # it tracks

@@ -208,3 +208,35 @@ def test_error_paths(ctx):
         ctx.step(ctx.zeros(5, 4), ctx.zeros(2, 4), (0, 0), -1.0, 1.0, 0.05)
     with pytest.raises(d2dhip.D2DError):
         ctx.gvf_run(ctx.zeros(5, 130), ctx.zeros(2, 130), ctx.zeros(130), 65, 3, 0.05, 12.0)
+
+
+@pytest.mark.gpu
+def test_dfff_run_loop(gold):
+    """d2d_sim_dfff_run (run_simulation of 05_test_simulation.py with the legacy DFFFController): against the oracle's loop
+    with the same integrator (tight), against the reference's own trace (bounded by its LSODA tolerances), and through the
+    reference-named host function with the mirror's trajectory classes."""
+    import d2dhip
+    from oracle import sim as S
+    g = gold('dfff_run_carestandin')
+    ctx = d2dhip.default_context()
+    T = len(g['time'])
+    n = 70                                                     # more than one wave; copies with different start states
+    rng = np.random.default_rng(1)
+    X0 = np.tile(g['X'][0], (n, 1)); X0[1:, :2] += rng.uniform(-3, 3, (n - 1, 2)); X0[1:, 4] += rng.uniform(-1, 1, n - 1)
+    Yd = np.ascontiguousarray(np.repeat(g['Yref'][:, None, :3, :], n, 1).transpose(0, 2, 3, 1).reshape(T, 6, n))
+    P = np.ascontiguousarray(np.repeat(g['perts'][:, None], n, 1).transpose(0, 2, 1))
+    kw = dict(w=tuple(g['W']), tau_phi=float(g['tau_phi']), tau_v=float(g['tau_v']))
+    out = ctx.dfff_run(ctx.dev(Yd), ctx.dev(np.ascontiguousarray(X0.T)), float(g['time'][1] - g['time'][0]), perts=ctx.dev(P), **kw)
+    ctx.sync()
+    X = out['X'].cpu().numpy().transpose(0, 2, 1); U = out['U'].cpu().numpy().transpose(0, 2, 1); Xr = out['Xr'].cpu().numpy().transpose(0, 2, 1)
+    for j in (0, 1, 69):
+        Xo, Uo, Xro = S.dfff_run(g['time'], g['Yref'], X0[j], perts=g['perts'], W=tuple(g['W']), tau_phi=float(g['tau_phi']),
+                                 tau_v=float(g['tau_v']), integrator='glrk')
+        np.testing.assert_allclose(Xr[:, j], Xro, rtol=0, atol=1e-12)
+        np.testing.assert_allclose(X[:, j], Xo, rtol=0, atol=2e-8)
+        np.testing.assert_allclose(U[:, j], Uo, rtol=0, atol=2e-7)
+    np.testing.assert_array_equal(out['X_final'].cpu().numpy().T, X[-1])
+    # the reference's trace
+    np.testing.assert_allclose(X[:, 0, 2:], g['X'][:, 2:], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(X[:, 0, :2], g['X'][:, :2], rtol=0, atol=1e-4)
+    assert np.abs(U[:, 0] - g['U']).max() < 1e-3
