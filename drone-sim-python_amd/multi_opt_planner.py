@@ -145,6 +145,17 @@ def plot_chrono(_p, _f=None, _a=None):
 
 
 # ---- scenarios (src/multi_opt_planner.py:170-242) ----------------------------------------
+def export_csv(_p, filename):
+    """The plan as the CSV the reference's scripts exchange (src/07_multioptyplan.py:476-489): columns time, then
+    x_i, y_i, psi_i, phi_i, v_i per aircraft (1-based) -- what ExtractTrajData of 11_full_sim_case1.py reads back."""
+    import pandas as pd
+    states = {'time': _p.sol_time}
+    for i in range(len(_p.sol_x)):
+        for k, v in (('x', _p.sol_x), ('y', _p.sol_y), ('psi', _p.sol_psi), ('phi', _p.sol_phi), ('v', _p.sol_v)):
+            states[f'{k}_{i + 1}'] = list(v[i])
+    pd.DataFrame(states).to_csv(filename, index=False)
+
+
 class exp_0:
     name, desc = 'exp_0', 'single aircraft'
     t0, t1, hz = 0., 10., 50.

@@ -173,3 +173,29 @@ def test_cost_lowering_and_scenarios():
     row = sop.scen_row((0, 0, 0, 0, 10), (0, 30, np.pi, 0, 10), 12., sop.lower_cost(d2ou.CostComposit([(1, 2, 3)], obs_kind=0)),
                        0.01, [0., 0.], (-0.5, 0.5), (9., 14.))
     assert row[d2dhip.SC_OKIND] == 1 and row[d2dhip.SC_BANKMAX] == 0 and row[d2dhip.SC_O0R] == 3
+
+
+def test_plan_csv_round_trip(tmp_path):
+    """multi_opt_planner.export_csv writes the column format of src/07_multioptyplan.py:476-489 and
+    full_sim.ExtractTrajData (src/11_full_sim_case1.py:206-217) reads it back; ExtendTraj_symm mirrors it."""
+    import pandas as pd
+    import full_sim as fs
+    T, n = 11, 4
+    p = types.SimpleNamespace(sol_time=np.linspace(0, 1, T))
+    rng = np.random.default_rng(2)
+    for k in ('x', 'y', 'psi', 'phi', 'v'):
+        setattr(p, 'sol_' + k, [rng.normal(size=T) for _ in range(n)])
+    # a symmetric pair structure: aircraft i ends where aircraft n-1-i starts
+    for i in range(n):
+        p.sol_x[i][-1], p.sol_y[i][-1] = p.sol_x[n - 1 - i][0], p.sol_y[n - 1 - i][0]
+    f = tmp_path / 'plan.csv'
+    mop.export_csv(p, f)
+    df = pd.read_csv(f)
+    assert list(df.columns)[:6] == ['time', 'x_1', 'y_1', 'psi_1', 'phi_1', 'v_1'] and len(df.columns) == 1 + 5 * n
+    t, x, y, psi = fs.ExtractTrajData(df, n)
+    np.testing.assert_allclose(x, np.stack(p.sol_x, 1), rtol=1e-14); np.testing.assert_allclose(psi, np.stack(p.sol_psi, 1), rtol=1e-14)   # (decimal text)
+    t2, x2, y2, psi2 = fs.ExtendTraj_symm(n, x, y, psi, t)
+    assert x2.shape == (2 * T, n) and t2[-1] == 2 * t[-1]
+    for i in range(n):
+        np.testing.assert_array_equal(x2[T:, i], x[:, n - 1 - i])
+        np.testing.assert_array_equal(psi2[T:, i], y[:, n - 1 - i])      # (the reference extends psi with y, :238)
