@@ -190,8 +190,8 @@ __device__ __forceinline__ void jtj_mfma(const FitGeom &g, const unsigned char *
     ta[c] = T32_AT(oa[c]); tb[c] = T32_AT(ob[c]);
   }
   // one k-step; KK is the compile-time offset from the running offsets so that every LDS read of
-  // the unrolled body carries an immediate offset (no per-sample address arithmetic).  Operands of
-  // sample k+1 are fetched before the MFMAs of sample k are issued.
+  // the unrolled body carries an immediate offset (no per-sample address arithmetic).  The records of
+  // sample k+1 are fetched while the MFMAs of sample k execute.
 #define JTJ_KSTEP(KK)                                                                          \
   {                                                                                            \
     float v[NB];                                                                               \
@@ -203,11 +203,18 @@ __device__ __forceinline__ void jtj_mfma(const FitGeom &g, const unsigned char *
       cc[c] = LDS_F2(oc[c] + ((KK) + 1) * 64);                                                 \
       ta[c] = T32_AT(oa[c] + ((KK) + 1) * nq * 4); tb[c] = T32_AT(ob[c] + ((KK) + 1) * nq * 4); \
     }                                                                                          \
-    __builtin_amdgcn_sched_barrier(0);                                                         \
     int t = 0;                                                                                 \
     _Pragma("unroll") for (int I = 0; I < NB; ++I)                                             \
       _Pragma("unroll") for (int J = I; J < NB; ++J, ++t)                                      \
         acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[I], v[J], acc[t], 0, 0, 0);            \
+    /* issue order: the operand VALU of this sample, then its MFMAs with the next sample's LDS reads in their   \
+       shadow (two per MFMA): +4 % on the pass.  VALU in that shadow costs time instead (measured: fp32 MFMA and \
+       VALU share the ALUs), and the same treatment of the second-order pass below made no difference. */       \
+    __builtin_amdgcn_sched_group_barrier(0x002, 2 * NB, 0);                                    \
+    _Pragma("unroll") for (int u = 0; u < NB * (NB + 1) / 2; ++u) {                            \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                       \
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                       \
+    }                                                                                          \
     __builtin_amdgcn_sched_barrier(0);                                                         \
   }
   int k = 0;
