@@ -134,6 +134,8 @@ def main():
                     help='damping below which the evaluations carry the second-order term (default: library default; 0 = Gauss-Newton)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=1024)
+    ap.add_argument('--iso-large', type=int, default=32768,
+                    help='also time the isolated J^T J kernel on this many resident trajectories (roofline_isolated.large; 0 = skip)')
     ap.add_argument('--large-batch', type=int, default=0,
                     help='extra single solve at this batch size, reported as large_batch (off by default: its launches '
                          'would mix into the kernel statistics of the headline configuration)')
@@ -259,6 +261,28 @@ def main():
                     'note': 'the split-path J^T J kernel on the full resident batch (kernel only, HIP events; rocprofv3 summary in profiles/); '
                             'frac is over the whole kernel (fp64 row phases + contraction), jtj_section_* is the contraction alone, by difference '
                             'against the same kernel launched without it'}
+
+        # the same two measurements with 32 768 trajectories resident (eight per wave slot of the J^T J kernel)
+        if world == 1 and a.iso_large > B:
+            Bi = a.iso_large
+            dsci = ctx.dev(synth.synth_scenarios(Bi, seed=20241008, rank=0, obj_scale=OBJ_SCALE, K=K))
+            q0i = plan.init(dsci)
+            res = []
+            for want_H in (True, False):
+                for _ in range(2):
+                    plan.eval(dsci, q0i, want_H=want_H)
+                torch.cuda.synchronize()
+                plan.profile(True)
+                for _ in range(10):
+                    plan.eval(dsci, q0i, want_H=want_H)
+                ms, cnt = plan.profile_read()[:2]
+                plan.profile(False)
+                res.append(ms / cnt)
+            roof_iso['large'] = {'units_per_launch': Bi, 'avg_launch_us': 1e3 * res[0], 'avg_launch_us_without_jtj': 1e3 * res[1],
+                                 'frac': ALG_FLOP_PER_EVAL * Bi / (res[0] * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
+                                 'jtj_section_frac': ALG_FLOP_PER_EVAL * Bi / ((res[0] - res[1]) * 1e-3) / 1e12 / FP32_PEAK_TFLOPS}
+            del dsci, q0i
+            torch.cuda.empty_cache()
 
     # ---- the same solve on a larger resident batch (rank 0, N = 1 only): 4096 fits on 2048 wave slots are
     # bound by the last 1 % of the fits (110..200 iterations); this shows the throughput-bound regime
