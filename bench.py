@@ -2,28 +2,34 @@
 """Headline benchmark: trajectory-optimisations/sec (6-segment polynomial, 50 waypoints).
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-One "step" = one complete Levenberg-Marquardt solve of the per-GPU batch (BASELINE.json
-configs[1]: 4096 independent single-drone fits, S=6, K=50) with the scenarios and the
-initial guesses already resident in HBM.  With N > 1 the batch shards by trajectory
-(4096 per rank, weak scaling); the only collective is the all-reduce of the convergence
-statistics [sum cost, max |J^T r|, trajectories still running] after every persistent launch
-of the LM kernel (`check_every` iterations; default = max_iter, i.e. one launch and one
-all-reduce per solve; RCCL, `nccl` backend).  Rank 0 prints ONE JSON line.
+N > 1 without a launcher (no WORLD_SIZE in the environment): bench.py starts its N ranks itself --
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same flags>` as a child
+process, BEFORE anything in this process touches the GPU -- and exits with the child's code.  Launched by
+torch.distributed.run it reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as usual.  Rank 0 prints ONE JSON line.
+
+One "step" = one complete Levenberg-Marquardt solve of the per-GPU batch (BASELINE.json configs[1]: 4096 independent
+single-drone fits, S=6, K=50) with the scenarios and the initial guesses already resident in HBM.  With N > 1 the batch
+shards by trajectory (4096 per rank, weak scaling); the only collective is the all-reduce of the convergence statistics
+[sum cost, max |J^T r|, trajectories still running] after every persistent launch of the LM kernel (`check_every`
+iterations; default = max_iter, i.e. one launch and one all-reduce per solve; RCCL, `nccl` backend).
 
 Besides the contract fields the line carries
-  roofline      -- the dominant kernel (fit_lm_kernel: the whole LM loop, J^T J on the fp32 MFMA), HIP events
-                   around each of its launches inside the timed region: algorithmic flop = 200*48*49 per J^T J
-                   evaluation x evaluations / summed HIP-event kernel time
-  roofline_isolated -- the J^T J kernel of the split path (fit_eval_kernel) alone on the full resident
-                   batch (every trajectory active), HIP events around the kernel only
-  cpu_baseline  -- scipy.optimize.least_squares (method 'lm', analytic Jacobian) on the
-                   oracle's residual function over a process pool, bounded sample
+  roofline          the dominant kernel (fit_lm_kernel: the whole LM loop, J^T J on the fp32 MFMA), HIP events around each of
+                    its launches inside the timed region: algorithmic flop = 200*48*49 per J^T J evaluation
+                    x evaluations / summed HIP-event kernel time
+  roofline_isolated the contraction-only kernel (fit_jtj_kernel: row records from HBM -> MFMA -> tiles to HBM; its whole
+                    duration is the J^T J contraction) on 4096 and on 32 768 resident trajectories, HIP events
+  config3           BASELINE configs[3]: 32 768 fits per rank (256 k at N = 8), same solve, barrier + max over ranks
+  parity            the SAME scenarios the cpu_baseline leg solved with scipy: fraction agreeing to 1e-6 (cost, coefficients)
+  sim               BASELINE configs[4] (65 536 drones x 10 000 steps GVF loop) and the tracking loop, with roofline + cpu_baseline
+  cpu_baseline      scipy.optimize.least_squares (method 'lm', analytic Jacobian) on the oracle's residual function over a
+                    process pool, bounded sample
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -36,15 +42,25 @@ import numpy as np   # noqa: E402
 
 K, S_ = 50, 6
 OBJ_SCALE = 0.1
+SEED = 20241008
 FP32_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: f32-input MFMA peak
+FP64_PEAK_TFLOPS = 78.6           # fp64 vector peak
+HBM_PEAK_GBS = 8000.0
 ROWS_CONTRACTED = 200             # v, phi and the two position rows of the 50 samples
 NQ2 = 48
 ALG_FLOP_PER_EVAL = ROWS_CONTRACTED * NQ2 * (NQ2 + 1)      # M*P*(P+1), SURVEY.md 8d
+JTJ_BYTES_PER_UNIT = 4 * K * 16 + 6 * 1024                  # contraction-only kernel: records read + tiles written
 
 
 def _plan_consts():
     from d2dhip import synth
     return synth.planner_timing(0, 4.9, 10)[2], synth.default_wref(OBJ_SCALE, K)
+
+
+def bench_scenarios(B, rank=0):
+    """The bench batch of one rank (SURVEY.md 8d synthetic inputs, seed 20241008 + rank)."""
+    from d2dhip import synth
+    return synth.synth_scenarios(B, seed=SEED, rank=rank, obj_scale=OBJ_SCALE, K=K)
 
 
 # ---------------------------------------------------------------------------------------
@@ -54,12 +70,20 @@ def _plan_consts():
 def _cpu_fit_one(args):
     from scipy.optimize import least_squares
     from oracle import fit as F
-    basis, sc = args
+    basis, sc, q0 = args
     wp = F.waypoints(sc, basis.K, basis.duration)
     fun = lambda qq: F.residuals(basis, sc, qq, wp).reshape(-1)                        # noqa: E731
     jac = lambda qq: F.jacobian(basis, F.residuals(basis, sc, qq, wp, True)[1])        # noqa: E731
-    res = least_squares(fun, F.initial_guess(basis, sc, wp), jac=jac, method='lm', xtol=1e-12, ftol=1e-12, gtol=1e-12)
-    return 2 * res.cost
+    res = least_squares(fun, F.initial_guess(basis, sc, wp) if q0 is None else q0, jac=jac, method='lm',
+                        xtol=1e-15, ftol=1e-15, gtol=1e-15)      # (1e-12 leaves |J^T r| ~ 2e-7: coefficients off by up to 6e-6)
+    return 2 * res.cost, res.x
+
+
+def _cpu_oracle_lm_one(args):
+    from oracle import fit as F
+    basis, sc = args
+    q, c, it, st = F.lm_solve(basis, sc)
+    return c, q, it
 
 
 def _host_cores():
@@ -75,27 +99,51 @@ def _host_cores():
     return max(1, min(n, int(os.environ.get('D2D_BENCH_CORES', 16))))
 
 
-def cpu_baseline(n_sample=1024):
+def cpu_baseline(batch, n_sample=1024, n_oracle=128):
+    """scipy least_squares('lm') on the FIRST n_sample scenarios of rank 0's bench batch (the same rows the GPU solves), and the
+    oracle's own lm_solve (the line-by-line fp64 CPU statement of the algorithm the kernel runs) on the first n_oracle of them.
+    Returns the cpu_baseline record and the arrays the parity record needs."""
     import multiprocessing as mp
     from oracle import fit as F               # the oracle is the thing timed in this leg only
-    from d2dhip import synth
     dur, wref = _plan_consts()
     basis = F.FitBasis(S_, K, dur, wref)
-    sc = synth.synth_scenarios(n_sample, seed=20241008, obj_scale=OBJ_SCALE, K=K)
+    sc = bench_scenarios(batch)[:n_sample]
+    n_sample = len(sc)
     cores = _host_cores()
     with mp.get_context('fork').Pool(cores) as pool:
-        pool.map(_cpu_fit_one, [(basis, sc[i]) for i in range(min(cores, n_sample))])   # warm the workers
+        pool.map(_cpu_fit_one, [(basis, sc[i], None) for i in range(min(cores, n_sample))])   # warm the workers
         t0 = time.perf_counter()
-        costs = pool.map(_cpu_fit_one, [(basis, sc[i]) for i in range(n_sample)], chunksize=1)
+        res = pool.map(_cpu_fit_one, [(basis, sc[i], None) for i in range(n_sample)], chunksize=1)
         dt = time.perf_counter() - t0
-    return {'value': n_sample / dt, 'unit': 'trajectory-optimisations/s', 'cores': cores, 'kind': 'port',
-            'sample': f'{n_sample} of the {4096} bench trajectories, scipy.optimize.least_squares(method=lm, analytic '
-                      f'Jacobian, tol 1e-12) on oracle/fit.py residuals, multiprocessing.Pool({cores}), {dt:.1f} s wall',
-            'mean_cost': float(np.mean(costs))}
+        t1 = time.perf_counter()
+        ores = pool.map(_cpu_oracle_lm_one, [(basis, sc[i]) for i in range(min(n_oracle, n_sample))], chunksize=1)
+        dto = time.perf_counter() - t1
+    costs = np.array([r[0] for r in res]); qs = np.array([r[1] for r in res])
+    z = np.array([F.coefficients(basis, sc[i], qs[i]) for i in range(n_sample)])
+    rec = {'value': n_sample / dt, 'unit': 'trajectory-optimisations/s', 'cores': cores, 'kind': 'port',
+           'sample': f'the first {n_sample} of the {batch} bench trajectories of rank 0, scipy.optimize.least_squares(method=lm, analytic '
+                     f'Jacobian, tol 1e-15) on oracle/fit.py residuals, multiprocessing.Pool({cores}), {dt:.1f} s wall',
+           'mean_cost': float(np.mean(costs)),
+           'oracle_lm': {'value': len(ores) / dto, 'unit': 'trajectory-optimisations/s',
+                         'sample': f'oracle/fit.py lm_solve (the CPU statement of the kernel\'s algorithm, fp64) on the first {len(ores)} '
+                                   f'of them, {dto:.1f} s wall', 'mean_iters': float(np.mean([r[2] for r in ores]))}}
+    keep = {'basis': basis, 'sc': sc, 'cost': costs, 'q': qs, 'z': z,
+            'o_cost': np.array([r[0] for r in ores]), 'o_q': np.array([r[1] for r in ores])}
+    return rec, keep
+
+
+def cpu_polish(keep, q_gpu, n_polish=256):
+    """scipy LM started FROM the GPU's solutions (CPU pool; the GPU context exists by now, so the pool is spawned, not forked):
+    how far does the CPU arbiter move them?  Returns the largest relative moves of cost and unknowns."""
+    import multiprocessing as mp
+    n = min(n_polish, len(q_gpu))
+    with mp.get_context('spawn').Pool(min(_host_cores(), 8)) as pool:
+        res = pool.map(_cpu_fit_one, [(keep['basis'], keep['sc'][i], q_gpu[i]) for i in range(n)], chunksize=4)
+    return np.array([r[0] for r in res]), np.array([r[1] for r in res])
 
 
 def cpu_baseline_sim_gvf(n_steps=300):
-    """cpu_baseline leg of the simulation bench (tools/bench_sim.py, BASELINE configs[4]): the oracle's restatement of
+    """cpu_baseline leg of the simulation records (BASELINE configs[4]): the oracle's restatement of
     the reference's phase-1 loop body (DCF + GVF + scipy odeint) on one core."""
     from oracle import sim as S               # the oracle is the thing timed in this leg only
     c = np.array([[0, -20], [25, -20], [25, -100], [0, -100.0]])
@@ -108,7 +156,7 @@ def cpu_baseline_sim_gvf(n_steps=300):
 
 
 def cpu_baseline_sim_track(n_steps=60):
-    """cpu_baseline leg of the tracking bench: flatness + scipy CARE + odeint (oracle/sim.py track_run) on one core."""
+    """cpu_baseline leg of the tracking record: flatness + scipy CARE + odeint (oracle/sim.py track_run) on one core."""
     from oracle import sim as S
     g = np.load(os.path.join(ROOT, 'tests', 'golden', 'tracking_trace_carestandin.npz'))
     t0 = time.perf_counter()
@@ -116,6 +164,76 @@ def cpu_baseline_sim_track(n_steps=60):
     dt = time.perf_counter() - t0
     return {'value': 4 * (n_steps - 1) / dt, 'unit': 'drone-steps/s', 'cores': 1, 'kind': 'port',
             'sample': f'{n_steps - 1} steps x 4 aircraft, flatness + scipy CARE + odeint (oracle/sim.py track_run)'}
+
+
+# ---------------------------------------------------------------------------------------
+def self_spawn(a, argv):
+    """bench.py --gpus N without a launcher: start the N ranks as a child torch.distributed.run BEFORE any GPU call here."""
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={a.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd, env=env)
+
+
+def sim_records(ctx, torch, cpu_g, cpu_t, drones=65536, steps=10000, track_steps=2000):
+    """BASELINE configs[4]: the full_sim_case1 guidance loops at scale, one launch each, histories resident (allocated before the
+    timed launch).  HIP events on the library's stream."""
+    import d2dhip   # noqa: F401
+    n_ac, N = 4, drones
+    n_form = N // n_ac
+    rng = np.random.default_rng(0)
+    centres = np.tile(np.array([[0, -20], [25, -20], [25, -100], [0, -100.0]]), (n_form, 1)) + np.repeat(rng.uniform(-5, 5, (n_form, 2)), n_ac, 0)
+    X0 = np.tile([20, 30, -np.pi / 2, 0, 10.0], (N, 1)) + np.concatenate([rng.uniform(-3, 3, (N, 2)), np.zeros((N, 3))], 1)
+    dX0, dC, dR = ctx.dev(np.ascontiguousarray(X0.T)), ctx.dev(np.ascontiguousarray(centres.T)), ctx.dev(np.full(N, 60.0))
+    rows = steps + 1
+
+    def timed(fn, reps=2):
+        out = fn(None); ctx.sync()
+        best = 1e30
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ctx.sync()
+            e0.record(ctx.stream); fn(out); e1.record(ctx.stream)
+            ctx.sync()
+            best = min(best, e0.elapsed_time(e1) * 1e-3)
+        return out, best
+
+    recs = {}
+    out, dte = timed(lambda o: ctx.gvf_run(dX0, dC, dR, n_ac, rows, 0.05, 15.0, record=('X', 'U'), out=o))
+    n_steps = N * steps
+    recs['gvf'] = {'metric': 'drone-steps/sec (GVF+DCF guidance + plant step, full X,U history)', 'value': n_steps / dte,
+                   'unit': 'drone-steps/s', 'drones': N, 'steps': steps, 'launch_s': dte, 'dtype': 'f64',
+                   'workload': 'BASELINE configs[4]: full_sim_case1 guidance loop, 65k drones x 10k plant steps, per-step controller evaluation',
+                   'roofline': {'bound': 'hbm', 'kernel': 'gvf_run_kernel', 'achieved': n_steps * 56 / dte / 1e9, 'peak': HBM_PEAK_GBS,
+                                'unit': 'GB/s', 'frac': n_steps * 56 / dte / 1e9 / HBM_PEAK_GBS, 'traffic': None, 'alg_bytes_per_unit': 56,
+                                'note': 'integration-bound (fp64 VALU); HBM GB/s reported as BASELINE configs[4] asks; PMC WRITE_SIZE = '
+                                        'algorithmic to 0.03 % (profiles/)'},
+                   'cpu_baseline': cpu_g}
+    del out
+    torch.cuda.empty_cache()
+    T = track_steps + 1
+    t = np.arange(T) * 0.1
+    ph = rng.uniform(0, 2 * np.pi, N)
+    x_ref = 60 * np.sin(0.15 * t[:, None] + ph[None, :]); y_ref = 40 * np.sin(0.3 * t[:, None] + 2 * ph[None, :])
+    X0t = np.stack([x_ref[0], y_ref[0], np.arctan2(y_ref[1] - y_ref[0], x_ref[1] - x_ref[0]), np.zeros(N), 12 * np.ones(N)])
+    dxr, dyr, dX0t = ctx.dev(x_ref), ctx.dev(y_ref), ctx.dev(X0t)
+    o, dte = timed(lambda oo: ctx.track_run(dxr, dyr, dX0t, 0.1, record=('X', 'U'), out=oo))
+    n_steps = N * track_steps
+    recs['track'] = {'metric': 'drone-steps/sec (flatness + 5x5 LQR/CARE + plant step, full X,U history)', 'value': n_steps / dte,
+                     'unit': 'drone-steps/s', 'drones': N, 'steps': track_steps, 'launch_s': dte, 'dtype': 'f64',
+                     'workload': 'implement_controller loop of 11_full_sim_case1.py (:272-290) for 65k independent drones',
+                     'roofline': {'bound': 'hbm', 'kernel': 'gradient_kernel x4 + track_run_kernel', 'achieved': n_steps * 104 / dte / 1e9,
+                                  'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': n_steps * 104 / dte / 1e9 / HBM_PEAK_GBS, 'traffic': None,
+                                  'alg_bytes_per_unit': 104, 'note': 'CARE-bound (fp64 VALU); HBM GB/s as configs[4] asks'},
+                     'cpu_baseline': cpu_t}
+    del o
+    torch.cuda.empty_cache()
+    return recs
 
 
 # ---------------------------------------------------------------------------------------
@@ -134,25 +252,29 @@ def main():
                     help='damping below which the evaluations carry the second-order term (default: library default; 0 = Gauss-Newton)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=1024)
-    ap.add_argument('--iso-large', type=int, default=32768,
-                    help='also time the isolated J^T J kernel on this many resident trajectories (roofline_isolated.large; 0 = skip)')
-    ap.add_argument('--large-batch', type=int, default=0,
-                    help='extra single solve at this batch size, reported as large_batch (off by default: its launches '
-                         'would mix into the kernel statistics of the headline configuration)')
+    ap.add_argument('--config3-batch', type=int, default=32768, help='fits per rank of the config3 record (0 = skip)')
+    ap.add_argument('--config3-steps', type=int, default=3)
+    ap.add_argument('--no-sim', action='store_true', help='skip the simulation records (BASELINE configs[4])')
+    ap.add_argument('--no-order', action='store_true',
+                    help='hand the fits out in index order instead of longest-first by the previous solve\'s iteration counts')
     a = ap.parse_args()
 
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_spawn(a, sys.argv[1:]))
     rank = int(os.environ.get('RANK', 0)); world = int(os.environ.get('WORLD_SIZE', 1))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
-    if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            sys.exit('bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)')
-    cpu = None
+    if os.environ.get('D2D_BENCH_SPAWN_TEST'):       # tests/test_dist_cpu.py: the launcher path without a GPU
+        print(json.dumps({'rank': rank, 'world': world, 'local_rank': local_rank, 'gpus': a.gpus}), flush=True)
+        return
+    B = a.batch
+    cpu = keep = cpu_g = cpu_t = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cpu = cpu_baseline(a.cpu_sample)
+        cpu, keep = cpu_baseline(B, a.cpu_sample)
+        if not a.no_sim:
+            cpu_g, cpu_t = cpu_baseline_sim_gvf(), cpu_baseline_sim_track()
 
     import torch
     import d2dhip
-    from d2dhip import synth
     dist = None
     # one rank per GPU; D2D_DIST_BACKEND=gloo lets several ranks share one GPU for a rehearsal of this path
     backend = os.environ.get('D2D_DIST_BACKEND', 'nccl')
@@ -168,20 +290,10 @@ def main():
     ctx = d2dhip.Context(dev_index)
     dur, wref = _plan_consts()
     plan = d2dhip.FitPlan(ctx, S_, K, dur, wref)
-    B = a.batch
-    sc = synth.synth_scenarios(B, seed=20241008, rank=rank, obj_scale=OBJ_SCALE, K=K)
-    dsc = ctx.dev(sc)
-    q0 = plan.init(dsc)
     from d2dhip.dist import StatsReducer, solve_sharded
-    reducer = StatsReducer(dist, ctx.device if backend == 'nccl' else 'cpu')
-
+    red_dev = ctx.device if backend == 'nccl' else 'cpu'
+    reducer = StatsReducer(dist, red_dev)
     tolkw = {} if a.so_lambda is None else {'so_lambda': a.so_lambda}
-
-    def one_step():
-        """Full LM solve of the resident shard with the global convergence check."""
-        q = q0.clone()
-        cost, iters, status, stats, glob, checks = solve_sharded(plan, dsc, q, reducer, a.check_every, a.max_iter, **tolkw)
-        return (cost, iters, status, stats), q
 
     def barrier():
         torch.cuda.synchronize()
@@ -189,36 +301,62 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        one_step()
-    # per-kernel HIP events over the timed region itself (d2d_fit_profile: two event records on the library's stream
-    # around each hot-path launch, no synchronisation until they are read back after the closing barrier)
-    plan.profile(True)
-    n_evals = 0.0
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        (cost, iters, status, stats), q = one_step()
-        n_evals += stats[3]                # evaluation units of this solve (host copy already made by the solve)
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=ctx.device if backend == 'nccl' else 'cpu')
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    st = status.cpu().numpy()
-    conv = float(np.isin(st, (d2dhip.ST_CONVERGED, d2dhip.ST_STALLED)).mean())
+    def allreduce(vals, op):
+        if dist is None:
+            return [float(v) for v in vals]
+        t = torch.tensor(list(vals), dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=getattr(dist.ReduceOp, op))
+        return [float(v) for v in t.cpu()]
 
-    # ---- per-kernel roofline from the events of the timed region -------------
+    def timed_solves(Bn, steps, warmup, order):
+        """warmup + `steps` timed full LM solves of this rank's Bn resident scenarios with the global convergence check; barrier
+        + synchronize on both sides, MAX over ranks.  Returns (seconds, last solve's results, evaluation units of the timed
+        solves, HIP-event profile of the timed region, global [sum cost, not converged, sum iters, evals of the last solve])."""
+        dsc = ctx.dev(bench_scenarios(Bn, rank))
+        q0 = plan.init(dsc)
+        res = None
+        for _ in range(warmup):
+            q = q0.clone()
+            res = solve_sharded(plan, dsc, q, reducer, a.check_every, a.max_iter, **tolkw)
+            if order:
+                plan.order_from_iters(res[1])     # longest fits of the previous solve are handed out first
+        plan.profile(True)
+        n_evals = 0.0
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            q = q0.clone()
+            res = solve_sharded(plan, dsc, q, reducer, a.check_every, a.max_iter, **tolkw)
+            n_evals += res[3][3]
+        barrier()
+        dt = time.perf_counter() - t0
+        dt = allreduce([dt], 'MAX')[0]
+        prof = plan.profile_read()
+        plan.profile(False)
+        cost, iters, status, stats = res[:4]
+        notconv = float((~torch.isin(status, torch.tensor([d2dhip.ST_CONVERGED, d2dhip.ST_STALLED], device=status.device))).sum().item())
+        glob = allreduce([stats[0], notconv, float(iters.double().sum().item()), stats[3]], 'SUM')
+        plan.clear_order()
+        return dt, (cost, iters, status, stats, q, dsc, q0), n_evals, prof, glob
+
+    # ---- headline: BASELINE configs[1] ------------------------------------------------------------------
+    dt, (cost, iters, status, stats, q, dsc, q0), n_evals, prof, glob = timed_solves(B, a.steps, a.warmup, not a.no_order)
+    ev_ms, ev_n, stp_ms, stp_n, lm_ms, lm_n = prof[:6]
+    total = B * world
+    headline = {'value': total * a.steps / dt, 'ms_per_step': 1e3 * dt / a.steps, 'converged_frac': 1.0 - glob[1] / total,
+                'mean_iters': glob[2] / total, 'evals_per_fit': glob[3] / total, 'mean_cost': glob[0] / total}
+    q_head = q[:a.cpu_sample].clone() if keep is not None else None
+    z_head = plan.coeffs(dsc[:a.cpu_sample], q[:a.cpu_sample]).cpu().numpy() if keep is not None else None
+    c_head = cost[:a.cpu_sample].cpu().numpy() if keep is not None else None
+
     roof = roof_iso = None
-    ev_ms, ev_n, stp_ms, stp_n, lm_ms, lm_n = plan.profile_read()
-    plan.profile(False)
     if rank == 0:
         if lm_n > 0:
             # the whole LM loop runs in one persistent kernel per convergence check: it IS the hot path
             ach = ALG_FLOP_PER_EVAL * n_evals / (lm_ms * 1e-3) / 1e12
             roof = {'bound': 'mfma', 'kernel': 'fit_lm_kernel<3,24> (fused LM loop: fp64 residual/J^T r, J^T J on v_mfma_f32_16x16x4_f32, fp32 Cholesky)',
-                    'achieved': ach, 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / FP32_PEAK_TFLOPS, 'traffic': None,
+                    'achieved': ach, 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / FP32_PEAK_TFLOPS,
+                    'traffic': None, 'traffic_note': 'per-launch PMC FETCH_SIZE / WRITE_SIZE of this kernel: profiles/ (bench.py cannot read PMC counters itself)',
                     'alg_flop_per_unit': ALG_FLOP_PER_EVAL, 'units_per_launch_avg': n_evals / lm_n,
                     'avg_launch_us': 1e3 * lm_ms / lm_n, 'launches': int(lm_n), 'kernel_ms_total': lm_ms,
                     'note': 'achieved counts only the J^T J contraction (M*P*(P+1) per evaluation); the same kernel also does the '
@@ -230,93 +368,102 @@ def main():
                     'alg_flop_per_unit': ALG_FLOP_PER_EVAL, 'units_per_launch_avg': n_evals / ev_n,
                     'avg_launch_us': 1e3 * ev_ms / ev_n, 'launches': int(ev_n),
                     'step_kernel_avg_launch_us': 1e3 * stp_ms / stp_n, 'eval_ms_total': ev_ms, 'step_ms_total': stp_ms}
-        # isolated: the J^T J kernel alone (fit_eval_kernel), every trajectory active in one launch, bracketed by
-        # HIP events on the library's stream (d2d_fit_profile); prep / untile launches of the public call excluded
-        for _ in range(3):
-            plan.eval(dsc, q0)
-        torch.cuda.synchronize()
-        plan.profile(True)
-        nit = 20
-        for _ in range(nit):
-            plan.eval(dsc, q0)
-        iso_ms, iso_n = plan.profile_read()[:2]
-        plan.profile(False)
-        iso_ms /= iso_n
-        # the same kernel without its MFMA section (no J^T J requested): the difference is the time of the contraction
-        for _ in range(3):
-            plan.eval(dsc, q0, want_H=False)
-        torch.cuda.synchronize()
-        plan.profile(True)
-        for _ in range(nit):
-            plan.eval(dsc, q0, want_H=False)
-        noh_ms, noh_n = plan.profile_read()[:2]
-        plan.profile(False)
-        noh_ms /= noh_n
-        ach_i = ALG_FLOP_PER_EVAL * B / (iso_ms * 1e-3) / 1e12
-        roof_iso = {'bound': 'mfma', 'kernel': 'fit_eval_kernel<3,24,true> (fp64 residual / J^T r phases + J^T J on v_mfma_f32_16x16x4_f32)',
-                    'achieved': ach_i, 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': ach_i / FP32_PEAK_TFLOPS, 'avg_launch_us': 1e3 * iso_ms, 'units_per_launch': B, 'launches': int(iso_n),
-                    'avg_launch_us_without_jtj': 1e3 * noh_ms, 'jtj_section_us': 1e3 * (iso_ms - noh_ms),
-                    'jtj_section_frac': ALG_FLOP_PER_EVAL * B / ((iso_ms - noh_ms) * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
-                    'note': 'the split-path J^T J kernel on the full resident batch (kernel only, HIP events; rocprofv3 summary in profiles/); '
-                            'frac is over the whole kernel (fp64 row phases + contraction), jtj_section_* is the contraction alone, by difference '
-                            'against the same kernel launched without it'}
 
-        # the same two measurements with 32 768 trajectories resident (eight per wave slot of the J^T J kernel)
-        if world == 1 and a.iso_large > B:
-            Bi = a.iso_large
-            dsci = ctx.dev(synth.synth_scenarios(Bi, seed=20241008, rank=0, obj_scale=OBJ_SCALE, K=K))
-            q0i = plan.init(dsci)
-            res = []
-            for want_H in (True, False):
-                for _ in range(2):
-                    plan.eval(dsci, q0i, want_H=want_H)
-                torch.cuda.synchronize()
-                plan.profile(True)
-                for _ in range(10):
-                    plan.eval(dsci, q0i, want_H=want_H)
-                ms, cnt = plan.profile_read()[:2]
-                plan.profile(False)
-                res.append(ms / cnt)
-            roof_iso['large'] = {'units_per_launch': Bi, 'avg_launch_us': 1e3 * res[0], 'avg_launch_us_without_jtj': 1e3 * res[1],
-                                 'frac': ALG_FLOP_PER_EVAL * Bi / (res[0] * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
-                                 'jtj_section_frac': ALG_FLOP_PER_EVAL * Bi / ((res[0] - res[1]) * 1e-3) / 1e12 / FP32_PEAK_TFLOPS}
-            del dsci, q0i
+        # ---- the contraction alone: fit_jtj_kernel on the records a previous launch (d2d_fit_rows) left in HBM -----------
+        def iso(dsc_i, q_i, nit):
+            Bi = dsc_i.shape[0]
+            plan.rows(dsc_i, q_i)
+            for _ in range(3):
+                plan.jtj(Bi, want_H=False)
+            torch.cuda.synchronize()
+            plan.profile(True)
+            for _ in range(nit):
+                plan.jtj(Bi, want_H=False)
+            pr = plan.profile_read()
+            plan.profile(False)
+            us = 1e3 * pr[6] / pr[7]
+            tf = ALG_FLOP_PER_EVAL * Bi / (us * 1e-6) / 1e12
+            return {'units_per_launch': Bi, 'avg_launch_us': us, 'launches': int(pr[7]), 'achieved': tf, 'frac': tf / FP32_PEAK_TFLOPS,
+                    'alg_hbm_gbs': JTJ_BYTES_PER_UNIT * Bi / (us * 1e-6) / 1e9}
+        i4 = iso(dsc, q0, 20)
+        roof_iso = {'bound': 'mfma', 'kernel': 'fit_jtj_kernel<3,24> (contraction only: fp32 row records HBM -> LDS, J^T J on v_mfma_f32_16x16x4_f32, '
+                                               'tile-major store)', 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                    'alg_flop_per_unit': ALG_FLOP_PER_EVAL, 'alg_bytes_per_unit': JTJ_BYTES_PER_UNIT, 'traffic': None, **i4,
+                    'note': 'the whole kernel is the contraction (HIP events around the kernel only; rocprofv3 kernel trace in profiles/); '
+                            'ceiling of frac = 0.766: the three diagonal 16x16 tiles are computed whole'}
+        if world == 1 and a.config3_batch > B:
+            dsci = ctx.dev(bench_scenarios(a.config3_batch, 0))
+            roof_iso['large'] = iso(dsci, plan.init(dsci), 10)
+            del dsci
             torch.cuda.empty_cache()
 
-    # ---- the same solve on a larger resident batch (rank 0, N = 1 only): 4096 fits on 2048 wave slots are
-    # bound by the last 1 % of the fits (110..200 iterations); this shows the throughput-bound regime
-    large = None
-    if rank == 0 and world == 1 and a.large_batch > B:
-        Bl = a.large_batch
-        dscl = ctx.dev(synth.synth_scenarios(Bl, seed=20241008, rank=0, obj_scale=OBJ_SCALE, K=K))
-        q0l = plan.init(dscl)
-        plan.solve(dscl, q0l.clone(), max_iter=a.max_iter, check_every=a.max_iter, **tolkw)
-        torch.cuda.synchronize()
-        tl = time.perf_counter()
-        _c, _i, _s, stl = plan.solve(dscl, q0l.clone(), max_iter=a.max_iter, check_every=a.max_iter, **tolkw)
-        torch.cuda.synchronize()
-        tl = time.perf_counter() - tl
-        large = {'batch': Bl, 'value': Bl / tl, 'unit': 'trajectory-optimisations/s', 'ms_per_step': 1e3 * tl,
-                 'jtj_frac_of_fp32_mfma_peak': ALG_FLOP_PER_EVAL * float(stl[3]) / tl / 1e12 / FP32_PEAK_TFLOPS,
-                 'note': 'one solve, wall clock around d2d_fit_solve; not the headline configuration'}
-        del dscl, q0l
+    # ---- BASELINE configs[3]: 32 768 fits per rank (256 k at N = 8), every rank, same timing discipline -------------------
+    config3 = None
+    if a.config3_batch > 0:
+        B3 = a.config3_batch
+        dt3, r3, ne3, prof3, glob3 = timed_solves(B3, a.config3_steps, 1, not a.no_order)
+        tot3 = B3 * world
+        config3 = {'workload': f'{B3} fits per GPU ({tot3} in total), sharded by trajectory, convergence all-reduce (BASELINE configs[3])',
+                   'value': tot3 * a.config3_steps / dt3, 'unit': 'trajectory-optimisations/s', 'n_gpus': world, 'per_gpu_batch': B3,
+                   'steps': a.config3_steps, 'ms_per_step': 1e3 * dt3 / a.config3_steps, 'converged_frac': 1.0 - glob3[1] / tot3,
+                   'mean_iters': glob3[2] / tot3, 'mean_cost': glob3[0] / tot3,
+                   'jtj_frac_of_fp32_mfma_peak_rank0': (ALG_FLOP_PER_EVAL * ne3 / (prof3[4] * 1e-3) / 1e12 / FP32_PEAK_TFLOPS) if prof3[5] > 0 else None}
+        del r3
+        torch.cuda.empty_cache()
+
+    # ---- parity: the SAME scenarios the cpu_baseline leg solved ------------------------------------------------------------
+    parity = None
+    if keep is not None:
+        n = len(keep['cost'])
+        cg, zg = c_head[:n], z_head[:n]
+        rel_c = np.abs(cg - keep['cost']) / np.maximum(np.abs(keep['cost']), 1e-300)
+        rel_z = np.abs(zg - keep['z']).reshape(n, -1).max(1) / np.abs(keep['z']).reshape(n, -1).max(1)
+        same = (rel_c <= 1e-6) & (rel_z <= 1e-6)
+        diff = (cg - keep['cost'])[~same]
+        no = len(keep['o_cost'])
+        qg = q_head[:no].cpu().numpy()
+        rel_co = np.abs(cg[:no] - keep['o_cost']) / np.maximum(np.abs(keep['o_cost']), 1e-300)
+        rel_qo = np.abs(qg - keep['o_q']).max(1) / np.abs(keep['o_q']).max(1)
+        pc, pq = cpu_polish(keep, q_head.cpu().numpy(), 256)
+        npol = len(pc)
+        qgp = q_head[:npol].cpu().numpy()
+        parity = {'scenarios': n, 'what': 'GPU (d2d_fit_solve) vs scipy.optimize.least_squares(lm) from the same start on the same scenarios',
+                  'same_minimum_frac': float(same.mean()), 'cost_rel_le_1e-6_frac': float((rel_c <= 1e-6).mean()),
+                  'coeff_rel_le_1e-6_frac': float((rel_z <= 1e-6).mean()),
+                  'others_gpu_minus_cpu_cost': {'n': int((~same).sum()), 'gpu_lower': int((diff < 0).sum()), 'gpu_higher': int((diff > 0).sum()),
+                                                'median': float(np.median(diff)) if len(diff) else 0.0,
+                                                'note': 'different local minima of a non-convex cost (two LM variants, same start)'},
+                  'mean_cost_gpu': float(cg.mean()), 'mean_cost_cpu': float(keep['cost'].mean()),
+                  'vs_oracle_lm': {'scenarios': no, 'what': 'GPU vs oracle/fit.py lm_solve (same algorithm, fp64 on the CPU)',
+                                   'same_minimum_frac': float(((rel_co <= 1e-6) & (rel_qo <= 1e-6)).mean())},
+                  'polish': {'scenarios': npol, 'what': 'scipy LM (tol 1e-15) started from the GPU solutions: largest relative move',
+                             'max_rel_cost_move': float(np.max(np.abs(pc - cg[:npol]) / np.abs(cg[:npol]))),
+                             'max_rel_q_move': float(np.max(np.abs(pq - qgp).max(1) / np.abs(qgp).max(1))),
+                             'frac_within_1e-6': float(((np.abs(pc - cg[:npol]) / np.abs(cg[:npol]) <= 1e-6) &
+                                                        (np.abs(pq - qgp).max(1) / np.abs(qgp).max(1) <= 1e-6)).mean())}}
+
+    # ---- BASELINE configs[4] ---------------------------------------------------------------------------------------------
+    sim = None
+    if rank == 0 and world == 1 and not a.no_sim:
+        del dsc, q0, q, cost, iters, status
+        torch.cuda.empty_cache()
+        sim = sim_records(ctx, torch, cpu_g, cpu_t)
 
     if rank == 0:
-        total = B * world * a.steps
         line = {
-            'metric': 'trajectory-optimisations/sec (6-seg poly, 50 wpts)', 'value': total / dt,
+            'metric': 'trajectory-optimisations/sec (6-seg poly, 50 wpts)', 'value': headline['value'],
             'unit': 'trajectory-optimisations/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
-            'ms_per_step': 1e3 * dt / a.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'ms_per_step': headline['ms_per_step'], 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f64 residual/gradient + f32 MFMA J^T J', 'data': 'synthetic',
             'config': {'workload': f'batch={B} per GPU independent single-drone 6-seg poly fits, 50 waypoints (BASELINE configs[1])',
                        'segments': S_, 'samples': K, 'unknowns_reduced': NQ2, 'max_iter': a.max_iter,
                        'check_every': a.check_every, 'so_lambda': d2dhip.SO_LAMBDA if a.so_lambda is None else a.so_lambda,
+                       'handout': 'index order' if a.no_order else 'longest-first by the iteration counts of the previous solve of the same batch (warmup)',
                        'parallelism': f'trajectory-sharded x{world}'},
-            'converged_frac': conv, 'mean_iters': float(iters.double().mean().item()),
-            'evals_per_fit': float(stats[3] / B),          # in Gauss-Newton units (200 rows); second-order evaluations count 1.5
-             'mean_cost': float(stats[0] / B),
-            'roofline': roof, 'roofline_isolated': roof_iso, 'large_batch': large, 'cpu_baseline': cpu,
+            'converged_frac': headline['converged_frac'], 'mean_iters': headline['mean_iters'],
+            'evals_per_fit': headline['evals_per_fit'],          # Gauss-Newton units (200 rows); second-order evaluations count 1.5
+            'mean_cost': headline['mean_cost'],
+            'roofline': roof, 'roofline_isolated': roof_iso, 'config3': config3, 'parity': parity, 'sim': sim, 'cpu_baseline': cpu,
         }
         print(json.dumps(line))
     if dist is not None:

@@ -108,7 +108,8 @@ fit_eval_kernel(int B, FitGeom g, FitLds L, int dbg, GroupArgs ga, const double 
                 const double *__restrict__ pk, const float *__restrict__ gG32,
                 const float *__restrict__ gW32, const double *__restrict__ prep,
                 const double *__restrict__ q_in, int32_t *__restrict__ flags,
-                double *__restrict__ cost_out, double *__restrict__ g_out, float *__restrict__ H_out) {
+                double *__restrict__ cost_out, double *__restrict__ g_out, float *__restrict__ H_out,
+                f32x4 *__restrict__ rows_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int wpb = blockDim.x >> 6;
@@ -155,6 +156,10 @@ fit_eval_kernel(int B, FitGeom g, FitLds L, int dbg, GroupArgs ga, const double 
     const GroupCtx gc{ga.pos, ga.n_ac, ga.n_ac > 0 ? b % ga.n_ac : 0, ga.n_ac > 0 ? (b / ga.n_ac) * ga.n_ac : 0, ga.pos ? ga.nds : 0};
     const double cost = eval_cost_grad<NQ>(g, G64, pk + (size_t)b * FIT_PK * g.K, qs, us, cf, s, lane, dbg, g_lane, gc, cfd);
     if (lane < n && g_out) g_out[(size_t)b * n + lane] = g_lane;
+    if (rows_out) {      // the fp32 row records of this evaluation, for a later fit_jtj_kernel launch (d2d_fit_rows / d2d_fit_jtj)
+      f32x4 *dst = rows_out + (size_t)b * 4 * (g.K + 1);
+      for (int i = lane; i < 4 * g.K; i += 64) dst[i] = cf[i];
+    }
     if (lane == 0) {
       if (cost_out) cost_out[b] = cost;
       if (flags) {
@@ -195,6 +200,70 @@ untile_kernel(int B, int n, int NB, const float *__restrict__ Ht, const float *_
     const int tile = I * NB - I * (I - 1) / 2 + (J - I);
     const int rr = r & 15, reg = rr & 3, ln = (rr >> 2) * 16 + (c & 15);
     dst[i] = fmaf(ww, Wt[(tile * 4 + reg) * 64 + ln], src[(tile * 4 + reg) * 64 + ln]);
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// The contraction alone: J^T J of every trajectory from the fp32 row records a previous launch left in HBM
+// (fit_eval_kernel with rows_out; d2d_fit_rows / d2d_fit_jtj).  The whole kernel is the MFMA pass of
+// jtj_mfma -- records HBM -> the wave's LDS block, operands from the LDS copy of the basis planes,
+// 6 x 50 v_mfma_f32_16x16x4_f32 per trajectory, tile-major store -- so its duration IS the contraction's
+// (the figure bench.py reports as roofline_isolated).  Algorithmic HBM bytes per trajectory: 4K records x 16 B
+// read + NB(NB+1)/2 tiles x 1 KiB written (3.2 kB + 6 kB at K = 50, nq = 24).
+struct JtjLds {
+  int G32, wave0, wave_stride, total;
+};
+static JtjLds jtj_lds_layout(int K, int nq, int wpb) {
+  JtjLds L;
+  L.G32 = 0;
+  L.wave0 = align16((3 * K + 1) * nq * 4);
+  L.wave_stride = align16((K + 1) * 4 * 16);
+  L.total = L.wave0 + wpb * L.wave_stride;
+  return L;
+}
+
+template <int NB, int NQ>
+__global__ void __launch_bounds__(64 * FIT_EVAL_WPB_MAX)
+fit_jtj_kernel(int B, FitGeom g, JtjLds L, const float *__restrict__ gG32, const f32x4 *__restrict__ rows,
+               float *__restrict__ H_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  stage(lds + L.G32, gG32, (3 * g.K + 1) * g.nq * 4);
+  const int cf_off = L.wave0 + wave * L.wave_stride;
+  f32x4 *cf = reinterpret_cast<f32x4 *>(lds + cf_off);
+  __syncthreads();
+  const int stride_bl = gridDim.x * wpb;
+  const int nrec = 4 * g.K;
+  // the records of the wave's next trajectory travel in registers while the MFMAs of the current one run
+  constexpr int NPF = 4;                          // 4 x 64 records = K <= 64 samples; longer horizons load the rest late
+  f32x4 pf[NPF];
+  int b = blockIdx.x * wpb + wave;
+  if (b < B) {
+#pragma unroll
+    for (int m = 0; m < NPF; ++m)
+      if (lane + 64 * m < nrec) pf[m] = rows[(size_t)b * 4 * (g.K + 1) + lane + 64 * m];
+  }
+  for (; b < B; b += stride_bl) {
+#pragma unroll
+    for (int m = 0; m < NPF; ++m)
+      if (lane + 64 * m < nrec) cf[lane + 64 * m] = pf[m];
+    for (int i = lane + 64 * NPF; i < nrec; i += 64) cf[i] = rows[(size_t)b * 4 * (g.K + 1) + i];
+    const int bn = b + stride_bl;
+    if (bn < B) {
+#pragma unroll
+      for (int m = 0; m < NPF; ++m)
+        if (lane + 64 * m < nrec) pf[m] = rows[(size_t)bn * 4 * (g.K + 1) + lane + 64 * m];
+    }
+    wave_lds_sync();
+    f32x4 acc[NB * (NB + 1) / 2];
+    jtj_mfma<NB, NQ, true>(g, lds, L.G32, gG32, cf_off, lane, g.K, acc);
+    float *Hb = H_out + (size_t)b * (NB * (NB + 1) / 2) * 256;
+#pragma unroll
+    for (int t = 0; t < NB * (NB + 1) / 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Hb[(t * 4 + r) * 64 + lane] = acc[t][r];
+    wave_lds_sync();     // the next trajectory's records overwrite this wave's LDS block
   }
 }
 
@@ -357,7 +426,12 @@ fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_budget,
               const float *__restrict__ gG32, const float *__restrict__ gWt,
               const double *__restrict__ prep, double *__restrict__ q_io, double *__restrict__ cost_io,
               double *__restrict__ g_io, double *__restrict__ lm, int32_t *__restrict__ flags,
-              int32_t *__restrict__ queue, unsigned long long *__restrict__ stamps) {
+              int32_t *__restrict__ queue, unsigned long long *__restrict__ stamps,
+              const int32_t *__restrict__ order, int prio_at) {
+  // order != NULL: hand-out position i takes trajectory order[i] (d2d_fit_plan_set_order: the longest fits of a previous solve
+  // first, so that the tail of the launch is not one long fit that was drawn late).  prio_at: a fit that has used this many
+  // iterations raises its wave's priority (s_setprio): the stragglers that decide when the launch ends get the SIMD's issue
+  // slots ahead of the co-resident wave instead of sharing them.
   // stamps != NULL (D2D_LM_STAMPS=1, diagnostics only): per-phase wave-cycle totals, see launch_lm
   unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = 0, st_solve[5] = {0, 0, 0, 0, 0};
 #define LM_STAMP(i)                                                     \
@@ -399,7 +473,8 @@ fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_budget,
     return __builtin_amdgcn_readfirstlane(t);
   };
   if (STAMPS) st_last = __builtin_amdgcn_s_memtime();
-  for (int b = blockIdx.x + gridDim.x * wave; (unsigned)b < (unsigned)B; b = next_index(b)) {
+  for (int bi = blockIdx.x + gridDim.x * wave; (unsigned)bi < (unsigned)B; bi = next_index(bi)) {
+    const int b = order ? __builtin_amdgcn_readfirstlane(order[bi]) : bi;
     if (flags[4 * b + FL_STATUS] != D2D_ST_RUNNING) continue;
     const double *prow = prep + (size_t)b * FIT_PREP_STRIDE;
     const double *pkb = pk + (size_t)b * FIT_PK * g.K;
@@ -455,6 +530,7 @@ fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_budget,
       if (local >= iter_budget || iters >= opts.max_iter) break;
       const double gmax = uniform_d(wave_max(fabs(gi)));
       if (gmax <= opts.gtol) { status = D2D_ST_CONVERGED; break; }
+      if (iters >= prio_at) __builtin_amdgcn_s_setprio(2);
       float dgi, dl;
       LM_STAMP(6)
       const int ok = uniform_i(damped_solve<N>(hrow, lam, act, lane, big, dgi, dl, STAMPS ? st_solve : nullptr) ? 1 : 0);
@@ -481,13 +557,18 @@ fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_budget,
     }
     if (status == D2D_ST_RUNNING && iters >= opts.max_iter) status = D2D_ST_MAXITER;
     const double gmax = uniform_d(wave_max(fabs(gi)));
-    if (act) { q_io[(size_t)b * n + lane] = qi; g_io[(size_t)b * n + lane] = gi; }
+    {
+      int lane_io = lane;      // (laundered: the per-lane output addresses are not worth two VGPR pairs held across the whole LM loop)
+      LAUNDER(lane_io);
+      if (act) { q_io[(size_t)b * n + lane_io] = qi; g_io[(size_t)b * n + lane_io] = gi; }
+    }
     if (lane == 0) {
       cost_io[b] = c;
       lm[4 * b + 0] = lam; lm[4 * b + 1] = nu; lm[4 * b + 2] = gmax; lm[4 * b + 3] = so_rows ? 1.0 : 0.0;
       flags[4 * b + FL_STATUS] = status; flags[4 * b + FL_ITERS] = iters; flags[4 * b + FL_NEED] = 1;
       flags[4 * b + FL_NEVAL] += nev;
     }
+    __builtin_amdgcn_s_setprio(0);
     LM_STAMP(0)
   }
   if (queue != nullptr && lane == 0) {
@@ -511,6 +592,34 @@ fit_state_init_kernel(int B, int off, int stride, double *__restrict__ lm, int32
   lm[4 * b + 0] = D2D_LM_LAMBDA0; lm[4 * b + 1] = 2.0; lm[4 * b + 2] = 0.0; lm[4 * b + 3] = 0.0;
   flags[4 * b + FL_STATUS] = D2D_ST_RUNNING; flags[4 * b + FL_ITERS] = 0; flags[4 * b + FL_NEED] = 1;
   if (stride == 1) flags[4 * b + FL_NEVAL] = 0;       // group sweeps keep counting across visits
+}
+
+
+// Hand-out order of the persistent LM kernel: order[0..B) = trajectory indices sorted by the iteration counts of a previous
+// solve, longest first (counting sort in one workgroup; ties in index order within a 64-wide stripe, otherwise as the
+// atomics fall: the fits are independent, the order only schedules them).
+#define ORDER_BINS 2048
+__global__ void __launch_bounds__(1024)
+fit_order_kernel(int B, const int32_t *__restrict__ iters, int32_t *__restrict__ order) {
+  __shared__ int hist[ORDER_BINS];
+  for (int i = threadIdx.x; i < ORDER_BINS; i += blockDim.x) hist[i] = 0;
+  __syncthreads();
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    int k = iters[b];
+    k = k < 0 ? 0 : (k >= ORDER_BINS ? ORDER_BINS - 1 : k);
+    atomicAdd(&hist[ORDER_BINS - 1 - k], 1);          // bin 0 = the longest fits
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {                             // exclusive prefix sum (2048 adds: negligible beside a solve)
+    int run = 0;
+    for (int i = 0; i < ORDER_BINS; ++i) { const int h = hist[i]; hist[i] = run; run += h; }
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    int k = iters[b];
+    k = k < 0 ? 0 : (k >= ORDER_BINS ? ORDER_BINS - 1 : k);
+    order[atomicAdd(&hist[ORDER_BINS - 1 - k], 1)] = b;
+  }
 }
 
 // sampled x, y of every trajectory: pos [B][2][K]
@@ -684,23 +793,46 @@ static int upload(T **dst, const std::vector<T> &src) {
 
 static FitGeom geom_of(const d2d_fit_plan *pl) { return FitGeom{pl->K, pl->nq, pl->nq + 1}; }
 
+static void free_scratch(d2d_fit_plan *pl) {
+  void **ptrs[] = {(void **)&pl->d_g, (void **)&pl->d_H, (void **)&pl->d_cost, (void **)&pl->d_lm, (void **)&pl->d_flags,
+                   (void **)&pl->d_prep, (void **)&pl->d_pos, (void **)&pl->d_qprev, (void **)&pl->d_pk, (void **)&pl->d_rows,
+                   (void **)&pl->d_order};
+  for (void **p : ptrs) {
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+  }
+  pl->cap_B = 0;
+  pl->order_B = 0;
+}
+
+// Scratch of a plan grows on demand.  A failed regrow leaves the plan with NO scratch (every pointer null, cap_B = 0):
+// the next call allocates afresh instead of running on freed memory.
 static int ensure_scratch(d2d_fit_plan *pl, int B) {
   if (B <= pl->cap_B) return D2D_OK;
   const size_t n = 2 * pl->nq;
-  if (pl->d_g) { hipFree(pl->d_g); hipFree(pl->d_H); hipFree(pl->d_cost); hipFree(pl->d_lm); hipFree(pl->d_flags); hipFree(pl->d_prep); }
-  D2D_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&pl->d_prep), (size_t)B * FIT_PREP_STRIDE * sizeof(double)));
-  if (pl->d_pos) { hipFree(pl->d_pos); hipFree(pl->d_qprev); hipFree(pl->d_pk); }
-  D2D_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&pl->d_pk), (size_t)B * FIT_PK * pl->K * sizeof(double)));
-  D2D_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&pl->d_pos), (size_t)B * 2 * pl->K * sizeof(double)));
-  D2D_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&pl->d_qprev), (size_t)B * n * sizeof(double)));
-  D2D_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&pl->d_g), (size_t)B * n * sizeof(double)));
+  free_scratch(pl);
+#define SCRATCH_ALLOC(field, bytes)                                                        \
+  if (hipMalloc(reinterpret_cast<void **>(&pl->field), (bytes)) != hipSuccess) {           \
+    pl->field = nullptr;                                                                   \
+    free_scratch(pl);                                                                      \
+    d2d_set_error("fit scratch: hipMalloc of %zu bytes for B=%d failed", (size_t)(bytes), B); \
+    return D2D_ENOMEM;                                                                     \
+  }
+  SCRATCH_ALLOC(d_prep, (size_t)B * FIT_PREP_STRIDE * sizeof(double))
+  SCRATCH_ALLOC(d_pk, (size_t)B * FIT_PK * pl->K * sizeof(double))
+  SCRATCH_ALLOC(d_pos, (size_t)B * 2 * pl->K * sizeof(double))
+  SCRATCH_ALLOC(d_qprev, (size_t)B * n * sizeof(double))
+  SCRATCH_ALLOC(d_g, (size_t)B * n * sizeof(double))
   {
     const size_t nb = (n + 15) / 16, tiles = nb * (nb + 1) / 2;
-    D2D_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&pl->d_H), (size_t)B * tiles * 256 * sizeof(float)));
+    SCRATCH_ALLOC(d_H, (size_t)B * tiles * 256 * sizeof(float))
   }
-  D2D_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&pl->d_cost), (size_t)B * sizeof(double)));
-  D2D_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&pl->d_lm), (size_t)B * 4 * sizeof(double)));
-  D2D_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&pl->d_flags), (size_t)B * 4 * sizeof(int32_t)));
+  SCRATCH_ALLOC(d_rows, (size_t)B * 4 * (pl->K + 1) * 4 * sizeof(float))
+  SCRATCH_ALLOC(d_order, (size_t)B * sizeof(int32_t))
+  SCRATCH_ALLOC(d_cost, (size_t)B * sizeof(double))
+  SCRATCH_ALLOC(d_lm, (size_t)B * 4 * sizeof(double))
+  SCRATCH_ALLOC(d_flags, (size_t)B * 4 * sizeof(int32_t))
+#undef SCRATCH_ALLOC
   pl->cap_B = B;
   return D2D_OK;
 }
@@ -716,7 +848,8 @@ static int launch_prep(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, const double
 static GroupArgs no_groups() { return GroupArgs{nullptr, 0, 0, 1, 0}; }
 
 static int launch_eval(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, const double *q,
-                       int32_t *flags, double *cost, double *g, float *H, GroupArgs ga = no_groups()) {
+                       int32_t *flags, double *cost, double *g, float *H, GroupArgs ga = no_groups(),
+                       f32x4 *rows = nullptr) {
   const FitGeom gm = geom_of(pl);
   const FitLds L = eval_lds_layout(pl->K, pl->nq, pl->g32_lds, pl->wpb_eval, pl->nds);
   const int NB = (2 * pl->nq + 15) / 16;
@@ -727,10 +860,10 @@ static int launch_eval(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, const double
 #define LAUNCH_EVAL(NBV, INLDS)                                                                    \
   if (pl->nq == 24 && NBV == 3)                                                                    \
     hipLaunchKernelGGL((fit_eval_kernel<3, 24, INLDS>), grid, block, L.total, ctx->stream, B, gm, L, dbg, ga, \
-                       pl->d_G, pl->d_pk, pl->d_G32, pl->d_W32, pl->d_prep, q, flags, cost, g, H);  \
+                       pl->d_G, pl->d_pk, pl->d_G32, pl->d_W32, pl->d_prep, q, flags, cost, g, H, rows);  \
   else                                                                                             \
   hipLaunchKernelGGL((fit_eval_kernel<NBV, 0, INLDS>), grid, block, L.total, ctx->stream, B, gm, L, dbg, ga, \
-                     pl->d_G, pl->d_pk, pl->d_G32, pl->d_W32, pl->d_prep, q, flags, cost, g, H)
+                     pl->d_G, pl->d_pk, pl->d_G32, pl->d_W32, pl->d_prep, q, flags, cost, g, H, rows)
   if (pl->g32_lds) {
     if (NB == 1) LAUNCH_EVAL(1, true);
     else if (NB == 2) LAUNCH_EVAL(2, true);
@@ -774,12 +907,14 @@ static int launch_lm(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, double *q, con
   const int blocks = B < pl->n_cu ? B : pl->n_cu;     // persistent: one workgroup per CU
   static const bool no_queue = getenv("D2D_LM_STATIC") != nullptr;      // A/B switch: static striding instead of the work queue
   int32_t *queue = no_queue ? nullptr : ctx->counter_dev + 8;
+  static const int prio_at = getenv("D2D_LM_PRIO_AT") ? atoi(getenv("D2D_LM_PRIO_AT")) : 48;     // (A/B switch; 1 << 30 = never)
+  const int32_t *order = (pl->order_B == B) ? pl->d_order : nullptr;
   if (want_stamps)
     hipLaunchKernelGGL((fit_lm_kernel<3, 24, true>), dim3(blocks), dim3(64 * pl->wpb_lm), L.total, ctx->stream, B, gm, L, o, budget,
-                       pl->d_G, pl->d_pk, pl->d_G32, pl->d_W32, pl->d_prep, q, pl->d_cost, pl->d_g, pl->d_lm, pl->d_flags, queue, stamps);
+                       pl->d_G, pl->d_pk, pl->d_G32, pl->d_W32, pl->d_prep, q, pl->d_cost, pl->d_g, pl->d_lm, pl->d_flags, queue, stamps, order, prio_at);
   else
     hipLaunchKernelGGL((fit_lm_kernel<3, 24, false>), dim3(blocks), dim3(64 * pl->wpb_lm), L.total, ctx->stream, B, gm, L, o, budget,
-                       pl->d_G, pl->d_pk, pl->d_G32, pl->d_W32, pl->d_prep, q, pl->d_cost, pl->d_g, pl->d_lm, pl->d_flags, queue, stamps);
+                       pl->d_G, pl->d_pk, pl->d_G32, pl->d_W32, pl->d_prep, q, pl->d_cost, pl->d_g, pl->d_lm, pl->d_flags, queue, stamps, order, prio_at);
   D2D_LAUNCH_CHECK();
   if (want_times) {
     D2D_CHECK_HIP(hipStreamSynchronize(ctx->stream));
@@ -866,6 +1001,7 @@ int d2d_fit_plan_create(d2d_ctx *ctx, int S, int K, double duration, const doubl
   allow_big_lds(&fit_eval_kernel<1, 0, true>); allow_big_lds(&fit_eval_kernel<2, 0, true>); allow_big_lds(&fit_eval_kernel<3, 0, true>);
   allow_big_lds(&fit_eval_kernel<1, 0, false>); allow_big_lds(&fit_eval_kernel<2, 0, false>); allow_big_lds(&fit_eval_kernel<3, 0, false>);
   allow_big_lds(&fit_eval_kernel<3, 24, true>); allow_big_lds(&fit_eval_kernel<3, 24, false>);
+  allow_big_lds(&fit_jtj_kernel<1, 0>); allow_big_lds(&fit_jtj_kernel<2, 0>); allow_big_lds(&fit_jtj_kernel<3, 0>); allow_big_lds(&fit_jtj_kernel<3, 24>);
   allow_big_lds(&fit_lm_kernel<3, 24, false>);
   allow_big_lds(&fit_lm_kernel<3, 24, true>);
   allow_big_lds(&fit_step_kernel<16>); allow_big_lds(&fit_step_kernel<32>); allow_big_lds(&fit_step_kernel<48>);
@@ -878,10 +1014,10 @@ int d2d_fit_plan_destroy(d2d_fit_plan *pl) {
   if (!pl) return D2D_OK;
   hipSetDevice(pl->device);
   for (hipEvent_t e : pl->prof_ev) (void)hipEventDestroy(e);
-  void *ptrs[] = {pl->d_G, pl->d_Gp, pl->d_G32, pl->d_W32, pl->d_Z, pl->d_Zp, pl->d_Pinit,
-                  pl->d_g, pl->d_H, pl->d_cost, pl->d_lm, pl->d_flags, pl->d_prep, pl->d_pos, pl->d_qprev, pl->d_pk};
+  void *ptrs[] = {pl->d_G, pl->d_Gp, pl->d_G32, pl->d_W32, pl->d_Z, pl->d_Zp, pl->d_Pinit};
   for (void *p : ptrs)
     if (p) hipFree(p);
+  free_scratch(pl);
   delete pl;
   return D2D_OK;
 }
@@ -936,6 +1072,54 @@ int d2d_fit_eval(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, const double *scen
   return D2D_OK;
 }
 
+
+// The two halves of d2d_fit_eval as separate launches (bench.py's contraction-only roofline): d2d_fit_rows evaluates the
+// rows at q (cost, J^T r) and leaves the fp32 row records in the plan's scratch; d2d_fit_jtj contracts them.
+int d2d_fit_rows(d2d_ctx *ctx, d2d_fit_plan *pl, int B, const double *scen, const double *q, double *cost, double *g) {
+  D2D_REQUIRE(ctx && pl && scen && q, "d2d_fit_rows: null argument");
+  D2D_REQUIRE(B >= 1, "d2d_fit_rows: B must be >= 1");
+  D2D_REQUIRE(pl->n_group <= 1, "d2d_fit_rows: not available for coupled groups");
+  if (pl->active_B != 0 && B > pl->cap_B) { d2d_set_error("d2d_fit_rows: a solve of a smaller batch is in progress on this plan"); return D2D_ESTATE; }
+  if (int rc = ensure_scratch(pl, B)) return rc;
+  if (int rc = launch_prep(ctx, pl, B, scen)) return rc;
+  pl->prep_valid_for = nullptr;
+  if (int rc = launch_eval(ctx, pl, B, q, nullptr, cost, g, nullptr, no_groups(), reinterpret_cast<f32x4 *>(pl->d_rows))) return rc;
+  pl->rows_B = B;
+  return D2D_OK;
+}
+
+int d2d_fit_jtj(d2d_ctx *ctx, d2d_fit_plan *pl, int B, float *H) {
+  D2D_REQUIRE(ctx && pl, "d2d_fit_jtj: null argument");
+  if (B < 1 || B != pl->rows_B || B > pl->cap_B) {
+    d2d_set_error("d2d_fit_jtj: call d2d_fit_rows(B=%d) on this plan first (records held: %d)", B, pl->rows_B);
+    return D2D_ESTATE;
+  }
+  const int NB = (2 * pl->nq + 15) / 16;
+  int wpb = FIT_EVAL_WPB_MAX;
+  while (wpb > 1 && jtj_lds_layout(pl->K, pl->nq, wpb).total > FIT_LDS_BYTES) --wpb;
+  const JtjLds L = jtj_lds_layout(pl->K, pl->nq, wpb);
+  D2D_REQUIRE(L.total <= FIT_LDS_BYTES, "d2d_fit_jtj: K=%d does not fit the LDS", pl->K);
+  int nblk = (B + wpb - 1) / wpb;
+  if (nblk > pl->n_cu) nblk = pl->n_cu;
+  const FitGeom gm = geom_of(pl);
+  const f32x4 *rows = reinterpret_cast<const f32x4 *>(pl->d_rows);
+  if (int rc = prof_begin(ctx, pl, 3)) return rc;
+#define LAUNCH_JTJ(NBV, NQV) \
+  hipLaunchKernelGGL((fit_jtj_kernel<NBV, NQV>), dim3(nblk), dim3(64 * wpb), L.total, ctx->stream, B, gm, L, pl->d_G32, rows, pl->d_H)
+  if (pl->nq == 24) LAUNCH_JTJ(3, 24);
+  else if (NB == 1) LAUNCH_JTJ(1, 0);
+  else if (NB == 2) LAUNCH_JTJ(2, 0);
+  else LAUNCH_JTJ(3, 0);
+#undef LAUNCH_JTJ
+  D2D_LAUNCH_CHECK();
+  if (int rc = prof_end(ctx, pl)) return rc;
+  if (H) {
+    hipLaunchKernelGGL(untile_kernel, dim3(B), dim3(256), 0, ctx->stream, B, 2 * pl->nq, NB, pl->d_H, pl->d_W32, pl->d_prep, H);
+    D2D_LAUNCH_CHECK();
+  }
+  return D2D_OK;
+}
+
 // ---- profiling: HIP event pairs around every eval / step launch of the LM loop -------
 static int prof_begin(d2d_ctx *ctx, d2d_fit_plan *pl, int kind) {
   if (!pl->prof_on) return D2D_OK;
@@ -965,7 +1149,7 @@ int d2d_fit_profile(d2d_fit_plan *pl, int enable) {
 
 int d2d_fit_profile_read(d2d_fit_plan *pl, double *out) {
   D2D_REQUIRE(pl && out, "d2d_fit_profile_read: null argument");
-  for (int i = 0; i < 6; ++i) out[i] = 0.0;
+  for (int i = 0; i < 8; ++i) out[i] = 0.0;
   for (size_t i = 0; i < pl->prof_kind.size(); ++i) {
     D2D_CHECK_HIP(hipEventSynchronize(pl->prof_ev[2 * i + 1]));
     float ms = 0.f;
@@ -985,6 +1169,10 @@ static d2d_fit_opts opts_or_default(const d2d_fit_opts *opts) {
 int d2d_fit_begin(d2d_ctx *ctx, d2d_fit_plan *pl, int B) {
   D2D_REQUIRE(ctx && pl, "d2d_fit_begin: null argument");
   D2D_REQUIRE(B >= 1, "d2d_fit_begin: B must be >= 1");
+  if (pl->active_B != 0 && B > pl->cap_B) {
+    d2d_set_error("d2d_fit_begin: a begin/iterate sequence of %d trajectories is in progress on this plan (finish it first)", pl->active_B);
+    return D2D_ESTATE;
+  }
   if (int rc = ensure_scratch(pl, B)) return rc;
   hipLaunchKernelGGL(fit_state_init_kernel, dim3((B + 255) / 256), dim3(256), 0, ctx->stream, B, 0, 1, pl->d_lm, pl->d_flags, ctx->counter_dev + 8);
   D2D_LAUNCH_CHECK();
@@ -1082,6 +1270,18 @@ int d2d_fit_solve(d2d_ctx *ctx, const d2d_fit_plan *plc, int B, const double *sc
   while (running > 0)
     if (int rc = d2d_fit_iterate(ctx, pl, B, scen, q, &o, per_call, &running)) return rc;
   return d2d_fit_finish(ctx, pl, B, scen, q, cost, iters, status, stats);
+}
+
+int d2d_fit_plan_set_order(d2d_ctx *ctx, d2d_fit_plan *pl, int B, const int32_t *iters) {
+  D2D_REQUIRE(ctx && pl, "d2d_fit_plan_set_order: null argument");
+  if (iters == nullptr) { pl->order_B = 0; return D2D_OK; }
+  D2D_REQUIRE(B >= 1, "d2d_fit_plan_set_order: B must be >= 1");
+  if (pl->active_B != 0 && B > pl->cap_B) { d2d_set_error("d2d_fit_plan_set_order: a solve of a smaller batch is in progress on this plan"); return D2D_ESTATE; }
+  if (int rc = ensure_scratch(pl, B)) return rc;
+  hipLaunchKernelGGL(fit_order_kernel, dim3(1), dim3(1024), 0, ctx->stream, B, iters, pl->d_order);
+  D2D_LAUNCH_CHECK();
+  pl->order_B = B;
+  return D2D_OK;
 }
 
 int d2d_fit_plan_set_groups(d2d_fit_plan *pl, int n_ac) {

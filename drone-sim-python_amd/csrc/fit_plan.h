@@ -30,6 +30,10 @@ struct d2d_fit_plan {
   double *d_pk = nullptr;      // [B][FIT_PK][K] per-sample constants (fit_prepk_kernel)
   double *d_pos = nullptr;     // [B][2][K] sampled positions (coupled groups)
   double *d_qprev = nullptr;   // [B][2nq] unknowns at the start of a Gauss-Seidel sweep
+  float *d_rows = nullptr;     // [B][K+1][4] f32x4 row records of the last d2d_fit_rows (input of d2d_fit_jtj)
+  int rows_B = 0;              // trajectories whose records d_rows holds
+  int32_t *d_order = nullptr;  // [B] hand-out order of the persistent LM kernel (longest fits of the previous solve first)
+  int order_B = 0;             // batch size the order was built for (0: none)
   int n_group = 1, nds = 0;    // aircraft per coupled group and padded collision-row slots per sample
   const double *prep_valid_for = nullptr;   // scen pointer d_prep was derived from
   // launch geometry chosen at plan creation from the LDS footprint
@@ -41,7 +45,7 @@ struct d2d_fit_plan {
   // optional per-launch timing (d2d_fit_profile)
   bool prof_on = false;
   std::vector<hipEvent_t> prof_ev;   // start/stop pairs
-  std::vector<int> prof_kind;        // 0 = eval (J^T J) launch, 1 = step launch, 2 = fused LM launch
+  std::vector<int> prof_kind;        // 0 = eval (J^T J) launch, 1 = step launch, 2 = fused LM launch, 3 = contraction-only (fit_jtj) launch
 };
 
 int fit_basis_build(d2d_fit_plan *pl);   // fills the host vectors

@@ -79,10 +79,13 @@ _SIGS = {
     'd2d_fit_init': (C.c_int, [_P, _P, C.c_int, _P, _P]),
     'd2d_fit_project': (C.c_int, [_P, _P, C.c_int, _P, _P, _P]),
     'd2d_fit_eval': (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P, _P]),
+    'd2d_fit_rows': (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P]),
+    'd2d_fit_jtj': (C.c_int, [_P, _P, C.c_int, _P]),
     'd2d_fit_solve': (C.c_int, [_P, _P, C.c_int, _P, _P, C.POINTER(FitOpts), _P, _P, _P, _P]),
     'd2d_fit_begin': (C.c_int, [_P, _P, C.c_int]),
     'd2d_fit_iterate': (C.c_int, [_P, _P, C.c_int, _P, _P, C.POINTER(FitOpts), C.c_int, C.POINTER(C.c_int32)]),
     'd2d_fit_finish': (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P, _P, _P]),
+    'd2d_fit_plan_set_order': (C.c_int, [_P, _P, C.c_int, _P]),
     'd2d_fit_plan_set_groups': (C.c_int, [_P, C.c_int]),
     'd2d_fit_solve_groups': (C.c_int, [_P, _P, C.c_int, _P, _P, C.POINTER(FitOpts), C.c_int, C.c_int, C.c_double, _P,
                                        C.POINTER(C.c_int32), _P]),
@@ -406,6 +409,14 @@ class FitPlan:
                                            _ptr(status), _hptr(stats)))
         return cost, iters, status, stats
 
+    def order_from_iters(self, iters):
+        """Scheduling hint: hand the fits of the next solves of this batch out longest-first (iters: device int32 [B] of a
+        previous solve of the same scenarios)."""
+        _check(self.ctx.lib.d2d_fit_plan_set_order(self.ctx.h, self.h, iters.shape[0], _ptr(iters)))
+
+    def clear_order(self):
+        _check(self.ctx.lib.d2d_fit_plan_set_order(self.ctx.h, self.h, 0, None))
+
     def set_groups(self, n_ac):
         _check(self.ctx.lib.d2d_fit_plan_set_groups(self.h, n_ac))
         self.n_group = n_ac
@@ -428,9 +439,25 @@ class FitPlan:
     def profile(self, enable):
         _check(self.ctx.lib.d2d_fit_profile(self.h, 1 if enable else 0))
 
+    def rows(self, scen, q):
+        """Residual rows at q: cost, J^T r (device); the fp32 row records stay in the plan's scratch for jtj()."""
+        B, n = scen.shape[0], 2 * self.nq
+        cost, g = self.ctx.empty(B), self.ctx.empty(B, n)
+        _check(self.ctx.lib.d2d_fit_rows(self.ctx.h, self.h, B, _ptr(scen), _ptr(q), _ptr(cost), _ptr(g)))
+        return cost, g
+
+    def jtj(self, B, want_H=True):
+        """J^T J from the records of the last rows(): the contraction-only launch.  H dev [B][2nq][2nq] or None."""
+        torch = _torch()
+        n = 2 * self.nq
+        H = torch.zeros(B, n, n, dtype=torch.float32, device=self.ctx.device) if want_H else None
+        _check(self.ctx.lib.d2d_fit_jtj(self.ctx.h, self.h, B, _ptr(H)))
+        return H
+
     def profile_read(self):
-        """(eval_ms, eval_launches, step_ms, step_launches, fused_lm_ms, fused_lm_launches) from HIP events."""
-        out = np.zeros(6)
+        """(eval_ms, eval_launches, step_ms, step_launches, fused_lm_ms, fused_lm_launches, jtj_ms, jtj_launches) from HIP
+        events."""
+        out = np.zeros(8)
         _check(self.ctx.lib.d2d_fit_profile_read(self.h, _hptr(out)))
         return out
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define D2D_VERSION 100
+#define D2D_VERSION 101
 
 /* error codes */
 #define D2D_OK 0
@@ -275,6 +275,16 @@ int d2d_fit_project(d2d_ctx *ctx, const d2d_fit_plan *plan, int B, const double 
 int d2d_fit_eval(d2d_ctx *ctx, const d2d_fit_plan *plan, int B, const double *scen,
                  const double *q, double *cost, double *g, float *H);
 
+/* The two halves of d2d_fit_eval as separate launches.  d2d_fit_rows evaluates the residual rows at q -- cost and
+ * g = J^T r as d2d_fit_eval (either may be NULL) -- and leaves the fp32 row records (four contracted rows per sample:
+ * airspeed, bank and the two position rows) in the plan's scratch, [B][K+1][4] x 16 B in HBM.
+ * d2d_fit_jtj contracts the records of the last d2d_fit_rows(B) into J^T J: ONE kernel whose whole duration is the
+ * MFMA contraction (records HBM -> LDS, v_mfma_f32_16x16x4_f32, tiles -> HBM) -- the kernel bench.py prices against
+ * the fp32 MFMA peak.  H dev [B][2nq][2nq] or NULL (NULL: the tiles stay in the plan's scratch).  Same cost
+ * plug-ins as d2d_fit_eval (CostInput, CostObstacle: src/d2d/opty_utils.py:85-134); uncoupled plans only. */
+int d2d_fit_rows(d2d_ctx *ctx, d2d_fit_plan *plan, int B, const double *scen, const double *q, double *cost, double *g);
+int d2d_fit_jtj(d2d_ctx *ctx, d2d_fit_plan *plan, int B, float *H);
+
 /* Full Levenberg-Marquardt solve from q (in/out).  cost dev [B], iters / status dev int32 [B]
  * (any may be NULL).  stats host double[4] (may be NULL): sum cost, max |J^T r|_inf,
  * trajectories still running, evaluations performed (in units of one Gauss-Newton evaluation = 200
@@ -295,6 +305,12 @@ int d2d_fit_iterate(d2d_ctx *ctx, d2d_fit_plan *plan, int B, const double *scen,
 int d2d_fit_finish(d2d_ctx *ctx, d2d_fit_plan *plan, int B, const double *scen, const double *q,
                    double *cost, int32_t *iters, int32_t *status, double *stats);
 
+/* Scheduling hint for d2d_fit_solve / d2d_fit_iterate on batches of B trajectories: iters dev int32 [B] = the iteration
+ * counts a previous solve of the same scenarios returned (receding-horizon replanning, repeated solves of one batch).  The
+ * persistent LM kernel then hands the fits out longest-first, so the launch does not end on one long fit that was drawn late.
+ * Results do not depend on it (the fits are independent).  iters = NULL clears the hint; a batch of another size ignores it. */
+int d2d_fit_plan_set_order(d2d_ctx *ctx, d2d_fit_plan *plan, int B, const int32_t *iters);
+
 /* Coupled groups (BASELINE configs[2], multi_opt_planner): trajectories g*n_ac .. g*n_ac+n_ac-1 are
  * the aircraft of one scenario and repel each other through CostCollision rows
  * (src/d2d/multiopty_utils.py:120-153; D2D_SC_KCOL/RCOL/SCOL/PMASK select weight, radius, scale and
@@ -314,8 +330,9 @@ int d2d_fit_solve_groups(d2d_ctx *ctx, d2d_fit_plan *plan, int R, const double *
 /* Per-launch timing of the LM loop with HIP events on the context's stream: enable = 1
  * starts a fresh recording, 0 stops (d2d_fit_eval's kernel launch is recorded too, as a fit_eval launch).
  * d2d_fit_profile_read waits for the recorded events:
- * out[6]: [0] = sum of fit_eval (J^T J) kernel ms, [1] = its launches, [2] = sum of fit_step kernel
- * ms, [3] = its launches, [4] = sum of fit_lm (fused persistent LM loop) kernel ms, [5] = its launches. */
+ * out[8]: [0] = sum of fit_eval (J^T J) kernel ms, [1] = its launches, [2] = sum of fit_step kernel
+ * ms, [3] = its launches, [4] = sum of fit_lm (fused persistent LM loop) kernel ms, [5] = its launches,
+ * [6] = sum of fit_jtj (contraction-only, d2d_fit_jtj) kernel ms, [7] = its launches. */
 int d2d_fit_profile(d2d_fit_plan *plan, int enable);
 int d2d_fit_profile_read(d2d_fit_plan *plan, double *out);
 

@@ -19,9 +19,5 @@ def pytest_configure(config):
 @pytest.fixture(scope='session')
 def gold():
     def load(name):
-        d = dict(np.load(os.path.join(GOLD, name + '.npz'), allow_pickle=False))
-        # scenario rows written when the row had 32 columns: obstacles 2.. (columns 32..) are absent = zero
-        if 'scen' in d and d['scen'].shape[-1] < 80:
-            d['scen'] = np.pad(d['scen'], [(0, 0)] * (d['scen'].ndim - 1) + [(0, 80 - d['scen'].shape[-1])])
-        return d
+        return dict(np.load(os.path.join(GOLD, name + '.npz'), allow_pickle=False))
     return load

@@ -333,6 +333,12 @@ def fx_fit_cost():
             J[j, :, 0] = p0 + (p1 - p0) * j / S + rng.normal(0, 2.0, 2)
             J[j, :, 1] = (p1 - p0) / dur + rng.normal(0, 1.5, 2)
             J[j, :, 2] = rng.normal(0, 2.0, 2); J[j, :, 3] = rng.normal(0, 2.0, 2)
+        # the end knots meet the scenario's end conditions exactly (position; velocity = vref along psi0 / psi1,
+        # src/single_opt_planner.py:46-49), so that the set lies in the fit's affine space z = Zp d + Z q and the GPU
+        # can be evaluated AT this trajectory (tests/test_gpu_fit.py test_cost_vs_reference_classes_golden)
+        vr = sc[i, ofit.SC_VREF]
+        J[0, :, 0] = p0; J[0, :, 1] = vr * np.array([np.cos(sc[i, ofit.SC_PSI0]), np.sin(sc[i, ofit.SC_PSI0])])
+        J[S, :, 0] = p1; J[S, :, 1] = vr * np.array([np.cos(sc[i, ofit.SC_PSI1]), np.sin(sc[i, ofit.SC_PSI1])])
         steps = [ddt.MinSnapPoly(J[j], J[j + 1], T) for j in range(S)]
         traj = ddt.CompositeTraj(steps)
         z = np.array([[st._polys[a].coefs[0] for st in steps] for a in range(2)])     # (2,S,8)

@@ -28,7 +28,7 @@ def test_header_symbols_exported():
     # the binding declares exactly the header's functions
     assert sorted(d2dhip.EXPORTS) == names
     lib.d2d_version.restype = ctypes.c_int
-    assert lib.d2d_version() == 100
+    assert lib.d2d_version() == 101
 
 
 def test_struct_layouts_match_header():
@@ -45,3 +45,13 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(d2dhip, 'LIB_PATH', '/nonexistent/libd2dhip.so')
     with pytest.raises(d2dhip.D2DError):
         d2dhip.load()
+
+
+def test_host_code_under_asan_ubsan():
+    """`make asan`: the CPU-side basis construction (csrc/fit_basis.cpp) built with -fsanitize=address,undefined and run over
+    the plan shapes the planners use (K = 50 ... 501) and a rank-deficient one (sanitizers on the CPU build only)."""
+    import subprocess
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'drone-sim-python_amd', 'csrc')
+    r = subprocess.run(['make', '-C', csrc, 'asan'], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert 'asan_host: ok' in r.stdout and 'ERROR: AddressSanitizer' not in r.stderr and 'runtime error' not in r.stderr

@@ -3,6 +3,7 @@ d2dhip.dist, driven with a stand-in plan that runs the oracle's LM on the shard 
 plan has the same begin / iterate / finish surface)."""
 import os
 import socket
+import sys
 
 import numpy as np
 import pytest
@@ -11,6 +12,8 @@ import torch.multiprocessing as mp
 
 from d2dhip.dist import shard_bounds, StatsReducer, solve_sharded
 from oracle import fit as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_shard_bounds_cover_everything():
@@ -102,3 +105,17 @@ def test_two_rank_gloo_sharded_solve():
     sc_all = F.set_scale(F.synth_scenarios(total, seed=3), 0.1, K)
     ref = np.array([F.lm_solve(basis, sc_all[i])[1] for i in range(total)])
     np.testing.assert_allclose(np.concatenate([r0['cost'], r1['cost']]), ref, rtol=1e-9)
+
+
+def test_bench_self_spawns_its_ranks():
+    """`python bench.py --gpus 2` with no launcher in the environment starts two ranks itself (before touching any GPU) and
+    returns their exit code; D2D_BENCH_SPAWN_TEST makes every rank report and leave before the GPU part."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['D2D_BENCH_SPAWN_TEST'] = '1'
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    recs = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert sorted(x['rank'] for x in recs) == [0, 1] and all(x['world'] == 2 and x['gpus'] == 2 for x in recs)

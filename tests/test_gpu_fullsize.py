@@ -1,0 +1,173 @@
+"""GPU tests at BASELINE.json's full sizes, through size-independent properties (the oracle cannot solve 32 768 fits in
+seconds), plus the contraction-only launch pair d2d_fit_rows / d2d_fit_jtj and the scheduling hint of the LM kernel.
+
+  configs[1]/[3]  32 768 independent fits: descent, stationarity (|J^T r| small at every converged fit), cost re-evaluated by a
+                  second kernel, a seeded sample checked against the oracle's cost function, invariance under the hand-out order
+  configs[2]      8 aircraft x 8192 replicas, collision rows: the replicas that share a scenario row agree, a sample is checked
+                  against the oracle's joint cost, stationarity of the sub-problems
+  configs[4]      65 536 drones x 10 000 GVF steps with rec_stride (history subsampled): formation 0 against the oracle's loop on
+                  the kept rows, translation invariance across formations, idempotence of the frozen final state
+"""
+import numpy as np
+import pytest
+
+from oracle import fit as F, sim as S
+
+pytestmark = pytest.mark.gpu
+
+K, S_ = 50, 6
+DUR = F.planner_timing(0, 4.9, 10)[2]
+SS = 0.1 / K
+WREF = (0.02 ** 2, SS * 5.0, SS / F.G_ACC ** 2)
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    import d2dhip
+    c = d2dhip.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope='module')
+def plan(ctx):
+    import d2dhip
+    p = d2dhip.FitPlan(ctx, S_, K, DUR, WREF)
+    yield p
+    p.close()
+
+
+@pytest.fixture(scope='module')
+def obasis(plan):
+    G, Gp, Z, Zp, P = plan.basis()
+    return F.FitBasis.from_arrays(S_, K, DUR, G, Gp, Z, Zp, P)
+
+
+def test_rows_then_jtj_equals_eval(ctx, plan, obasis):
+    """The contraction-only kernel (records from HBM) gives the SAME J^T J as the one-launch evaluation, bit for bit
+    (same operands, same MFMA order), and the oracle's to fp32 accuracy; ragged batch; wrong call order is refused."""
+    import d2dhip
+    B = 173
+    sc = F.set_scale(F.synth_scenarios(B, seed=5), 0.1, K)
+    dsc = ctx.dev(sc)
+    rng = np.random.default_rng(1)
+    qh = plan.init(dsc).cpu().numpy() + rng.normal(0, 0.4, (B, 48))
+    dq = ctx.dev(qh)
+    c1, g1, H1 = plan.eval(dsc, dq)
+    c2, g2 = plan.rows(dsc, dq)
+    H2 = plan.jtj(B)
+    ctx.sync()
+    assert np.array_equal(c1.cpu().numpy(), c2.cpu().numpy())
+    assert np.array_equal(g1.cpu().numpy(), g2.cpu().numpy())
+    assert np.array_equal(H1.cpu().numpy(), H2.cpu().numpy())
+    Hh = H2.cpu().numpy()
+    for i in (0, 77, 172):
+        _, _, Ho = F.eval_normal(obasis, sc[i], qh[i])
+        assert np.abs(Hh[i] - Ho).max() <= 2e-5 * np.abs(Ho).max()
+    with pytest.raises(d2dhip.D2DError):
+        plan.jtj(B - 1)                               # no records for that batch size
+
+
+def test_32768_fits_properties_and_order_invariance(ctx, plan, obasis):
+    """BASELINE configs[3], one GPU's share: 32 768 fits in one solve."""
+    import d2dhip
+    import torch
+    B = 32768
+    sc = F.set_scale(F.synth_scenarios(B, seed=20241008), 0.1, K)
+    dsc = ctx.dev(sc)
+    q0 = plan.init(dsc)
+    c0, _, _ = plan.eval(dsc, q0, want_H=False)
+    q = q0.clone()
+    cost, iters, status, stats = plan.solve(dsc, q)
+    st = status.cpu().numpy()
+    conv = np.isin(st, (d2dhip.ST_CONVERGED, d2dhip.ST_STALLED))
+    assert conv.mean() >= 0.998, conv.mean()
+    assert not (st == d2dhip.ST_NONFINITE).any()
+    # descent everywhere, and the cost the solver reports is the cost a second kernel evaluates at the returned point
+    c1, g1, _ = plan.eval(dsc, q, want_H=False)
+    c0h, c1h, ch = c0.cpu().numpy(), c1.cpu().numpy(), cost.cpu().numpy()
+    assert (ch <= c0h * (1 + 1e-12)).all()
+    assert np.abs(c1h - ch).max() <= 1e-12 * np.abs(ch).max()
+    # stationarity: |J^T r|_inf tiny relative to the scale of the gradient at the start, at every converged fit
+    _, g0, _ = plan.eval(dsc, q0, want_H=False)
+    gn1 = g1.abs().max(1).values.cpu().numpy(); gn0 = g0.abs().max(1).values.cpu().numpy()
+    assert (gn1[conv] <= 1e-6 * np.maximum(gn0[conv], 1e-3)).mean() >= 0.999
+    assert abs(stats[0] - ch.sum()) <= 1e-9 * ch.sum() and stats[2] == (~conv).sum()
+    # a seeded sample against the oracle's cost function at the GPU's solution
+    qh = q.cpu().numpy()
+    for i in np.random.default_rng(0).integers(0, B, 12):
+        co = F.cost(obasis, sc[i], qh[i])
+        assert abs(ch[i] - co) <= 1e-10 * co
+    # the scheduling hint changes which wave solves which fit, and nothing else: same bits
+    plan.order_from_iters(iters)
+    q2 = q0.clone()
+    cost2, iters2, status2, _ = plan.solve(dsc, q2)
+    plan.clear_order()
+    assert torch.equal(q, q2) and torch.equal(iters, iters2) and torch.equal(cost, cost2) and torch.equal(status, status2)
+
+
+def test_8x8192_groups_properties(ctx, obasis):
+    """BASELINE configs[2]: 8-drone circular formation x 8192 replicas with collision rows (block Gauss-Seidel)."""
+    import d2dhip
+    from d2dhip import synth
+    n_ac, R = 8, 8192
+    s = 1.0 / K
+    wref = (0.02 ** 2, s / n_ac * 5.0, s / n_ac / F.G_ACC ** 2)
+    p = d2dhip.FitPlan(ctx, S_, K, DUR, wref)
+    try:
+        sc = synth.circle_group_scenarios(n_ac, R, DUR, K=K, seed=3, sigma=2.0)
+        sc[R // 2:] = sc[:R // 2]                     # the second half repeats the first: replicas of identical scenarios
+        rows = sc.reshape(R * n_ac, -1)
+        dsc = ctx.dev(rows)
+        q = p.init(dsc)
+        cost, sweeps, stats = p.solve_groups(dsc, q, n_ac, max_sweeps=150, inner_iters=8, tol=1e-9)
+        qh = q.cpu().numpy().reshape(R, n_ac, 48); ch = cost.cpu().numpy().reshape(R, n_ac)
+        assert np.isfinite(qh).all() and stats[2] <= 1e-6
+        # identical scenarios, identical answers (determinism across workgroups / positions in the batch)
+        assert np.array_equal(qh[:R // 2], qh[R // 2:])
+        ob = F.FitBasis.from_arrays(S_, K, DUR, *p.basis())
+        for r in (0, 1234, 4095):
+            scs = sc[r]
+            # sub-problem costs: own rows + collision rows against the others' final positions
+            pos = F.group_positions(ob, scs, qh[r])
+            for i in (0, 5):
+                oth = [pos[j] for j in F.partners(scs[i], i, n_ac)]
+                co = F.cost(ob, scs[i], qh[r, i], others=oth)
+                assert abs(ch[r, i] - co) <= 1e-9 * co
+                # stationarity of the sub-problem
+                _, go, _ = F.eval_normal(ob, scs[i], qh[r, i], others=oth)
+                assert np.abs(go).max() <= 1e-5
+        # the collision rows did something: every pair keeps apart around the centre crossing
+        pos = F.group_positions(ob, sc[0], qh[0])
+        dmin = min(np.hypot(pos[i][0] - pos[j][0], pos[i][1] - pos[j][1]).min() for i in range(n_ac) for j in range(i))
+        assert dmin > 1.0
+    finally:
+        p.close()
+
+
+def test_65536_drones_10000_steps_gvf(ctx):
+    """BASELINE configs[4] at full size; history kept every 500th row so that the check reads 21 rows, not 36 GB."""
+    n_ac, N, rows, rs = 4, 65536, 10001, 500
+    n_form = N // n_ac
+    base_c = np.array([[0, -20], [25, -40], [25, -80], [0, -100.0]])
+    rng = np.random.default_rng(7)
+    shift = rng.uniform(-300, 300, (n_form, 2)); shift[0] = 0.0; shift[1] = (128.0, -64.0)   # (exactly representable shift)
+    centres = (base_c[None] + shift[:, None, :]).reshape(N, 2)
+    X0 = np.tile([20, 30, -np.pi / 2, 0, 10.0], (N, 1)); X0[:, :2] += np.repeat(shift, n_ac, 0)
+    out = ctx.gvf_run(ctx.dev(np.ascontiguousarray(X0.T)), ctx.dev(np.ascontiguousarray(centres.T)), ctx.dev(np.full(N, 60.0)),
+                      n_ac, rows, 0.05, 15.0, rec_stride=rs, record=('X',))
+    ctx.sync()
+    X = out['X'].cpu().numpy()                        # [21][5][N]
+    assert X.shape == (21, 5, N) and np.isfinite(X).all()
+    # formation 0 against the oracle's loop on a prefix (the oracle runs 1000 steps in seconds)
+    Xo, *_ = S.formation_gvf_run(base_c, 60.0, 15.0, X0[:n_ac], 1001, 0.05)
+    for r in (1, 2):
+        assert np.abs(X[r, :, :n_ac].T - Xo[r * rs]).max() < 1e-6, r
+    # translation invariance: formation 1 is formation 0 shifted by an exactly representable vector
+    d = X[:, :, n_ac:2 * n_ac] - X[:, :, :n_ac]
+    assert np.abs(d[:, 0] - 128.0).max() < 1e-6 and np.abs(d[:, 1] + 64.0).max() < 1e-6 and np.abs(d[:, 2:]).max() < 1e-7
+    # every formation converges to its circle (|p - c| -> r up to the DCF radius modulation) and to the commanded speed
+    xf = out['X_final'].cpu().numpy()
+    rad = np.hypot(xf[0] - centres[:, 0], xf[1] - centres[:, 1])
+    assert np.abs(rad - 60.0).max() < 8.0 and np.abs(xf[4] - 15.0).max() < 1e-6
+    assert np.array_equal(X[-1], xf)                  # row 10000 is the final state
