@@ -222,10 +222,12 @@ static JtjLds jtj_lds_layout(int K, int nq, int wpb) {
   return L;
 }
 
+// clk != NULL (diagnostic launch, D2D_JTJ_CLOCK=1): wave 0 of every workgroup adds its shader-clock and 100 MHz real-time ticks
+// around the trajectory loop to clk[0..1] (in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz, MICROARCH guide).
 template <int NB, int NQ>
 __global__ void __launch_bounds__(64 * FIT_EVAL_WPB_MAX)
 fit_jtj_kernel(int B, FitGeom g, JtjLds L, const float *__restrict__ gG32, const f32x4 *__restrict__ rows,
-               float *__restrict__ H_out) {
+               float *__restrict__ H_out, unsigned long long *__restrict__ clk) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int wpb = blockDim.x >> 6;
@@ -238,6 +240,8 @@ fit_jtj_kernel(int B, FitGeom g, JtjLds L, const float *__restrict__ gG32, const
   // the records of the wave's next trajectory travel in registers while the MFMAs of the current one run
   constexpr int NPF = 4;                          // 4 x 64 records = K <= 64 samples; longer horizons load the rest late
   f32x4 pf[NPF];
+  unsigned long long t0 = 0, r0 = 0;
+  if (clk) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
   int b = blockIdx.x * wpb + wave;
   if (b < B) {
 #pragma unroll
@@ -264,6 +268,10 @@ fit_jtj_kernel(int B, FitGeom g, JtjLds L, const float *__restrict__ gG32, const
 #pragma unroll
       for (int r = 0; r < 4; ++r) Hb[(t * 4 + r) * 64 + lane] = acc[t][r];
     wave_lds_sync();     // the next trajectory's records overwrite this wave's LDS block
+  }
+  if (clk && wave == 0 && lane == 0) {
+    atomicAdd(&clk[0], __builtin_amdgcn_s_memtime() - t0);
+    atomicAdd(&clk[1], __builtin_amdgcn_s_memrealtime() - r0);
   }
 }
 
@@ -1095,17 +1103,24 @@ int d2d_fit_jtj(d2d_ctx *ctx, d2d_fit_plan *pl, int B, float *H) {
     return D2D_ESTATE;
   }
   const int NB = (2 * pl->nq + 15) / 16;
-  int wpb = FIT_EVAL_WPB_MAX;
+  // launch geometry (A/B knobs for tools/bench_jtj.py: D2D_JTJ_WPB wavefronts per workgroup, D2D_JTJ_WGS workgroups per CU)
+  static const int env_wpb = getenv("D2D_JTJ_WPB") ? atoi(getenv("D2D_JTJ_WPB")) : 0;
+  static const int env_wgs = getenv("D2D_JTJ_WGS") ? atoi(getenv("D2D_JTJ_WGS")) : 0;
+  int wpb = (env_wpb >= 1 && env_wpb <= FIT_EVAL_WPB_MAX) ? env_wpb : FIT_EVAL_WPB_MAX;
   while (wpb > 1 && jtj_lds_layout(pl->K, pl->nq, wpb).total > FIT_LDS_BYTES) --wpb;
   const JtjLds L = jtj_lds_layout(pl->K, pl->nq, wpb);
   D2D_REQUIRE(L.total <= FIT_LDS_BYTES, "d2d_fit_jtj: K=%d does not fit the LDS", pl->K);
   int nblk = (B + wpb - 1) / wpb;
-  if (nblk > pl->n_cu) nblk = pl->n_cu;
+  const int max_blk = pl->n_cu * (env_wgs >= 1 ? env_wgs : 1);
+  if (nblk > max_blk) nblk = max_blk;
   const FitGeom gm = geom_of(pl);
   const f32x4 *rows = reinterpret_cast<const f32x4 *>(pl->d_rows);
   if (int rc = prof_begin(ctx, pl, 3)) return rc;
+  static const bool want_clock = getenv("D2D_JTJ_CLOCK") != nullptr;
+  unsigned long long *clk = want_clock ? reinterpret_cast<unsigned long long *>(ctx->stats_dev + 24) : nullptr;
+  if (want_clock) D2D_CHECK_HIP(hipMemsetAsync(clk, 0, 2 * sizeof(unsigned long long), ctx->stream));
 #define LAUNCH_JTJ(NBV, NQV) \
-  hipLaunchKernelGGL((fit_jtj_kernel<NBV, NQV>), dim3(nblk), dim3(64 * wpb), L.total, ctx->stream, B, gm, L, pl->d_G32, rows, pl->d_H)
+  hipLaunchKernelGGL((fit_jtj_kernel<NBV, NQV>), dim3(nblk), dim3(64 * wpb), L.total, ctx->stream, B, gm, L, pl->d_G32, rows, pl->d_H, clk)
   if (pl->nq == 24) LAUNCH_JTJ(3, 24);
   else if (NB == 1) LAUNCH_JTJ(1, 0);
   else if (NB == 2) LAUNCH_JTJ(2, 0);
@@ -1113,6 +1128,13 @@ int d2d_fit_jtj(d2d_ctx *ctx, d2d_fit_plan *pl, int B, float *H) {
 #undef LAUNCH_JTJ
   D2D_LAUNCH_CHECK();
   if (int rc = prof_end(ctx, pl)) return rc;
+  if (want_clock) {
+    unsigned long long h[2];
+    D2D_CHECK_HIP(hipMemcpyAsync(h, clk, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    D2D_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    fprintf(stderr, "[fit_jtj clock] B=%d: %.3f GHz in-kernel (s_memtime / s_memrealtime over the trajectory loop, %d workgroups)\n", B,
+            h[1] ? 0.1 * (double)h[0] / (double)h[1] : 0.0, nblk);
+  }
   if (H) {
     hipLaunchKernelGGL(untile_kernel, dim3(B), dim3(256), 0, ctx->stream, B, 2 * pl->nq, NB, pl->d_H, pl->d_W32, pl->d_prep, H);
     D2D_LAUNCH_CHECK();
