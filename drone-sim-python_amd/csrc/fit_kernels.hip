@@ -359,19 +359,37 @@ fit_step_kernel(int B, FitGeom g, StepLds L, d2d_fit_opts opts, GroupArgs ga,
   float dgi, dl;
   const bool ok = damped_solve<N>(hrow, lam, act, lane, Lm, dgi, dl);
   const double delta = (double)dl;
-  // ---- trial point, predicted and actual reduction ------------------------------------
-  if (act) qt[q_slot(lane, g.nq)] = qi + delta;
-  wave_lds_sync();
+  // ---- trial points (the full step, then up to two shortened ones), predicted and actual reduction ------
   const ScenP s = load_scenp(prep + (size_t)b * FIT_PREP_STRIDE);
   const GroupCtx gc{ga.pos, ga.n_ac, ga.n_ac > 0 ? b % ga.n_ac : 0, ga.n_ac > 0 ? (b / ga.n_ac) * ga.n_ac : 0, ga.pos ? ga.nds : 0};
-  const double ct = wave_cost(g, G64, pk + (size_t)b * FIT_PK * g.K, qt, s, lane, gc);
   const double pred = wave_sum(delta * (lam * (double)dgi * delta - gi));
   const double dmax = wave_max(fabs(delta)), qmax = wave_max(fabs(qi));
-  const StepOutcome so = judge_step(ok, c, ct, pred, dmax, qmax, lam, nu, opts);
+  double ct = 0.0, pred_s = pred, alpha = 1.0;
+  bool fin = false, accept = false;
+  if (ok) {
+    if (act) qt[q_slot(lane, g.nq)] = qi + delta;
+    wave_lds_sync();
+    ct = wave_cost(g, G64, pk + (size_t)b * FIT_PK * g.K, qt, s, lane, gc);
+    fin = (fabs(ct) <= 1.79e308) && (pred > 0.0);
+    accept = fin && (c - ct) / pred > 0.0;
+    if (!accept && fin) {
+      const double a = -2.0 * wave_sum(gi * delta), bq = a - pred;
+      double al = bt_first_alpha(a, c, ct);
+      for (int att = 0; att < 2; ++att) {
+        wave_lds_sync();
+        if (act) qt[q_slot(lane, g.nq)] = qi + al * delta;
+        wave_lds_sync();
+        const double c2 = wave_cost(g, G64, pk + (size_t)b * FIT_PK * g.K, qt, s, lane, gc);
+        if ((fabs(c2) <= 1.79e308) && c2 < c) { accept = true; alpha = al; ct = c2; pred_s = a * al - bq * al * al; break; }
+        al = fmax(D2D_LM_BT_SHRINK * al, D2D_LM_BT_FLOOR);
+      }
+    }
+  }
+  const StepOutcome so = lm_update(ok, fin, accept, alpha, c, ct, pred, pred_s, dmax, qmax, lam, nu, opts);
   int status = so.status;
   const double lam_n = so.lam, nu_n = so.nu;
   if (so.accept) {
-    if (act) q_io[(size_t)b * n + lane] = qi + delta;
+    if (act) q_io[(size_t)b * n + lane] = qi + alpha * delta;
     if (lane == 0) {
       cost_io[b] = ct;
       flags[4 * b + FL_NEED] = 1;     // gradient / Hessian at the new point (also when converged)
@@ -543,21 +561,39 @@ fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_budget,
       LM_STAMP(6)
       const int ok = uniform_i(damped_solve<N>(hrow, lam, act, lane, big, dgi, dl, STAMPS ? st_solve : nullptr) ? 1 : 0);
       const double delta = (double)dl;
-      if (act) qs[q_slot(lane, g.nq)] = qi + delta;      // the trial point
-      wave_lds_sync();
       LM_STAMP(5)
-      // full phase 1 at the trial point: if the step is accepted its rows are the next evaluation -- with the
-      // second-order blocks once the damping (before this step's update) has fallen to so_lambda
+      // Trial points: the full step (att 0) and, if its gain ratio is not positive, up to two shortened steps along it.
+      // Every trial is a full phase 1: if a step is accepted its rows are the next evaluation -- with the second-order
+      // blocks once the damping (before this step's update) has fallen to so_lambda.  One copy of phase 1 in the loop.
       const bool so_next = opts.so_lambda > 0.0 && lam <= opts.so_lambda;
-      const double ct = uniform_d(eval_phase1_reg<NQ>(g, G64, pkr, pkb, sp, qs, us, cf, cfp, so_next, lane));
-      LM_STAMP(1)
       const double pred = uniform_d(wave_sum(delta * (lam * (double)dgi * delta - gi)));
       const double dmax = uniform_d(wave_max(fabs(delta))), qmax = uniform_d(wave_max(fabs(qi)));
-      const StepOutcome so = judge_step(ok != 0, c, ct, pred, dmax, qmax, lam, nu, opts);
+      double ct = 0.0, pred_s = pred, alpha = 1.0, bt_a = 0.0, bt_b = 0.0;
+      bool fin = false, accept = false;
+      if (ok) {
+        for (int att = 0; att < 3; ++att) {
+          if (act) qs[q_slot(lane, g.nq)] = qi + alpha * delta;
+          wave_lds_sync();
+          const double ca = uniform_d(eval_phase1_reg<NQ>(g, G64, pkr, pkb, sp, qs, us, cf, cfp, so_next, lane));
+          LM_STAMP(1)
+          if (att == 0) {
+            ct = ca;
+            fin = (fabs(ct) <= 1.79e308) && (pred > 0.0);
+            if (fin && (c - ct) / pred > 0.0) { accept = true; break; }
+            if (!fin) break;
+            bt_a = uniform_d(-2.0 * wave_sum(gi * delta)); bt_b = bt_a - pred;
+            alpha = bt_first_alpha(bt_a, c, ct);
+          } else {
+            if ((fabs(ca) <= 1.79e308) && ca < c) { accept = true; ct = ca; pred_s = bt_a * alpha - bt_b * alpha * alpha; break; }
+            alpha = fmax(D2D_LM_BT_SHRINK * alpha, D2D_LM_BT_FLOOR);
+          }
+        }
+      }
+      const StepOutcome so = lm_update(ok != 0, fin, accept, accept ? alpha : 1.0, c, ct, pred, pred_s, dmax, qmax, lam, nu, opts);
       ++iters; ++local;
       lam = so.lam; nu = so.nu; status = so.status;
       if (so.accept) {
-        qi += delta; c = ct;
+        qi += alpha * delta; c = ct;
         fresh = true;                                    // also when converged: refresh J^T r
         so_rows = so_next;
       }

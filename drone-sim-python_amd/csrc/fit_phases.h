@@ -472,35 +472,52 @@ __device__ __forceinline__ bool damped_solve(const f32x2 (&hrow)[N / 2], double 
   return pivmin > 0;
 }
 
-// Outcome of one damped step (Nielsen gain-ratio rule, oracle/fit.py lm_solve).  All values are
-// wave-uniform.
+// Outcome of one damped step (oracle/fit.py lm_solve): Nielsen's gain-ratio rule for a full step, the parabola
+// rule for a shortened one.  All values are wave-uniform.
 struct StepOutcome {
   bool accept;
   int status;
-  double lam, nu, ct;
+  double lam, nu;
 };
-__device__ __forceinline__ StepOutcome judge_step(bool ok, double c, double ct, double pred, double dmax,
-                                                  double qmax, double lam, double nu, const d2d_fit_opts &o) {
+// The trial loop of one LM iteration tries the full step first (att = 0) and, if its gain ratio is not positive,
+// up to two shortened steps alpha*delta along the same direction: the cost along the step is known at 0 (c, slope -a,
+// a = -2 g.delta) and at 1 (ct), the parabola through those has its minimum at a / (2 (ct - c + a)).
+struct BtState {
+  double a, b, alpha;     // slope, model curvature delta^T H delta (= a - pred), current step fraction
+};
+__device__ __forceinline__ double bt_first_alpha(double a, double c, double ct) {
+  const double den = 2.0 * (ct - c + a);
+  const double al = den > 0.0 ? a / den : D2D_LM_BT_MAX;
+  return fmin(fmax(al, D2D_LM_BT_MIN), D2D_LM_BT_MAX);
+}
+// ok: the factorisation succeeded; fin: the full step's trial cost is finite and its predicted reduction positive;
+// accept: a step (full or shortened, fraction alpha) was taken to a point of cost ct with model reduction pred_s;
+// pred: the full step's predicted reduction; dmax = max |delta| of the FULL step.
+__device__ __forceinline__ StepOutcome lm_update(bool ok, bool fin, bool accept, double alpha, double c, double ct, double pred,
+                                                 double pred_s, double dmax, double qmax, double lam, double nu,
+                                                 const d2d_fit_opts &o) {
   StepOutcome r;
-  const bool fin = ok && (fabs(ct) <= 1.79e308) && (pred > 0.0);
-  const double rho = fin ? (c - ct) / pred : -1.0;
   r.status = D2D_ST_RUNNING;
-  r.ct = ct;
-  r.accept = rho > 0.0;
-  if (r.accept) {
-    const double t = 2.0 * rho - 1.0;
-    r.lam = fmax(lam * fmax(1.0 / 3.0, 1.0 - t * t * t), D2D_LM_LAMBDA_MIN);
+  r.accept = accept;
+  if (accept) {
+    if (alpha == 1.0) {
+      const double rho = (c - ct) / pred_s;
+      const double t = 2.0 * rho - 1.0;
+      r.lam = fmax(lam * fmax(1.0 / 3.0, 1.0 - t * t * t), D2D_LM_LAMBDA_MIN);
+    } else {
+      r.lam = fmin(lam / alpha, D2D_LM_LAMBDA_MAX);       // the step of a damped system shrinks like 1 / lam
+    }
     r.nu = 2.0;
-    const bool small_x = dmax <= o.xtol * (qmax + o.xtol);
-    const bool small_f = ((c - ct) <= o.ftol * c) && (pred <= o.ftol * c);
+    const bool small_x = alpha * dmax <= o.xtol * (qmax + o.xtol);
+    const bool small_f = ((c - ct) <= o.ftol * c) && (pred_s <= o.ftol * c);
     if (small_f || small_x) r.status = D2D_ST_CONVERGED;
   } else {
-    r.lam = lam * nu;
-    r.nu = nu * 2.0;
-    if (r.lam > D2D_LM_LAMBDA_MAX) r.status = D2D_ST_STALLED;
     // a rejected step whose predicted reduction is already below ftol: the iterate sits on the rounding
     // floor of the cost (typical after the quadratic phase of the second-order mode) -- converged
-    if (fin && pred <= o.ftol * c) r.status = D2D_ST_CONVERGED;
+    if (ok && fin && pred <= o.ftol * c) r.status = D2D_ST_CONVERGED;
+    if (ok) { r.lam = lam * nu; r.nu = nu * 2.0; }
+    else { r.lam = lam * D2D_LM_FAIL_MULT; r.nu = nu; }   // indefinite exact Hessian: no step was tried
+    if (r.status == D2D_ST_RUNNING && r.lam > D2D_LM_LAMBDA_MAX) r.status = D2D_ST_STALLED;
   }
   return r;
 }

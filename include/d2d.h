@@ -238,6 +238,14 @@ enum {
 #define D2D_LM_LAMBDA_MAX 1e12
 #define D2D_LM_DIAG_FLOOR 1e-30
 #define D2D_LM_SO_LAMBDA 1e-4     /* default of d2d_fit_opts.so_lambda */
+/* A step whose gain ratio is not positive is shortened along its direction before the damping grows: fraction = minimiser of
+ * the parabola through the cost at 0 (value, slope) and at 1, clipped to [BT_MIN, BT_MAX]; then BT_SHRINK of it, not below
+ * BT_FLOOR.  A failed factorisation (indefinite exact Hessian) multiplies the damping by FAIL_MULT. */
+#define D2D_LM_BT_MIN 0.1
+#define D2D_LM_BT_MAX 0.5
+#define D2D_LM_BT_SHRINK 0.25
+#define D2D_LM_BT_FLOOR 0.02
+#define D2D_LM_FAIL_MULT 8.0
 enum { D2D_ST_RUNNING = 0, D2D_ST_CONVERGED = 1, D2D_ST_MAXITER = 2, D2D_ST_NONFINITE = 3, D2D_ST_STALLED = 4 };
 
 typedef struct {

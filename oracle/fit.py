@@ -497,20 +497,29 @@ def initial_guess(basis, sc, wp=None):
 LM_LAMBDA0 = 1e-3
 LM_LAMBDA_MIN, LM_LAMBDA_MAX = 1e-12, 1e12
 LM_DIAG_FLOOR = 1e-30
+LM_BT_MIN, LM_BT_MAX = 0.1, 0.5      # clip of the parabola's minimiser along a rejected step (include/d2d.h D2D_LM_BT_*)
+LM_BT_SHRINK, LM_BT_FLOOR = 0.25, 0.02   # second attempt: a quarter of the first, not below 2 % of the step
+LM_FAIL_MULT = 8.0      # damping growth after a failed factorisation (indefinite exact Hessian)
 LM_SO_LAMBDA = 1e-4     # below this damping the next evaluation carries the second-order term (include/d2d.h D2D_LM_SO_LAMBDA)
 ST_RUNNING, ST_CONVERGED, ST_MAXITER, ST_NONFINITE, ST_STALLED = 0, 1, 2, 3, 4
 
 
 def lm_solve(basis, sc, q0=None, max_iter=200, ftol=1e-14, gtol=1e-9, xtol=1e-11,
-             hess_dtype=np.float64, chol_dtype=np.float64, others=None, so_lambda=None):
+             hess_dtype=np.float64, chol_dtype=np.float64, others=None, so_lambda=None, backtrack=True):
     """(H + lam*diag|H|) delta = -J^T r with Nielsen's gain-ratio damping, H = J^T J (Gauss-Newton) or, once the
     damping has fallen to so_lambda, J^T J + sum_i r_i Hessian(r_i) (the exact Hessian of 0.5*sum r^2).
 
     One "iteration" = one damped solve + one trial cost; H is re-evaluated only after an accepted step, in the
     mode decided by the damping BEFORE that step (the kernel computes the rows of the trial point
-    speculatively, before it knows the gain ratio).  so_lambda: None = LM_SO_LAMBDA for single trajectories and
-    off for coupled groups; 0 = Gauss-Newton only.  hess_dtype / chol_dtype = np.float32 mimic the HIP path's
-    fp32 MFMA Hessian and fp32 Cholesky (residuals, cost and J^T r stay fp64).
+    speculatively, before it knows the gain ratio).  A step whose gain ratio is not positive is not thrown away:
+    the cost along it is known at 0 (value and slope) and at 1, so the minimiser of the parabola through those,
+    alpha = a / (2 (c1 - c0 + a)) clipped to [LM_BT_MIN, LM_BT_MAX], is tried (and LM_BT_SHRINK of it if that fails
+    too); an accepted shortened step divides the damping by... multiplies it by 1/alpha (the step of a damped system
+    shrinks like 1/lam), instead of re-solving with a doubled, quadrupled, ... damping.  Only when both shortened steps
+    fail does the damping grow by Nielsen's nu; a factorisation that fails (indefinite exact Hessian) multiplies it by
+    LM_FAIL_MULT.  so_lambda: None = LM_SO_LAMBDA for single trajectories and off for coupled groups; 0 = Gauss-Newton
+    only.  hess_dtype / chol_dtype = np.float32 mimic the HIP path's fp32 MFMA Hessian and fp32 Cholesky (residuals,
+    cost and J^T r stay fp64).  backtrack=False: the plain reject-and-grow rule (round 1's algorithm).
     Returns q, cost, iters, status."""
     if so_lambda is None:
         so_lambda = LM_SO_LAMBDA if others is None else 0.0
@@ -536,27 +545,51 @@ def lm_solve(basis, sc, q0=None, max_iter=200, ftol=1e-14, gtol=1e-9, xtol=1e-11
             delta = -np.linalg.solve(L.T, np.linalg.solve(L, g.astype(chol_dtype))).astype(np.float64)
         except np.linalg.LinAlgError:
             ok = False
-        rho = -1.0
+        rho, fin, accept = -1.0, False, False
+        ct, pred = np.inf, 0.0
         if ok:
             ct = cost(basis, sc, q + delta, wp, others)
             pred = float(delta @ (lam * dg * delta - g))
-            if np.isfinite(ct) and pred > 0:
+            fin = bool(np.isfinite(ct) and pred > 0)
+            if fin:
                 rho = (c - ct) / pred
+        step, pred_s = None, pred
         if rho > 0:
-            small_x = np.max(np.abs(delta)) <= xtol * (np.max(np.abs(q)) + xtol)
-            q = q + delta
-            lam = max(lam * max(1.0 / 3.0, 1.0 - (2.0 * rho - 1.0) ** 3), LM_LAMBDA_MIN); nu = 2.0
-            small_f = (c - ct) <= ftol * c and pred <= ftol * c
+            accept, step = True, delta
+            lam_new = max(lam * max(1.0 / 3.0, 1.0 - (2.0 * rho - 1.0) ** 3), LM_LAMBDA_MIN)
+        elif fin and backtrack:
+            # cost along the step: c at 0 with slope -a, ct at 1  ->  parabola, its minimiser alpha
+            a = -2.0 * float(g @ delta)
+            b = a - pred                                     # delta^T H delta (the model's curvature along the step)
+            den = 2.0 * (ct - c + a)
+            al = a / den if den > 0.0 else LM_BT_MAX
+            al = min(max(al, LM_BT_MIN), LM_BT_MAX)
+            for attempt in range(2):
+                c2 = cost(basis, sc, q + al * delta, wp, others)
+                if np.isfinite(c2) and c2 < c:
+                    accept, step, ct = True, al * delta, c2
+                    pred_s = a * al - b * al * al
+                    lam_new = min(lam / al, LM_LAMBDA_MAX)
+                    break
+                al = max(LM_BT_SHRINK * al, LM_BT_FLOOR)
+        if accept:
+            small_x = np.max(np.abs(step)) <= xtol * (np.max(np.abs(q)) + xtol)
+            q = q + step
+            lam, nu = lam_new, 2.0
+            small_f = (c - ct) <= ftol * c and pred_s <= ftol * c
             c, g, H = eval_normal(basis, sc, q, wp, others, second_order=so_next)
             H = H.astype(hess_dtype).astype(np.float64)
             if small_f or small_x:
                 status = ST_CONVERGED
                 break
         else:
-            lam *= nu; nu *= 2.0
-            if ok and np.isfinite(ct) and 0 < pred <= ftol * c:     # rejected on the rounding floor of the cost: converged
+            if ok and fin and pred <= ftol * c:     # rejected on the rounding floor of the cost: converged
                 status = ST_CONVERGED
                 break
+            if ok or not backtrack:
+                lam *= nu; nu *= 2.0
+            else:
+                lam *= LM_FAIL_MULT
             if lam > LM_LAMBDA_MAX:
                 status = ST_STALLED
                 break
