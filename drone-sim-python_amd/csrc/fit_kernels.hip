@@ -626,6 +626,189 @@ fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_budget,
 }
 
 // ------------------------------------------------------------------------------------
+// Long horizons (K > 64: the reference's own single-aircraft scenarios have 101 .. 151 nodes, its 50 Hz caches 351 .. 1501):
+// the same LM loop with the samples processed in chunks of 64 (lane = sample inside a chunk) and the basis tables read
+// from global memory / L2 (fit_phases.h long_*), so that the LDS footprint does not depend on K.  One evaluation =
+// for every chunk: rows (phase 1) -> J^T r (phase 2) -> MFMA pass accumulating into the same six tiles.  Trial points
+// are cost-only passes (no row records are kept across chunks), an accepted step is followed by a full evaluation.
+struct LongLds {
+  int Wt, wave0, wave_stride, qs, sp, big, cf, cfp, total;
+};
+static LongLds long_lds_layout(int N, int wpb) {
+  LongLds L;
+  int o = 0;
+  L.Wt = o; o = align16(o + (N / 16) * (N / 16 + 1) / 2 * 256 * 4);
+  L.wave0 = o;
+  int w = 0;
+  L.qs = w; w = align16(w + N * 8);
+  L.sp = w; w = align16(w + FIT_PREP_STRIDE * 8);
+  L.big = w;
+  const int us_bytes = 64 * 6 * 8, cf_bytes = 65 * 4 * 16, cfp_bytes = align16(65 * 2 * 8);
+  L.cf = w + us_bytes;
+  L.cfp = L.cf + cf_bytes;
+  int big = us_bytes + cf_bytes + cfp_bytes;
+  if ((N + 3) * (N + 4) * 4 > big) big = (N + 3) * (N + 4) * 4;
+  w = align16(w + big);
+  L.wave_stride = w;
+  L.total = o + wpb * w;
+  return L;
+}
+
+template <int NB, int NQ>
+__global__ void __launch_bounds__(64 * FIT_LM_WPB_MAX)
+fit_lm_long_kernel(int B, FitGeom g, LongLds L, d2d_fit_opts opts, int iter_budget,
+                   const double *__restrict__ GT, const double *__restrict__ G64g, const double *__restrict__ pk,
+                   const float *__restrict__ gG32, const float *__restrict__ gWt, const double *__restrict__ prep,
+                   double *__restrict__ q_io, double *__restrict__ cost_io, double *__restrict__ g_io,
+                   double *__restrict__ lm, int32_t *__restrict__ flags, int32_t *__restrict__ queue,
+                   const int32_t *__restrict__ order) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  constexpr int N = 16 * NB, NT = NB * (NB + 1) / 2;
+  stage(lds + L.Wt, gWt, NT * 256 * 4);
+  __syncthreads();
+  const float *Wt = reinterpret_cast<const float *>(lds + L.Wt);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int woff = L.wave0 + wave * L.wave_stride;
+  unsigned char *wl = lds + woff;
+  double *qs = reinterpret_cast<double *>(wl + L.qs);
+  double *sp = reinterpret_cast<double *>(wl + L.sp);
+  double *us = reinterpret_cast<double *>(wl + L.big);
+  f32x4 *cf = reinterpret_cast<f32x4 *>(wl + L.cf);
+  float2 *cfp = reinterpret_cast<float2 *>(wl + L.cfp);
+  float *big = reinterpret_cast<float *>(wl + L.big);          // image of J^T J, then of its Cholesky factor (aliases us / cf / cfp)
+  const int nq = NQ ? NQ : g.nq, n = 2 * nq;
+  const bool act = lane < n;
+  const int stride = gridDim.x * (blockDim.x >> 6);
+  auto next_index = [&](int b) -> int {
+    if (queue == nullptr) return b + stride;
+    int t = 0;
+    if (lane == 0) t = stride + atomicAdd(queue, 1);
+    return __builtin_amdgcn_readfirstlane(t);
+  };
+  for (int bi = blockIdx.x + gridDim.x * wave; (unsigned)bi < (unsigned)B; bi = next_index(bi)) {
+    const int b = order ? __builtin_amdgcn_readfirstlane(order[bi]) : bi;
+    if (flags[4 * b + FL_STATUS] != D2D_ST_RUNNING) continue;
+    const double *pkb = pk + (size_t)b * FIT_PK * g.K;
+    double qi = act ? q_io[(size_t)b * n + lane] : 0.0;
+    double lam = lm[4 * b + 0], nu = lm[4 * b + 1];
+    int iters = flags[4 * b + FL_ITERS];
+    int nev = 0, local = 0, status = D2D_ST_RUNNING;
+    bool so_rows = uniform_i(lm[4 * b + 3] != 0.0 ? 1 : 0) != 0;
+    double c = 0.0, gi = 0.0;
+    f32x2 hrow[N / 2];
+#pragma unroll
+    for (int m = 0; m < N / 2; ++m) hrow[m] = f32x2{0.f, 0.f};
+    for (int i = lane; i < FIT_PREP_STRIDE; i += 64) sp[i] = prep[(size_t)b * FIT_PREP_STRIDE + i];
+    wave_lds_sync();
+
+    // cost at qi + alpha * delta (cost-only pass over the chunks)
+    auto cost_at = [&](double alpha, double delta) -> double {
+      if (act) qs[q_slot(lane, nq)] = qi + alpha * delta;
+      wave_lds_sync();
+      const int kbank = long_bank_argmax<NQ>(g, GT, pkb, qs, load_scenp(sp), lane);
+      double ca = 0.0;
+      for (int k0 = 0; k0 < g.K; k0 += 64) ca += long_phase1<NQ, false>(g, GT, pkb, sp, qs, us, cf, cfp, false, kbank, k0, lane);
+      return uniform_d(ca);
+    };
+    // full evaluation at qi: c, gi, and (want_H) hrow = this lane's row of J^T J (+ the waypoint block) with -g as row N
+    auto eval_full = [&](bool so, bool want_H) {
+      if (act) qs[q_slot(lane, nq)] = qi;
+      wave_lds_sync();
+      const int kbank = long_bank_argmax<NQ>(g, GT, pkb, qs, load_scenp(sp), lane);
+      f32x4 acc[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      double ca = 0.0, ga = 0.0;
+      for (int k0 = 0; k0 < g.K; k0 += 64) {
+        const int kn = g.K - k0 < 64 ? g.K - k0 : 64;
+        ca += long_phase1<NQ, true>(g, GT, pkb, sp, qs, us, cf, cfp, so, kbank, k0, lane);
+        ga += long_phase2<NQ>(g, G64g, us, k0, kn, lane);
+        if (want_H) {
+          if (so) jtj_mfma_so<NB, NQ, false>(g, lds, 0, woff + L.cf, woff + L.cfp, lane, acc, gG32 + (size_t)k0 * nq, kn, true);
+          else jtj_mfma<NB, NQ, false>(g, lds, 0, gG32 + (size_t)k0 * nq, woff + L.cf, lane, kn, acc, 0, 0, true);
+        }
+        wave_lds_sync();                              // every lane is done with this chunk's records
+      }
+      c = uniform_d(ca); gi = ga;
+      if (want_H) {
+        const float ww = (float)(sp[PR_WWP] * sp[PR_WWP]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[t][r] = fmaf(ww, Wt[(t * 4 + r) * 64 + lane], acc[t][r]);
+        tiles_to_image<N>(acc, big, lane);
+        image_put_rhs<N>(big, lane, gi);
+        wave_lds_sync();
+        image_row<N>(big, lane, hrow);
+        wave_lds_sync();
+        nev += (so ? 3 : 2) * ((g.K + 49) / 50);      // contracted rows in units of 100 (FL_NEVAL; one unit = 200 rows)
+      }
+    };
+
+    bool need_eval = true;
+    for (;;) {
+      if (need_eval) {
+        eval_full(so_rows, status == D2D_ST_RUNNING);
+        need_eval = false;
+        if (!(fabs(c) <= 1.79e308)) status = D2D_ST_NONFINITE;
+      }
+      if (status != D2D_ST_RUNNING) break;
+      if (local >= iter_budget || iters >= opts.max_iter) break;
+      const double gmax = uniform_d(wave_max(fabs(gi)));
+      if (gmax <= opts.gtol) { status = D2D_ST_CONVERGED; break; }
+      float dgi, dl;
+      const int ok = uniform_i(damped_solve<N>(hrow, lam, act, lane, big, dgi, dl) ? 1 : 0);
+      const double delta = (double)dl;
+      const bool so_next = opts.so_lambda > 0.0 && lam <= opts.so_lambda;
+      const double pred = uniform_d(wave_sum(delta * (lam * (double)dgi * delta - gi)));
+      const double dmax = uniform_d(wave_max(fabs(delta))), qmax = uniform_d(wave_max(fabs(qi)));
+      double ct = 0.0, pred_s = pred, alpha = 1.0, bt_a = 0.0, bt_b = 0.0;
+      bool fin = false, accept = false;
+      if (ok) {
+        for (int att = 0; att < 3; ++att) {
+          const double ca = cost_at(alpha, delta);
+          if (att == 0) {
+            ct = ca;
+            fin = (fabs(ct) <= 1.79e308) && (pred > 0.0);
+            if (fin && (c - ct) / pred > 0.0) { accept = true; break; }
+            if (!fin) break;
+            bt_a = uniform_d(-2.0 * wave_sum(gi * delta)); bt_b = bt_a - pred;
+            alpha = bt_first_alpha(bt_a, c, ct);
+          } else {
+            if ((fabs(ca) <= 1.79e308) && ca < c) { accept = true; ct = ca; pred_s = bt_a * alpha - bt_b * alpha * alpha; break; }
+            alpha = fmax(D2D_LM_BT_SHRINK * alpha, D2D_LM_BT_FLOOR);
+          }
+        }
+      }
+      const StepOutcome so = lm_update(ok != 0, fin, accept, accept ? alpha : 1.0, c, ct, pred, pred_s, dmax, qmax, lam, nu, opts);
+      ++iters; ++local;
+      lam = so.lam; nu = so.nu; status = so.status;
+      if (so.accept) {
+        qi += alpha * delta;
+        need_eval = true;                                // (also when converged: cost and J^T r at the final point)
+        so_rows = so_next;
+      }
+    }
+    if (status == D2D_ST_RUNNING && iters >= opts.max_iter) status = D2D_ST_MAXITER;
+    const double gmax = uniform_d(wave_max(fabs(gi)));
+    {
+      int lane_io = lane;
+      LAUNDER(lane_io);
+      if (act) { q_io[(size_t)b * n + lane_io] = qi; g_io[(size_t)b * n + lane_io] = gi; }
+    }
+    if (lane == 0) {
+      cost_io[b] = c;
+      lm[4 * b + 0] = lam; lm[4 * b + 1] = nu; lm[4 * b + 2] = gmax; lm[4 * b + 3] = so_rows ? 1.0 : 0.0;
+      flags[4 * b + FL_STATUS] = status; flags[4 * b + FL_ITERS] = iters; flags[4 * b + FL_NEED] = 1;
+      flags[4 * b + FL_NEVAL] += nev;
+    }
+  }
+  if (queue != nullptr && lane == 0) {
+    if (atomicAdd(queue + 1, 1) == stride - 1) { queue[0] = 0; queue[1] = 0; }
+  }
+}
+
+// ------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 fit_state_init_kernel(int B, int off, int stride, double *__restrict__ lm, int32_t *__restrict__ flags,
                       int32_t *__restrict__ queue) {
@@ -980,6 +1163,26 @@ static int launch_lm(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, double *q, con
   return D2D_OK;
 }
 
+static int launch_lm_long(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, double *q, const d2d_fit_opts &o, int budget) {
+  const FitGeom gm = geom_of(pl);
+  const int NB = (2 * pl->nq + 15) / 16;
+  const LongLds L = long_lds_layout(16 * NB, pl->wpb_lm);
+  const int blocks = B < pl->n_cu ? B : pl->n_cu;
+  static const bool no_queue = getenv("D2D_LM_STATIC") != nullptr;
+  int32_t *queue = no_queue ? nullptr : ctx->counter_dev + 8;
+  const int32_t *order = (pl->order_B == B) ? pl->d_order : nullptr;
+#define LAUNCH_LONG(NBV, NQV)                                                                                          \
+  hipLaunchKernelGGL((fit_lm_long_kernel<NBV, NQV>), dim3(blocks), dim3(64 * pl->wpb_lm), L.total, ctx->stream, B, gm, L, o, budget, \
+                     pl->d_GT, pl->d_G, pl->d_pk, pl->d_G32, pl->d_W32, pl->d_prep, q, pl->d_cost, pl->d_g, pl->d_lm, pl->d_flags, queue, order)
+  if (pl->nq == 24) LAUNCH_LONG(3, 24);
+  else if (NB == 1) LAUNCH_LONG(1, 0);
+  else if (NB == 2) LAUNCH_LONG(2, 0);
+  else LAUNCH_LONG(3, 0);
+#undef LAUNCH_LONG
+  D2D_LAUNCH_CHECK();
+  return D2D_OK;
+}
+
 template <typename KernelT>
 static void allow_big_lds(KernelT k) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, FIT_LDS_BYTES);
@@ -999,13 +1202,20 @@ int d2d_fit_plan_create(d2d_ctx *ctx, int S, int K, double duration, const doubl
   for (int i = 0; i < 3; ++i) pl->wref[i] = wref[i];
   if (int rc = fit_basis_build(pl)) { delete pl; return rc; }
   const int nq = pl->nq, gstr = nq + 1;
-  if (!pick_eval_layout(K, nq, &pl->g32_lds, &pl->wpb_eval, 0) ||
-      !pick_step_layout(K, nq, 16 * ((2 * nq + 15) / 16), &pl->wpb_step)) {
+  // the split-path kernels (public d2d_fit_eval, coupled groups) stage the whole basis block in LDS: K <~ 229 at S = 6
+  pl->split_ok = pick_eval_layout(K, nq, &pl->g32_lds, &pl->wpb_eval, 0) &&
+                 pick_step_layout(K, nq, 16 * ((2 * nq + 15) / 16), &pl->wpb_step);
+  pl->use_lm = (nq == 24) && pick_fused_layout(K, nq, 48, &pl->wpb_lm) && !getenv("D2D_FIT_SPLIT");
+  // long horizons: the chunked persistent kernel reads the basis through L2, any K (also chosen when the split path cannot
+  // hold K; D2D_FIT_LONG=1 forces it for K <= 64, tests do)
+  pl->use_long = !pl->use_lm && (K > 64 || getenv("D2D_FIT_LONG")) && (!getenv("D2D_FIT_SPLIT") || !pl->split_ok);
+  if (getenv("D2D_FIT_LONG") && !getenv("D2D_FIT_SPLIT")) { pl->use_lm = false; pl->use_long = true; }
+  if (pl->use_long) pl->wpb_lm = FIT_LM_WPB_MAX;
+  if (!pl->split_ok && !pl->use_long) {
     d2d_set_error("d2d_fit_plan_create: K=%d, S=%d does not fit the 160 KiB LDS image of the basis block", K, S);
     delete pl;
     return D2D_EINVAL;
   }
-  pl->use_lm = (nq == 24) && pick_fused_layout(K, nq, 48, &pl->wpb_lm) && !getenv("D2D_FIT_SPLIT");
   {
     hipDeviceProp_t prop;
     D2D_CHECK_HIP(hipGetDeviceProperties(&prop, ctx->device));
@@ -1032,8 +1242,13 @@ int d2d_fit_plan_create(d2d_ctx *ctx, int S, int K, double duration, const doubl
               w32[((size_t)t * 4 + r) * 64 + l] = (float)pl->G0tG0[(size_t)(row % nq) * nq + (col % nq)];
           }
   }
+  std::vector<double> gt((size_t)3 * nq * K);            // [d][j][k]: the chunked kernel's flat-output pass reads 64 consecutive k
+  for (int d = 0; d < 3; ++d)
+    for (int k = 0; k < K; ++k)
+      for (int j = 0; j < nq; ++j) gt[((size_t)d * nq + j) * K + k] = pl->G[((size_t)d * K + k) * nq + j];
   D2D_CHECK_HIP(hipSetDevice(ctx->device));
   int rc = upload(&pl->d_G, g64);
+  if (!rc) rc = upload(&pl->d_GT, gt);
   if (!rc) rc = upload(&pl->d_Gp, pl->Gp);
   if (!rc) rc = upload(&pl->d_G32, g32);
   if (!rc) rc = upload(&pl->d_W32, w32);
@@ -1046,6 +1261,7 @@ int d2d_fit_plan_create(d2d_ctx *ctx, int S, int K, double duration, const doubl
   allow_big_lds(&fit_eval_kernel<1, 0, false>); allow_big_lds(&fit_eval_kernel<2, 0, false>); allow_big_lds(&fit_eval_kernel<3, 0, false>);
   allow_big_lds(&fit_eval_kernel<3, 24, true>); allow_big_lds(&fit_eval_kernel<3, 24, false>);
   allow_big_lds(&fit_jtj_kernel<1, 0>); allow_big_lds(&fit_jtj_kernel<2, 0>); allow_big_lds(&fit_jtj_kernel<3, 0>); allow_big_lds(&fit_jtj_kernel<3, 24>);
+  allow_big_lds(&fit_lm_long_kernel<3, 24>); allow_big_lds(&fit_lm_long_kernel<3, 0>); allow_big_lds(&fit_lm_long_kernel<2, 0>); allow_big_lds(&fit_lm_long_kernel<1, 0>);
   allow_big_lds(&fit_lm_kernel<3, 24, false>);
   allow_big_lds(&fit_lm_kernel<3, 24, true>);
   allow_big_lds(&fit_step_kernel<16>); allow_big_lds(&fit_step_kernel<32>); allow_big_lds(&fit_step_kernel<48>);
@@ -1058,12 +1274,17 @@ int d2d_fit_plan_destroy(d2d_fit_plan *pl) {
   if (!pl) return D2D_OK;
   hipSetDevice(pl->device);
   for (hipEvent_t e : pl->prof_ev) (void)hipEventDestroy(e);
-  void *ptrs[] = {pl->d_G, pl->d_Gp, pl->d_G32, pl->d_W32, pl->d_Z, pl->d_Zp, pl->d_Pinit};
+  void *ptrs[] = {pl->d_G, pl->d_GT, pl->d_Gp, pl->d_G32, pl->d_W32, pl->d_Z, pl->d_Zp, pl->d_Pinit};
   for (void *p : ptrs)
     if (p) hipFree(p);
   free_scratch(pl);
   delete pl;
   return D2D_OK;
+}
+
+int d2d_fit_plan_kernel(const d2d_fit_plan *pl) {
+  if (!pl) return D2D_EINVAL;
+  return pl->use_lm ? D2D_FIT_KERNEL_FUSED : (pl->use_long ? D2D_FIT_KERNEL_LONG : D2D_FIT_KERNEL_SPLIT);
 }
 
 int d2d_fit_plan_get(const d2d_fit_plan *pl, double *G, double *Gp, double *Z, double *Zp, double *Pinit) {
@@ -1101,6 +1322,7 @@ int d2d_fit_eval(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, const double *scen
                  double *cost, double *g, float *H) {
   D2D_REQUIRE(ctx && pl && scen && q, "d2d_fit_eval: null argument");
   D2D_REQUIRE(B >= 1, "d2d_fit_eval: B must be >= 1");
+  D2D_REQUIRE(pl->split_ok, "d2d_fit_eval: K=%d does not fit the LDS image of the evaluation kernel (d2d_fit_solve handles any K)", pl->K);
   d2d_fit_plan *plm = const_cast<d2d_fit_plan *>(pl);
   if (plm->active_B != 0 && B > plm->cap_B) { d2d_set_error("d2d_fit_eval: a solve of a smaller batch is in progress on this plan"); return D2D_ESTATE; }
   if (int rc = ensure_scratch(plm, B)) return rc;
@@ -1123,6 +1345,7 @@ int d2d_fit_rows(d2d_ctx *ctx, d2d_fit_plan *pl, int B, const double *scen, cons
   D2D_REQUIRE(ctx && pl && scen && q, "d2d_fit_rows: null argument");
   D2D_REQUIRE(B >= 1, "d2d_fit_rows: B must be >= 1");
   D2D_REQUIRE(pl->n_group <= 1, "d2d_fit_rows: not available for coupled groups");
+  D2D_REQUIRE(pl->split_ok, "d2d_fit_rows: K=%d does not fit the LDS image of the evaluation kernel", pl->K);
   if (pl->active_B != 0 && B > pl->cap_B) { d2d_set_error("d2d_fit_rows: a solve of a smaller batch is in progress on this plan"); return D2D_ESTATE; }
   if (int rc = ensure_scratch(pl, B)) return rc;
   if (int rc = launch_prep(ctx, pl, B, scen)) return rc;
@@ -1251,12 +1474,12 @@ int d2d_fit_iterate(d2d_ctx *ctx, d2d_fit_plan *pl, int B, const double *scen, d
     if (int rc = launch_prep(ctx, pl, B, scen)) return rc;
     pl->prep_valid_for = scen;
   }
-  if (pl->use_lm && pl->n_group <= 1) {
+  if ((pl->use_lm || pl->use_long) && pl->n_group <= 1) {
     int budget = o.max_iter - pl->it_done;
     if (budget > n_iters) budget = n_iters;
     if (budget > 0) {
       if (int rc = prof_begin(ctx, pl, 2)) return rc;
-      if (int rc = launch_lm(ctx, pl, B, q, o, budget)) return rc;
+      if (int rc = pl->use_lm ? launch_lm(ctx, pl, B, q, o, budget) : launch_lm_long(ctx, pl, B, q, o, budget)) return rc;
       if (int rc = prof_end(ctx, pl)) return rc;
       pl->it_done += budget;
     }
@@ -1295,7 +1518,7 @@ int d2d_fit_finish(d2d_ctx *ctx, d2d_fit_plan *pl, int B, const double *scen, co
     pl->prep_valid_for = scen;
   }
   // (the persistent LM kernel leaves cost and J^T r of every trajectory evaluated at its final point)
-  if (!(pl->use_lm && pl->n_group <= 1 && pl->it_done > 0))
+  if (!((pl->use_lm || pl->use_long) && pl->n_group <= 1 && pl->it_done > 0))
     if (int rc = launch_eval(ctx, pl, B, q, nullptr, pl->d_cost, pl->d_g, nullptr)) return rc;
   if (cost) D2D_CHECK_HIP(hipMemcpyAsync(cost, pl->d_cost, (size_t)B * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
   hipLaunchKernelGGL(fit_export_kernel, g1, b1, 0, ctx->stream, B, pl->d_flags, iters, status);
@@ -1324,7 +1547,7 @@ int d2d_fit_solve(d2d_ctx *ctx, const d2d_fit_plan *plc, int B, const double *sc
   int32_t running = B;
   // the persistent LM kernel masks finished trajectories itself and ends when its last one stops: one
   // launch for the whole solve; the split path counts the running trajectories every check_every iterations
-  const int per_call = (pl->use_lm && pl->n_group <= 1) ? o.max_iter : o.check_every;
+  const int per_call = ((pl->use_lm || pl->use_long) && pl->n_group <= 1) ? o.max_iter : o.check_every;
   while (running > 0)
     if (int rc = d2d_fit_iterate(ctx, pl, B, scen, q, &o, per_call, &running)) return rc;
   return d2d_fit_finish(ctx, pl, B, scen, q, cost, iters, status, stats);
@@ -1345,6 +1568,14 @@ int d2d_fit_plan_set_order(d2d_ctx *ctx, d2d_fit_plan *pl, int B, const int32_t 
 int d2d_fit_plan_set_groups(d2d_fit_plan *pl, int n_ac) {
   D2D_REQUIRE(pl != nullptr, "d2d_fit_plan_set_groups: plan is NULL");
   D2D_REQUIRE(n_ac >= 1 && n_ac <= 8, "d2d_fit_plan_set_groups: n_ac=%d not in 1..8", n_ac);
+  if (n_ac == 1) {                      // back to independent trajectories (any K)
+    pl->n_group = 1; pl->nds = 0;
+    bool g32;
+    int we;
+    if (pl->split_ok && pick_eval_layout(pl->K, pl->nq, &g32, &we, 0)) { pl->g32_lds = g32; pl->wpb_eval = we; }
+    return D2D_OK;
+  }
+  D2D_REQUIRE(pl->split_ok, "d2d_fit_plan_set_groups: K=%d does not fit the LDS image of the coupled-group kernels", pl->K);
   const int nds = n_ac > 1 ? 4 * ((n_ac - 1 + 3) / 4) : 0;
   bool g32;
   int we, ws;

@@ -134,6 +134,127 @@ __device__ __forceinline__ double eval_cost_grad(const FitGeom &g, const double 
   return cost;
 }
 
+// ---- long horizons (K > 64): the same phases over chunks of 64 samples, basis tables read from global memory --------
+// fit_lm_long_kernel keeps lane = sample inside a chunk (sample k = k0 + lane).  The basis does not fit the LDS beside
+// the per-wave blocks once K grows (3 K (nq+1) 8 B: 90 kB at K = 151, 300 kB at K = 501), so it stays in HBM / L2:
+//   GT  [3][nq][K]   fp64, TRANSPOSED: the flat-output pass reads GT[d][j][k0 + lane] -- 64 consecutive doubles per load
+//   G64 [3][K][gstr] fp64, row-major (the split path's table): the J^T r pass reads G64[d][k][lane's unknown]
+//   G32 [3][K][nq]   fp32 planes for the MFMA operands (jtj_mfma<.., T_LDS = false>)
+// Flat outputs of sample k from the per-sample base pk[0..5] plus G_d[k] . q; qs = interleaved LDS copy of q.
+template <int NQ>
+__device__ __forceinline__ void flat_outputs_gt(const FitGeom &g, const double *__restrict__ GT, const double *qs,
+                                                const double pk[FIT_PK], int k, double Y[6]) {
+  typedef double __attribute__((ext_vector_type(2), may_alias)) f64x2a;
+  const int nq = NQ ? NQ : g.nq;
+#pragma unroll
+  for (int c = 0; c < 6; ++c) Y[c] = pk[c];
+  const double *t0 = GT + k, *t1 = t0 + (size_t)nq * g.K, *t2 = t1 + (size_t)nq * g.K;
+#pragma unroll 4
+  for (int j = 0; j < nq; ++j) {
+    const f64x2a qq = *reinterpret_cast<const f64x2a *>(qs + 2 * j);
+    const double a0 = t0[(size_t)j * g.K], a1 = t1[(size_t)j * g.K], a2 = t2[(size_t)j * g.K];
+    Y[0] = fma(a0, qq.x, Y[0]); Y[1] = fma(a0, qq.y, Y[1]);
+    Y[2] = fma(a1, qq.x, Y[2]); Y[3] = fma(a1, qq.y, Y[3]);
+    Y[4] = fma(a2, qq.x, Y[4]); Y[5] = fma(a2, qq.y, Y[5]);
+  }
+}
+
+// CostBank max mode over a long horizon: index of the sample with the largest |phi| (first on ties); -1 in mean mode.
+template <int NQ>
+__device__ __forceinline__ int long_bank_argmax(const FitGeom &g, const double *__restrict__ GT, const double *__restrict__ pkb,
+                                                const double *qs, const ScenP &s, int lane) {
+  if (!(s.cphimax > 0.0)) return -1;
+  double best = -1.0;
+  int kstar = 0;
+  for (int k0 = 0; k0 < g.K; k0 += 64) {
+    const int k = k0 + lane;
+    double aw = -1.0;
+    if (k < g.K) {
+      double pk[FIT_PK], Y[6];
+#pragma unroll
+      for (int c = 0; c < FIT_PK; ++c) pk[c] = pkb[(size_t)c * g.K + k];
+      flat_outputs_gt<NQ>(g, GT, qs, pk, k, Y);
+      aw = sample_absw(s, Y);
+    }
+    const double m = wave_max(aw);
+    if (m > best) { best = m; kstar = k0 + (int)__builtin_ctzll(__ballot(aw == m)); }
+  }
+  return __builtin_amdgcn_readfirstlane(kstar);
+}
+
+// Phase 1 of one chunk (samples k0 .. k0+63): rows, u = D^T r -> us [64][6], row records -> cf [65][4] (+ cfp [65][2] in
+// second-order mode), chunk-local indices; a lane beyond the horizon writes zero records (the MFMA passes read the
+// whole chunk up to its last sample and one padded sample).  Returns the chunk's sum r^2 (wave-uniform).
+// WANT_JAC = false: the cost alone (trial points).
+template <int NQ, bool WANT_JAC>
+__device__ __forceinline__ double long_phase1(const FitGeom &g, const double *__restrict__ GT, const double *__restrict__ pkb,
+                                              const double *sp, const double *qs, double *us, f32x4 *cf, float2 *cfp,
+                                              bool so, int kbank, int k0, int lane) {
+  LAUNDER(lane);
+  const int k = k0 + lane;
+  double cacc = 0.0;
+  if (k < g.K) {
+    double pk[FIT_PK], Y[6], u[6] = {0, 0, 0, 0, 0, 0};
+    f32x4 coef[4];
+#pragma unroll
+    for (int c = 0; c < FIT_PK; ++c) pk[c] = pkb[(size_t)c * g.K + k];
+    flat_outputs_gt<NQ>(g, GT, qs, pk, k, Y);
+    const ScenP s = load_scenp(sp);
+    if (!WANT_JAC) {
+      cacc = sample_terms<false>(s, Y, pk[6], pk[7], nullptr, nullptr, k == kbank);
+    } else {
+      if (so) {
+        float2 pos[2];
+        cacc = sample_terms<true>(s, Y, pk[6], pk[7], u, coef, k == kbank, pos);
+        cfp[lane * 2] = pos[0]; cfp[lane * 2 + 1] = pos[1];
+      } else {
+        cacc = sample_terms<true>(s, Y, pk[6], pk[7], u, coef, k == kbank);
+      }
+#pragma unroll
+      for (int c = 0; c < 6; ++c) us[lane * 6 + c] = u[c];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cf[lane * 4 + r] = coef[r];
+    }
+  } else if (WANT_JAC) {
+#pragma unroll
+    for (int c = 0; c < 6; ++c) us[lane * 6 + c] = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cf[lane * 4 + r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    cfp[lane * 2] = float2{0.f, 0.f}; cfp[lane * 2 + 1] = float2{0.f, 0.f};
+  }
+  if (WANT_JAC && lane == 0) {             // the padded sample behind the chunk (index 64)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cf[64 * 4 + r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    cfp[64 * 2] = float2{0.f, 0.f}; cfp[64 * 2 + 1] = float2{0.f, 0.f};
+  }
+  const double cost = wave_sum(cacc);
+  wave_lds_sync();
+  return cost;
+}
+
+// Phase 2 of one chunk (lane = unknown): sum over the chunk's samples of G_k^T u_k, basis rows from the row-major global table.
+template <int NQ>
+__device__ __forceinline__ double long_phase2(const FitGeom &g, const double *__restrict__ G64g, const double *us, int k0,
+                                              int kn, int lane) {
+  const int nq = NQ ? NQ : g.nq, gstr = nq + 1;
+  double g_lane = 0.0;
+  LAUNDER(lane);
+  if (lane < 2 * nq) {
+    const int ax = lane >= nq ? 1 : 0, jj = lane - ax * nq;
+    const double *g0 = G64g + (size_t)k0 * gstr + jj, *g1 = g0 + (size_t)g.K * gstr, *g2 = g1 + (size_t)g.K * gstr;
+    const double *uk = us + ax;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+#pragma unroll 4
+    for (int k = 0; k < kn; ++k) {
+      a0 = fma(uk[k * 6], g0[(size_t)k * gstr], a0);
+      a1 = fma(uk[k * 6 + 2], g1[(size_t)k * gstr], a1);
+      a2 = fma(uk[k * 6 + 4], g2[(size_t)k * gstr], a2);
+    }
+    g_lane = (a0 + a1) + a2;
+  }
+  return g_lane;
+}
+
 // (accesses whose type differs from the one the bytes were stored with go through may_alias types:
 // type-based alias analysis must not reorder them against those stores)
 template <typename T>
@@ -157,7 +278,10 @@ __device__ __forceinline__ void lds_put(void *p, const T &v) {
 template <int NB, int NQ, bool T_LDS>
 __device__ __forceinline__ void jtj_mfma(const FitGeom &g, const unsigned char *lds_base, int t32_off,
                                          const float *T32g, int cf_off, int lane, int Kmf,
-                                         f32x4 (&acc)[NB * (NB + 1) / 2], int cfd_off = 0, int nds = 0) {
+                                         f32x4 (&acc)[NB * (NB + 1) / 2], int cfd_off = 0, int nds = 0,
+                                         bool accumulate = false) {
+  // accumulate (long horizons, fit_lm_long_kernel): the pass covers one chunk of samples -- the records of samples
+  // k0 .. k0+Kmf-1 at cf_off, T32g already advanced by k0 rows -- and adds to acc instead of starting from zero
   // All LDS operands are addressed as lds_base + integer byte offset so that the compiler keeps them
   // in the LDS address space (ds_read with immediate offsets) through the unrolled loop.
   LAUNDER(lane);
@@ -180,8 +304,10 @@ __device__ __forceinline__ void jtj_mfma(const FitGeom &g, const unsigned char *
 #define LDS_F(off) lds_get<float>(lds_base + (off))
 #define LDS_F2(off) lds_get<float2>(lds_base + (off))
 #define T32_AT(off) (T_LDS ? LDS_F(t32_off + (off)) : T32g[(off) >> 2])
+  if (!accumulate) {
 #pragma unroll
-  for (int t = 0; t < NB * (NB + 1) / 2; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NB * (NB + 1) / 2; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   float2 cc[NB];
   float ta[NB], tb[NB];
 #pragma unroll
@@ -258,9 +384,13 @@ __device__ __forceinline__ void jtj_mfma(const FitGeom &g, const unsigned char *
 // coefficient records).  One velocity k-step per sample (its four rows) and one position k-step per PAIR of
 // samples (two rows each): 1.5 k-steps per sample.  Only the upper block triangle is accumulated; M_k is
 // symmetric, so A^T B is (to fp32 rounding).
-template <int NB, int NQ>
+template <int NB, int NQ, bool T_LDS = true>
 __device__ __forceinline__ void jtj_mfma_so(const FitGeom &g, const unsigned char *lds_base, int t32_off, int cf_off,
-                                            int cfp_off, int lane, f32x4 (&acc)[NB * (NB + 1) / 2]) {
+                                            int cfp_off, int lane, f32x4 (&acc)[NB * (NB + 1) / 2],
+                                            const float *T32g = nullptr, int Kmf = -1, bool accumulate = false) {
+  // T_LDS = false / Kmf / accumulate: one chunk of a long horizon (see jtj_mfma); Kmf samples, records at cf_off / cfp_off,
+  // T32g = the fp32 planes in global memory advanced by the chunk's first sample
+  if (Kmf < 0) Kmf = g.K;
   LAUNDER(lane);
   const int rho = lane >> 4, ci = lane & 15;
   const int nq = NQ ? NQ : g.nq;
@@ -273,11 +403,13 @@ __device__ __forceinline__ void jtj_mfma_so(const FitGeom &g, const unsigned cha
     ayc[c] = col >= nq;
     jj[c] = col < 2 * nq ? col - (ayc[c] ? nq : 0) : 0;
   }
+ if (!accumulate) {
 #pragma unroll
-  for (int t = 0; t < NB * (NB + 1) / 2; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NB * (NB + 1) / 2; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   const bool row_y = (rho & 1) != 0;          // velocity rows: a, c act on the x columns, b, d on the y columns
   const bool row_2 = rho >= 2;                // velocity rows c, d use G2; position rows 2, 3 belong to the next sample
-#define SO_T(pl, kk, j) lds_get<float>(lds_base + t32_off + 4 * ((pl) * plane + (kk) * nq + (j)))
+#define SO_T(pl, kk, j) (T_LDS ? lds_get<float>(lds_base + t32_off + 4 * ((pl) * plane + (kk) * nq + (j))) : T32g[(pl) * plane + (kk) * nq + (j)])
 #define SO_MFMAS                                                                              \
   {                                                                                           \
     int t = 0;                                                                                \
@@ -285,7 +417,7 @@ __device__ __forceinline__ void jtj_mfma_so(const FitGeom &g, const unsigned cha
       _Pragma("unroll") for (int J = I; J < NB; ++J, ++t)                                     \
         acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(va_[I], vb_[J], acc[t], 0, 0, 0);       \
   }
-  for (int k = 0; k < g.K; k += 2) {
+  for (int k = 0; k < Kmf; k += 2) {
 #pragma unroll
     for (int half = 0; half < 2; ++half) {                  // velocity k-steps of samples k and k+1
       const int ks = k + half;

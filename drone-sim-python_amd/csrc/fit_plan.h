@@ -13,6 +13,7 @@ struct d2d_fit_plan {
   std::vector<double> G, Gp, Z, Zp, Pinit, G0tG0;
   // device copies
   double *d_G = nullptr;     // [3][K][GSTR]   GSTR = nq+1 (odd stride: conflict-free LDS image)
+  double *d_GT = nullptr;    // [3][nq][K]    transposed copy for the long-horizon kernel (lane = sample reads are contiguous)
   double *d_Gp = nullptr;    // [3][K][4]
   float *d_G32 = nullptr;    // [3][K][nq] fp32 planes for the MFMA operand generation
   float *d_W32 = nullptr;    // [nq][nq]  G0^T G0 (waypoint rows' constant J^T J block)
@@ -40,6 +41,8 @@ struct d2d_fit_plan {
   bool g32_lds = true;
   int wpb_eval = 8, wpb_step = 8, wpb_lm = 0;
   bool use_lm = false;      // whole LM loop in one persistent launch (fit_lm_kernel)
+  bool use_long = false;    // ... in fit_lm_long_kernel: K > 64, samples in chunks of 64, basis through L2
+  bool split_ok = true;     // the split-path kernels' LDS image holds this K (d2d_fit_eval, coupled groups)
   int n_cu = 256;
   int it_done = 0, active_B = 0;   // LM loop state between d2d_fit_begin / iterate / finish
   // optional per-launch timing (d2d_fit_profile)

@@ -76,6 +76,7 @@ _SIGS = {
     'd2d_fit_plan_create': (C.c_int, [_P, C.c_int, C.c_int, C.c_double, _P, C.POINTER(_P)]),
     'd2d_fit_plan_destroy': (C.c_int, [_P]),
     'd2d_fit_plan_get': (C.c_int, [_P] * 6),
+    'd2d_fit_plan_kernel': (C.c_int, [_P]),
     'd2d_fit_init': (C.c_int, [_P, _P, C.c_int, _P, _P]),
     'd2d_fit_project': (C.c_int, [_P, _P, C.c_int, _P, _P, _P]),
     'd2d_fit_eval': (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P, _P]),
@@ -343,6 +344,11 @@ class FitPlan:
             self.h = None
 
     __del__ = close
+
+    @property
+    def kernel(self):
+        """'fused' | 'long' | 'split': the kernel d2d_fit_solve runs for this plan (include/d2d.h D2D_FIT_KERNEL_*)."""
+        return ('split', 'fused', 'long')[self.ctx.lib.d2d_fit_plan_kernel(self.h)]
 
     def basis(self):
         """Host copies: G (3,K,nq), Gp (3,K,4), Z (8S,nq), Zp (8S,4), Pinit (nq,K)."""

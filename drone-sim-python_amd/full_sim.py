@@ -159,8 +159,10 @@ def full_sim_phases_batch(c, r, v, n_ac, X1_f, scen, X2_f, t_opt, ref3=None, t_s
     dsc[:, d2dhip.SC_X0], dsc[:, d2dhip.SC_Y0], dsc[:, d2dhip.SC_PSI0] = Xs1[0], Xs1[1], Xs1[2]
     q = plan.init(dsc)
     if coupled:
-        cost, sweeps, stats = plan.solve_groups(dsc, q, n_ac, max_sweeps=max_sweeps, inner_iters=8)
-        plan.set_groups(1)
+        try:
+            cost, sweeps, stats = plan.solve_groups(dsc, q, n_ac, max_sweeps=max_sweeps, inner_iters=8)
+        finally:
+            plan.set_groups(1)
     else:
         cost, iters, status, stats = plan.solve(dsc, q)
     _, Xs = plan.sample(dsc, q)                                     # dev [N][5][K]

@@ -85,8 +85,10 @@ class Planner:
         q = plan.project(dsc, ctx.dev(xy))
         max_iter = int(min(max(self.prob.options.get('max_iter', 200), 1), 2000))
         if coupled:
-            cost, sweeps, stats = plan.solve_groups(dsc, q, n, max_sweeps=max(1, max_iter // 8), inner_iters=8)
-            plan.set_groups(1)
+            try:
+                cost, sweeps, stats = plan.solve_groups(dsc, q, n, max_sweeps=max(1, max_iter // 8), inner_iters=8)
+            finally:
+                plan.set_groups(1)                   # the cached plan goes back to independent trajectories whatever happened
             torch = d2dhip._torch()
             iters = torch.full((n,), sweeps, dtype=torch.int32); status = torch.full((n,), 1 if stats[2] <= 1e-9 else 2, dtype=torch.int32)
         else:
@@ -101,8 +103,9 @@ class Planner:
             sol[self._slice_x[i]], sol[self._slice_y[i]], sol[self._slice_psi[i]] = Xs[i, 0], Xs[i, 1], Xs[i, 2]
             sol[self._slice_phi[i]], sol[self._slice_v[i]] = Xs[i, 3], Xs[i, 4]
         st = status.cpu().numpy()
+        vphi, vv = sop.bound_violation(Xs[:, 3], Xs[:, 4], self.scen.phi_constraint, self.scen.v_constraint)
         info = {'status': st.tolist(), 'iters': iters.cpu().numpy().tolist(), 'obj_val': float(cost.sum().item()),
-                'box_violation': viol}
+                'box_violation': viol, 'phi_violation': vphi, 'v_violation': vv}
         return sol, info
 
     def run(self, initial_guess=None, tol=1e-8, max_iter=500):
@@ -177,7 +180,7 @@ class exp_0:
 
 class exp_5(exp_0):
     name, desc = 'exp_5', '2 aicraft face to face'
-    t1, hz = 4.2, 10.
+    t1 = 4.2                                   # (hz = 50 inherited, as in the reference: 211 nodes)
     vref = 12.
     x_constraint, y_constraint = None, None
     p0s = ((0., 0., 0., 0., 12.), (50., 0., np.pi, 0., 12.))

@@ -22,12 +22,15 @@ _plans = {}
 
 
 def get_plan(K, duration, obj_scale_over_n, kv=5., kphi=1.):
-    """Fit plans are cached per (K, duration): the basis block is shared by every trajectory."""
+    """Fit plans are cached per (K, duration, whitening metric): the basis block is shared by every trajectory that is
+    fitted with the same node grid AND the same cost weights (the metric is the quadratic skeleton of the cost; a plan built
+    for other weights spans the same space but is conditioned differently, so it is not reused)."""
     ctx = d2dhip.default_context()
-    key = (K, round(float(duration), 9))
+    s = obj_scale_over_n
+    wref = (W_WAYPOINT ** 2, s * max(kv, 1e-3), s * max(kphi, 1e-3) / 9.81 ** 2)
+    key = (K, round(float(duration), 9)) + tuple(float(f'{w:.6e}') for w in wref)
     if key not in _plans:
-        s = obj_scale_over_n
-        _plans[key] = d2dhip.FitPlan(ctx, N_SEG, K, duration, (W_WAYPOINT ** 2, s * max(kv, 1e-3), s * max(kphi, 1e-3) / 9.81 ** 2))
+        _plans[key] = d2dhip.FitPlan(ctx, N_SEG, K, duration, wref)
     return _plans[key]
 
 
@@ -98,6 +101,15 @@ def box_violation(x, y, x_constraint, y_constraint):
         if box is not None:
             v = max(v, float(box[0] - np.min(val)), float(np.max(val) - box[1]))
     return max(v, 0.0)
+
+
+def bound_violation(phi, v, phi_constraint, v_constraint):
+    """Largest overshoot of the sampled plan beyond phi_constraint (rad) and v_constraint (m/s): like the boxes these are soft
+    bound rows of the fit, and a scenario whose bounds bind hard (or conflict) ends in a compromise that the planners report as
+    info['phi_violation'] / info['v_violation'] instead of hiding it."""
+    vp = max(float(np.max(phi) - phi_constraint[1]), float(phi_constraint[0] - np.min(phi)), 0.0)
+    vv = max(float(np.max(v) - v_constraint[1]), float(v_constraint[0] - np.min(v)), 0.0)
+    return vp, vv
 
 
 class _FitProblem:
@@ -173,7 +185,9 @@ class Planner:
         self.fit_coefs = plan.coeffs(dsc, q).cpu().numpy()[0]
         info = {'status': int(status.cpu().numpy()[0]), 'iters': int(iters.cpu().numpy()[0]),
                 'obj_val': float(cost.cpu().numpy()[0]),
-                'box_violation': box_violation(Xh[0], Xh[1], self.exp.x_constraint, self.exp.y_constraint), 'status_msg': ('running', 'converged', 'max_iter', 'non-finite', 'stalled')[int(status.cpu().numpy()[0])]}
+                'box_violation': box_violation(Xh[0], Xh[1], self.exp.x_constraint, self.exp.y_constraint),
+                'phi_violation': bound_violation(Xh[3], Xh[4], self.exp.phi_constraint, self.exp.v_constraint)[0],
+                'v_violation': bound_violation(Xh[3], Xh[4], self.exp.phi_constraint, self.exp.v_constraint)[1], 'status_msg': ('running', 'converged', 'max_iter', 'non-finite', 'stalled')[int(status.cpu().numpy()[0])]}
         return Xs.cpu().numpy()[0].reshape(-1), info
 
     def run(self, initial_guess=None):

@@ -1,0 +1,150 @@
+"""GPU parity: the long-horizon persistent LM kernel (fit_lm_long_kernel: K > 64, samples in chunks of 64, basis tables
+through L2) against the oracle's lm_solve (the same algorithm in fp64 on the CPU), the fused K <= 64 kernel on the same
+scenarios, and the scipy arbiter -- at the node counts the reference's own scenarios use (src/d2d/optyplan_scenarios.py:
+exp_14 121 nodes, exp_0 151; src/multi_opt_planner.py:170-185 exp_0: 501 nodes at 50 Hz)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import fit as F
+
+pytestmark = pytest.mark.gpu
+S_ = 6
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    import d2dhip
+    c = d2dhip.Context(0)
+    yield c
+    c.close()
+
+
+def _plan(ctx, K, hz=10.0, env=None):
+    import d2dhip
+    dur = (K - 1) / hz
+    s = 0.1 / K
+    old = {}
+    for k, v in (env or {}).items():
+        old[k] = os.environ.get(k); os.environ[k] = v
+    try:
+        p = d2dhip.FitPlan(ctx, S_, K, dur, (0.02 ** 2, s * 5.0, s / F.G_ACC ** 2))
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+    return p, dur
+
+
+def _scen(B, K, dur, seed):
+    """Bench-style scenarios stretched to the horizon: end points vref*dur*(0.55..0.95) apart, obstacles beside the line."""
+    sc = F.set_scale(F.synth_scenarios(B, seed=seed), 0.1, K)
+    scale = 12.0 * dur / 49.0
+    for a, b in ((F.SC_X1, F.SC_X0), (F.SC_Y1, F.SC_Y0)):
+        sc[:, a] = sc[:, b] + (sc[:, a] - sc[:, b]) * scale
+    for ox, oy, _ in F.SC_OBS[:2]:
+        sc[:, ox] = sc[:, F.SC_X0] + (sc[:, ox] - sc[:, F.SC_X0]) * scale
+        sc[:, oy] = sc[:, F.SC_Y0] + (sc[:, oy] - sc[:, F.SC_Y0]) * scale
+    return sc
+
+
+@pytest.mark.parametrize('K', [121, 151, 65, 128])
+def test_long_kernel_vs_oracle_lm(ctx, K):
+    """Chunk boundaries: K = 65 (one sample in the second chunk), 128 (two full chunks), 121 / 151 (the reference's scenarios)."""
+    import d2dhip
+    plan, dur = _plan(ctx, K)
+    try:
+        assert plan.kernel == 'long'
+        ob = F.FitBasis.from_arrays(S_, K, dur, *plan.basis())
+        B = 21
+        sc = _scen(B, K, dur, seed=K)
+        sc[1, F.SC_WX], sc[1, F.SC_WY] = 1.0, -0.5
+        sc[2, F.SC_BANKMAX] = 1.0                         # CostBank max mode: the argmax pass over every chunk
+        sc[3, F.SC_O1R] = 0.0
+        dsc = ctx.dev(sc)
+        q0 = plan.init(dsc)
+        q = q0.clone()
+        cost, iters, status, stats = plan.solve(dsc, q)
+        qh, ch, ih = q.cpu().numpy(), cost.cpu().numpy(), iters.cpu().numpy()
+        st = status.cpu().numpy()
+        assert np.isin(st, (d2dhip.ST_CONVERGED, d2dhip.ST_STALLED)).all(), st
+        same, dit = 0, []
+        for i in range(B):
+            co = F.cost(ob, sc[i], qh[i])
+            assert abs(ch[i] - co) <= 1e-10 * co, (i, ch[i], co)        # the kernel's cost IS the oracle's cost at its point
+            assert co <= F.cost(ob, sc[i], q0.cpu().numpy()[i]) * (1 + 1e-12)
+            if i < 9:
+                # fp32 Hessian + fp32 Cholesky on the GPU, mimicked by the oracle: the same minimum in about as many iterations
+                qo, c_or, it_or, _ = F.lm_solve(ob, sc[i], hess_dtype=np.float32, chol_dtype=np.float32)
+                ok = abs(c_or - ch[i]) <= 1e-6 * c_or and np.abs(qo - qh[i]).max() <= 1e-5 * np.abs(qo).max()
+                same += int(ok)
+                if ok:
+                    dit.append(abs(int(ih[i]) - it_or))
+        assert same >= 7, same                                         # (a basin flip on a rounding-level difference is allowed)
+        assert np.median(dit) <= 2 and (np.array(dit) <= 3).mean() >= 0.7, dit   # (long wandering fits drift apart in fp32)
+        # scipy polish from the GPU points must not move them
+        from scipy.optimize import least_squares
+        for i in (0, 5):
+            wp = F.waypoints(sc[i], K, dur)
+            fun = lambda qq: F.residuals(ob, sc[i], qq, wp).reshape(-1)                        # noqa: E731
+            jac = lambda qq: F.jacobian(ob, F.residuals(ob, sc[i], qq, wp, True)[1])           # noqa: E731
+            pol = least_squares(fun, qh[i], jac=jac, method='lm', xtol=1e-15, ftol=1e-15, gtol=1e-15)
+            assert abs(2 * pol.cost - ch[i]) <= 1e-9 * ch[i]
+            assert np.abs(pol.x - qh[i]).max() <= 1e-6 * np.abs(qh[i]).max()
+    finally:
+        plan.close()
+
+
+def test_long_kernel_equals_fused_kernel_at_K50(ctx):
+    """The same algorithm through both persistent kernels (D2D_FIT_LONG=1 forces the chunked one at K = 50): same minima,
+    iteration counts within rounding-level differences of the two summation orders."""
+    import d2dhip
+    K = 50
+    pf, dur = _plan(ctx, K)
+    pl, _ = _plan(ctx, K, env={'D2D_FIT_LONG': '1'})
+    try:
+        assert pf.kernel == 'fused' and pl.kernel == 'long'
+        B = 300
+        sc = F.set_scale(F.synth_scenarios(B, seed=11), 0.1, K)
+        dsc = ctx.dev(sc)
+        q0 = pf.init(dsc)
+        qa, qb = q0.clone(), q0.clone()
+        ca, ia, sa, _ = pf.solve(dsc, qa)
+        cb, ib, sb, _ = pl.solve(dsc, qb)
+        ca, cb, ia, ib = ca.cpu().numpy(), cb.cpu().numpy(), ia.cpu().numpy(), ib.cpu().numpy()
+        same = np.abs(ca - cb) <= 1e-7 * np.abs(ca)
+        assert same.mean() >= 0.97, same.mean()
+        assert (np.abs(ia - ib)[same] <= 3).mean() >= 0.95
+        qa, qb = qa.cpu().numpy(), qb.cpu().numpy()
+        assert (np.abs(qa - qb).max(1)[same] <= 1e-5 * np.abs(qa).max(1)[same]).mean() >= 0.97
+    finally:
+        pf.close(); pl.close()
+
+
+def test_501_nodes_plan_and_eval_limits(ctx):
+    """K = 501 (multi_opt_planner.exp_0: 10 s at 50 Hz, src/multi_opt_planner.py:170-185): the plan exists, d2d_fit_solve runs the
+    long kernel, the basis-in-LDS entry points refuse it with a clear error instead of a launch failure."""
+    import d2dhip
+    plan, dur = _plan(ctx, 501, hz=50.0)
+    try:
+        assert plan.kernel == 'long'
+        ob = F.FitBasis.from_arrays(S_, 501, dur, *plan.basis())
+        sc = _scen(3, 501, dur, seed=3)
+        sc[:, F.SC_S] = 0.1 / 501
+        dsc = ctx.dev(sc)
+        q = plan.init(dsc)
+        c0 = [F.cost(ob, sc[i], q.cpu().numpy()[i]) for i in range(3)]
+        cost, iters, status, stats = plan.solve(dsc, q)
+        ch, qh = cost.cpu().numpy(), q.cpu().numpy()
+        for i in range(3):
+            co = F.cost(ob, sc[i], qh[i])
+            assert abs(ch[i] - co) <= 1e-10 * co and co < c0[i]
+            _, go, _ = F.eval_normal(ob, sc[i], qh[i])
+            assert np.abs(go).max() <= 1e-6
+        with pytest.raises(d2dhip.D2DError, match='LDS'):
+            plan.eval(dsc, q)
+    finally:
+        plan.close()
