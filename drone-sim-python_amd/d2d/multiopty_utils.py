@@ -14,7 +14,8 @@ class AircraftSet:
         self._input_symbols = tuple(s for ac in self.aircraft for s in ac._input_symbols)
 
     def get_eom(self, wind, g=9.81):
-        return tuple(e for ac in self.aircraft for e in ac.get_eom(wind, g))
+        """The stacked model of all aircraft (src/d2d/multiopty_utils.py:25-26)."""
+        return d2ou.Eom(wind.sample_sym(self.st, None, None), g, tuple(ac._id for ac in self.aircraft))
 
 
 def _scale(_p):

@@ -34,18 +34,66 @@ class WindField:
 
 
 class _Sym:
-    """Named placeholder standing where the reference holds a sympy Function/Symbol; the HIP
-    planner needs no symbolic model (the flat-output parameterisation satisfies the
-    kinematics identically), only the names survive for printing."""
+    """Named placeholder standing where the reference holds a sympy Function / Symbol.  No computer algebra is needed on this
+    side -- the model is fixed (the three kinematic equations below) and lives in the kernels -- but the reference's planner
+    code builds its instance constraints and bounds out of these objects (`_g._sx(t0) - x0`, `bounds[_g._sphi(_g._st)] = ...`,
+    src/single_opt_planner.py:46-57), so they support exactly that: calling (-> the function at a time), subtraction of a
+    number (-> an instance constraint), hashing (-> keys of the bounds dictionary)."""
 
     def __init__(self, name):
         self.name = name
 
-    def __call__(self, *a):
-        return self
+    def __call__(self, t=None):
+        return _SymAt(self, t)
 
     def __repr__(self):
         return self.name
+
+
+class _SymAt:
+    """`x(t)`: a state / input function at a time (a number for instance constraints, the time symbol for bounds)."""
+
+    def __init__(self, sym, t):
+        self.sym, self.t = sym, t
+
+    def __sub__(self, value):
+        return InstanceConstraint(self.sym.name, self.t, float(value))
+
+    def __hash__(self):
+        return hash((self.sym.name, repr(self.t)))
+
+    def __eq__(self, other):
+        return isinstance(other, _SymAt) and (self.sym.name, repr(self.t)) == (other.sym.name, repr(other.t))
+
+    def diff(self):
+        return _SymAt(_Sym(self.sym.name + "'"), self.t)
+
+    def __repr__(self):
+        return f'{self.sym.name}({self.t})'
+
+
+class InstanceConstraint:
+    """`name(t) - value = 0` (what `_g._sx(t0) - x0` evaluates to)."""
+
+    def __init__(self, name, t, value):
+        self.name, self.t, self.value = name, float(t), value
+
+    def __repr__(self):
+        return f'{self.name}({self.t}) - {self.value}'
+
+
+class Eom(tuple):
+    """The symbolic model of the reference (src/d2d/opty_utils.py:38-50) as data: residual form, wind entering with a + sign
+    (the reference's quirk: the plant, src/d2d/dynamic.py:18-19, has the opposite sign).  A tuple of printable equations that
+    also carries what the solver needs: the wind vector and g."""
+
+    def __new__(cls, wind, g=9.81, ids=('',)):
+        eqs = []
+        for i in ids:
+            eqs += [f"x{i}' - v{i} cos(psi{i}) + {wind[0]}", f"y{i}' - v{i} sin(psi{i}) + {wind[1]}", f"psi{i}' - {g}/v{i} tan(phi{i})"]
+        self = super().__new__(cls, eqs)
+        self.wind, self.g, self.n_aircraft = (float(wind[0]), float(wind[1])), g, len(ids)
+        return self
 
 
 class Aircraft:
@@ -53,13 +101,14 @@ class Aircraft:
 
     def __init__(self, st=None, id=''):
         self._st = st or _Sym('t')
+        self._id = id
         self._sx, self._sy, self._sv, self._sphi, self._spsi = (_Sym(f'{n}{id}') for n in ('x', 'y', 'v', 'phi', 'psi'))
-        self._state_symbols = (self._sx, self._sy, self._spsi)
+        self._state_symbols = (self._sx(self._st), self._sy(self._st), self._spsi(self._st))
         self._input_symbols = (self._sv, self._sphi)
 
     def get_eom(self, atm, g=9.81):
-        """Description of the kinematic model the fit satisfies by construction."""
-        return ('xdot = v cos(psi) + wx', 'ydot = v sin(psi) + wy', f'psidot = {g}/v tan(phi)')
+        """xdot - v cos(psi) + wx, ydot - v sin(psi) + wy, psidot - g/v tan(phi)  (residual form, :42-44)."""
+        return Eom(atm.sample_sym(self._st, self._sx(self._st), self._sy(self._st)), g, (self._id,))
 
 
 # ---------------------------------------------------------------------------------------

@@ -47,6 +47,11 @@ class TrackParams(C.Structure):
                 ('phi_lim', C.c_double), ('q_diag', C.c_double * 5), ('r_diag', C.c_double * 2)]
 
 
+class NlpOpts(C.Structure):
+    _fields_ = [('rho0', C.c_double), ('mub0', C.c_double), ('mub_min', C.c_double), ('feas_tol', C.c_double),
+                ('opt_tol', C.c_double), ('inner_max', C.c_int32), ('outer_max', C.c_int32)]
+
+
 class FitOpts(C.Structure):
     _fields_ = [('max_iter', C.c_int32), ('check_every', C.c_int32), ('ftol', C.c_double),
                 ('gtol', C.c_double), ('xtol', C.c_double), ('so_lambda', C.c_double)]
@@ -73,6 +78,8 @@ _SIGS = {
     'd2d_flatness': (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_double, C.c_double, C.c_double, C.c_double, _P, _P, _P]),
     'd2d_cont_jac': (C.c_int, [_P, C.c_int, _P, C.c_double, C.c_double, _P, _P]),
     'd2d_lqr': (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P]),
+    'd2d_nlp_workspace_doubles': (C.c_int, [C.c_int]),
+    'd2d_nlp_solve': (C.c_int, [_P, C.c_int, C.c_int, C.c_double, _P, C.POINTER(NlpOpts)] + [_P] * 8),
     'd2d_fit_plan_create': (C.c_int, [_P, C.c_int, C.c_int, C.c_double, _P, C.POINTER(_P)]),
     'd2d_fit_plan_destroy': (C.c_int, [_P]),
     'd2d_fit_plan_get': (C.c_int, [_P] * 6),
@@ -297,6 +304,24 @@ class Context:
             out['X_final'] = self.empty(5, n)
         _check(self.lib.d2d_sim_dfff_run(self.h, C.byref(p), _ptr(Yref), _ptr(perts), _ptr(X0), _ptr(out['X']), _ptr(out['U']),
                                          _ptr(out['Xr']), _ptr(out['X_final'])))
+        return out
+
+    def nlp_solve(self, scen, W, h, partner=None, rho0=10.0, mub0=0.1, mub_min=1e-9, feas_tol=1e-9, opt_tol=1e-7, inner_max=60,
+                  outer_max=40, want_mult=False):
+        """Direct-collocation NLP in node variables (d2d_nlp_solve): scen dev [B][SCEN_STRIDE], W dev [N][5][B] in/out (initial
+        guess -> solution), partner dev [N][2][B] or None.  Returns dict(cost, feas, iters, status[, mult]) of device tensors."""
+        torch = _torch()
+        N, _, B = W.shape
+        work = self.empty(self.lib.d2d_nlp_workspace_doubles(N) * B)
+        cost, feas = self.empty(B), self.empty(B)
+        iters = torch.empty(B, dtype=torch.int32, device=self.device); status = torch.empty(B, dtype=torch.int32, device=self.device)
+        mult = self.zeros(N, 3, B) if want_mult else None
+        o = NlpOpts(rho0, mub0, mub_min, feas_tol, opt_tol, inner_max, outer_max)
+        _check(self.lib.d2d_nlp_solve(self.h, B, N, float(h), _ptr(scen), C.byref(o), _ptr(W), _ptr(partner), _ptr(work), _ptr(mult),
+                                      _ptr(cost), _ptr(feas), _ptr(iters), _ptr(status)))
+        out = dict(cost=cost, feas=feas, iters=iters, status=status, work=work)
+        if want_mult:
+            out['mult'] = mult
         return out
 
     def track_run(self, x_ref, y_ref, X0, dt, record=('X', 'U', 'Xr', 'dX', 'Yd', 'Ydd'), out=None, **kw):

@@ -37,8 +37,9 @@ def scenario_rows(scen, p0s, p1s, N, duration, obj_scale, wind):
 
 
 class Planner:
-    def __init__(self, scen, initialize=True):
+    def __init__(self, scen, initialize=True, backend=None):
         self.scen = scen
+        self.backend = backend or sop.BACKEND            # 'fit' | 'nlp' (single_opt_planner.BACKEND)
         self.obj_scale = scen.obj_scale
         self.wind = scen.wind
         self.acs = d2mou.AircraftSet(n=len(scen.p0s))
@@ -52,7 +53,29 @@ class Planner:
         self._slice_phi = [slice(o + i * N, o + (i + 1) * N, 1) for i in range(n)]
         o += n * N
         self._slice_v = [slice(o + i * N, o + (i + 1) * N, 1) for i in range(n)]
-        if initialize:
+        if initialize and self.backend == 'nlp':
+            import itertools
+            import opty.direct_collocation
+
+            def ic(_ac, _p, _t): return (_ac._sx(_t) - _p[0], _ac._sy(_t) - _p[1], _ac._spsi(_t) - _p[2])
+            cons = [ic(_ac, _p, scen.t0) for _ac, _p in zip(self.acs.aircraft, scen.p0s)]
+            cons += [ic(_ac, _p, scen.t1) for _ac, _p in zip(self.acs.aircraft, scen.p1s)]
+            self._instance_constraints = tuple(itertools.chain(*cons))
+            self._bounds = {}
+            for _ac in self.acs.aircraft:
+                self._bounds[_ac._sphi(_ac._st)] = scen.phi_constraint
+                self._bounds[_ac._sv(_ac._st)] = scen.v_constraint
+                if scen.x_constraint is not None:
+                    self._bounds[_ac._sx(_ac._st)] = scen.x_constraint
+                if scen.y_constraint is not None:
+                    self._bounds[_ac._sy(_ac._st)] = scen.y_constraint
+            obj = scen.cost
+            self.prob = opty.direct_collocation.Problem(lambda _free: obj.cost(_free, self),
+                                                        lambda _free: obj.cost_grad(_free, self),
+                                                        self.acs.get_eom(self.wind), self.acs._state_symbols, self.num_nodes,
+                                                        self.time_step, known_parameter_map={},
+                                                        instance_constraints=self._instance_constraints, bounds=self._bounds, parallel=False)
+        elif initialize:
             self.prob = sop._FitProblem(self, n)
 
     def get_initial_guess(self, what='rnd'):
@@ -114,6 +137,8 @@ class Planner:
         self.prob.add_option('tol', tol)
         self.prob.addOption('max_iter', max_iter)
         self.solution, self.info = self.prob.solve(initial_guess)
+        if self.backend == 'nlp':
+            self.fit_q = self.fit_plan = self.fit_scen = self.fit_coefs = None
 
     def interpret_solution(self):
         self.sol_time = np.linspace(0.0, self.duration, num=self.num_nodes)

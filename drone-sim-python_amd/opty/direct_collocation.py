@@ -1,0 +1,157 @@
+"""`opty.direct_collocation.Problem` with the constructor and the members the reference uses (src/single_opt_planner.py:62-71,
+76-81,124; src/multi_opt_planner.py:69-78,84-86): the direct-collocation NLP in node variables, solved by d2d_nlp_solve
+(csrc/nlp_kernels.hip) instead of sympy code generation + IPOPT.
+
+    Problem(obj, obj_grad, eom, state_symbols, num_nodes, time_step, known_parameter_map=, instance_constraints=, bounds=,
+            parallel=False)
+    .num_free, .addOption(k, v) / .add_option(k, v), .solve(x0) -> (solution, info)
+
+What is interpreted instead of compiled:
+  * eom / state_symbols  -- the fixed kinematic model of d2d.opty_utils.Aircraft.get_eom (an `Eom`: wind, g, aircraft count);
+  * instance_constraints -- `x(t) - value` objects: the end conditions of every aircraft;
+  * bounds               -- {phi(t): (lo, hi), v(t): ..., x(t): ..., y(t): ...}: HARD boxes (primal-dual barrier);
+  * obj / obj_grad       -- the reference passes closures over a cost plug-in and the planner
+                            (`lambda _free: obj.cost(_free, self)`); the plug-in is taken from the closure (or from the explicit
+                            `cost=` / `planner=` keywords) and lowered structurally (single_opt_planner.lower_cost): the known
+                            classes of d2d.opty_utils / d2d.multiopty_utils have a kernel, anything else raises NotImplementedError.
+                            The gradient the solver follows is the plug-in's cost_grad (reference quirks included, oracle/nlp.py).
+Collision coupling (CostCollision acts on the pair of aircraft 0 and 1 only, src/d2d/multiopty_utils.py:124-125) is resolved by
+alternating solves of the two aircraft against each other's frozen positions until they stop moving."""
+import numpy as np
+
+import d2dhip
+
+
+def _closure_objects(fn):
+    out = []
+    for c in getattr(fn, '__closure__', None) or ():
+        try:
+            out.append(c.cell_contents)
+        except ValueError:
+            pass
+    return out
+
+
+class Problem:
+    def __init__(self, obj, obj_grad, eom, state_symbols, num_nodes, time_step, known_parameter_map=None,
+                 instance_constraints=(), bounds=None, parallel=False, cost=None, planner=None):
+        self.obj, self.obj_grad = obj, obj_grad
+        self.num_nodes, self.time_step = int(num_nodes), float(time_step)
+        self.n_aircraft = len(state_symbols) // 3
+        self.num_free = 5 * self.num_nodes * self.n_aircraft
+        self.options = {'tol': 1e-8, 'max_iter': 3000}
+        self.wind = tuple(getattr(eom, 'wind', (0., 0.)))
+        if getattr(eom, 'n_aircraft', self.n_aircraft) != self.n_aircraft:
+            raise ValueError('eom and state_symbols disagree on the number of aircraft')
+        # the cost plug-in and the planner behind the obj closure (the reference's call sites close over both)
+        if cost is None or planner is None:
+            for o in _closure_objects(obj):
+                if cost is None and hasattr(o, 'cost') and hasattr(o, 'cost_grad'):
+                    cost = o
+                if planner is None and hasattr(o, 'num_nodes') and hasattr(o, 'obj_scale'):
+                    planner = o
+        if cost is None or planner is None:
+            raise NotImplementedError('Problem: pass the objective as a closure over a d2d cost plug-in and the planner (as the '
+                                      'reference does) or give cost= / planner= explicitly: arbitrary Python callables have no kernel')
+        self.cost, self.planner = cost, planner
+        # end conditions per aircraft from the instance constraints: names x<i>, y<i>, psi<i>
+        ids = [str(s.sym.name)[1:] for s in state_symbols[0::3]]
+        t_all = sorted({c.t for c in instance_constraints})
+        if len(t_all) != 2:
+            raise NotImplementedError('instance constraints at exactly two times (t0 and t1) are supported')
+        self.p0s = np.zeros((self.n_aircraft, 3)); self.p1s = np.zeros((self.n_aircraft, 3))
+        seen = set()
+        for c in instance_constraints:
+            for k, nm in enumerate(('x', 'y', 'psi')):
+                for a, i in enumerate(ids):
+                    if c.name == nm + i:
+                        (self.p0s if c.t == t_all[0] else self.p1s)[a, k] = c.value
+                        seen.add((a, k, c.t == t_all[0]))
+        if len(seen) != 6 * self.n_aircraft:
+            raise NotImplementedError('every aircraft needs x, y, psi fixed at t0 and t1 (src/single_opt_planner.py:46-49)')
+        # bounds per aircraft
+        self.bounds = [{} for _ in range(self.n_aircraft)]
+        for key, (lo, hi) in (bounds or {}).items():
+            for nm in ('phi', 'psi', 'v', 'x', 'y'):
+                for a, i in enumerate(ids):
+                    if key.sym.name == nm + i:
+                        self.bounds[a][nm] = (float(lo), float(hi))
+        for bd in self.bounds:
+            if 'phi' not in bd or 'v' not in bd:
+                raise NotImplementedError('phi and v bounds are required (the model divides by v)')
+            if 'psi' in bd:
+                raise NotImplementedError('bounds on psi have no kernel')
+
+    def addOption(self, k, v):
+        self.options[k] = v
+    add_option = addOption
+
+    def _rows(self):
+        import single_opt_planner as sop
+        low = sop.lower_cost(self.cost)
+        n, N = self.n_aircraft, self.num_nodes
+        multi = hasattr(self.planner, 'acs')
+        s = self.planner.obj_scale / N / (n if multi else 1)
+        rows = []
+        for a in range(n):
+            la = low if (a == 0 or not multi) else low[:4] + ((),) + low[5:]     # static obstacles act on aircraft 0 only (multi, :74)
+            bd = self.bounds[a]
+            if abs(bd['phi'][0] + bd['phi'][1]) > 1e-12:
+                raise NotImplementedError('asymmetric phi bounds')
+            r = sop.scen_row(tuple(self.p0s[a]) + (0., 0.), tuple(self.p1s[a]) + (0., 0.), 0., la, s, self.wind, bd['phi'], bd['v'],
+                             x_c=bd.get('x'), y_c=bd.get('y'))
+            if multi and la[4]:
+                r[d2dhip.SC_KOBS] *= n                                             # obstacle scale has no 1/n_ac (:91)
+            rows.append(r)
+        rows = np.stack(rows)
+        coupled = multi and n >= 2 and not np.isnan(low[5]) and low[5] > 0
+        if coupled:
+            rows[:2, d2dhip.SC_KCOL], rows[:2, d2dhip.SC_RCOL], rows[:2, d2dhip.SC_SCOL] = low[5], low[6], self.planner.obj_scale / N
+        if low[8]:
+            raise NotImplementedError('CostBank max mode has no collocation kernel (use the polynomial-fit backend)')
+        return rows, coupled
+
+    def solve(self, x0):
+        ctx = d2dhip.default_context()
+        n, N = self.n_aircraft, self.num_nodes
+        x0 = np.asarray(x0, dtype=np.float64)
+        sl = self.planner
+        single = not isinstance(sl._slice_x, (list, tuple))
+        get = (lambda s, a: x0[s]) if single else (lambda s, a: x0[s[a]])
+        W = np.stack([np.stack([get(sl._slice_x, a), get(sl._slice_y, a), get(sl._slice_psi, a), get(sl._slice_phi, a),
+                                get(sl._slice_v, a)], 1) for a in range(n)], 2)                       # (N, 5, n)
+        rows, coupled = self._rows()
+        # IPOPT's max_iter counts Newton steps; here they are grouped as outer (multiplier / barrier updates) x inner (<= 60)
+        kw = dict(inner_max=60, outer_max=int(min(max(self.options.get('max_iter', 3000) // 60, 12), 60)))
+        dsc = ctx.dev(rows)
+        dW = ctx.dev(np.ascontiguousarray(W))
+        sweeps = 1
+        if not coupled:
+            out = ctx.nlp_solve(dsc, dW, self.time_step, **kw)
+        else:
+            # aircraft 0 and 1 repel each other: alternate (others are independent and solved in the first pass)
+            rows_nc = rows.copy(); rows_nc[:, d2dhip.SC_KCOL] = 0.0
+            out = ctx.nlp_solve(ctx.dev(rows_nc), dW, self.time_step, **kw)                          # uncoupled start for everybody
+            for sweeps in range(1, 13):
+                prev = dW[:, :2, :2].clone()
+                for a, o in ((0, 1), (1, 0)):
+                    Wa = dW[:, :, a:a + 1].contiguous()
+                    partner = dW[:, :2, o:o + 1].contiguous()
+                    oa = ctx.nlp_solve(dsc[a:a + 1].contiguous(), Wa, self.time_step, partner=partner, **kw)
+                    dW[:, :, a] = Wa[:, :, 0]
+                    for k in ('cost', 'feas', 'iters', 'status'):
+                        out[k][a] = oa[k][0]
+                if float((dW[:, :2, :2] - prev).abs().max().item()) <= 1e-7:
+                    break
+        ctx.sync()
+        Wh = dW.cpu().numpy()
+        sol = np.zeros(self.num_free)
+        for a in range(n):
+            for c, s in enumerate((sl._slice_x, sl._slice_y, sl._slice_psi, sl._slice_phi, sl._slice_v)):
+                sol[s if single else s[a]] = Wh[:, c, a]
+        st = out['status'].cpu().numpy()
+        info = {'status': int(st.max()) if single else st.tolist(), 'feas': float(out['feas'].max().item()),
+                'iters': out['iters'].cpu().numpy().tolist(), 'sweeps': sweeps,
+                'obj_val': float(self.obj(sol)), 'status_msg': 'converged' if (st == 1).all() else 'max_iter',
+                'box_violation': 0.0, 'phi_violation': 0.0, 'v_violation': 0.0}       # hard bounds: an interior-point iterate never leaves its box
+        return sol, info

@@ -14,6 +14,11 @@ import d2d.multiopty_utils as d2mou
 import d2d.optyplan_scenarios as d2oscen
 
 seed = None
+# Which solver stands behind Planner.prob:
+#   'fit' -- the batched polynomial fit (flat outputs, soft bounds; the north-star path)
+#   'nlp' -- opty.direct_collocation.Problem on the GPU: the reference's own parameterisation (node values, backward-Euler
+#            equalities, HARD bounds), built by the very call the reference makes (src/single_opt_planner.py:62-71)
+BACKEND = 'fit'
 N_SEG = 6
 W_WAYPOINT = 0.02      # weight of the 'tri' waypoint rows (regulariser)
 W_BOUND = 1.0          # weight of the soft phi / v bound rows
@@ -130,8 +135,9 @@ class _FitProblem:
 
 
 class Planner:
-    def __init__(self, exp, initialize=True):
+    def __init__(self, exp, initialize=True, backend=None):
         self.exp = exp
+        self.backend = backend or BACKEND
         self.obj_scale = exp.obj_scale
         self.num_nodes, self.time_step, self.duration = d2ou.planner_timing(exp.t0, exp.t1, exp.hz)
         self.wind = exp.wind
@@ -140,7 +146,25 @@ class Planner:
         self._slice_x, self._slice_y, self._slice_psi, self._slice_phi, self._slice_v = (
             slice(i * N, (i + 1) * N, 1) for i in range(5))
         self.obstacles = exp.obstacles
-        if initialize:
+        if initialize and self.backend == 'nlp':
+            import opty.direct_collocation
+            _g = self.aircraft
+            t0, (x0, y0, psi0, phi0, v0) = exp.t0, exp.p0
+            self._instance_constraints = (_g._sx(t0) - x0, _g._sy(t0) - y0, _g._spsi(t0) - psi0)
+            t1, (x1, y1, psi1, phi1, v1) = exp.t1, exp.p1
+            self._instance_constraints += (_g._sx(t1) - x1, _g._sy(t1) - y1, _g._spsi(t1) - psi1)
+            self._bounds = {_g._sphi(_g._st): exp.phi_constraint, _g._sv(_g._st): exp.v_constraint}
+            if exp.x_constraint is not None:
+                self._bounds[_g._sx(_g._st)] = exp.x_constraint
+            if exp.y_constraint is not None:
+                self._bounds[_g._sy(_g._st)] = exp.y_constraint
+            obj = exp.cost
+            self.prob = opty.direct_collocation.Problem(lambda _free: obj.cost(_free, self),
+                                                        lambda _free: obj.cost_grad(_free, self),
+                                                        _g.get_eom(self.wind), _g._state_symbols, self.num_nodes, self.time_step,
+                                                        known_parameter_map={}, instance_constraints=self._instance_constraints,
+                                                        bounds=self._bounds, parallel=False)
+        elif initialize:
             self.prob = _FitProblem(self, 1)
 
     def configure(self, tol=1e-8, max_iter=3000):

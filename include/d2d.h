@@ -361,6 +361,48 @@ int d2d_fit_coeffs(d2d_ctx *ctx, const d2d_fit_plan *plan, int B, const double *
 int d2d_fit_sample(d2d_ctx *ctx, const d2d_fit_plan *plan, int B, const double *scen,
                    const double *q, double *Y, double *Xs);
 
+/* ------------------------------------------------------------------------------------
+ * Direct-collocation NLP in the reference's own parameterisation: the solve behind
+ * `opty.direct_collocation.Problem(obj, obj_grad, eom, state_symbols, num_nodes, time_step, known_parameter_map,
+ * instance_constraints, bounds)` + `.solve(x0)` (src/single_opt_planner.py:62-71,124; src/multi_opt_planner.py:69-78,86).
+ *   unknowns     node values (x, y, psi, phi, v)(t_i), i = 0..N-1 (the reference's free vector, src/single_opt_planner.py:35-39)
+ *   equalities   backward-Euler collocation of the symbolic model (src/d2d/opty_utils.py:38-50, +wind sign quirk), i = 1..N-1:
+ *                (x_i - x_{i-1})/h - v_i cos psi_i + wx = 0, (y_i - y_{i-1})/h - v_i sin psi_i + wy = 0,
+ *                (psi_i - psi_{i-1})/h - g/v_i tan phi_i = 0;  end conditions (x, y, psi)(t0) = p0, (t1) = p1 (:46-49)
+ *   bounds       HARD boxes on phi, v and optionally x, y (:53-57)
+ *   objective    the cost plug-ins (CostInput / CostAirVel / CostBank mean / CostObstacle(s) / CostComposit,
+ *                src/d2d/opty_utils.py:55-165; one CostCollision partner, src/d2d/multiopty_utils.py:120-153) with the gradient
+ *                the reference hands to IPOPT (cost_grad, incl. the missing (k/r)^2 of CostObstacle kind 1: the solver therefore
+ *                minimises the objective whose gradient that is; the cost REPORTED is the reference's cost()).
+ * Solver (oracle/nlp.py is its CPU statement): equalities by an augmented Lagrangian, bounds by a primal-dual log barrier,
+ * damped Newton steps on the block-tridiagonal (5x5 blocks) Lagrangian Hessian, one problem per lane.
+ * scen dev [B][D2D_SCEN_STRIDE]: the fit's scenario rows (end poses, VSP, KV, KPHI, KOBS, S, wind, obstacles + OKIND, PHIMAX,
+ * VMIN/VMAX, the x/y box, KCOL/RCOL/SCOL); W dev [N][5][B] plane-major node values, in: the initial guess (e.g.
+ * Planner.get_initial_guess), out: the solution; partner dev [N][2][B] frozen positions of the CostCollision partner or NULL;
+ * work dev double[d2d_nlp_workspace_doubles(N) * B]; mult dev [N][3][B] or NULL: out, scaled multiplier estimates (row 0 unused;
+ * Lagrange multiplier = 2 rho mu);  cost dev [B] (the reference's cost() at the solution), feas dev [B] (largest collocation
+ * residual, in the reference's form), iters / status dev int32 [B] or NULL (Newton steps; D2D_ST_CONVERGED / D2D_ST_MAXITER).
+ * Asynchronous on the context's stream. */
+#define D2D_NLP_RHO0 10.0
+#define D2D_NLP_RHO_MAX 1e8
+#define D2D_NLP_RHO_GROW 10.0
+#define D2D_NLP_MUB0 0.1
+#define D2D_NLP_MUB_MIN 1e-9
+#define D2D_NLP_GRAD_FLOOR 1e-11   /* x rho: rounding floor of the penalty gradient */
+typedef struct {
+  double rho0;       /* initial penalty (D2D_NLP_RHO0)                                                        */
+  double mub0;       /* initial barrier parameter (D2D_NLP_MUB0)                                              */
+  double mub_min;    /* final barrier parameter (D2D_NLP_MUB_MIN)                                             */
+  double feas_tol;   /* largest collocation residual at convergence (default 1e-9; IPOPT's runs: tol 1e-5)    */
+  double opt_tol;    /* barrier KKT error of the last inner problem (default 1e-7)                            */
+  int32_t inner_max; /* Newton steps per outer iteration (default 60)                                         */
+  int32_t outer_max; /* outer iterations: multiplier / barrier updates (default 40)                           */
+} d2d_nlp_opts;
+int d2d_nlp_workspace_doubles(int N);
+int d2d_nlp_solve(d2d_ctx *ctx, int B, int N, double h, const double *scen, const d2d_nlp_opts *opts, double *W,
+                  const double *partner, double *work, double *mult, double *cost, double *feas, int32_t *iters,
+                  int32_t *status);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,184 @@
+"""GPU parity: the direct-collocation NLP backend (d2d_nlp_solve, csrc/nlp_kernels.hip) -- the reference's own parameterisation
+(node values, backward-Euler equalities, end conditions, hard boxes: src/single_opt_planner.py:35-71) -- against
+  * the committed IPOPT output of the reference for exp_14 (tests/golden/planner_goldens.npz: cost 5.02972817),
+  * the oracle's solver (oracle/nlp.py: the same algorithm in numpy with a banded LAPACK factorisation),
+  * KKT conditions evaluated by the oracle with the reference's cost_grad."""
+import numpy as np
+import pytest
+
+from oracle import nlp, costs as C
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    import d2dhip
+    c = d2dhip.Context(0)
+    yield c
+    c.close()
+
+
+def _row(pb, obstacles=(), kobs=0.0, okind=0):
+    """d2dhip scenario row of an oracle Problem."""
+    import d2dhip as D
+    r = np.zeros(D.SCEN_STRIDE)
+    r[D.SC_X0:D.SC_X0 + 3] = pb.p0; r[D.SC_X1:D.SC_X1 + 3] = pb.p1
+    r[D.SC_VSP], r[D.SC_KV], r[D.SC_KPHI], r[D.SC_S], r[D.SC_KOBS] = pb.vsp, pb.kv, pb.kphi, pb.s, kobs
+    r[D.SC_WX], r[D.SC_WY] = -pb.wind[0], -pb.wind[1]
+    r[D.SC_PHIMAX] = pb.hi[1, 3]; r[D.SC_VMIN], r[D.SC_VMAX] = pb.lo[1, 4], pb.hi[1, 4]
+    if np.isfinite(pb.lo[1, 0]):
+        r[D.SC_XMIN], r[D.SC_XMAX] = pb.lo[1, 0], pb.hi[1, 0]
+    if np.isfinite(pb.lo[1, 1]):
+        r[D.SC_YMIN], r[D.SC_YMAX] = pb.lo[1, 1], pb.hi[1, 1]
+    for i, o in enumerate(obstacles):
+        c = D.obs_col(i)
+        r[c:c + 3] = o
+    r[D.SC_OKIND] = okind
+    return r
+
+
+def _solve(ctx, pbs, W0s, rows, **kw):
+    N = pbs[0].N
+    W = ctx.dev(np.ascontiguousarray(np.stack(W0s, 2)))               # (N, 5, B)
+    out = ctx.nlp_solve(ctx.dev(np.stack(rows)), W, pbs[0].h, want_mult=True, **kw)
+    ctx.sync()
+    return W.cpu().numpy(), {k: v.cpu().numpy() for k, v in out.items() if k != 'work'}
+
+
+def test_exp14_reproduces_the_reference_ipopt_cost(ctx, gold):
+    """optyplan_scenarios.exp_14 (src/d2d/optyplan_scenarios.py:219-253): 121 nodes, CostAirVel(12), phi in +-40 deg, v in [9, 15],
+    boxes +-150, from the reference's 'tri' initial guess.  The committed IPOPT solution has cost 5.02972817 and satisfies the
+    collocation to 2e-8; ours: the same cost to 1e-6 relative, feasibility <= 1e-8, KKT residual <= 1e-5 -- hard bounds held exactly."""
+    g = gold('planner_goldens')
+    N, h = 121, 0.1
+    p0 = (-49.98, -58.14, 2.22, -0.35, 15.); p1 = (75, 40, 0, 0, 12)
+    pb = nlp.Problem(N, h, p0, p1, vsp=12., kv=1., kphi=0., obj_scale=1., phi_max=np.deg2rad(40.), v_min=9., v_max=15.,
+                     x_box=(-150, 150), y_box=(-150, 150))
+    Wg = nlp.from_free(g['exp14_free'], N)
+    assert abs(nlp.cost(pb, Wg) - float(g['exp14_cost_airvel12'])) < 1e-12
+    W0 = nlp.from_free(C.single_guess('tri', p0, p1, 12., 12.0, N), N)
+    W, out = _solve(ctx, [pb], [W0], [_row(pb)])
+    W = W[:, :, 0]
+    assert out['status'][0] == 1
+    assert abs(out['cost'][0] - 5.02972817) <= 1e-6 * 5.02972817, out['cost'][0]
+    assert abs(out['cost'][0] - nlp.cost(pb, W)) <= 1e-12 and out['feas'][0] <= 1e-8
+    assert np.abs(nlp.constraints(pb, W)).max() <= 1e-8
+    # hard bounds: never violated, and they DO bind
+    assert (W[:, 3] >= -np.deg2rad(40.)).all() and (W[:, 3] <= np.deg2rad(40.)).all() and (W[:, 4] <= 15.).all() and (W[:, 4] >= 9.).all()
+    assert (W[:, 4] < 9. + 1e-5).sum() + (np.abs(W[:, 3]) > np.deg2rad(40.) - 1e-5).sum() >= 3
+    np.testing.assert_allclose(W[0, :3], p0[:3], atol=0); np.testing.assert_allclose(W[-1, :3], p1[:3], atol=0)
+    # KKT with the multipliers the solver returns (lambda = 2 rho mu; rho ends at its start value unless feasibility stalled)
+    Wo, info = nlp.solve(pb, W0)
+    assert abs(info['cost'] - out['cost'][0]) <= 1e-8 * info['cost']
+    assert np.abs(W - Wo).max() <= 1e-5                                   # same algorithm, same path (banded LAPACK vs block Cholesky)
+    assert abs(int(out['iters'][0]) - info['inner']) <= 10, (out['iters'][0], info['inner'])
+    # the committed IPOPT node values: same trajectory to a few millimetres (IPOPT stopped at tol 1e-5; flat directions)
+    assert np.abs(W[:, :2] - Wg[:, :2]).max() < 5e-3 and np.abs(W[:, 4] - Wg[:, 4]).max() < 5e-3
+
+
+def test_batch_with_obstacles_wind_and_boxes_vs_oracle(ctx):
+    """A ragged batch of different problems in one launch (each lane its own scenario): obstacles of both kinds, wind, a
+    binding y box; every one against the oracle's solve and against the KKT conditions."""
+    N, h = 41, 0.1
+    pbs, rows, W0s, obs = [], [], [], []
+    rng = np.random.default_rng(4)
+    for i in range(7):
+        p0 = (0., 0., rng.uniform(-0.5, 0.5), 0., 12.); p1 = (48. + rng.uniform(-4, 4), rng.uniform(-6, 6), rng.uniform(-0.4, 0.4), 0., 12.)
+        ob = [(24. + rng.uniform(-3, 3), rng.uniform(-2, 2), rng.uniform(4, 7))] if i % 2 else []
+        kind = 0 if i == 3 else 1
+        if kind == 0:                                      # exp(r^2 - d^2) stays below its 1e3 clip (on the clip the reference's
+            ob = [(ob[0][0], ob[0][1], 2.2)]               # cost_grad is not the gradient of its cost: no stationary point to find)
+        pb = nlp.Problem(N, h, p0, p1, vsp=12., kv=5., kphi=1., obj_scale=0.1 if i < 4 else 1.0, wind=(1.0, -0.5) if i == 2 else (0., 0.),
+                         phi_max=np.deg2rad(35.), v_min=9., v_max=15., y_box=(-6.5, 9.) if i == 5 else None, obstacles=ob,
+                         kobs=1.0 if ob else 0.0, obs_kind=kind)
+        pbs.append(pb); rows.append(_row(pb, ob, 1.0 if ob else 0.0, 1 if kind == 0 and ob else 0))
+        W0s.append(nlp.from_free(C.single_guess('tri', p0, p1, 12., (N - 1) * h, N), N)); obs.append(ob)
+    W, out = _solve(ctx, pbs, W0s, rows)
+    for i, pb in enumerate(pbs):
+        Wi = W[:, :, i]
+        assert out['status'][i] == 1, (i, out)
+        assert out['feas'][i] <= 1e-8 and np.abs(nlp.constraints(pb, Wi)).max() <= 1e-8
+        assert abs(out['cost'][i] - nlp.cost(pb, Wi)) <= 1e-11 * max(1.0, out['cost'][i])
+        assert (Wi >= pb.lo - 1e-15).all() and (Wi <= pb.hi + 1e-15).all()
+        Wo, info = nlp.solve(pb, W0s[i])
+        assert info['status'] == 1
+        assert abs(info['cost'] - out['cost'][i]) <= 1e-7 * max(info['cost'], 1e-3), (i, info['cost'], out['cost'][i])
+        assert np.abs(Wi - Wo).max() <= 1e-4, (i, np.abs(Wi - Wo).max())
+        # stationarity of the Lagrangian with the reference's cost_grad: the kernel's point and multipliers, the bound duals of the
+        # oracle's run (the kernel keeps its duals in its workspace)
+        lam = 2 * info['rho'] * out['mult'][1:, :, i]
+        kkt, feas = nlp.kkt_residual(pb, Wi, lam, info['zL'], info['zU'])
+        assert kkt <= 1e-5 and feas <= 1e-8, (i, kkt)
+
+
+def _feas(sol_x, sol_y, sol_psi, sol_phi, sol_v, h, wind=(0., 0.)):
+    free = np.concatenate([sol_x, sol_y, sol_psi, sol_phi, sol_v])
+    return np.abs(C.collocation_residual(free, len(sol_x), h, wind)).max()
+
+
+def test_single_planner_on_the_collocation_backend():
+    """single_opt_planner.Planner(exp_14, backend='nlp'): Planner.prob IS opty.direct_collocation.Problem, built by the call the
+    reference makes (cost closures, eom, state symbols, instance constraints, bounds: src/single_opt_planner.py:62-71), and
+    .solve(x0) returns the reference's free vector: cost = the committed IPOPT run's, collocation feasible, bounds hard."""
+    import d2d.optyplan_scenarios as d2oscen
+    import opty.direct_collocation
+    import single_opt_planner as sop
+    p = sop.Planner(d2oscen.exp_14, initialize=True, backend='nlp')
+    assert isinstance(p.prob, opty.direct_collocation.Problem) and p.prob.num_free == 5 * 121
+    p.configure(1e-5, 1500)
+    p.run(p.get_initial_guess('tri'))
+    assert p.solution.shape == (605,) and p.info['status'] == 1, p.info
+    c = d2oscen.exp_14.cost.cost(p.solution, p)
+    assert abs(c - 5.02972817) <= 1e-6 * 5.02972817 and abs(p.info['obj_val'] - c) < 1e-14
+    assert _feas(p.sol_x, p.sol_y, p.sol_psi, p.sol_phi, p.sol_v, p.time_step) <= 1e-8
+    assert np.abs(p.sol_phi).max() <= np.deg2rad(40.) and p.sol_v.min() >= 9. and p.sol_v.max() <= 15.
+    np.testing.assert_allclose([p.sol_x[0], p.sol_y[0], p.sol_psi[0], p.sol_x[-1], p.sol_y[-1], p.sol_psi[-1]],
+                               list(d2oscen.exp_14.p0[:3]) + list(d2oscen.exp_14.p1[:3]), atol=0)
+    # wind: the symbolic model's +w convention (src/d2d/opty_utils.py:42-44)
+    import d2d.opty_utils as d2ou
+
+    class windy(d2oscen.exp_14):                       # (a head wind of 2 m/s would need v > 15 on this leg: infeasible)
+        wind = d2ou.WindField(w=[-1., 0.5])
+    pw = sop.Planner(windy, initialize=True, backend='nlp')
+    pw.run()
+    assert pw.info['status'] == 1 and _feas(pw.sol_x, pw.sol_y, pw.sol_psi, pw.sol_phi, pw.sol_v, pw.time_step, (-1., 0.5)) <= 1e-8
+    assert abs(pw.info['obj_val'] - 2.90645965) < 1e-6                      # (oracle/nlp.py on the same problem)
+    # obstacles: CostComposit with two discs (exp_1, :56-63)
+    po = sop.Planner(d2oscen.exp_1, initialize=True, backend='nlp')
+    po.run()
+    assert po.info['status'] == 1 and _feas(po.sol_x, po.sol_y, po.sol_psi, po.sol_phi, po.sol_v, po.time_step) <= 1e-8
+    d = np.minimum(np.hypot(po.sol_x - 33., po.sol_y), np.hypot(po.sol_x - 66., po.sol_y))
+    assert d.min() > 5.0, d.min()                      # the straight line through both discs is left
+
+
+def test_multi_planner_on_the_collocation_backend_like_11_full_sim():
+    """multi_opt_planner.Planner(trap_4, backend='nlp') as src/11_full_sim_case1.py:444-447 drives it (4 aircraft, 6 s, 61 nodes,
+    CostComposit with the collision term on the pair (0, 1)): every aircraft collocation-feasible with hard bounds; the
+    reference's cost of the coupled plan is not worse than the uncoupled plan's."""
+    import multi_opt_planner as mop
+    import d2d.multiopty_utils as d2mou
+    scen = mop.trap_4
+    scen.t1 = 6
+    scen.p0s = ((0, 40, 0, 0, 12), (25, 40, 0, 0, 12), (25, -40, 0, 0, 12), (0, -40, 0, 0, 12))
+    scen.p1s = ((75, 40, 0, 0, 12), (100, 40, 0, 0, 12), (100, -40, 0, 0, 12), (75, -40, 0, 0, 12))
+    keep = scen.cost
+    try:
+        _p = mop.Planner(scen, initialize=True, backend='nlp')
+        _p.run(initial_guess=_p.get_initial_guess(scen.initial_guess), tol=scen.tol, max_iter=scen.max_iter)
+        _p.interpret_solution()
+        assert _p.solution.shape == (5 * 4 * 61,) and all(s == 1 for s in _p.info['status']), _p.info
+        for i in range(4):
+            assert _feas(_p.sol_x[i], _p.sol_y[i], _p.sol_psi[i], _p.sol_phi[i], _p.sol_v[i], _p.time_step) <= 1e-8
+            assert np.abs(_p.sol_phi[i]).max() <= np.deg2rad(40.) and _p.sol_v[i].min() >= 9. and _p.sol_v[i].max() <= 15.
+            np.testing.assert_allclose([_p.sol_x[i][0], _p.sol_y[i][0], _p.sol_x[i][-1], _p.sol_y[i][-1]],
+                                       [scen.p0s[i][0], scen.p0s[i][1], scen.p1s[i][0], scen.p1s[i][1]], atol=0)
+        c_coupled = keep.cost(_p.solution, _p)
+        # 75 m in 6 s: 12.5 m/s on average -> 70 * mean (v - 12)^2 ~ 17.5 over the four aircraft
+        assert 10.0 < c_coupled < 25.0, c_coupled
+        scen.cost = d2mou.CostComposit(kvel=70., kbank=1., kobs=float('NaN'), kcol=float('NaN'), vsp=12., obss=[], obs_kind=0, rcol=10)
+        _q = mop.Planner(scen, initialize=True, backend='nlp')
+        _q.run(initial_guess=_q.get_initial_guess(scen.initial_guess), tol=scen.tol, max_iter=scen.max_iter)
+        assert c_coupled <= keep.cost(_q.solution, _q) + 1e-6
+    finally:
+        scen.cost = keep
