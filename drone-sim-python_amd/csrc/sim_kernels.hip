@@ -47,7 +47,7 @@ gvf_run_kernel(d2d_gvf_params p, GlMesh mesh, int fpb, const double *__restrict_
                const double *__restrict__ Bz, const double *__restrict__ X0f,
                double *__restrict__ X_hist, double *__restrict__ U_hist,
                double *__restrict__ Rr_hist, double *__restrict__ eth_hist,
-               double *__restrict__ X_final, int32_t *__restrict__ stop_row) {
+               double *__restrict__ X_final, int32_t *__restrict__ stop_row, int32_t *__restrict__ conv_row) {
   extern __shared__ double lds[];
   double *sh_theta = lds;
   double *sh_e = lds + 256;
@@ -80,10 +80,13 @@ gvf_run_kernel(d2d_gvf_params p, GlMesh mesh, int fpb, const double *__restrict_
   const int rs = p.rec_stride;
   int my_stop = p.n_rows;      // formation-uniform
   bool prev_all_ok = false;    // result of the stop test at the end of the previous step
+  int n_true = 0, first_true = -1;   // phase-error rule (use_stop == 2): steps on which it held so far, loop index i-1 of the first one
   for (int i = 1; i < p.n_rows; ++i) {
     // src/11_full_sim_case1.py:140 -- `if np.all(stop)==1 and t>0: break` at the top of step i
     if (p.use_stop) {
-      if (prev_all_ok && (i - 1) > 0 && my_stop == p.n_rows) my_stop = i;
+      // use_stop == 2: src/12_full_sim_case2.py:156-164 / 12_full_sim_case3.py:163-178 -- `break` at the END of the step on
+      // which the rule fired, rows [:i+1] are kept, which is the same row count as a break at the top of the next step
+      if (prev_all_ok && (p.use_stop == 2 || (i - 1) > 0) && my_stop == p.n_rows) my_stop = i;
       // every formation of this block has stopped: nothing left to integrate
       if (__syncthreads_and((!live || my_stop != p.n_rows) ? 1 : 0)) break;
     }
@@ -128,20 +131,33 @@ gvf_run_kernel(d2d_gvf_params p, GlMesh mesh, int fpb, const double *__restrict_
     }
     if (p.use_stop) {
       // :170-175 -- |X[0:3]-X0f[0:3]| <= tol for every aircraft of the formation
-      const bool ok = fabs(sn.x - fx) <= p.stop_tol[0] && fabs(sn.y - fy) <= p.stop_tol[1] &&
-                      fabs(sn.psi - fpsi) <= p.stop_tol[2];
+      bool ok = fabs(sn.x - fx) <= p.stop_tol[0] && fabs(sn.y - fy) <= p.stop_tol[1] &&
+                fabs(sn.psi - fpsi) <= p.stop_tol[2];
+      // phase-error rule: every (signed) inter-vehicle phase error of this step, in degrees, <= stop_tol[0]
+      if (p.use_stop == 2) ok = (a < nm) ? (e * (180.0 / D2D_PI) <= p.stop_tol[0]) : true;
       sh_ok[t] = ok ? 1 : 0;
       __syncthreads();
       bool all_ok = true;
       for (int k = 0; k < n_ac; ++k) all_ok = all_ok && (sh_ok[base + k] != 0);
-      prev_all_ok = all_ok;
+      if (p.use_stop == 2) {
+        // ... and the loop goes on for stop_hold more steps on which the rule holds (the time the planner needs, case 3)
+        if (all_ok && my_stop == p.n_rows) {
+          if (first_true < 0) first_true = i - 1;
+          if (n_true >= p.stop_hold) prev_all_ok = true; else { ++n_true; prev_all_ok = false; }
+        } else {
+          prev_all_ok = false;
+        }
+      } else {
+        prev_all_ok = all_ok;
+      }
       // (the next iteration's first barrier orders these reads before sh_ok is rewritten)
     }
   }
   if (live) {
     X_final[d] = s.x; X_final[N + d] = s.y; X_final[2 * N + d] = s.psi; X_final[3 * N + d] = s.phi;
     X_final[4 * N + d] = s.v;
-    if (a == 0 && stop_row) stop_row[f] = my_stop;
+    if (a == 0 && stop_row) stop_row[f] = (p.use_stop == 2 && prev_all_ok && my_stop == p.n_rows) ? p.n_rows : my_stop;
+    if (a == 0 && conv_row) conv_row[f] = first_true;
   }
 }
 
@@ -441,6 +457,71 @@ lqr_kernel(int n, LqrWeights w, const double *__restrict__ A, const double *__re
 }
 
 // ------------------------------------------------------------------------------------
+// Reference trajectories of the legacy simulations (src/d2d/trajectory.py, src/d2d/trajectory_factory.py) sampled on the
+// device: every trajectory is a CompositeTraj of up to D2D_TRAJ_MAX_SEG segments (a plain trajectory = one segment), each a
+// line, a circle arc, a slalom or a degree-7 polynomial pair, described by D2D_TRAJ_SEG_STRIDE doubles (include/d2d.h).
+// One thread per (sample time, trajectory); output Yref [T][6][n] = x, y, xd, yd, xdd, ydd -- the input of d2d_sim_dfff_run.
+__global__ void __launch_bounds__(256)
+traj_sample_kernel(int n, int T, double t_start, double dt, const double *__restrict__ desc, double *__restrict__ Y) {
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= (long)n * T) return;
+  const int it = i / n, d = i - (long)it * n;
+  const double t = t_start + it * dt;
+  const double *td = desc + (size_t)d * D2D_TRAJ_STRIDE;
+  const int nseg = (int)td[0];
+  const double T0 = td[1], dur = td[2];
+  // CompositeTraj.get (src/d2d/trajectory.py:202-208): lapse = fmod(t - t0, duration), first segment whose end is beyond it
+  double lapse = t;
+  const double *sg = td + 4;
+  if (nseg > 1 || td[3] != 0.0) {
+    lapse = fmod(t - T0, dur);
+    int k = 0;
+    for (; k < nseg - 1; ++k)
+      if (sg[k * D2D_TRAJ_SEG_STRIDE + 2] > lapse) break;
+    sg += k * D2D_TRAJ_SEG_STRIDE;
+  }
+  const int type = (int)sg[0];
+  const double ts = lapse - sg[1];                       // time since the segment's own t0
+  const double *p = sg + 3;
+  double y[6] = {0, 0, 0, 0, 0, 0};
+  if (type == D2D_TRAJ_LINE || type == D2D_TRAJ_SLALOM) {
+    // TrajectoryLine.get (:132-141): p1 + un v (t - t0); slalom (trajectory_factory.py:120-136): + a sin(om (t - t0 + phi)) on y
+    y[0] = p[0] + p[2] * p[4] * ts; y[1] = p[1] + p[3] * p[4] * ts;
+    y[2] = p[2] * p[4]; y[3] = p[3] * p[4];
+    if (type == D2D_TRAJ_SLALOM) {
+      const double a = p[5], om = p[6], al = om * (ts + p[7]);
+      double sn, cs;
+      sincos(al, &sn, &cs);
+      y[1] += a * sn; y[3] += a * om * cs; y[5] += -a * om * om * sn;
+    }
+  } else if (type == D2D_TRAJ_CIRCLE) {
+    // TrajectoryCircle.get (:153-160): c + r (cos, sin)(omega (t - t0) + alpha0)
+    const double r = p[2], om = p[3], al = ts * om + p[4];
+    double sn, cs;
+    sincos(al, &sn, &cs);
+    y[0] = p[0] + r * cs; y[1] = p[1] + r * sn;
+    y[2] = -om * r * sn; y[3] = om * r * cs;
+    y[4] = -om * om * r * cs; y[5] = -om * om * r * sn;
+  } else if (type == D2D_TRAJ_POLY) {
+    // MinSnapPoly / PolynomialOne.get (:74-82, :166-187): Horner on coefs[0,:] and its derivative rows
+#pragma unroll
+    for (int ax = 0; ax < 2; ++ax) {
+      const double *c = p + 8 * ax;
+      double v0 = c[7], v1 = 7.0 * c[7], v2 = 42.0 * c[7];
+#pragma unroll
+      for (int j = 6; j >= 0; --j) {
+        v0 = v0 * ts + c[j];
+        if (j >= 1) v1 = v1 * ts + j * c[j];
+        if (j >= 2) v2 = v2 * ts + j * (j - 1) * c[j];
+      }
+      y[ax] = v0; y[2 + ax] = v1; y[4 + ax] = v2;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 6; ++c) Y[((size_t)it * 6 + c) * n + d] = y[c];
+}
+
+// ------------------------------------------------------------------------------------
 static int upload_Bz(d2d_ctx *ctx, int n_ac, const double *Bmat, const double *z_des);
 
 extern "C" {
@@ -458,12 +539,14 @@ int d2d_step(d2d_ctx *ctx, int n, const double *X, const double *U, double wx, d
 int d2d_sim_gvf_run(d2d_ctx *ctx, const d2d_gvf_params *p, const double *X0,
                     const double *centres, const double *radius, const double *Bmat,
                     const double *z_des, const double *X0f, double *X_hist, double *U_hist,
-                    double *Rr_hist, double *eth_hist, double *X_final, int32_t *stop_row) {
+                    double *Rr_hist, double *eth_hist, double *X_final, int32_t *stop_row, int32_t *conv_row) {
   D2D_REQUIRE(ctx && p && X0 && centres && radius && X_final, "d2d_sim_gvf_run: null argument");
+  D2D_REQUIRE(p->use_stop >= 0 && p->use_stop <= 2 && p->stop_hold >= 0, "d2d_sim_gvf_run: use_stop in 0..2, stop_hold >= 0");
   D2D_REQUIRE(p->n_ac >= 1 && p->n_ac <= 64, "d2d_sim_gvf_run: n_ac=%d not in 1..64", p->n_ac);
   D2D_REQUIRE(p->n_form >= 1 && p->n_rows >= 1 && p->rec_stride >= 1, "d2d_sim_gvf_run: n_form, n_rows, rec_stride must be >= 1");
   D2D_REQUIRE(p->n_ac == 1 || (Bmat && z_des), "d2d_sim_gvf_run: Bmat / z_des missing");
-  D2D_REQUIRE(!p->use_stop || X0f, "d2d_sim_gvf_run: use_stop needs X0f");
+  D2D_REQUIRE(p->use_stop != 1 || X0f, "d2d_sim_gvf_run: use_stop = 1 needs X0f");
+  D2D_REQUIRE(p->use_stop != 2 || p->n_ac >= 2, "d2d_sim_gvf_run: the phase-error rule needs at least two aircraft");
   D2D_REQUIRE(p->dt > 0 && p->tau_phi > 0 && p->tau_v > 0, "d2d_sim_gvf_run: dt, tau_phi, tau_v must be > 0");
   const int n_ac = p->n_ac, nm = n_ac - 1;
   const size_t nb = (size_t)n_ac * nm + nm;
@@ -475,7 +558,7 @@ int d2d_sim_gvf_run(d2d_ctx *ctx, const d2d_gvf_params *p, const double *X0,
   const size_t lds = (512 + 128 + nb + 8) * sizeof(double);
   const GlMesh mesh = make_mesh(p->dt, p->tau_phi, p->tau_v);
   hipLaunchKernelGGL(gvf_run_kernel, dim3(blocks), dim3(threads), lds, ctx->stream, *p, mesh, fpb, X0, centres,
-                     radius, ctx->Bmat_dev, X0f, X_hist, U_hist, Rr_hist, eth_hist, X_final, stop_row);
+                     radius, ctx->Bmat_dev, X0f, X_hist, U_hist, Rr_hist, eth_hist, X_final, stop_row, conv_row);
   D2D_LAUNCH_CHECK();
   return D2D_OK;
 }
@@ -540,6 +623,15 @@ int d2d_sim_track_run(d2d_ctx *ctx, const d2d_track_params *p, const double *x_r
                      yd, xdd, ydd, X0, X_hist, U_hist, Xr_hist, dX_hist, Yd_hist, Ydd_hist, X_final);
   D2D_LAUNCH_CHECK();
   D2D_CHECK_HIP(hipFreeAsync(deriv, ctx->stream));
+  return D2D_OK;
+}
+
+int d2d_traj_sample(d2d_ctx *ctx, int n, int T, double t_start, double dt, const double *desc, double *Yref) {
+  D2D_REQUIRE(ctx && desc && Yref, "d2d_traj_sample: null argument");
+  D2D_REQUIRE(n >= 1 && T >= 1, "d2d_traj_sample: n, T must be >= 1");
+  const long tot = (long)n * T;
+  hipLaunchKernelGGL(traj_sample_kernel, dim3((tot + 255) / 256), dim3(256), 0, ctx->stream, n, T, t_start, dt, desc, Yref);
+  D2D_LAUNCH_CHECK();
   return D2D_OK;
 }
 

@@ -25,6 +25,9 @@ def obs_col(i):
     return SC_O0X + 3 * i if i < 2 else SC_OEXT + 3 * (i - 2)
 
 
+TRAJ_MAX_SEG, TRAJ_SEG_STRIDE = 8, 20
+TRAJ_STRIDE = 4 + TRAJ_MAX_SEG * TRAJ_SEG_STRIDE
+TRAJ_LINE, TRAJ_CIRCLE, TRAJ_SLALOM, TRAJ_POLY = 1, 2, 3, 4
 ST_RUNNING, ST_CONVERGED, ST_MAXITER, ST_NONFINITE, ST_STALLED = range(5)
 
 
@@ -36,7 +39,7 @@ class GvfParams(C.Structure):
     _fields_ = [('n_form', C.c_int32), ('n_ac', C.c_int32), ('n_rows', C.c_int32), ('rec_stride', C.c_int32),
                 ('dt', C.c_double), ('tau_phi', C.c_double), ('tau_v', C.c_double),
                 ('ke', C.c_double), ('kd', C.c_double), ('kr', C.c_double), ('v_c', C.c_double),
-                ('wx', C.c_double), ('wy', C.c_double), ('use_stop', C.c_int32), ('pad_', C.c_int32),
+                ('wx', C.c_double), ('wy', C.c_double), ('use_stop', C.c_int32), ('stop_hold', C.c_int32),
                 ('stop_tol', C.c_double * 3)]
 
 
@@ -68,11 +71,12 @@ _SIGS = {
     'd2d_ctx_destroy': (C.c_int, [_P]),
     'd2d_ctx_sync': (C.c_int, [_P]),
     'd2d_step': (C.c_int, [_P, C.c_int, _P, _P, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _P]),
-    'd2d_sim_gvf_run': (C.c_int, [_P, C.POINTER(GvfParams)] + [_P] * 12),
+    'd2d_sim_gvf_run': (C.c_int, [_P, C.POINTER(GvfParams)] + [_P] * 13),
     'd2d_ctrl_gain': (C.c_int, [_P, C.POINTER(TrackParams)] + [_P] * 6),
     'd2d_dfff_eval': (C.c_int, [_P, C.POINTER(TrackParams)] + [_P] * 5),
     'd2d_sim_dfff_run': (C.c_int, [_P, C.POINTER(TrackParams)] + [_P] * 7),
     'd2d_sim_track_run': (C.c_int, [_P, C.POINTER(TrackParams)] + [_P] * 10),
+    'd2d_traj_sample': (C.c_int, [_P, C.c_int, C.c_int, C.c_double, C.c_double, _P, _P]),
     'd2d_dcf_eval': (C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.c_double, _P, _P, _P, _P]),
     'd2d_gvf_eval': (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_double, C.c_double, _P]),
     'd2d_flatness': (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_double, C.c_double, C.c_double, C.c_double, _P, _P, _P]),
@@ -196,7 +200,8 @@ class Context:
 
     def gvf_run(self, X0, centres, radius, n_ac, n_rows, dt, v_c, ke=4e-4, kd=25.0, kr=20.0,
                 B=None, z_des=None, tau_phi=0.01, tau_v=1.0, W=(0.0, 0.0), X0f=None,
-                stop_tol=(3.0, 3.0, np.deg2rad(0.5)), rec_stride=1, record=('X', 'U', 'Rr', 'eth'), out=None):
+                stop_tol=(3.0, 3.0, np.deg2rad(0.5)), rec_stride=1, record=('X', 'U', 'Rr', 'eth'), out=None,
+                etheta_tol_deg=None, stop_hold=0):
         """Circular-formation phase for N = n_form*n_ac drones.  X0 dev [5][N], centres dev
         [2][N], radius dev [N].  Returns dict of device tensors (plane-major).  out: the dictionary of an earlier
         call with the same shapes and `record` -- its buffers are written again instead of allocating new ones
@@ -212,8 +217,12 @@ class Context:
                 B[i, i] = -1.0; B[i + 1, i] = 1.0
         B = np.ascontiguousarray(B, dtype=np.float64)
         z_des = np.zeros(max(n_ac - 1, 0)) if z_des is None else np.ascontiguousarray(z_des, dtype=np.float64).reshape(-1)
+        # stop rule: X0f -> the state rule of case 1; etheta_tol_deg -> the phase-error rule of cases 2 / 3 (+ stop_hold steps)
+        use_stop = 2 if etheta_tol_deg is not None else (1 if X0f is not None else 0)
+        if use_stop == 2:
+            stop_tol = (float(etheta_tol_deg), 0.0, 0.0)
         p = GvfParams(n_form, n_ac, n_rows, rec_stride, dt, tau_phi, tau_v, ke, kd, kr, v_c, W[0], W[1],
-                      1 if X0f is not None else 0, 0, (C.c_double * 3)(*stop_tol))
+                      use_stop, int(stop_hold), (C.c_double * 3)(*stop_tol))
         n_rec = (n_rows + rec_stride - 1) // rec_stride
         if out is None:
             out = {}
@@ -223,11 +232,12 @@ class Context:
             out['eth'] = self.zeros(n_rec, n_form * max(n_ac - 1, 0)) if ('eth' in record and n_ac > 1) else None
             out['X_final'] = self.empty(5, N)
             out['stop_row'] = torch.empty(n_form, dtype=torch.int32, device=self.device)
+            out['conv_row'] = torch.empty(n_form, dtype=torch.int32, device=self.device)
         else:
             assert out['X_final'].shape == (5, N) and all(out[k] is None or out[k].shape[0] == n_rec for k in ('X', 'U', 'Rr', 'eth'))
         _check(self.lib.d2d_sim_gvf_run(self.h, C.byref(p), _ptr(X0), _ptr(centres), _ptr(radius), _hptr(B), _hptr(z_des),
-                                        _ptr(X0f), _ptr(out['X']), _ptr(out['U']), _ptr(out['Rr']), _ptr(out['eth']),
-                                        _ptr(out['X_final']), _ptr(out['stop_row'])))
+                                        _ptr(X0f if use_stop == 1 else None), _ptr(out['X']), _ptr(out['U']), _ptr(out['Rr']), _ptr(out['eth']),
+                                        _ptr(out['X_final']), _ptr(out['stop_row']), _ptr(out.get('conv_row'))))
         return out
 
     # -- single evaluations behind the reference's per-call helpers --------------------
@@ -291,6 +301,13 @@ class Context:
         Xr, U, K = self.empty(5, n), self.empty(2, n), self.empty(6, n)
         _check(self.lib.d2d_dfff_eval(self.h, C.byref(p), _ptr(X), _ptr(Yref), _ptr(Xr), _ptr(U), _ptr(K)))
         return Xr, U, K
+
+    def traj_sample(self, desc, T, t_start, dt):
+        """desc dev [n][TRAJ_STRIDE] trajectory descriptors (d2d.trajectory.describe) -> Yref dev [T][6][n]."""
+        n = desc.shape[0]
+        Y = self.empty(T, 6, n)
+        _check(self.lib.d2d_traj_sample(self.h, n, T, float(t_start), float(dt), _ptr(desc), _ptr(Y)))
+        return Y
 
     def dfff_run(self, Yref, X0, dt, perts=None, record=('X', 'U', 'Xr'), w=(0.0, 0.0), tau_phi=0.01, tau_v=1.0, out=None):
         """run_simulation of src/05_test_simulation.py with the legacy DFFFController for n aircraft: Yref dev [T][6][n]

@@ -27,11 +27,23 @@ def _planes(a):
     return np.ascontiguousarray(np.asarray(a, dtype=np.float64).T)
 
 
+def hold_steps(t_opt_comp, t_step):
+    """How many further steps the phase-error rule must hold before the reference's case-3 loop breaks: it adds t_step to a
+    running dt on every such step and breaks once dt >= t_opt_comp (src/12_full_sim_case3.py:163-178); same floating-point sum."""
+    k, acc = 0, 0.0
+    while not acc >= t_opt_comp:
+        acc += t_step
+        k += 1
+    return k
+
+
 def CircularFormationGVF_batch(c, r, v, n_ac, X0f=None, t_start=0, t_step=0.05, t_end=1000, X0=None,
-                               tau_phi=None, rec_stride=1, record=('X', 'U', 'Rr', 'eth'), W=(0., 0.)):
+                               tau_phi=None, rec_stride=1, record=('X', 'U', 'Rr', 'eth'), W=(0., 0.), etheta_tol_deg=None,
+                               t_opt_comp=0.0):
     """Many formations at once.  c (n_form, n_ac, 2) centres; r scalar or (n_form, n_ac); X0
     (n_form, n_ac, 5) or None (every aircraft starts at the reference's X1); X0f (n_form, n_ac, >=3)
-    or None.  Returns the raw device dictionary of d2dhip.Context.gvf_run plus `time`."""
+    or None.  etheta_tol_deg: stop by the phase-error rule of cases 2 / 3 instead of the state rule (after t_opt_comp more seconds on
+    which it holds).  Returns the raw device dictionary of d2dhip.Context.gvf_run plus `time`."""
     ctx = d2dhip.default_context()
     c = np.asarray(c, dtype=np.float64).reshape(-1, n_ac, 2)
     n_form = c.shape[0]
@@ -44,7 +56,8 @@ def CircularFormationGVF_batch(c, r, v, n_ac, X0f=None, t_start=0, t_step=0.05, 
     out = ctx.gvf_run(ctx.dev(_planes(X0)), ctx.dev(_planes(c.reshape(N, 2))), ctx.dev(np.ascontiguousarray(R)), n_ac,
                       len(time), t_step, float(v), KE, KD, KR, B=ConstructBMatrix(n_ac), z_des=np.zeros(max(n_ac - 1, 0)),
                       tau_phi=ac.tau_phi if tau_phi is None else tau_phi, tau_v=ac.tau_v, W=W, X0f=x0f,
-                      rec_stride=rec_stride, record=record)
+                      rec_stride=rec_stride, record=record, etheta_tol_deg=etheta_tol_deg,
+                      stop_hold=hold_steps(t_opt_comp, t_step) if etheta_tol_deg is not None else 0)
     out['time'] = time
     return out
 
@@ -67,6 +80,58 @@ def CircularFormationGVF(c, r, v, n_ac, X0f, t_start=0, t_step=0.05, t_end=1000)
         t_f = time[i - 1]
         return X[:i], U[:i], U1[:i], U2[i, :], Rr[:i], eth[:i], time[:i], t_f
     return X, U, U1, U2, Rr, eth, time, t_end
+
+
+def _gvf_trimmed(out, n_ac, t_end):
+    d2dhip.default_context().sync()
+    time = out['time']
+    rows = int(out['stop_row'].cpu().numpy()[0])
+    X = out['X'].cpu().numpy().transpose(0, 2, 1); U = out['U'].cpu().numpy().transpose(0, 2, 1)
+    Rr = out['Rr'].cpu().numpy(); eth = out['eth'].cpu().numpy()
+    U1 = np.zeros((len(time), n_ac)); U2 = np.zeros((len(time), n_ac))        # (debug decomposition, not kept by the fused loop)
+    fired = rows < len(time) or bool(out['conv_row'].cpu().numpy()[0] >= 0 and rows == len(time))
+    return X, U, U1, U2, Rr, eth, time, rows, fired
+
+
+def CircularFormationGVF_case2(c, r, v, n_ac, t_start=0, t_step=0.05, t_end=1000, etheta_tol=0.5):
+    """src/12_full_sim_case2.py:85-164: the circular-formation phase that ends when every inter-vehicle phase error is <= 0.5 deg.
+    The reference's 8-tuple, trimmed to [:i+1] (its `U2_array[i+1,:]` slice quirk reproduced), t_f = time[i-1]."""
+    out = CircularFormationGVF_batch(np.asarray(c)[None], r, v, n_ac, t_start=t_start, t_step=t_step, t_end=t_end,
+                                     etheta_tol_deg=etheta_tol)
+    X, U, U1, U2, Rr, eth, time, rows, fired = _gvf_trimmed(out, n_ac, t_end)
+    if fired and rows < len(time):
+        return X[:rows], U[:rows], U1[:rows], U2[rows, :], Rr[:rows], eth[:rows], time[:rows], time[rows - 2]
+    return X, U, U1, U2, Rr, eth, time, t_end
+
+
+def CircularFormationGVF_case3(c, r, v, n_ac, t_start=0, t_step=0.05, t_end=1000, etheta_tol=2., t_opt_comp=0.7):
+    """src/12_full_sim_case3.py:85-181: as case 2 with a 2 deg tolerance, flying on for t_opt_comp seconds after the first
+    convergence (the time the planner takes); the last element is the reference's convergence = [index, t_convergence, t_f]."""
+    out = CircularFormationGVF_batch(np.asarray(c)[None], r, v, n_ac, t_start=t_start, t_step=t_step, t_end=t_end,
+                                     etheta_tol_deg=etheta_tol, t_opt_comp=t_opt_comp)
+    X, U, U1, U2, Rr, eth, time, rows, fired = _gvf_trimmed(out, n_ac, t_end)
+    idx = int(out['conv_row'].cpu().numpy()[0])
+    if rows < len(time):
+        conv = [idx, time[idx], time[rows - 2]]
+        return X[:rows], U[:rows], U1[:rows], U2[rows, :], Rr[:rows], eth[:rows], time[:rows], conv
+    return X, U, U1, U2, Rr, eth, time, [idx, time[idx] if idx >= 0 else None, None]
+
+
+def trajectory_gen_multi(p, delta):
+    """A second aircraft flying the single-aircraft plan shifted by delta (src/12_full_sim_case3.py:195-201): sol_x, sol_y (N, 2)."""
+    x, y = p.sol_x.reshape(-1, 1), p.sol_y.reshape(-1, 1)
+    p.sol_x, p.sol_y = np.append(x, x + delta[0], axis=1), np.append(y, y + delta[1], axis=1)
+    return p
+
+
+def trajectory_optimization_single(scen, delta, backend=None):
+    """src/12_full_sim_case3.py:184-193 without the plots: one single-aircraft plan (scen.p0 injected by the caller, :456-460),
+    duplicated with an offset for the wingman."""
+    import single_opt_planner as sop
+    p = sop.Planner(scen, backend=backend)
+    p.configure(tol=1e-5, max_iter=1500)
+    p.run(initial_guess=p.get_initial_guess())
+    return trajectory_gen_multi(p, delta)
 
 
 def ComputeDerivatives(x_ref, y_ref, dt):
@@ -211,3 +276,45 @@ def run_simulation(time, aircraft, windfield, ctl, X0, perts):
                                w=w, record=('X', 'U'))
     d2dhip.default_context().sync()
     return out['X'].cpu().numpy()[:, :, 0], out['U'].cpu().numpy()[:, :, 0], Yref
+
+
+def sample_references_batch(trajs, time):
+    """Flat outputs of many reference trajectories at the sample times, as run_simulation_batch wants them: device tensor
+    [T][6][n].  Trajectories with a descriptor (lines, circle arcs, slaloms, min-snap polynomials, composites of them:
+    d2d.trajectory.describe) are evaluated by d2d_traj_sample on the GPU -- the reference calls traj.get(t) in a Python loop per
+    aircraft and step (src/05_test_simulation.py:25); the others (splines, space-indexed, tabulated) are sampled on the host and
+    uploaded into their columns."""
+    import d2d.trajectory as ddt
+    ctx = d2dhip.default_context()
+    time = np.asarray(time, dtype=np.float64)
+    T, n = len(time), len(trajs)
+    dt = float(time[1] - time[0])
+    rows = [ddt.describe(tr) for tr in trajs]
+    dev_ok = [r is not None for r in rows]
+    desc = np.stack([r if r is not None else np.zeros(d2dhip.TRAJ_STRIDE) for r in rows])
+    Y = ctx.traj_sample(ctx.dev(desc), T, float(time[0]), dt)
+    for j, tr in enumerate(trajs):
+        if not dev_ok[j]:
+            Yh = np.array([np.asarray(tr.get(t))[:3].reshape(-1) for t in time])       # rows x, y, xd, yd, xdd, ydd
+            Y[:, :, j] = ctx.dev(np.ascontiguousarray(Yh))
+    return Y
+
+
+def test_simulation(scen, record=('X', 'U')):
+    """src/05_test_simulation.py:37-54 without the plots: every aircraft of a d2d.scenario.Scenario flown with the DFFFController
+    along its reference, all of them in ONE device loop.  Returns Xs, Us (lists of (T, 5) / (T, 2) arrays, one per aircraft)
+    and Yrefs (T, n, 3, 2)."""
+    ctx = d2dhip.default_context()
+    time = np.asarray(scen.time, dtype=np.float64)
+    n = len(scen.trajs)
+    Y = sample_references_batch(scen.trajs, time)                                        # dev [T][6][n]
+    ac = scen.aircrafts[0]
+    w = scen.windfield.sample(time[0], None)
+    perts = ctx.dev(np.ascontiguousarray(np.stack([np.asarray(p, dtype=np.float64) for p in scen.perts[:n]], 2)))   # [T][5][n]
+    X0 = np.stack([np.asarray(x, dtype=np.float64) for x in scen.X0s[:n]])
+    out = ctx.dfff_run(Y, ctx.dev(_planes(X0)), float(time[1] - time[0]), perts=perts, record=record,
+                       w=(float(w[0]), float(w[1])), tau_phi=ac.tau_phi, tau_v=ac.tau_v)
+    ctx.sync()
+    Xh, Uh, Yh = out['X'].cpu().numpy(), out['U'].cpu().numpy(), Y.cpu().numpy()
+    Yrefs = Yh.transpose(0, 2, 1).reshape(len(time), n, 3, 2)
+    return [Xh[:, :, j] for j in range(n)], [Uh[:, :, j] for j in range(n)], Yrefs

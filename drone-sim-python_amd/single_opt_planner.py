@@ -52,6 +52,13 @@ def lower_cost(cost):
         return cost.vsp, cost.kv, cost.kphi, 0., (), nan, 0., 0, 0
     if isinstance(cost, d2mou.CostNull):
         return 0., 0., 0., 0., (), nan, 0., 0, 0
+    if isinstance(cost, (d2ou.CostObstacle, d2mou.CostObstacle)):          # one disc on its own (07_multioptyplan exp_3)
+        return 0., 0., 0., 1., ((cost.c[0], cost.c[1], cost.r),), nan, 0., 1 if cost.kind == 0 else 0, 0
+    if isinstance(cost, (d2ou.CostObstacles, d2mou.CostObstacles)):
+        obss = tuple((o.c[0], o.c[1], o.r) for o in cost.obss)
+        return 0., 0., 0., 1., obss, nan, 0., sum(1 << i for i, o in enumerate(cost.obss) if o.kind == 0), 0
+    if isinstance(cost, d2mou.CostCollision):                              # the collision term on its own
+        return 0., 0., 0., 0., (), 1., cost.r, 0, 0
     if isinstance(cost, d2ou.CostComposit):
         obss = [(o.c[0], o.c[1], o.r) for o in cost.cobs.obss] if hasattr(cost, 'cobs') else []
         okind = sum(1 << i for i, o in enumerate(cost.cobs.obss) if o.kind == 0) if obss else 0
@@ -269,4 +276,25 @@ def plot_chrono(_p, _f=None, _a=None):
     return _f, _a
 
 
-exp_0, exp_1 = d2oscen.exp_0, d2oscen.exp_1
+exp_0 = d2oscen.exp_0
+
+
+class exp_1:
+    """src/single_opt_planner.py:227-248: the leg of full-sim case 3; p0 is injected by the caller (src/12_full_sim_case3.py:185-190)."""
+    name, desc = 'exp 1 - joining 2 points', 'single ac traj computation for test case 2 of full sim'
+    ncases = 1
+    tol, max_iter = 1e-5, 1500
+    vref = 12
+    cost, obj_scale = d2ou.CostAirVel(vref), 1
+    wind = d2ou.WindField(w=[0, 0])
+    obstacles = ()
+    t0 = 0
+    t1, p1 = 12, (75, 40, 0, 0, 12)
+    x_constraint, y_constraint = (-150, 150), (-150, 150)
+    v_constraint = (9., 15.)
+    phi_constraint = (-np.deg2rad(40.), np.deg2rad(40.))
+    initial_guess = 'tri'
+    hz = 10
+
+    def set_case(idx): pass
+    def label(idx): return ''

@@ -73,9 +73,13 @@ typedef struct {
   double ke, kd, kr;   /* GVF / DCF gains (src/11_full_sim_case1.py:108-110)       */
   double v_c;          /* commanded airspeed (the `v` argument, :93)               */
   double wx, wy;       /* wind                                                     */
-  int32_t use_stop;    /* 1: apply the phase-1 stop rule (:140,170-175)            */
-  int32_t pad_;
-  double stop_tol[3];  /* |x|,|y|,|psi| tolerances, reference: 3, 3, 0.5 deg       */
+  int32_t use_stop;    /* 1: the state rule of case 1 (:140,170-175): every aircraft within stop_tol of X0f;
+                          2: the phase-error rule of cases 2 / 3 (src/12_full_sim_case2.py:156-164,
+                          src/12_full_sim_case3.py:163-178): every inter-vehicle phase error (degrees,
+                          signed) <= stop_tol[0]                                      */
+  int32_t stop_hold;   /* rule 2: the loop goes on for this many further steps on which the rule holds
+                          (case 3 waits t_opt_comp = 0.7 s for the planner: 14 steps); 0 = case 2 */
+  double stop_tol[3];  /* rule 1: |x|,|y|,|psi| tolerances, reference: 3, 3, 0.5 deg; rule 2: [0] = degrees */
 } d2d_gvf_params;
 
 /* Circular-formation phase: DCF phase consensus + GVF circle following + plant step, the
@@ -97,13 +101,15 @@ typedef struct {
  *            [n_rec][n_form*(n_ac-1)] or NULL (phase errors in degrees, row i)
  *            with n_rec = ceil(n_rows / rec_stride)
  *   X_final  dev [5][N]: state after the last executed step
- *   stop_row dev int32 [n_form]: value of the reference's loop index i at its `break`
- *            (== rows kept by the reference's trim), or n_rows if the rule never fired.
+ *   stop_row dev int32 [n_form]: rows kept by the reference's trim when its `break` fires (rule 1 breaks at the top of
+ *            step i: i rows; rule 2 at the end of step i: i + 1 rows), or n_rows if the rule never fired;
+ *   conv_row dev int32 [n_form] or NULL: rule 2, the reference's `index` = i - 1 of the first step on which the rule held
+ *            (-1: never).
  * A formation that has stopped is frozen (its rows beyond stop_row are not written). */
 int d2d_sim_gvf_run(d2d_ctx *ctx, const d2d_gvf_params *p, const double *X0,
                     const double *centres, const double *radius, const double *Bmat,
                     const double *z_des, const double *X0f, double *X_hist, double *U_hist,
-                    double *Rr_hist, double *eth_hist, double *X_final, int32_t *stop_row);
+                    double *Rr_hist, double *eth_hist, double *X_final, int32_t *stop_row, int32_t *conv_row);
 
 typedef struct {
   int32_t n;           /* drones (independent)                                     */
@@ -159,6 +165,23 @@ int d2d_sim_track_run(d2d_ctx *ctx, const d2d_track_params *p, const double *x_r
  *   X_final dev [5][n] or NULL.  Controller constants as d2d_dfff_eval (p->q_diag[0..2], r_diag, err_sats, limits). */
 int d2d_sim_dfff_run(d2d_ctx *ctx, const d2d_track_params *p, const double *Yref, const double *perts,
                      const double *X0, double *X_hist, double *U_hist, double *Xr_hist, double *X_final);
+
+/* Reference trajectories of the legacy simulations, sampled on the device: Yref [T][6][n] (x, y, xd, yd, xdd, ydd at
+ * t_start + i dt) -- the input of d2d_sim_dfff_run -- for n trajectories described by desc dev [n][D2D_TRAJ_STRIDE]:
+ *   desc[0] = number of segments (1..D2D_TRAJ_MAX_SEG), desc[1] = the composite's t0, desc[2] = its total duration,
+ *   desc[3] = 1: periodic composite (CompositeTraj.get, src/d2d/trajectory.py:202-208: fmod(t - t0, duration), first segment
+ *   whose cumulative end is beyond the lapse) / 0: one plain segment evaluated at t;
+ *   then per segment D2D_TRAJ_SEG_STRIDE doubles: type, the segment's t0, its cumulative end, parameters:
+ *     D2D_TRAJ_LINE    p1x, p1y, unx, uny, v                      TrajectoryLine (src/d2d/trajectory.py:125-141)
+ *     D2D_TRAJ_CIRCLE  cx, cy, r, omega = v/r, alpha0             TrajectoryCircle (:143-160)
+ *     D2D_TRAJ_SLALOM  p1x, p1y, unx, uny, v, a, om, phi          TrajSlalom (src/d2d/trajectory_factory.py:113-137)
+ *     D2D_TRAJ_POLY    coefs[0,:] of the x polynomial (8), of y (8)  MinSnapPoly (src/d2d/trajectory.py:166-187)
+ * (d2d/trajectory.py `describe` builds these rows from the mirrored trajectory classes). */
+#define D2D_TRAJ_MAX_SEG 8
+#define D2D_TRAJ_SEG_STRIDE 20
+#define D2D_TRAJ_STRIDE (4 + D2D_TRAJ_MAX_SEG * D2D_TRAJ_SEG_STRIDE)
+enum { D2D_TRAJ_LINE = 1, D2D_TRAJ_CIRCLE = 2, D2D_TRAJ_SLALOM = 3, D2D_TRAJ_POLY = 4 };
+int d2d_traj_sample(d2d_ctx *ctx, int n, int T, double t_start, double dt, const double *desc, double *Yref);
 
 /* Single batched evaluations behind the reference's per-call helper methods (the time
  * loops above fuse them; these exist so that host code written against the reference's

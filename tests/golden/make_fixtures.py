@@ -442,10 +442,56 @@ def fx_dfff():
              tau_phi=ac.tau_phi, tau_v=ac.tau_v)
 
 
+def fx_traj_scen():
+    """Demo trajectories (src/d2d/trajectory_factory.py) and simulation scenarios (src/d2d/scenario.py) of the reference: flat outputs
+    traj.get(t) at seeded times, the scenarios' start states / time grids / winds / perturbations, the planner scenario catalogues'
+    numeric attributes, and one run of the reference's run_simulation loop on scenario 'line2' (CARE stand-in)."""
+    import importlib
+    import d2d.trajectory_factory as ddtf
+    import d2d.scenario as dds
+    import d2d.optyplan_scenarios as d2oscen
+    out = {}
+    r = np.random.default_rng(11)
+    for name in ('circle', 'two_lines', 'square', 'line_with_intro', 'demo_minsnap', 'slalom', 'sidemo'):
+        traj, _ = quiet(ddtf.get, name)
+        ts = np.sort(r.uniform(0, 2.2 * traj.duration, 40))
+        out[f'traj_{name}_t'] = ts
+        out[f'traj_{name}_Y'] = np.array([traj.get(t) for t in ts])
+        out[f'traj_{name}_duration'] = traj.duration
+    for name in ('line', 'line2', 'square', 'mucir', 'mucir2', 'patrol', 'patrol_2', 'patrol_3', 'circForm'):
+        scen, _ = quiet(dds.get, name)
+        out[f'scen_{name}_X0s'] = np.array(scen.X0s, dtype=float)
+        out[f'scen_{name}_time'] = np.array([scen.time[0], scen.time[-1], len(scen.time)], dtype=float)
+        out[f'scen_{name}_wind'] = np.array(scen.windfield.sample(0., [0., 0.]), dtype=float)
+        out[f'scen_{name}_extends'] = np.array(scen.extends, dtype=float)
+        ts = scen.time[::97][:30]
+        out[f'scen_{name}_ts'] = ts
+        out[f'scen_{name}_Y'] = np.array([[traj.get(t) for traj in scen.trajs] for t in ts])       # (nt, n, 4, 2)
+        out[f'scen_{name}_pert_nz'] = np.array([[i, j, k, p[j, k]] for i, p in enumerate(scen.perts) for j, k in zip(*np.nonzero(p))],
+                                                dtype=float).reshape(-1, 4)
+    # planner catalogues: numeric attributes only (names and numbers, no code)
+    sims = importlib.import_module('05_test_simulation')
+    scen, _ = quiet(dds.get, 'line2')
+    ctl = ddg.DFFFController(scen.trajs[0], scen.aircrafts[0], scen.windfield)
+    X, U, Yref = sims.run_simulation(scen.time[:400], scen.aircrafts[0], scen.windfield, ctl, scen.X0s[0], scen.perts[0])
+    out['run_line2_X'], out['run_line2_U'], out['run_line2_Yref'] = X, U, Yref
+    for i, sc in enumerate(d2oscen.scens):
+        out[f'plan_{i}_name'] = np.array(sc.name)
+        out[f'plan_{i}_num'] = np.array([sc.t0, sc.t1, sc.hz, sc.obj_scale, sc.vref, sc.ncases, len(sc.obstacles)] + list(sc.p0) + list(sc.p1)
+                                        + list(sc.phi_constraint) + list(sc.v_constraint), dtype=float)
+    m07 = importlib.import_module('07_multioptyplan')
+    for i, sc in enumerate(m07.scens):
+        out[f'mplan_{i}_name'] = np.array(sc.name)
+        out[f'mplan_{i}_num'] = np.array([sc.t0, sc.t1, sc.hz, sc.obj_scale, sc.vref, sc.ncases, len(sc.obstacles), len(sc.p0s)]
+                                         + list(np.ravel(sc.p0s)) + list(np.ravel(sc.p1s)) + list(sc.phi_constraint) + list(sc.v_constraint),
+                                         dtype=float)
+    np.savez(os.path.join(OUT, 'traj_scen.npz'), **out)
+
+
 if __name__ == '__main__':
     only = sys.argv[1:]
     for f in (fx_plant, fx_flatness_ctrl, fx_guidance, fx_states_over_time, fx_costs, fx_guess_poly,
-              fx_fit_cost, fx_planner_goldens, fx_tracking_trace, fx_dfff, fx_costs3, fx_dfff_run):
+              fx_fit_cost, fx_planner_goldens, fx_tracking_trace, fx_dfff, fx_costs3, fx_dfff_run, fx_traj_scen):
         if only and f.__name__ not in only:
             continue
         f(); print('wrote', f.__name__)

@@ -144,8 +144,12 @@ def test_single_planner_on_the_collocation_backend():
     pw.run()
     assert pw.info['status'] == 1 and _feas(pw.sol_x, pw.sol_y, pw.sol_psi, pw.sol_phi, pw.sol_v, pw.time_step, (-1., 0.5)) <= 1e-8
     assert abs(pw.info['obj_val'] - 2.90645965) < 1e-6                      # (oracle/nlp.py on the same problem)
-    # obstacles: CostComposit with two discs (exp_1, :56-63)
-    po = sop.Planner(d2oscen.exp_1, initialize=True, backend='nlp')
+    # obstacles: CostComposit with two discs (kind 1) on the straight line
+    class discs(d2oscen.exp_0):
+        t1, p1 = 10., (100., 0., 0., 0., 10.)
+        obstacles = ((33, 0, 15), (66, 0, 15))
+        cost, obj_scale = d2ou.CostComposit(obstacles, vsp=12., kobs=1., kvel=1., kbank=1., obs_kind=1), 1.
+    po = sop.Planner(discs, initialize=True, backend='nlp')
     po.run()
     assert po.info['status'] == 1 and _feas(po.sol_x, po.sol_y, po.sol_psi, po.sol_phi, po.sol_v, po.time_step) <= 1e-8
     d = np.minimum(np.hypot(po.sol_x - 33., po.sol_y), np.hypot(po.sol_x - 66., po.sol_y))

@@ -240,3 +240,29 @@ def test_dfff_run_loop(gold):
     np.testing.assert_allclose(X[:, 0, 2:], g['X'][:, 2:], rtol=0, atol=2e-5)
     np.testing.assert_allclose(X[:, 0, :2], g['X'][:, :2], rtol=0, atol=1e-4)
     assert np.abs(U[:, 0] - g['U']).max() < 1e-3
+
+
+def test_gvf_phase_error_stop_rules_of_cases_2_and_3():
+    """The stop rules of src/12_full_sim_case2.py:156-164 (every phase error <= 0.5 deg: break at once) and
+    src/12_full_sim_case3.py:163-178 (<= 2 deg, then 0.7 s more while the planner works) inside the device loop, against the
+    oracle's restatement of those loops: same break row, same convergence index, same trimmed arrays."""
+    import full_sim
+    from oracle import sim as S
+    c = np.array([[0, -20], [25, -40], [25, -80], [0, -100.0]])
+    X0 = np.tile([20, 30, -np.pi / 2, 0, 10.0], (4, 1))
+    n_steps = len(np.arange(0, 120, 0.05))
+    Xo, Uo, Rro, etho, stop2, conv2 = S.formation_gvf_run(c, 60.0, 15.0, X0, n_steps, 0.05, etheta_tol_deg=0.5)
+    X, U, U1, U2, Rr, eth, time, t_f = full_sim.CircularFormationGVF_case2(c, 60.0, 15.0, 4, 0, 0.05, 120)
+    assert 10 < stop2 < n_steps and len(X) == stop2 == len(time) and abs(t_f - conv2[2]) < 1e-12, (stop2, len(X))
+    assert np.abs(X - Xo[:stop2]).max() < 1e-7 and np.abs(eth - etho[:stop2]).max() < 1e-6
+    Xo, Uo, Rro, etho, stop3, conv3 = S.formation_gvf_run(c, 60.0, 15.0, X0, n_steps, 0.05, etheta_tol_deg=2.0, t_opt_comp=0.7)
+    out = full_sim.CircularFormationGVF_case3(c, 60.0, 15.0, 4, 0, 0.05, 120)
+    X3, conv = out[0], out[-1]
+    assert len(X3) == stop3 and conv[0] == conv3[0] and abs(conv[1] - conv3[1]) < 1e-12 and abs(conv[2] - conv3[2]) < 1e-12, (conv, conv3, stop3)
+    assert stop3 - 1 - conv3[0] == full_sim.hold_steps(0.7, 0.05) + 1           # first convergence, then the planner's 0.7 s
+    assert np.abs(X3 - Xo[:stop3]).max() < 1e-7
+    # case 3's planning step: one single-aircraft plan + the wingman's offset copy
+    import single_opt_planner as sop
+    sop.exp_1.p0 = tuple(X3[-1, 0])
+    p = full_sim.trajectory_optimization_single(sop.exp_1, (0., -20.))
+    assert p.sol_x.shape == (121, 2) and np.allclose(p.sol_y[:, 1] - p.sol_y[:, 0], -20.) and np.allclose(p.sol_x[:, 1], p.sol_x[:, 0])

@@ -199,3 +199,47 @@ def test_plan_csv_round_trip(tmp_path):
     for i in range(n):
         np.testing.assert_array_equal(x2[T:, i], x[:, n - 1 - i])
         np.testing.assert_array_equal(psi2[T:, i], y[:, n - 1 - i])      # (the reference extends psi with y, :238)
+
+
+def test_trajectory_factory_and_catalogues_vs_reference(gold):
+    """Demo trajectories (src/d2d/trajectory_factory.py) against the reference's traj.get(t) at seeded times, beyond one period of
+    the composites; the planner scenario catalogues (single: src/d2d/optyplan_scenarios.py, 15 entries; multi:
+    src/07_multioptyplan.py:170-435, 15 entries) against the reference's names and numeric attributes; the simulation scenarios
+    whose start states are given explicitly (no device call in their construction)."""
+    import d2d.trajectory_factory as ddtf
+    import d2d.optyplan_scenarios as d2oscen
+    import d2d.multioptyplan_scenarios as d2mscen
+    import d2d.scenario as dds
+    g = gold('traj_scen')
+    for name in ('circle', 'two_lines', 'square', 'line_with_intro', 'demo_minsnap', 'slalom', 'sidemo'):
+        traj, desc = ddtf.get(name)
+        assert abs(traj.duration - float(g[f'traj_{name}_duration'])) < 1e-12
+        Y = np.array([traj.get(t) for t in g[f'traj_{name}_t']])
+        np.testing.assert_allclose(Y, g[f'traj_{name}_Y'], rtol=1e-12, atol=1e-10, err_msg=name)
+    assert len(ddtf.list_available()) == 10 and len(dds.list_available()) == 13
+    import importlib
+    importlib.reload(d2oscen); importlib.reload(d2mscen)       # (other tests mutate base classes through set_case, as the protocol allows)
+    assert len(d2oscen.scens) == 15 and len(d2mscen.scens) == 15
+    for i, sc in enumerate(d2oscen.scens):
+        assert sc.name == str(g[f'plan_{i}_name']), (i, sc.name)
+        num = [sc.t0, sc.t1, sc.hz, sc.obj_scale, sc.vref, sc.ncases, len(sc.obstacles)] + list(sc.p0) + list(sc.p1) + list(sc.phi_constraint) + list(sc.v_constraint)
+        np.testing.assert_allclose(num, g[f'plan_{i}_num'], rtol=0, atol=1e-15, err_msg=sc.name)
+    for i, sc in enumerate(d2mscen.scens):
+        assert sc.name == str(g[f'mplan_{i}_name']), (i, sc.name)
+        num = ([sc.t0, sc.t1, sc.hz, sc.obj_scale, sc.vref, sc.ncases, len(sc.obstacles), len(sc.p0s)] + list(np.ravel(sc.p0s)) + list(np.ravel(sc.p1s))
+               + list(sc.phi_constraint) + list(sc.v_constraint))
+        np.testing.assert_allclose(num, g[f'mplan_{i}_num'], rtol=0, atol=1e-15, err_msg=sc.name)
+    for sc in d2mscen.scens:                                   # (set_case mutates class attributes of base classes: after the comparison)
+        for c in range(sc.ncases):
+            sc.set_case(c); sc.label(c)
+            sop.lower_cost(sc.cost)                            # every cost of the catalogue has a kernel lowering
+    for name in ('line', 'line2', 'square', 'mucir', 'mucir2', 'patrol', 'patrol_2'):
+        scen, _ = dds.get(name)
+        np.testing.assert_allclose(np.array(scen.X0s, dtype=float), g[f'scen_{name}_X0s'], atol=1e-15)
+        np.testing.assert_allclose([scen.time[0], scen.time[-1], len(scen.time)], g[f'scen_{name}_time'], atol=1e-12)
+        np.testing.assert_allclose(scen.windfield.sample(0., [0., 0.]), g[f'scen_{name}_wind'])
+        np.testing.assert_allclose(scen.extends, g[f'scen_{name}_extends'], atol=1e-12)
+        Y = np.array([[traj.get(t) for traj in scen.trajs] for t in g[f'scen_{name}_ts']])
+        np.testing.assert_allclose(Y, g[f'scen_{name}_Y'], rtol=1e-12, atol=1e-10, err_msg=name)
+        nz = np.array([[i, j, k, p[j, k]] for i, p in enumerate(scen.perts) for j, k in zip(*np.nonzero(p))], dtype=float).reshape(-1, 4)
+        np.testing.assert_allclose(nz, g[f'scen_{name}_pert_nz'])
