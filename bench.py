@@ -20,6 +20,7 @@ Besides the contract fields the line carries
                     x evaluations / summed HIP-event kernel time
   roofline_isolated the contraction-only kernel (fit_jtj_kernel: row records from HBM -> MFMA -> tiles to HBM; its whole
                     duration is the J^T J contraction) on 4096 and on 32 768 resident trajectories, HIP events
+  config2           BASELINE configs[2]: 8-drone formation x 8192 replicas with collision rows (coupled groups), one persistent launch
   config3           BASELINE configs[3]: 32 768 fits per rank (256 k at N = 8), same solve, barrier + max over ranks
   parity            the SAME scenarios the cpu_baseline leg solved with scipy: fraction agreeing to 1e-6 (cost, coefficients)
   sim               BASELINE configs[4] (65 536 drones x 10 000 steps GVF loop) and the tracking loop, with roofline + cpu_baseline
@@ -255,6 +256,7 @@ def main():
     ap.add_argument('--config3-batch', type=int, default=32768, help='fits per rank of the config3 record (0 = skip)')
     ap.add_argument('--config3-steps', type=int, default=3)
     ap.add_argument('--no-sim', action='store_true', help='skip the simulation records (BASELINE configs[4])')
+    ap.add_argument('--no-groups', action='store_true', help='skip the coupled-groups record (BASELINE configs[2])')
     ap.add_argument('--no-order', action='store_true',
                     help='hand the fits out in index order instead of longest-first by the previous solve\'s iteration counts')
     a = ap.parse_args()
@@ -411,6 +413,33 @@ def main():
         del r3
         torch.cuda.empty_cache()
 
+    # ---- BASELINE configs[2]: multi_opt_planner's 8-drone circular formation x 8192 replicas, collision rows between all pairs ----
+    config2 = None
+    if rank == 0 and world == 1 and not a.no_groups:
+        from d2dhip import synth
+        n_ac, Rg = 8, 8192
+        plan_g = d2dhip.FitPlan(ctx, S_, K, dur, synth.default_wref(1.0, K))
+        dscg = ctx.dev(synth.circle_group_scenarios(n_ac, Rg, dur, K, seed=1).reshape(Rg * n_ac, -1))
+        q0g = plan_g.init(dscg)
+        best, resg = 1e30, None
+        for rep in range(3):
+            qg = q0g.clone()
+            torch.cuda.synchronize()
+            tg = time.perf_counter()
+            resg = plan_g.solve_groups(dscg, qg, n_ac, max_sweeps=120, inner_iters=8, tol=1e-10)
+            torch.cuda.synchronize()
+            if rep:
+                best = min(best, time.perf_counter() - tg)
+        config2 = {'workload': '8-drone circular formation x 8192 replicas (65 536 coupled trajectories), CostCollision rows between all pairs '
+                               '(BASELINE configs[2]); block Gauss-Seidel per scenario in one persistent launch (fit_groups_kernel)',
+                   'value': Rg / best, 'unit': 'scenarios/s', 'trajectories_per_s': Rg * n_ac / best, 'seconds': best,
+                   'max_sweeps_used': int(resg[1]), 'last_sweep_max_rel_move': float(resg[2][2]), 'evaluations': float(resg[2][3]),
+                   'jtj_frac_of_fp32_mfma_peak': ALG_FLOP_PER_EVAL * float(resg[2][3]) / best / 1e12 / FP32_PEAK_TFLOPS,
+                   'round1_seconds': 0.80}
+        plan_g.close()
+        del dscg, q0g, qg
+        torch.cuda.empty_cache()
+
     # ---- parity: the SAME scenarios the cpu_baseline leg solved ------------------------------------------------------------
     parity = None
     if keep is not None:
@@ -463,7 +492,7 @@ def main():
             'converged_frac': headline['converged_frac'], 'mean_iters': headline['mean_iters'],
             'evals_per_fit': headline['evals_per_fit'],          # Gauss-Newton units (200 rows); second-order evaluations count 1.5
             'mean_cost': headline['mean_cost'],
-            'roofline': roof, 'roofline_isolated': roof_iso, 'config3': config3, 'parity': parity, 'sim': sim, 'cpu_baseline': cpu,
+            'roofline': roof, 'roofline_isolated': roof_iso, 'config2': config2, 'config3': config3, 'parity': parity, 'sim': sim, 'cpu_baseline': cpu,
         }
         print(json.dumps(line))
     if dist is not None:

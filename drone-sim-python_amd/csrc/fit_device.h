@@ -159,6 +159,7 @@ enum { PR_DX = 0, PR_DY = 4, PR_P2X = 8, PR_P2Y, PR_SAX, PR_SAY, PR_SBX, PR_SBY,
        PR_NEXT = PR_BOX + 4 };   // index of the last present extra obstacle + 1, + FIT_XBOX if there is a position box
                                  // (0: a trajectory with at most two obstacles and no box -- the fast path)
 #define FIT_XBOX 64
+#define FIT_XIN 128         // (sample_terms: position-row sums handed in by the caller)
 static_assert(PR_NEXT < FIT_PREP_STRIDE, "prep row overflow");
 
 struct ScenP {
@@ -335,9 +336,12 @@ __device__ __forceinline__ double sample_absw(const ScenP &s, const double Y[6])
 // out as (M[m][a], M[m][c], M[m][b], M[m][d]) (x-axis G1/G2 pair, y-axis G1/G2 pair), and so[m] row m of the 2x2
 // position block M_pos of the obstacle rows (oracle/fit.py curvature_blocks + the Gauss-Newton part).
 template <bool WANT_JAC>
+// xin != nullptr: further position rows that the caller has already summed over -- {sum h^2, sum o_x h, sum o_y h, sum o_x^2,
+// sum o_x o_y, sum o_y^2} with o = d row / d (x, y): the collision rows of a coupled group (partner_sums).  They join the
+// two contracted position rows like obstacles 2.. do.
 __device__ __forceinline__ double sample_terms(const ScenP &s, const double Y[6], double wpx,
                                                double wpy, double u[6], f32x4 coef[4], bool bank_sel = false,
-                                               float2 *so = nullptr) {
+                                               float2 *so = nullptr, const double *xin = nullptr) {
   const double cphi = s.cphimax > 0.0 ? (bank_sel ? s.cphimax : 0.0) : s.cphi;
   const double cphi2 = s.cphimax > 0.0 ? cphi * cphi : s.cphi2;
   const double x = Y[0], y = Y[1];
@@ -367,7 +371,8 @@ __device__ __forceinline__ double sample_terms(const ScenP &s, const double Y[6]
   // obstacles 2.. and the position box (rare): their rows only enter through sums -- cost, D^T r and the 2x2
   // position block
   double xh2 = 0.0, xux = 0.0, xuy = 0.0, xpxx = 0.0, xpxy = 0.0, xpyy = 0.0;
-  const int xcode = (int)s.ext[PR_NEXT - PR_EXT];
+  if (xin) { xh2 = xin[0]; xux = xin[1]; xuy = xin[2]; xpxx = xin[3]; xpxy = xin[4]; xpyy = xin[5]; }
+  const int xcode = (int)s.ext[PR_NEXT - PR_EXT] | (xin ? FIT_XIN : 0);
   const int next = xcode & (FIT_XBOX - 1);
   if (xcode & FIT_XBOX) {                             // rows w_b*dist(x, [xmin, xmax]), w_b*dist(y, [ymin, ymax])
     const double *bx = s.ext + (PR_BOX - PR_EXT);
@@ -476,6 +481,24 @@ __device__ __forceinline__ double sample_terms(const ScenP &s, const double Y[6]
     }
   }
   return cost;
+}
+
+// The collision rows of sample k against the coupled aircraft of the group as SUMS (cost, D^T r and the 2x2 Gauss-Newton
+// position block): out = {sum h^2, sum o_x h, sum o_y h, sum o_x^2, sum o_x o_y, sum o_y^2} -- sample_terms' xin.
+__device__ __forceinline__ void partner_sums(const ScenP &s, const GroupCtx &gc, int K, int k, double x, double y, double out[6]) {
+#pragma unroll
+  for (int i = 0; i < 6; ++i) out[i] = 0.0;
+  if (gc.pos && s.ccol > 0.0) {
+    for (int m = 0; m < gc.n_ac; ++m) {
+      if (m == gc.self || !((s.pmask >> m) & 1)) continue;
+      const double *pm = gc.pos + (size_t)(gc.gbase + m) * 2 * K;
+      const double ex = (x - pm[k]) * s.kc, ey = (y - pm[K + k]) * s.kc;
+      const double h = s.ccol * exp(-0.5 * (ex * ex + ey * ey));
+      const double ox = -h * ex * s.kc, oy = -h * ey * s.kc;
+      out[0] = fma(h, h, out[0]); out[1] = fma(ox, h, out[1]); out[2] = fma(oy, h, out[2]);
+      out[3] = fma(ox, ox, out[3]); out[4] = fma(ox, oy, out[4]); out[5] = fma(oy, oy, out[5]);
+    }
+  }
 }
 
 // Collision rows of sample k against the coupled aircraft of the group (CostCollision,

@@ -8,6 +8,7 @@
 // One wavefront per trajectory; the basis block shared by the whole batch is staged in LDS
 // once per workgroup; the phases themselves live in fit_phases.h.  Restates oracle/fit.py
 // (lm_solve, eval_normal, bgs_solve).
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -416,7 +417,7 @@ struct FusedLds {
   int qs, sp, big, cf, cfp; // inside a wave's block; `big` holds us + cf + cfp, then the image of J^T J / its factor
   int total;
 };
-static FusedLds fused_lds_layout(int K, int nq, int N, int wpb) {
+static FusedLds fused_lds_layout(int K, int nq, int N, int wpb, int nds = 0) {
   FusedLds L;
   const int gstr = nq + 1;
   int o = 0;
@@ -431,17 +432,18 @@ static FusedLds fused_lds_layout(int K, int nq, int N, int wpb) {
   const int us_bytes = align16(K * 6 * 8), cf_bytes = (K + 1) * 4 * 16;
   L.cf = w + us_bytes;
   L.cfp = L.cf + cf_bytes;                      // second-order mode: position-block records [K+1][2] float2
-  int big = us_bytes + cf_bytes + align16((K + 1) * 2 * 8);
+  // (coupled groups, fit_groups_kernel: the collision-row records [K+1][nds] float2 take the place of the second-order records)
+  int big = us_bytes + cf_bytes + align16((K + 1) * (nds > 2 ? nds : 2) * 8);
   if ((N + 3) * (N + 4) * 4 > big) big = (N + 3) * (N + 4) * 4;
   w = align16(w + big);
   L.wave_stride = w;
   L.total = o + wpb * w;
   return L;
 }
-static bool pick_fused_layout(int K, int nq, int N, int *wpb) {
+static bool pick_fused_layout(int K, int nq, int N, int *wpb, int nds = 0) {
   if (K > 64) return false;      // the fused kernel keeps one sample per lane
   for (int w = FIT_LM_WPB_MAX; w >= 4; --w)
-    if (fused_lds_layout(K, nq, N, w).total <= FIT_LDS_BYTES) { *wpb = w; return true; }
+    if (fused_lds_layout(K, nq, N, w, nds).total <= FIT_LDS_BYTES) { *wpb = w; return true; }
   return false;
 }
 
@@ -623,6 +625,192 @@ fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_budget,
     for (int i = 0; i < 5; ++i) atomicAdd(&stamps[8 + i], st_solve[i]);
   }
 #undef LM_STAMP
+}
+
+// ------------------------------------------------------------------------------------
+// Coupled groups (BASELINE configs[2]) in ONE persistent launch: a wavefront takes a whole scenario (group of n_ac aircraft,
+// consecutive trajectories) and runs the block Gauss-Seidel of oracle/fit.py bgs_solve on it by itself -- sweep after sweep,
+// aircraft after aircraft, each visit a restarted LM solve of at most inner_iters iterations with the partners' sampled
+// positions frozen -- until ITS OWN scenario stops moving (largest relative move of a sweep <= tol) or max_sweeps.  No
+// cross-wave synchronisation, no host round trips; the positions table pos [B][2][K] lives in HBM (L2) and is read and
+// written by the owning wave only.  The launch-pair driver ran every scenario as long as the slowest one and paid two
+// launches per iteration (7 700 launch pairs at 8 x 8192); a scenario that settles after 30 sweeps now costs 30.
+template <int NB, int NQ>
+__global__ void __launch_bounds__(64 * FIT_LM_WPB_MAX)
+fit_groups_kernel(int R, int n_ac, int nds, FitGeom g, FusedLds L, d2d_fit_opts opts, int max_sweeps, int inner_iters, double tol,
+                  const double *__restrict__ gG64, const double *__restrict__ pk, const float *__restrict__ gG32,
+                  const float *__restrict__ gWt, const double *__restrict__ prep, double *q_io, double *pos,
+                  double *__restrict__ cost_out, double *__restrict__ g_out, int32_t *__restrict__ flags,
+                  int32_t *__restrict__ sweeps_out, double *__restrict__ moved_out, int32_t *__restrict__ queue) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  constexpr int N = 16 * NB, NT = NB * (NB + 1) / 2;
+  double *G64 = reinterpret_cast<double *>(lds + L.G64);
+  stage(G64, gG64, 3 * g.K * g.gstr * 8);
+  stage(lds + L.G32, gG32, (3 * g.K + 1) * g.nq * 4);
+  stage(lds + L.Wt, gWt, NT * 256 * 4);
+  __syncthreads();
+  const float *Wt = reinterpret_cast<const float *>(lds + L.Wt);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int woff = L.wave0 + wave * L.wave_stride;
+  unsigned char *wl = lds + woff;
+  double *qs = reinterpret_cast<double *>(wl + L.qs);
+  double *sp = reinterpret_cast<double *>(wl + L.sp);
+  double *us = reinterpret_cast<double *>(wl + L.big);
+  f32x4 *cf = reinterpret_cast<f32x4 *>(wl + L.cf);
+  float *big = reinterpret_cast<float *>(wl + L.big);
+  const int n = 2 * g.nq;
+  const bool act = lane < n;
+  const int stride = gridDim.x * (blockDim.x >> 6);
+  auto next_index = [&](int r) -> int {
+    int t = 0;
+    if (lane == 0) t = stride + atomicAdd(queue, 1);
+    return __builtin_amdgcn_readfirstlane(t);
+  };
+  for (int r = blockIdx.x + gridDim.x * wave; (unsigned)r < (unsigned)R; r = next_index(r)) {
+    const int gbase = r * n_ac;
+    // sampled positions of every aircraft of the group at the start
+    for (int a = 0; a < n_ac; ++a) {
+      const int b = gbase + a;
+      const double *pkb = pk + (size_t)b * FIT_PK * g.K;
+      const double *qb = q_io + (size_t)b * n;
+      double x = 0.0, y = 0.0;
+      if (lane < g.K) {
+        x = pkb[lane]; y = pkb[g.K + lane];
+        const double *g0 = G64 + (size_t)lane * g.gstr;
+        for (int j = 0; j < g.nq; ++j) { x = fma(g0[j], qb[j], x); y = fma(g0[j], qb[g.nq + j], y); }
+        pos[(size_t)b * 2 * g.K + lane] = x; pos[(size_t)b * 2 * g.K + g.K + lane] = y;
+      }
+    }
+    __threadfence_block();
+    int sweep = 0, nev_total = 0;
+    double moved = 0.0;
+    bool settled = false;
+    for (sweep = 1; sweep <= max_sweeps; ++sweep) {
+      moved = 0.0;
+      if (sweep == D2D_GS_PRIO_AT) __builtin_amdgcn_s_setprio(2);      // a scenario that is still sweeping decides when the launch ends
+      for (int a = 0; a < n_ac; ++a) {
+        const int b = gbase + a;
+        const double *prow = prep + (size_t)b * FIT_PREP_STRIDE;
+        const double *pkb = pk + (size_t)b * FIT_PK * g.K;
+        const GroupCtx gc{pos, n_ac, a, gbase, nds};
+        double qi = act ? q_io[(size_t)b * n + lane] : 0.0;
+        const double q_start = qi;
+        double lam = D2D_LM_LAMBDA0, nu = 2.0;
+        int iters = 0, status = D2D_ST_RUNNING;
+        double c = 0.0, gi = 0.0;
+        f32x2 hrow[N / 2];
+#pragma unroll
+        for (int m = 0; m < N / 2; ++m) hrow[m] = f32x2{0.f, 0.f};
+        if (act) qs[q_slot(lane, g.nq)] = qi;
+        for (int i = lane; i < FIT_PREP_STRIDE; i += 64) sp[i] = prow[i];
+        double pkr[FIT_PK];
+#pragma unroll
+        for (int cc = 0; cc < FIT_PK; ++cc) pkr[cc] = lane < g.K ? pkb[(size_t)cc * g.K + lane] : 0.0;
+        wave_lds_sync();
+        c = uniform_d(eval_phase1_grp<NQ>(g, G64, pkr, pkb, sp, qs, us, cf, gc, lane));
+        bool fresh = true;
+        if (!(fabs(c) <= 1.79e308)) { status = D2D_ST_NONFINITE; fresh = false; }
+        while (status == D2D_ST_RUNNING || fresh) {
+          if (fresh) {
+            gi = eval_phase2<NQ>(g, G64, us, lane, 0);
+            fresh = false;
+            if (status != D2D_ST_RUNNING) break;
+            // (a visit that finds its aircraft stationary -- most visits of the late sweeps -- needs no Hessian)
+            if (iters >= inner_iters) break;
+            if (uniform_d(wave_max(fabs(gi))) <= opts.gtol) { status = D2D_ST_CONVERGED; break; }
+            f32x4 acc[NT];
+            jtj_mfma<NB, NQ, true>(g, lds, L.G32, gG32, woff + L.cf, lane, g.K, acc);
+            nev_total += 2;
+            wave_lds_sync();
+            const float ww = (float)(sp[PR_WWP] * sp[PR_WWP]);
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+              for (int rr = 0; rr < 4; ++rr) acc[t][rr] = fmaf(ww, Wt[(t * 4 + rr) * 64 + lane], acc[t][rr]);
+            tiles_to_image<N>(acc, big, lane);
+            image_put_rhs<N>(big, lane, gi);
+            wave_lds_sync();
+            image_row<N>(big, lane, hrow);
+            wave_lds_sync();
+          }
+          if (iters >= inner_iters) break;
+          const double gmax = uniform_d(wave_max(fabs(gi)));
+          if (gmax <= opts.gtol) { status = D2D_ST_CONVERGED; break; }
+          float dgi, dl;
+          const int ok = uniform_i(damped_solve<N>(hrow, lam, act, lane, big, dgi, dl) ? 1 : 0);
+          const double delta = (double)dl;
+          const double pred = uniform_d(wave_sum(delta * (lam * (double)dgi * delta - gi)));
+          const double dmax = uniform_d(wave_max(fabs(delta))), qmax = uniform_d(wave_max(fabs(qi)));
+          double ct = 0.0, pred_s = pred, alpha = 1.0, bt_a = 0.0, bt_b = 0.0;
+          bool fin = false, accept = false;
+          if (ok) {
+            for (int att = 0; att < 3; ++att) {
+              if (act) qs[q_slot(lane, g.nq)] = qi + alpha * delta;
+              wave_lds_sync();
+              const double ca = uniform_d(eval_phase1_grp<NQ>(g, G64, pkr, pkb, sp, qs, us, cf, gc, lane));
+              if (att == 0) {
+                ct = ca;
+                fin = (fabs(ct) <= 1.79e308) && (pred > 0.0);
+                if (fin && (c - ct) / pred > 0.0) { accept = true; break; }
+                if (!fin) break;
+                bt_a = uniform_d(-2.0 * wave_sum(gi * delta)); bt_b = bt_a - pred;
+                alpha = bt_first_alpha(bt_a, c, ct);
+              } else {
+                if ((fabs(ca) <= 1.79e308) && ca < c) { accept = true; ct = ca; pred_s = bt_a * alpha - bt_b * alpha * alpha; break; }
+                alpha = fmax(D2D_LM_BT_SHRINK * alpha, D2D_LM_BT_FLOOR);
+              }
+            }
+          }
+          const StepOutcome so = lm_update(ok != 0, fin, accept, accept ? alpha : 1.0, c, ct, pred, pred_s, dmax, qmax, lam, nu, opts);
+          ++iters;
+          lam = so.lam; nu = so.nu; status = so.status;
+          if (so.accept) { qi += alpha * delta; c = ct; fresh = true; }
+        }
+        // the visit is over: store q, publish this aircraft's positions for the partners, account the move
+        const double dq = uniform_d(wave_max(fabs(qi - q_start))), qa = uniform_d(wave_max(fabs(q_start)));
+        moved = fmax(moved, dq / (1.0 + qa));
+        if (act) { q_io[(size_t)b * n + lane] = qi; qs[q_slot(lane, g.nq)] = qi; }
+        wave_lds_sync();
+        if (lane < g.K) {
+          double Y[6];
+          flat_outputs_pk<NQ>(g, G64, qs, pkr, lane, Y);
+          pos[(size_t)b * 2 * g.K + lane] = Y[0]; pos[(size_t)b * 2 * g.K + g.K + lane] = Y[1];
+        }
+        __threadfence_block();
+      }
+      if (moved <= tol) { settled = true; break; }
+    }
+    if (sweep > max_sweeps) sweep = max_sweeps;
+    __builtin_amdgcn_s_setprio(0);
+    // per-aircraft sub-problem cost and gradient with everybody's final positions
+    for (int a = 0; a < n_ac; ++a) {
+      const int b = gbase + a;
+      const double *prow = prep + (size_t)b * FIT_PREP_STRIDE;
+      const double *pkb = pk + (size_t)b * FIT_PK * g.K;
+      const GroupCtx gc{pos, n_ac, a, gbase, nds};
+      const double qi = act ? q_io[(size_t)b * n + lane] : 0.0;
+      if (act) qs[q_slot(lane, g.nq)] = qi;
+      for (int i = lane; i < FIT_PREP_STRIDE; i += 64) sp[i] = prow[i];
+      double pkr[FIT_PK];
+#pragma unroll
+      for (int cc = 0; cc < FIT_PK; ++cc) pkr[cc] = lane < g.K ? pkb[(size_t)cc * g.K + lane] : 0.0;
+      wave_lds_sync();
+      const double c = uniform_d(eval_phase1_grp<NQ>(g, G64, pkr, pkb, sp, qs, us, cf, gc, lane));
+      const double gi = eval_phase2<NQ>(g, G64, us, lane, 0);
+      wave_lds_sync();
+      if (act) g_out[(size_t)b * n + lane] = gi;
+      if (lane == 0) {
+        cost_out[b] = c;
+        flags[4 * b + FL_STATUS] = settled ? D2D_ST_CONVERGED : D2D_ST_MAXITER;
+        flags[4 * b + FL_ITERS] = sweep;
+        flags[4 * b + FL_NEVAL] = (a == 0) ? nev_total : 0;
+      }
+    }
+    if (lane == 0) { sweeps_out[r] = sweep; moved_out[r] = moved; }
+  }
+  if (lane == 0) {
+    if (atomicAdd(queue + 1, 1) == stride - 1) { queue[0] = 0; queue[1] = 0; }
+  }
 }
 
 // ------------------------------------------------------------------------------------
@@ -1262,6 +1450,7 @@ int d2d_fit_plan_create(d2d_ctx *ctx, int S, int K, double duration, const doubl
   allow_big_lds(&fit_eval_kernel<3, 24, true>); allow_big_lds(&fit_eval_kernel<3, 24, false>);
   allow_big_lds(&fit_jtj_kernel<1, 0>); allow_big_lds(&fit_jtj_kernel<2, 0>); allow_big_lds(&fit_jtj_kernel<3, 0>); allow_big_lds(&fit_jtj_kernel<3, 24>);
   allow_big_lds(&fit_lm_long_kernel<3, 24>); allow_big_lds(&fit_lm_long_kernel<3, 0>); allow_big_lds(&fit_lm_long_kernel<2, 0>); allow_big_lds(&fit_lm_long_kernel<1, 0>);
+  allow_big_lds(&fit_groups_kernel<3, 24>);
   allow_big_lds(&fit_lm_kernel<3, 24, false>);
   allow_big_lds(&fit_lm_kernel<3, 24, true>);
   allow_big_lds(&fit_step_kernel<16>); allow_big_lds(&fit_step_kernel<32>); allow_big_lds(&fit_step_kernel<48>);
@@ -1601,6 +1790,54 @@ int d2d_fit_solve_groups(d2d_ctx *ctx, d2d_fit_plan *pl, int R, const double *sc
   if (int rc = launch_prep(ctx, pl, B, scen)) return rc;
   pl->prep_valid_for = nullptr;
   pl->active_B = 0;
+  // ---- one persistent launch: a wavefront per scenario runs the whole block Gauss-Seidel of its group (fit_groups_kernel)
+  int wpb_g = 0;
+  if (pl->nq == 24 && !getenv("D2D_FIT_SPLIT") && pick_fused_layout(pl->K, pl->nq, 48, &wpb_g)) {
+    const FusedLds L = fused_lds_layout(pl->K, pl->nq, 48, wpb_g);
+    const FitGeom gm = geom_of(pl);
+    int32_t *queue = ctx->counter_dev + 8;
+    D2D_CHECK_HIP(hipMemsetAsync(queue, 0, 2 * sizeof(int32_t), ctx->stream));
+    int32_t *d_sweeps = pl->d_order;                      // [R] scratch (any scheduling hint is dropped)
+    pl->order_B = 0;
+    double *d_moved = pl->d_lm;                           // [R] scratch
+    const int blocks = R < pl->n_cu ? R : pl->n_cu;
+    if (int rc = prof_begin(ctx, pl, 2)) return rc;
+    hipLaunchKernelGGL((fit_groups_kernel<3, 24>), dim3(blocks), dim3(64 * wpb_g), L.total, ctx->stream, R, n_ac, pl->nds, gm, L, o,
+                       max_sweeps, inner_iters, tol, pl->d_G, pl->d_pk, pl->d_G32, pl->d_W32, pl->d_prep, q, pl->d_pos, pl->d_cost,
+                       pl->d_g, pl->d_flags, d_sweeps, d_moved, queue);
+    D2D_LAUNCH_CHECK();
+    if (int rc = prof_end(ctx, pl)) return rc;
+    if (cost) D2D_CHECK_HIP(hipMemcpyAsync(cost, pl->d_cost, (size_t)B * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    const dim3 gBs((B + 255) / 256), b1s(256);
+    D2D_CHECK_HIP(hipMemsetAsync(ctx->stats_dev, 0, 4 * sizeof(double), ctx->stream));
+    hipLaunchKernelGGL(fit_stats_kernel, gBs, b1s, 0, ctx->stream, B, n, pl->d_cost, pl->d_g, pl->d_flags, ctx->stats_dev);
+    D2D_LAUNCH_CHECK();
+    D2D_CHECK_HIP(hipMemcpyAsync(ctx->stats_host, ctx->stats_dev, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<int32_t> hs(R);
+    std::vector<double> hm(R);
+    D2D_CHECK_HIP(hipMemcpyAsync(hs.data(), d_sweeps, (size_t)R * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    D2D_CHECK_HIP(hipMemcpyAsync(hm.data(), d_moved, (size_t)R * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    D2D_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    int smax = 0;
+    double mmax = 0.0;
+    for (int r = 0; r < R; ++r) { if (hs[r] > smax) smax = hs[r]; if (hm[r] > mmax) mmax = hm[r]; }
+    if (getenv("D2D_GROUPS_DIAG")) {                       // diagnostics: distribution of the sweeps over the scenarios
+      std::vector<int32_t> srt(hs);
+      std::sort(srt.begin(), srt.end());
+      long tot = 0;
+      int n_cap = 0;
+      for (int v : srt) { tot += v; n_cap += v >= max_sweeps; }
+      fprintf(stderr, "[groups] R=%d sweeps: mean %.1f p50 %d p90 %d p99 %d max %d, at the cap: %d scenarios\n", R, (double)tot / R,
+              srt[R / 2], srt[(size_t)R * 9 / 10], srt[(size_t)R * 99 / 100], srt[R - 1], n_cap);
+    }
+    if (stats) {
+      for (int i = 0; i < 4; ++i) stats[i] = ctx->stats_host[i];
+      stats[2] = mmax;                                    // the largest last-sweep move of any scenario
+    }
+    if (sweeps_done) *sweeps_done = smax;
+    return D2D_OK;
+  }
+  // ---- launch-pair path (other plan shapes): every scenario sweeps until the slowest one has settled
   const FitGeom gm = geom_of(pl);
   const dim3 gB((B + 255) / 256), b1(256), gR((R + 255) / 256);
   hipLaunchKernelGGL(fit_state_init_kernel, gB, b1, 0, ctx->stream, B, 0, 1, pl->d_lm, pl->d_flags, (int32_t *)nullptr);

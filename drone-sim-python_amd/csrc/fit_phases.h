@@ -83,6 +83,36 @@ __device__ __forceinline__ double eval_phase1_reg(const FitGeom &g, const double
   return cost;
 }
 
+// phase 1 of the coupled-group kernel (fit_groups_kernel; K <= 64): eval_phase1_reg plus the collision rows against the
+// partners' frozen positions.  Every collision row depends on (x, y) only, so -- like obstacles 2.. -- they join the two
+// contracted position rows through the 2x2 block sum o o^T (partner_sums -> sample_terms' xin): the MFMA pass of a coupled
+// aircraft is the same 300 instructions as an uncoupled one (as extra k-steps, 7 partners cost 600 more).  Gauss-Newton rows only.
+template <int NQ>
+__device__ __forceinline__ double eval_phase1_grp(const FitGeom &g, const double *G64, const double (&pkr)[FIT_PK],
+                                                  const double *__restrict__ pkb, const double *sp, const double *qs,
+                                                  double *us, f32x4 *cf, const GroupCtx &gc, int lane) {
+  double cacc = 0.0;
+  LAUNDER(lane);
+  const int k = lane;
+  int kbank = -1;
+  if (sp[PR_CPHIMAX] > 0.0) kbank = bank_argmax<NQ>(g, G64, pkb, qs, load_scenp(sp), lane);
+  if (k < g.K) {
+    double Y[6], u[6] = {0, 0, 0, 0, 0, 0}, xin[6];
+    f32x4 coef[4];
+    flat_outputs_pk<NQ>(g, G64, qs, pkr, k, Y);
+    const ScenP s = load_scenp(sp);
+    partner_sums(s, gc, g.K, k, Y[0], Y[1], xin);
+    cacc = sample_terms<true>(s, Y, pkr[6], pkr[7], u, coef, k == kbank, nullptr, xin);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) us[k * 6 + c] = u[c];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cf[k * 4 + r] = coef[r];
+  }
+  const double cost = wave_sum(cacc);
+  wave_lds_sync();
+  return cost;
+}
+
 // phase 2 (lane = unknown): (J^T r)[lane] = sum_k G_k^T u_k, three independent fp64 accumulation chains.
 // NQ > 0: nq is a compile-time constant, so every LDS read of a chunk of five samples carries an
 // immediate offset and the whole chunk (15 basis values + 15 u's) is requested before its FMAs run.

@@ -269,6 +269,8 @@ enum {
 #define D2D_LM_BT_SHRINK 0.25
 #define D2D_LM_BT_FLOOR 0.02
 #define D2D_LM_FAIL_MULT 8.0
+/* block Gauss-Seidel over coupled aircraft: a scenario still sweeping after GS_PRIO_AT sweeps raises its wave's priority */
+#define D2D_GS_PRIO_AT 40
 enum { D2D_ST_RUNNING = 0, D2D_ST_CONVERGED = 1, D2D_ST_MAXITER = 2, D2D_ST_NONFINITE = 3, D2D_ST_STALLED = 4 };
 
 typedef struct {
