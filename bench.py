@@ -53,6 +53,17 @@ ALG_FLOP_PER_EVAL = ROWS_CONTRACTED * NQ2 * (NQ2 + 1)      # M*P*(P+1), SURVEY.m
 JTJ_BYTES_PER_UNIT = 4 * K * 16 + 6 * 1024                  # contraction-only kernel: records read + tiles written
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of a hot kernel from the committed rocprofv3 PMC passes of THIS command (tools/profile_bench.sh ->
+    tools/condense_profile.py -> profiles/r02/04_bench_final_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate passes,
+    corrected as MI355X_MICROARCH.md prescribes).  bench.py cannot read hardware counters itself; None when the file is absent."""
+    try:
+        t = json.load(open(os.path.join(ROOT, 'profiles', 'r02', '04_bench_final_traffic.json')))[kernel][0]
+    except (OSError, KeyError, IndexError, ValueError):
+        return None, None
+    return t['fetch_bytes_per_launch'] + t['write_bytes_per_launch'], t
+
+
 def _plan_consts():
     from d2dhip import synth
     return synth.planner_timing(0, 4.9, 10)[2], synth.default_wref(OBJ_SCALE, K)
@@ -358,7 +369,7 @@ def main():
             ach = ALG_FLOP_PER_EVAL * n_evals / (lm_ms * 1e-3) / 1e12
             roof = {'bound': 'mfma', 'kernel': 'fit_lm_kernel<3,24> (fused LM loop: fp64 residual/J^T r, J^T J on v_mfma_f32_16x16x4_f32, fp32 Cholesky)',
                     'achieved': ach, 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / FP32_PEAK_TFLOPS,
-                    'traffic': None, 'traffic_note': 'per-launch PMC FETCH_SIZE / WRITE_SIZE of this kernel: profiles/ (bench.py cannot read PMC counters itself)',
+                    'traffic': pmc_traffic('fit_lm_kernel')[0], 'traffic_source': pmc_traffic('fit_lm_kernel')[1],
                     'alg_flop_per_unit': ALG_FLOP_PER_EVAL, 'units_per_launch_avg': n_evals / lm_n,
                     'avg_launch_us': 1e3 * lm_ms / lm_n, 'launches': int(lm_n), 'kernel_ms_total': lm_ms,
                     'note': 'achieved counts only the J^T J contraction (M*P*(P+1) per evaluation); the same kernel also does the '
@@ -390,7 +401,9 @@ def main():
         i4 = iso(dsc, q0, 20)
         roof_iso = {'bound': 'mfma', 'kernel': 'fit_jtj_kernel<3,24> (contraction only: fp32 row records HBM -> LDS, J^T J on v_mfma_f32_16x16x4_f32, '
                                                'tile-major store)', 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                    'alg_flop_per_unit': ALG_FLOP_PER_EVAL, 'alg_bytes_per_unit': JTJ_BYTES_PER_UNIT, 'traffic': None, **i4,
+                    'alg_flop_per_unit': ALG_FLOP_PER_EVAL, 'alg_bytes_per_unit': JTJ_BYTES_PER_UNIT,
+                    'traffic': pmc_traffic('fit_jtj_kernel')[0], 'traffic_source': pmc_traffic('fit_jtj_kernel')[1],
+                    'alg_bytes_per_launch': JTJ_BYTES_PER_UNIT * B, **i4,
                     'note': 'the whole kernel is the contraction (HIP events around the kernel only; rocprofv3 kernel trace in profiles/); '
                             'ceiling of frac = 0.766: the three diagonal 16x16 tiles are computed whole'}
         if world == 1 and a.config3_batch > B:

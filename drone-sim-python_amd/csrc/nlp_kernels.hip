@@ -475,8 +475,11 @@ nlp_solve_kernel(NlpDims d, d2d_nlp_opts o, const double *__restrict__ scen, con
   double rho = o.rho0, lam = D2D_LM_LAMBDA0, feas_prev = INFINITY;
   int total_inner = 0, status = D2D_ST_MAXITER;
   double err = 0.0, cost_ref = 0.0, feas = 0.0;
+  int n_stalled = 0;                        // outer iterations in a row at the largest penalty without feasibility progress
   for (int outer = 1; outer <= o.outer_max; ++outer) {
     const double tol_in = fmax(fmax(o.opt_tol, fmin(1e-1, 10.0 * mub)), D2D_NLP_GRAD_FLOOR * rho);
+    // merit value of the current point for this (mub, rho, mu): one sweep here, afterwards the accepted trial's value
+    double phi0 = nlp_merit(d, s, sc, partner, u, b, 0.0, rho, mub, nullptr, nullptr);
     for (int it = 0; it < o.inner_max; ++it) {
       ++total_inner;
       bool accepted = false, converged = false;
@@ -488,15 +491,15 @@ nlp_solve_kernel(NlpDims d, d2d_nlp_opts o, const double *__restrict__ scen, con
         double dphi, amax, az;
         nlp_backsolve(d, s, u, b, mub, tau, &dphi, &amax, &az);
         if (!(dphi < 0.0)) { lam = fmin(lam * 8.0, D2D_LM_LAMBDA_MAX); continue; }
-        const double phi0 = nlp_merit(d, s, sc, partner, u, b, 0.0, rho, mub, nullptr, nullptr);
-        double a = amax;
+        double a = amax, pt = 0.0;
         bool ok = false;
         for (int ls = 0; ls < 8; ++ls) {
-          const double pt = nlp_merit(d, s, sc, partner, u, b, a, rho, mub, nullptr, nullptr);
+          pt = nlp_merit(d, s, sc, partner, u, b, a, rho, mub, nullptr, nullptr);
           if (pt <= phi0 + 1e-4 * a * dphi) { ok = true; break; }
           a *= 0.5;
         }
         if (ok) {
+          phi0 = pt;
           nlp_apply(d, s, u, b, a, az, mub);
           if (a == amax) lam = fmax(lam / 3.0, D2D_LM_LAMBDA_MIN);
           accepted = true;
@@ -508,6 +511,10 @@ nlp_solve_kernel(NlpDims d, d2d_nlp_opts o, const double *__restrict__ scen, con
     }
     (void)nlp_merit(d, s, sc, partner, u, b, 0.0, rho, mub, &cost_ref, &feas);
     if (feas <= o.feas_tol && mub <= o.mub_min * 1.0001 && err <= tol_in) { status = D2D_ST_CONVERGED; break; }
+    // an infeasible problem (e.g. end points too far apart for v_max) sits at the largest penalty with its constraint violation
+    // no longer shrinking: give up instead of holding the whole batch for outer_max x inner_max steps
+    n_stalled = (rho >= D2D_NLP_RHO_MAX && feas > 0.5 * feas_prev && feas > 1e3 * o.feas_tol) ? n_stalled + 1 : 0;
+    if (n_stalled >= 3) { status = D2D_ST_STALLED; break; }
     // first-order multiplier update (lambda = 2 rho mu); the penalty grows when feasibility stalls
     const bool grow = feas > 0.25 * feas_prev && rho < D2D_NLP_RHO_MAX;
     {

@@ -247,6 +247,7 @@ def solve(pb, W0, verbose=False, rho0=RHO0, inner_max=INNER_MAX, outer_max=OUTER
     feas_prev = np.inf
     total_inner = 0
     status = 2
+    n_stalled = 0
     for outer in range(1, outer_max + 1):
         tol_in = max(opt_tol, min(1e-1, 10.0 * mub), GRAD_FLOOR * rho)
         for it in range(inner_max):
@@ -315,6 +316,11 @@ def solve(pb, W0, verbose=False, rho0=RHO0, inner_max=INNER_MAX, outer_max=OUTER
             print(f'outer {outer:2d} rho {rho:.1e} mub {mub:.1e} inner {it + 1:3d} cost {cost(pb, W):.10f} feas {feas:.2e} err {err:.2e} lam {lam:.1e}')
         if feas <= feas_tol and mub <= MUB_MIN * 1.0001 and err <= tol_in:
             status = 1
+            break
+        # an infeasible problem sits at the largest penalty with its violation no longer shrinking: give up (status 4)
+        n_stalled = n_stalled + 1 if (rho >= RHO_MAX and feas > 0.5 * feas_prev and feas > 1e3 * feas_tol) else 0
+        if n_stalled >= 3:
+            status = 4
             break
         mu = mu + c                                          # first-order multiplier update (lambda = 2 rho mu)
         if feas > 0.25 * feas_prev and rho < RHO_MAX:

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Condense the rocprofv3 output of tools/profile_bench.sh into the files committed under profiles/:
+  <prefix>_kernel_stats.csv        the kernel-trace --stats summary (as rocprofv3 wrote it)
+  <prefix>_pmc_summary.txt         per-kernel mean of every collected counter
+  <prefix>_traffic.json            per-launch HBM traffic of the hot kernels from the FETCH_SIZE / WRITE_SIZE passes, as
+                                   MI355X_MICROARCH.md prescribes (separate passes; the counters are in KiB; FETCH_SIZE of wide
+                                   coalesced streaming reads reports half the bytes on gfx950: doubled for the kernel whose
+                                   reads are 16-B-per-lane streams, left as is -- and flagged uncalibrated -- elsewhere)
+  python tools/condense_profile.py gpurun_out/r2_prof profiles/r02/04_bench_final"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+src, prefix = sys.argv[1], sys.argv[2]
+os.makedirs(os.path.dirname(prefix), exist_ok=True)
+shutil.copy(os.path.join(src, 'trace', 'bench_kernel_stats.csv'), prefix + '_kernel_stats.csv')
+if os.path.exists(os.path.join(src, 'bench.json')):
+    shutil.copy(os.path.join(src, 'bench.json'), prefix + '_under_rocprof.json')
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in sorted(glob.glob(os.path.join(src, 'pmc_*', '*counter_collection.csv'))):
+    for r in csv.DictReader(open(f)):
+        acc[r['Kernel_Name']][r['Counter_Name']].append(float(r['Counter_Value']))
+with open(prefix + '_pmc_summary.txt', 'w') as out:
+    for k in sorted(acc):
+        if not any(t in k for t in ('fit_', 'gvf_', 'track_', 'nlp_', 'gradient_')):
+            continue
+        out.write(k[:110] + '\n')
+        for c, v in sorted(acc[k].items()):
+            out.write(f'    {c:34s} launches={len(v):4d} mean={sum(v) / len(v):.6g} min={min(v):.6g} max={max(v):.6g}\n')
+traffic = {}
+for k, cs in acc.items():
+    if 'FETCH_SIZE' in cs and 'WRITE_SIZE' in cs:
+        name = 'fit_lm_kernel' if 'fit_lm_kernel' in k else ('fit_jtj_kernel' if 'fit_jtj_kernel' in k else None)
+        if name is None:
+            continue
+        fetch_kib = sum(cs['FETCH_SIZE']) / len(cs['FETCH_SIZE'])
+        write_kib = sum(cs['WRITE_SIZE']) / len(cs['WRITE_SIZE'])
+        wide = name == 'fit_jtj_kernel'                 # 16-B-per-lane streaming reads: FETCH_SIZE reports half of them
+        traffic.setdefault(name, []).append({
+            'kernel': k[:80], 'launches': len(cs['FETCH_SIZE']), 'fetch_bytes_per_launch': fetch_kib * 1024 * (2 if wide else 1),
+            'write_bytes_per_launch': write_kib * 1024, 'fetch_doubled': wide,
+            'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (KiB), separate passes, mean over the launches of the pass'
+                    + ('' if wide else '; 8-B-per-lane loads: FETCH_SIZE uncalibrated for this width (MI355X_MICROARCH.md)')})
+json.dump(traffic, open(prefix + '_traffic.json', 'w'), indent=1)
+print(open(prefix + '_pmc_summary.txt').read()[:3000])
+print(json.dumps(traffic, indent=1)[:2000])

@@ -5,11 +5,11 @@ set -o pipefail
 export TMPDIR=/tmp
 OUT=gpurun_out/${1:-prof_bench}
 mkdir -p $OUT
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python3 bench.py > $OUT/bench.json 2> $OUT/bench.err || exit 1
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python3 bench.py --no-cpu-baseline > $OUT/bench.json 2> $OUT/bench.err || exit 1
 tail -1 $OUT/bench.json | cut -c1-300
 for pass in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES SQ_INST_CYCLES_VMEM" "FETCH_SIZE" "WRITE_SIZE"; do
   tag=$(echo $pass | cut -d' ' -f1)
-  timeout -k 10 300 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $OUT/pmc_$tag -o bench -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc_$tag.json 2> $OUT/pmc_$tag.err || echo "pass $tag failed"
+  timeout -k 10 300 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $OUT/pmc_$tag -o bench -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-sim --no-groups --config3-batch 0 > $OUT/pmc_$tag.json 2> $OUT/pmc_$tag.err || echo "pass $tag failed"
   echo "pass $tag done"
 done
 ls -R $OUT | head -40
