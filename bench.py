@@ -434,21 +434,27 @@ def main():
         plan_g = d2dhip.FitPlan(ctx, S_, K, dur, synth.default_wref(1.0, K))
         dscg = ctx.dev(synth.circle_group_scenarios(n_ac, Rg, dur, K, seed=1).reshape(Rg * n_ac, -1))
         q0g = plan_g.init(dscg)
-        best, resg = 1e30, None
-        for rep in range(3):
+        best, cold, resg = 1e30, 1e30, None
+        for rep in range(5):
+            # reps 0-1: no scheduling hint (rep 0 also warms the launch up); reps 2-4: the scenarios that swept longest in the previous
+            # solve start first (d2d_fit_plan_set_group_order: the replanning pattern, like the order hint of the headline solve)
+            if rep == 2 and not a.no_order:
+                plan_g.group_order_from_last(Rg)
             qg = q0g.clone()
             torch.cuda.synchronize()
             tg = time.perf_counter()
             resg = plan_g.solve_groups(dscg, qg, n_ac, max_sweeps=120, inner_iters=8, tol=1e-10)
             torch.cuda.synchronize()
-            if rep:
+            if rep == 1:
+                cold = time.perf_counter() - tg
+            if rep >= 2:
                 best = min(best, time.perf_counter() - tg)
         config2 = {'workload': '8-drone circular formation x 8192 replicas (65 536 coupled trajectories), CostCollision rows between all pairs '
                                '(BASELINE configs[2]); block Gauss-Seidel per scenario in one persistent launch (fit_groups_kernel)',
                    'value': Rg / best, 'unit': 'scenarios/s', 'trajectories_per_s': Rg * n_ac / best, 'seconds': best,
                    'max_sweeps_used': int(resg[1]), 'last_sweep_max_rel_move': float(resg[2][2]), 'evaluations': float(resg[2][3]),
                    'jtj_frac_of_fp32_mfma_peak': ALG_FLOP_PER_EVAL * float(resg[2][3]) / best / 1e12 / FP32_PEAK_TFLOPS,
-                   'round1_seconds': 0.80}
+                   'seconds_without_order_hint': cold, 'round1_seconds': 0.80}
         plan_g.close()
         del dscg, q0g, qg
         torch.cuda.empty_cache()

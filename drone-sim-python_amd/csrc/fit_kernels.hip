@@ -641,7 +641,10 @@ fit_groups_kernel(int R, int n_ac, int nds, FitGeom g, FusedLds L, d2d_fit_opts 
                   const double *__restrict__ gG64, const double *__restrict__ pk, const float *__restrict__ gG32,
                   const float *__restrict__ gWt, const double *__restrict__ prep, double *q_io, double *pos,
                   double *__restrict__ cost_out, double *__restrict__ g_out, int32_t *__restrict__ flags,
-                  int32_t *__restrict__ sweeps_out, double *__restrict__ moved_out, int32_t *__restrict__ queue) {
+                  int32_t *__restrict__ sweeps_out, double *__restrict__ moved_out, int32_t *__restrict__ queue,
+                  const int32_t *__restrict__ order) {
+  // order != NULL: hand-out position i takes scenario order[i] (d2d_fit_plan_set_group_order: the scenarios that swept longest
+  // in a previous solve start first, so the tail of the launch is not one late straggler)
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   constexpr int N = 16 * NB, NT = NB * (NB + 1) / 2;
   double *G64 = reinterpret_cast<double *>(lds + L.G64);
@@ -666,7 +669,8 @@ fit_groups_kernel(int R, int n_ac, int nds, FitGeom g, FusedLds L, d2d_fit_opts 
     if (lane == 0) t = stride + atomicAdd(queue, 1);
     return __builtin_amdgcn_readfirstlane(t);
   };
-  for (int r = blockIdx.x + gridDim.x * wave; (unsigned)r < (unsigned)R; r = next_index(r)) {
+  for (int ri = blockIdx.x + gridDim.x * wave; (unsigned)ri < (unsigned)R; ri = next_index(ri)) {
+    const int r = order ? __builtin_amdgcn_readfirstlane(order[ri]) : ri;
     const int gbase = r * n_ac;
     // sampled positions of every aircraft of the group at the start
     for (int a = 0; a < n_ac; ++a) {
@@ -694,7 +698,6 @@ fit_groups_kernel(int R, int n_ac, int nds, FitGeom g, FusedLds L, d2d_fit_opts 
         const double *pkb = pk + (size_t)b * FIT_PK * g.K;
         const GroupCtx gc{pos, n_ac, a, gbase, nds};
         double qi = act ? q_io[(size_t)b * n + lane] : 0.0;
-        const double q_start = qi;
         double lam = D2D_LM_LAMBDA0, nu = 2.0;
         int iters = 0, status = D2D_ST_RUNNING;
         double c = 0.0, gi = 0.0;
@@ -767,9 +770,14 @@ fit_groups_kernel(int R, int n_ac, int nds, FitGeom g, FusedLds L, d2d_fit_opts 
           if (so.accept) { qi += alpha * delta; c = ct; fresh = true; }
         }
         // the visit is over: store q, publish this aircraft's positions for the partners, account the move
-        const double dq = uniform_d(wave_max(fabs(qi - q_start))), qa = uniform_d(wave_max(fabs(q_start)));
-        moved = fmax(moved, dq / (1.0 + qa));
-        if (act) { q_io[(size_t)b * n + lane] = qi; qs[q_slot(lane, g.nq)] = qi; }
+        {
+          int lane_io = lane;      // (laundered address; the start value is read back instead of being held across the LM loop)
+          LAUNDER(lane_io);
+          const double q_start = act ? q_io[(size_t)b * n + lane_io] : 0.0;
+          const double dq = uniform_d(wave_max(fabs(qi - q_start))), qa = uniform_d(wave_max(fabs(q_start)));
+          moved = fmax(moved, dq / (1.0 + qa));
+          if (act) { q_io[(size_t)b * n + lane_io] = qi; qs[q_slot(lane, g.nq)] = qi; }
+        }
         wave_lds_sync();
         if (lane < g.K) {
           double Y[6];
@@ -1217,7 +1225,7 @@ static void free_scratch(d2d_fit_plan *pl) {
     *p = nullptr;
   }
   pl->cap_B = 0;
-  pl->order_B = 0;
+  pl->order_B = 0; pl->gorder_R = 0; pl->gsweeps_R = 0;
 }
 
 // Scratch of a plan grows on demand.  A failed regrow leaves the plan with NO scratch (every pointer null, cap_B = 0):
@@ -1750,7 +1758,21 @@ int d2d_fit_plan_set_order(d2d_ctx *ctx, d2d_fit_plan *pl, int B, const int32_t 
   if (int rc = ensure_scratch(pl, B)) return rc;
   hipLaunchKernelGGL(fit_order_kernel, dim3(1), dim3(1024), 0, ctx->stream, B, iters, pl->d_order);
   D2D_LAUNCH_CHECK();
-  pl->order_B = B;
+  pl->order_B = B; pl->gorder_R = 0; pl->gsweeps_R = 0;
+  return D2D_OK;
+}
+
+int d2d_fit_plan_set_group_order(d2d_ctx *ctx, d2d_fit_plan *pl, int R, int from_last) {
+  D2D_REQUIRE(ctx && pl, "d2d_fit_plan_set_group_order: null argument");
+  if (!from_last) { pl->gorder_R = 0; return D2D_OK; }
+  D2D_REQUIRE(R >= 1 && pl->n_group >= 2, "d2d_fit_plan_set_group_order: needs R >= 1 and a plan in group mode");
+  if (pl->gsweeps_R != R) {
+    d2d_set_error("d2d_fit_plan_set_group_order: the last d2d_fit_solve_groups of this plan was not over R=%d scenarios", R);
+    return D2D_ESTATE;
+  }
+  hipLaunchKernelGGL(fit_order_kernel, dim3(1), dim3(1024), 0, ctx->stream, R, pl->d_order + R, pl->d_order);
+  D2D_LAUNCH_CHECK();
+  pl->gorder_R = R;
   return D2D_OK;
 }
 
@@ -1797,14 +1819,16 @@ int d2d_fit_solve_groups(d2d_ctx *ctx, d2d_fit_plan *pl, int R, const double *sc
     const FitGeom gm = geom_of(pl);
     int32_t *queue = ctx->counter_dev + 8;
     D2D_CHECK_HIP(hipMemsetAsync(queue, 0, 2 * sizeof(int32_t), ctx->stream));
-    int32_t *d_sweeps = pl->d_order;                      // [R] scratch (any scheduling hint is dropped)
+    // d_order [B >= 2R]: [0, R) the scenario hand-out order (if set), [R, 2R) the sweeps of this solve; a trajectory hint is dropped
+    int32_t *d_sweeps = pl->d_order + R;
     pl->order_B = 0;
+    const int32_t *gorder = (pl->gorder_R == R) ? pl->d_order : nullptr;
     double *d_moved = pl->d_lm;                           // [R] scratch
     const int blocks = R < pl->n_cu ? R : pl->n_cu;
     if (int rc = prof_begin(ctx, pl, 2)) return rc;
     hipLaunchKernelGGL((fit_groups_kernel<3, 24>), dim3(blocks), dim3(64 * wpb_g), L.total, ctx->stream, R, n_ac, pl->nds, gm, L, o,
                        max_sweeps, inner_iters, tol, pl->d_G, pl->d_pk, pl->d_G32, pl->d_W32, pl->d_prep, q, pl->d_pos, pl->d_cost,
-                       pl->d_g, pl->d_flags, d_sweeps, d_moved, queue);
+                       pl->d_g, pl->d_flags, d_sweeps, d_moved, queue, gorder);
     D2D_LAUNCH_CHECK();
     if (int rc = prof_end(ctx, pl)) return rc;
     if (cost) D2D_CHECK_HIP(hipMemcpyAsync(cost, pl->d_cost, (size_t)B * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
@@ -1835,6 +1859,7 @@ int d2d_fit_solve_groups(d2d_ctx *ctx, d2d_fit_plan *pl, int R, const double *sc
       stats[2] = mmax;                                    // the largest last-sweep move of any scenario
     }
     if (sweeps_done) *sweeps_done = smax;
+    pl->gsweeps_R = R;
     return D2D_OK;
   }
   // ---- launch-pair path (other plan shapes): every scenario sweeps until the slowest one has settled

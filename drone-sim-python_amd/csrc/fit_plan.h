@@ -35,6 +35,7 @@ struct d2d_fit_plan {
   int rows_B = 0;              // trajectories whose records d_rows holds
   int32_t *d_order = nullptr;  // [B] hand-out order of the persistent LM kernel (longest fits of the previous solve first)
   int order_B = 0;             // batch size the order was built for (0: none)
+  int gorder_R = 0, gsweeps_R = 0;   // coupled groups: d_order[0, R) holds a scenario order / d_order[R, 2R) the sweeps of the last solve
   int n_group = 1, nds = 0;    // aircraft per coupled group and padded collision-row slots per sample
   const double *prep_valid_for = nullptr;   // scen pointer d_prep was derived from
   // launch geometry chosen at plan creation from the LDS footprint

@@ -98,6 +98,7 @@ _SIGS = {
     'd2d_fit_iterate': (C.c_int, [_P, _P, C.c_int, _P, _P, C.POINTER(FitOpts), C.c_int, C.POINTER(C.c_int32)]),
     'd2d_fit_finish': (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P, _P, _P]),
     'd2d_fit_plan_set_order': (C.c_int, [_P, _P, C.c_int, _P]),
+    'd2d_fit_plan_set_group_order': (C.c_int, [_P, _P, C.c_int, C.c_int]),
     'd2d_fit_plan_set_groups': (C.c_int, [_P, C.c_int]),
     'd2d_fit_solve_groups': (C.c_int, [_P, _P, C.c_int, _P, _P, C.POINTER(FitOpts), C.c_int, C.c_int, C.c_double, _P,
                                        C.POINTER(C.c_int32), _P]),
@@ -464,6 +465,11 @@ class FitPlan:
 
     def clear_order(self):
         _check(self.ctx.lib.d2d_fit_plan_set_order(self.ctx.h, self.h, 0, None))
+
+    def group_order_from_last(self, R, enable=True):
+        """Scheduling hint for solve_groups over R scenarios: start the scenarios that swept longest in the LAST solve_groups
+        of this plan first (enable=False clears it)."""
+        _check(self.ctx.lib.d2d_fit_plan_set_group_order(self.ctx.h, self.h, R, 1 if enable else 0))
 
     def set_groups(self, n_ac):
         _check(self.ctx.lib.d2d_fit_plan_set_groups(self.h, n_ac))

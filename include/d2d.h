@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define D2D_VERSION 101
+#define D2D_VERSION 102
 
 /* error codes */
 #define D2D_OK 0
@@ -351,6 +351,10 @@ int d2d_fit_finish(d2d_ctx *ctx, d2d_fit_plan *plan, int B, const double *scen, 
  * persistent LM kernel then hands the fits out longest-first, so the launch does not end on one long fit that was drawn late.
  * Results do not depend on it (the fits are independent).  iters = NULL clears the hint; a batch of another size ignores it. */
 int d2d_fit_plan_set_order(d2d_ctx *ctx, d2d_fit_plan *plan, int B, const int32_t *iters);
+/* The same hint for d2d_fit_solve_groups over R scenarios: from_last != 0 orders the next solves by the sweep counts the
+ * LAST d2d_fit_solve_groups of this plan (same R) recorded, longest first; 0 clears it.  Results do not depend on it (the
+ * scenarios are independent).  D2D_ESTATE if the plan holds no sweep counts for R scenarios. */
+int d2d_fit_plan_set_group_order(d2d_ctx *ctx, d2d_fit_plan *plan, int R, int from_last);
 
 /* Coupled groups (BASELINE configs[2], multi_opt_planner): trajectories g*n_ac .. g*n_ac+n_ac-1 are
  * the aircraft of one scenario and repel each other through CostCollision rows

@@ -82,8 +82,19 @@ def test_groups_config2_batch_properties(env):
     dsc = ctx.dev(sc.reshape(R * n_ac, -1))
     q = plan.init(dsc)
     cost, sweeps, stats = plan.solve_groups(dsc, q, n_ac, max_sweeps=300, inner_iters=8, tol=1e-10)
-    plan.set_groups(1)
     assert stats[2] <= 1e-10 and sweeps < 300, (sweeps, stats)
     qh = q.cpu().numpy().reshape(R, n_ac, -1)
     np.testing.assert_array_equal(qh[0], qh[1])
     assert np.isfinite(cost.cpu().numpy()).all()
+    # the scheduling hint (longest-sweeping scenarios first) changes the hand-out order, never a result
+    plan.group_order_from_last(R)
+    q2 = plan.init(dsc)
+    cost2, sweeps2, stats2 = plan.solve_groups(dsc, q2, n_ac, max_sweeps=300, inner_iters=8, tol=1e-10)
+    assert sweeps2 == sweeps
+    np.testing.assert_array_equal(q2.cpu().numpy(), q.cpu().numpy())
+    np.testing.assert_array_equal(cost2.cpu().numpy(), cost.cpu().numpy())
+    plan.group_order_from_last(R, False)
+    import d2dhip
+    with pytest.raises(d2dhip.D2DError):
+        plan.group_order_from_last(R + 1)          # no sweep counts of a solve over R + 1 scenarios
+    plan.set_groups(1)
