@@ -6,20 +6,18 @@
 //   bounds      -> primal-dual log barrier (parameter mub, duals zL / zU), fraction-to-the-boundary rule
 //   inner step  -> damped Newton on the block-tridiagonal system  H/2 + Sigma/2 + lam |diag|  (Lagrangian Hessian incl. the
 //                  constraint curvature, 5x5 blocks, block Cholesky), backtracking line search on the barrier-AL merit function
-// One problem per LANE: the recursion over the N nodes is sequential, the batch supplies the parallelism; every per-node
-// quantity lives plane-major in HBM ([node][component][problem]: a wavefront touches 64 consecutive doubles).
+// One problem per WAVEFRONT.  Everything that is independent from node to node -- merit function, assembly of the Hessian
+// blocks, ratio tests, the update -- runs with lane = node (chunks of 64, DPP reductions); only the two block recursions
+// (Cholesky + forward substitution, back substitution) are serial in the nodes and run wave-uniform with the next node's
+// inputs requested a node ahead.  Per-problem data lives in planes of N doubles ([component][node]: coalesced for lane = node,
+// one broadcast request for the serial recursions); control flow is uniform, so no problem waits for another one's line search.
 #include <cmath>
+#include <cstdlib>
 
 #include "common.h"
 #include "fit_device.h"      // scenario row columns (D2D_SC_*), FIT_G, FIT_OBS_K
 
 #define NLP_NV 5
-#define NLP_FAC 45           // per node: L (15, lower triangle by rows), Lo (25, block (i, i-1) of the factor), y (5)
-
-struct NlpDims {
-  int B, N;
-  double h;
-};
 
 // per-problem scenario constants in registers
 struct NlpScen {
@@ -104,11 +102,56 @@ __device__ __forceinline__ void nlp_exp_terms(const NlpScen &s, const double *__
   }
 }
 
-struct NlpBuf {
-  double *W, *zL, *zU, *mu, *fac, *dw, *rhs;     // [N][5], [N][5], [N][5], [N][3], [N][45], [N][5], [N][5]  (x B, plane-major)
+// ---- per-problem workspace (WS_TOTAL * N doubles) ---------------------------------------------------------------------------
+// Data that the node-parallel phases touch lives in planes of N doubles ([component][node]: lane = node reads 64 consecutive
+// doubles).  What the two serial recursions read and write is NODE-major ([node][component]): one base address per node and
+// immediate offsets (plane-major, every component would need its own 64-bit address -- measured: that address arithmetic
+// alone cost more than the block arithmetic).
+enum {
+  WS_ZL = 0, WS_ZU = 5,                  // bound duals (5 + 5 planes)
+  WS_MU = 10,                            // scaled multiplier estimates (3 planes) unless the caller wants them (mult)
+  WS_DW = 13,                            // step (5 planes)
+  WS_RAW = 18,                           // assembled node, undamped (35 planes): rhs (5), D lower triangle by rows (15), E [a][k] (15)
+  WS_EL = 53,                            // local elimination of (phi, v) (17 planes): 1/l00, l10, 1/l11; Qt [j][k] (6); Rt [j][k] (6); tt (2)
+  WS_UP = 70,                            // what node i hands to node i-1 (9 planes): Rt^T Rt lower triangle (6), Rt^T tt (3)
+  WS_SIN = 79,                           // reduced node [N][18]: D' lower triangle (6), E' [a][k] (9), t' (3)
+  WS_SF = 97,                            // factor of the reduced system [N][18]: L (6, RECIPROCAL diagonal), Lo [a][k] (9), y (3)
+  WS_DS = 115,                           // reduced step [N][3]
+  WS_TOTAL = 118,
+  RAW_RHS = 0, RAW_D = 5, RAW_E = 20,
+  EL_LP = 0, EL_Q = 3, EL_R = 9, EL_T = 15,
+  UP_RR = 0, UP_RT = 6,
+  SIN_D = 0, SIN_E = 6, SIN_T = 15, SIN_N = 18,
+  SF_L = 0, SF_LO = 6, SF_Y = 15, SF_N = 18
 };
 
-#define NLP_AT(arr, C, i, c) (arr)[((long)(i) * (C) + (c)) * B + b]
+struct NlpProb {
+  int N;
+  double h;
+  double *W;                 // [5][N] node values
+  double *ws;                // WS_TOTAL * N doubles (see above)
+  double *mu;                // [3][N]
+  const double *partner;     // [2][N] or null
+};
+#define NLP_W(c, i) pb.W[(c) * pb.N + (i)]
+#define NLP_P(plane, i) pb.ws[(plane) * pb.N + (i)]
+#define NLP_MU(k, i) pb.mu[(k) * pb.N + (i)]
+#define NLP_DW(c, i) NLP_P(WS_DW + (c), i)
+#define NLP_RAW(k, i) NLP_P(WS_RAW + (k), i)
+#define NLP_EL(k, i) NLP_P(WS_EL + (k), i)
+#define NLP_UP(k, i) NLP_P(WS_UP + (k), i)
+#define NLP_SIN(k, i) pb.ws[(size_t)WS_SIN * pb.N + (i) * SIN_N + (k)]
+#define NLP_SF(k, i) pb.ws[(size_t)WS_SF * pb.N + (i) * SF_N + (k)]
+#define NLP_DS(k, i) pb.ws[(size_t)WS_DS * pb.N + (i) * 3 + (k)]
+
+// stores of one phase -> loads of the next phase by OTHER lanes of the same wavefront (one wavefront owns a problem)
+__device__ __forceinline__ void nlp_phase_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ double wave_min(double v) { return -wave_max(-v); }
 
 // collocation residual of node i (>= 1) from the states of node i-1 and the node itself (oracle/nlp.py constraints)
 __device__ __forceinline__ void nlp_constraint(const NlpScen &s, double h, const double wp[3], const double w[NLP_NV], double c[3]) {
@@ -122,69 +165,80 @@ __device__ __forceinline__ void nlp_constraint(const NlpScen &s, double h, const
 __device__ __forceinline__ bool nlp_fixed(int i, int N, int c) { return c < 3 && (i == 0 || i == N - 1); }
 
 // Merit function of the inner problem at W + a*dw: objective + rho sum (c + mu)^2 - mub sum log(slacks); +inf outside the box.
-// Also returns (a == 0 only) nothing else.  One sweep over the nodes.
-__device__ double nlp_merit(const NlpDims &d, const NlpScen &s, const double *__restrict__ sc, const double *__restrict__ partner,
-                            const NlpBuf &u, int b, double a, double rho, double mub, double *cost_ref_out, double *feas_out) {
-  const int B = d.B, N = d.N;
+// Node-parallel (lane = node, chunks of 64) + wave reductions.  All results are wave-uniform.
+__device__ double nlp_merit(const NlpProb &pb, const NlpScen &s, const double *__restrict__ sc, int lane, double a, double rho,
+                            double mub, double *cost_ref_out, double *feas_out) {
+  const int N = pb.N;
   double val = 0.0, bar = 0.0, cref = 0.0, feas = 0.0;
-  double wp[3] = {0, 0, 0};
-  bool inside = true;
-  for (int i = 0; i < N; ++i) {
-    double w[NLP_NV];
+  int outside = 0;
+  for (int i0 = 0; i0 < N; i0 += 64) {
+    const int i = i0 + lane;
+    if (i < N) {
+      double w[NLP_NV], wp[3] = {0, 0, 0};
 #pragma unroll
-    for (int c = 0; c < NLP_NV; ++c) w[c] = NLP_AT(u.W, NLP_NV, i, c) + (a != 0.0 ? a * NLP_AT(u.dw, NLP_NV, i, c) : 0.0);
+      for (int c = 0; c < NLP_NV; ++c) w[c] = NLP_W(c, i) + (a != 0.0 ? a * NLP_DW(c, i) : 0.0);
+      if (i >= 1) {
 #pragma unroll
-    for (int c = 0; c < NLP_NV; ++c) {
-      if (nlp_fixed(i, N, c)) continue;
-      if (s.lo[c] > -1e299) { const double sl = w[c] - s.lo[c]; inside = inside && sl > 0.0; bar += log(sl > 0.0 ? sl : 1.0); }
-      if (s.hi[c] < 1e299) { const double su = s.hi[c] - w[c]; inside = inside && su > 0.0; bar += log(su > 0.0 ? su : 1.0); }
-    }
-    const double dv = w[4] - s.vsp;
-    double obj = s.skv * dv * dv + s.skphi * w[3] * w[3];
-    cref += obj;
-    nlp_exp_terms(s, sc, partner, (long)i * 2 * B + b, B, w[0], w[1], obj, cref, nullptr, nullptr, nullptr, nullptr, nullptr);
-    val += obj;
-    if (i >= 1) {
-      double c3[3];
-      nlp_constraint(s, d.h, wp, w, c3);
+        for (int c = 0; c < 3; ++c) wp[c] = NLP_W(c, i - 1) + (a != 0.0 ? a * NLP_DW(c, i - 1) : 0.0);
+      }
+      double prod = 1.0;
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const double cm = c3[k] + NLP_AT(u.mu, 3, i, k);
-        val += rho * cm * cm;
-        feas = fmax(feas, fabs(c3[k]));
+      for (int c = 0; c < NLP_NV; ++c) {
+        if (nlp_fixed(i, N, c)) continue;
+        if (s.lo[c] > -1e299) { const double sl = w[c] - s.lo[c]; if (!(sl > 0.0)) outside = 1; prod *= (sl > 0.0 ? sl : 1.0); }
+        if (s.hi[c] < 1e299) { const double su = s.hi[c] - w[c]; if (!(su > 0.0)) outside = 1; prod *= (su > 0.0 ? su : 1.0); }
+      }
+      bar += log(prod);               // one log per node: at most ten slacks in [1e-12, 1e3], their product stays in range
+      const double dv = w[4] - s.vsp;
+      double obj = s.skv * dv * dv + s.skphi * w[3] * w[3];
+      cref += obj;
+      nlp_exp_terms(s, sc, pb.partner, i, N, w[0], w[1], obj, cref, nullptr, nullptr, nullptr, nullptr, nullptr);
+      val += obj;
+      if (i >= 1) {
+        double c3[3];
+        nlp_constraint(s, pb.h, wp, w, c3);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const double cm = c3[k] + NLP_MU(k, i);
+          val += rho * cm * cm;
+          feas = fmax(feas, fabs(c3[k]));
+        }
       }
     }
-    wp[0] = w[0]; wp[1] = w[1]; wp[2] = w[2];
   }
-  if (cost_ref_out) *cost_ref_out = cref;
-  if (feas_out) *feas_out = feas;
-  if (!inside || !(fabs(val) <= 1.79e308)) return INFINITY;
+  val = wave_sum(val); bar = wave_sum(bar);
+  if (cost_ref_out) *cost_ref_out = wave_sum(cref);
+  if (feas_out) *feas_out = wave_max(feas);
+  const bool any_out = __builtin_amdgcn_ballot_w64(outside != 0) != 0ull;
+  if (any_out || !(fabs(val) <= 1.79e308)) return INFINITY;
   return val - mub * bar;
 }
 
-// Sweep 1: assemble node by node (half gradient g, half Hessian blocks D, E with the constraint curvature), add the barrier
-// diagonal and the damping, block Cholesky + forward substitution; stores L, Lo, y and rhs.  Returns false if a pivot is not
-// positive.  err_out: barrier KKT error of the inner problem (stationarity with the duals, complementarity).
-__device__ bool nlp_factor(const NlpDims &d, const NlpScen &s, const double *__restrict__ sc, const double *__restrict__ partner,
-                           const NlpBuf &u, int b, double rho, double mub, double lam, double *err_out) {
-  const int B = d.B, N = d.N;
-  const double h = d.h, ih = 1.0 / h;
-  double Lp[15], yp[NLP_NV];                    // factor of the previous node's diagonal block, its forward-substituted rhs
-  double wp[3] = {0, 0, 0}, wc[NLP_NV], wn[NLP_NV];
-  double cc[3] = {0, 0, 0}, cn[3] = {0, 0, 0};  // (c + mu) of the constraint that ends at this node / at the next one
-  double Ac[3][NLP_NV];                         // Jacobian of the current constraint wrt this node
+// Assembly (node-parallel): half gradient g, half Hessian blocks D (diagonal) and E (i, i-1) of the barrier-AL Lagrangian incl.
+// the constraint curvature, barrier diagonal, right-hand side; barrier KKT error of the inner problem (wave-uniform return).
+// The damping is NOT in D: the factorisation adds it (a retry with a larger damping needs no re-assembly).
+__device__ double nlp_assemble(const NlpProb &pb, const NlpScen &s, const double *__restrict__ sc, int lane, double rho, double mub) {
+  const int N = pb.N;
+  const double h = pb.h, ih = 1.0 / h;
   double err = 0.0;
-  bool ok = true;
-#pragma unroll
-  for (int c = 0; c < NLP_NV; ++c) wc[c] = NLP_AT(u.W, NLP_NV, 0, c);
-  for (int i = 0; i < N; ++i) {
+  for (int i0 = 0; i0 < N; i0 += 64) {
+    const int i = i0 + lane;
+    if (i >= N) continue;
     const bool has_next = i + 1 < N;
+    double wp[3] = {0, 0, 0}, wc[NLP_NV], wn[NLP_NV] = {0, 0, 0, 0, 1};
+    double cc[3] = {0, 0, 0}, cn[3] = {0, 0, 0};     // (c + mu) of the constraint that ends at this node / at the next one
+#pragma unroll
+    for (int c = 0; c < NLP_NV; ++c) wc[c] = NLP_W(c, i);
+    if (i >= 1) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) wp[c] = NLP_W(c, i - 1);
+    }
     if (has_next) {
 #pragma unroll
-      for (int c = 0; c < NLP_NV; ++c) wn[c] = NLP_AT(u.W, NLP_NV, i + 1, c);
+      for (int c = 0; c < NLP_NV; ++c) wn[c] = NLP_W(c, i + 1);
       nlp_constraint(s, h, wc, wn, cn);
 #pragma unroll
-      for (int k = 0; k < 3; ++k) cn[k] += NLP_AT(u.mu, 3, i + 1, k);
+      for (int k = 0; k < 3; ++k) cn[k] += NLP_MU(k, i + 1);
     }
     double g[NLP_NV] = {0, 0, 0, 0, 0};
     double D[NLP_NV][NLP_NV];
@@ -192,12 +246,11 @@ __device__ bool nlp_factor(const NlpDims &d, const NlpScen &s, const double *__r
     for (int a = 0; a < NLP_NV; ++a)
 #pragma unroll
       for (int c = 0; c < NLP_NV; ++c) D[a][c] = 0.0;
-    // cost rows
     D[4][4] += s.skv; g[4] += s.skv * (wc[4] - s.vsp);
     D[3][3] += s.skphi; g[3] += s.skphi * wc[3];
     {
       double obj = 0.0, cref = 0.0;
-      nlp_exp_terms(s, sc, partner, (long)i * 2 * B + b, B, wc[0], wc[1], obj, cref, &g[0], &g[1], &D[0][0], &D[0][1], &D[1][1]);
+      nlp_exp_terms(s, sc, pb.partner, i, N, wc[0], wc[1], obj, cref, &g[0], &g[1], &D[0][0], &D[0][1], &D[1][1]);
       D[1][0] = D[0][1];
     }
     double E[NLP_NV][3];                        // block (i, i-1): only the (x, y, psi) columns of node i-1 are non-zero
@@ -207,6 +260,10 @@ __device__ bool nlp_factor(const NlpDims &d, const NlpScen &s, const double *__r
       double sp, cp;
       sincos(wc[2], &sp, &cp);
       const double tp = tan(wc[3]), vi = wc[4], sec2 = 1.0 + tp * tp;
+      cc[0] = (wc[0] - wp[0]) * ih - vi * cp + s.wx + NLP_MU(0, i);
+      cc[1] = (wc[1] - wp[1]) * ih - vi * sp + s.wy + NLP_MU(1, i);
+      cc[2] = (wc[2] - wp[2]) * ih - FIT_G / vi * tp + NLP_MU(2, i);
+      double Ac[3][NLP_NV];                     // Jacobian of the constraint wrt this node
 #pragma unroll
       for (int k = 0; k < 3; ++k)
 #pragma unroll
@@ -237,26 +294,23 @@ __device__ bool nlp_factor(const NlpDims &d, const NlpScen &s, const double *__r
       for (int k = 0; k < 3; ++k) { D[k][k] += rho * ih * ih; g[k] += -rho * cn[k] * ih; }
     }
     // barrier terms, stationarity / complementarity error, right-hand side
-    double rhs[NLP_NV];
 #pragma unroll
     for (int c = 0; c < NLP_NV; ++c) {
       const bool fx = nlp_fixed(i, N, c);
       double sig = 0.0, r = -2.0 * g[c], st = 2.0 * g[c];
       if (!fx && s.lo[c] > -1e299) {
-        const double sl = wc[c] - s.lo[c], z = NLP_AT(u.zL, NLP_NV, i, c);
-        sig += z / sl; r += mub / sl; st -= z;
+        const double sl = wc[c] - s.lo[c], z = NLP_P(WS_ZL + c, i), isl = 1.0 / sl;
+        sig += z * isl; r += mub * isl; st -= z;
         err = fmax(err, fabs(z * sl - mub));
       }
       if (!fx && s.hi[c] < 1e299) {
-        const double su = s.hi[c] - wc[c], z = NLP_AT(u.zU, NLP_NV, i, c);
-        sig += z / su; r -= mub / su; st += z;
+        const double su = s.hi[c] - wc[c], z = NLP_P(WS_ZU + c, i), isu = 1.0 / su;
+        sig += z * isu; r -= mub * isu; st += z;
         err = fmax(err, fabs(z * su - mub));
       }
       if (!fx) err = fmax(err, fabs(st));
-      rhs[c] = fx ? 0.0 : r;
-      NLP_AT(u.rhs, NLP_NV, i, c) = rhs[c];
+      NLP_RAW(RAW_RHS + c, i) = fx ? 0.0 : r;
       D[c][c] += 0.5 * sig;
-      D[c][c] += lam * fmax(fabs(D[c][c]), 1e-12);
       if (fx) {
 #pragma unroll
         for (int a = 0; a < NLP_NV; ++a) { D[c][a] = 0.0; D[a][c] = 0.0; }
@@ -265,48 +319,171 @@ __device__ bool nlp_factor(const NlpDims &d, const NlpScen &s, const double *__r
         for (int k = 0; k < 3; ++k) E[c][k] = 0.0;
       }
     }
-    if (i >= 1 && (i - 1 == 0)) {               // columns of E that belong to fixed variables of node i-1
+    if (i == 1) {                               // columns of E that belong to the fixed variables of node 0
 #pragma unroll
       for (int a = 0; a < NLP_NV; ++a) { E[a][0] = 0.0; E[a][1] = 0.0; E[a][2] = 0.0; }
     }
-    // Lo = E Lp^-T (row a of Lo solves Lp x = E[a,:]^T), S = D - Lo Lo^T, L = chol(S), y = L^-1 (rhs/2 - Lo yp)
-    double Lo[NLP_NV][NLP_NV];
-#pragma unroll
-    for (int a = 0; a < NLP_NV; ++a)
-#pragma unroll
-      for (int c = 0; c < NLP_NV; ++c) Lo[a][c] = 0.0;
-    double t[NLP_NV];
-#pragma unroll
-    for (int c = 0; c < NLP_NV; ++c) t[c] = 0.5 * rhs[c];
-    if (i >= 1) {
-#pragma unroll
-      for (int a = 0; a < NLP_NV; ++a) {
-#pragma unroll
-        for (int c = 0; c < NLP_NV; ++c) {
-          double v = c < 3 ? E[a][c] : 0.0;
-#pragma unroll
-          for (int k = 0; k < c; ++k) v -= Lp[c * (c + 1) / 2 + k] * Lo[a][k];
-          Lo[a][c] = v / Lp[c * (c + 1) / 2 + c];
-        }
-      }
-#pragma unroll
-      for (int a = 0; a < NLP_NV; ++a) {
-#pragma unroll
-        for (int c = 0; c < NLP_NV; ++c) {
-          double v = 0.0;
-#pragma unroll
-          for (int k = 0; k < NLP_NV; ++k) v += Lo[a][k] * Lo[c][k];
-          D[a][c] -= v;
-        }
-        double v = 0.0;
-#pragma unroll
-        for (int k = 0; k < NLP_NV; ++k) v += Lo[a][k] * yp[k];
-        t[a] -= v;
-      }
-    }
-    double L[15];
 #pragma unroll
     for (int a = 0; a < NLP_NV; ++a) {
+#pragma unroll
+      for (int c = 0; c <= a; ++c) NLP_RAW(RAW_D + a * (a + 1) / 2 + c, i) = D[a][c];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) NLP_RAW(RAW_E + a * 3 + k, i) = E[a][k];
+    }
+  }
+  return wave_max(err);
+}
+
+// 1/sqrt(v), v > 0 (normal range): hardware estimate + two Newton steps (the pivots of the serial recursion are a dependent
+// chain -- the library's sqrt followed by a division is four times as long)
+__device__ __forceinline__ double nlp_rsqrt(double v) {
+  double y = __builtin_amdgcn_rsq(v);
+  const double hv = 0.5 * v;
+  y = fma(y, fma(-hv * y, y, 0.5), y);
+  y = fma(y, fma(-hv * y, y, 0.5), y);
+  return y;
+}
+
+// The Newton system  M dw = rhs / 2  (M: block tridiagonal, 5x5 blocks D_i + damping, sub-diagonal blocks E_i whose only
+// non-zero columns are x, y, psi of node i-1).  phi_i and v_i are coupled to (x, y, psi) of nodes i and i-1 only and to no
+// other node's phi, v: they are eliminated NODE BY NODE IN PARALLEL (2x2 Cholesky + Schur complement), which leaves a block
+// tridiagonal system with 3x3 blocks in (x, y, psi) for the serial recursion -- 80 instead of 280 fp64 operations per node on
+// the serial chain.
+// Pass A (lane = node): P = LP LP^T, Qt = LP^-1 M[pv, s_i], Rt = LP^-1 M[pv, s_{i-1}], tt = LP^-1 rhs_pv / 2; what node i-1 gets.
+// Returns false (wave-uniform) if a 2x2 pivot is not positive.
+__device__ bool nlp_eliminate_a(const NlpProb &pb, int lane, double lam) {
+  const int N = pb.N;
+  int bad = 0;
+  for (int i0 = 0; i0 < N; i0 += 64) {
+    const int i = i0 + lane;
+    if (i >= N) continue;
+    double P00 = NLP_RAW(RAW_D + 9, i), P10 = NLP_RAW(RAW_D + 13, i), P11 = NLP_RAW(RAW_D + 14, i);     // (3,3), (4,3), (4,4)
+    P00 += lam * fmax(fabs(P00), 1e-12);
+    P11 += lam * fmax(fabs(P11), 1e-12);
+    if (!(P00 > 0.0)) { bad = 1; P00 = 1.0; }
+    const double i00 = nlp_rsqrt(P00), l10 = P10 * i00;
+    double v11 = P11 - l10 * l10;
+    if (!(v11 > 0.0)) { bad = 1; v11 = 1.0; }
+    const double i11 = nlp_rsqrt(v11);
+    NLP_EL(EL_LP + 0, i) = i00; NLP_EL(EL_LP + 1, i) = l10; NLP_EL(EL_LP + 2, i) = i11;
+    double Qt[2][3], Rt[2][3], tt[2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const double q0 = NLP_RAW(RAW_D + 6 + k, i), q1 = NLP_RAW(RAW_D + 10 + k, i);      // rows 3 and 4 of the lower triangle
+      Qt[0][k] = q0 * i00; Qt[1][k] = (q1 - l10 * Qt[0][k]) * i11;
+      const double r0 = NLP_RAW(RAW_E + 9 + k, i), r1 = NLP_RAW(RAW_E + 12 + k, i);      // E[3][k], E[4][k]
+      Rt[0][k] = r0 * i00; Rt[1][k] = (r1 - l10 * Rt[0][k]) * i11;
+    }
+    tt[0] = 0.5 * NLP_RAW(RAW_RHS + 3, i) * i00;
+    tt[1] = (0.5 * NLP_RAW(RAW_RHS + 4, i) - l10 * tt[0]) * i11;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { NLP_EL(EL_Q + j * 3 + k, i) = Qt[j][k]; NLP_EL(EL_R + j * 3 + k, i) = Rt[j][k]; }
+      NLP_EL(EL_T + j, i) = tt[j];
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+      for (int c = 0; c <= a; ++c) NLP_UP(UP_RR + a * (a + 1) / 2 + c, i) = Rt[0][a] * Rt[0][c] + Rt[1][a] * Rt[1][c];
+      NLP_UP(UP_RT + a, i) = Rt[0][a] * tt[0] + Rt[1][a] * tt[1];
+    }
+  }
+  return __builtin_amdgcn_ballot_w64(bad != 0) == 0ull;
+}
+// Pass B (lane = node): the reduced node  D' = D_ss + damping - Qt^T Qt - (Rt^T Rt)_{i+1},  E' = E_ss - Qt^T Rt,
+// t' = rhs_s / 2 - Qt^T tt - (Rt^T tt)_{i+1}  -> node-major input of the serial recursion.
+__device__ void nlp_eliminate_b(const NlpProb &pb, int lane, double lam) {
+  const int N = pb.N;
+  for (int i0 = 0; i0 < N; i0 += 64) {
+    const int i = i0 + lane;
+    if (i >= N) continue;
+    const bool has_next = i + 1 < N;
+    double Qt[2][3], Rt[2][3], tt[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { Qt[j][k] = NLP_EL(EL_Q + j * 3 + k, i); Rt[j][k] = NLP_EL(EL_R + j * 3 + k, i); }
+      tt[j] = NLP_EL(EL_T + j, i);
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+      for (int c = 0; c <= a; ++c) {
+        double d = NLP_RAW(RAW_D + a * (a + 1) / 2 + c, i);
+        if (a == c && !nlp_fixed(i, N, a)) d += lam * fmax(fabs(d), 1e-12);
+        d -= Qt[0][a] * Qt[0][c] + Qt[1][a] * Qt[1][c];
+        if (has_next) d -= NLP_UP(UP_RR + a * (a + 1) / 2 + c, i + 1);
+        NLP_SIN(SIN_D + a * (a + 1) / 2 + c, i) = d;
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) NLP_SIN(SIN_E + a * 3 + k, i) = NLP_RAW(RAW_E + a * 3 + k, i) - (Qt[0][a] * Rt[0][k] + Qt[1][a] * Rt[1][k]);
+      double t = 0.5 * NLP_RAW(RAW_RHS + a, i) - (Qt[0][a] * tt[0] + Qt[1][a] * tt[1]);
+      if (has_next) t -= NLP_UP(UP_RT + a, i + 1);
+      NLP_SIN(SIN_T + a, i) = t;
+    }
+  }
+}
+
+// Serial recursion 1 (forward over the nodes; every lane computes and stores the same values): block Cholesky of the reduced
+// block-tridiagonal matrix and the forward substitution.  Lo = E' Lp^-T, S = D' - Lo Lo^T, L = chol(S), y = L^-1 (t' - Lo yp).
+// The inputs of node i+1 are requested before node i is processed (nothing else hides the memory latency: one wave per SIMD).
+struct NlpNodeIn {
+  double v[SIN_N];
+};
+// (own functions, not inlined: inside the solver's loop nest the compiler spilled a dozen scalar registers around every node of
+// the recursion; global address space stated explicitly: through a generic pointer the loads would be FLAT ones, whose waits
+// also wait for the stores)
+typedef __attribute__((address_space(1))) double gdouble;
+__device__ __attribute__((noinline)) bool nlp_factor(double *sin_generic, double *sf_generic, int N) {
+  const gdouble *sin = (const gdouble *)sin_generic;
+  gdouble *sf = (gdouble *)sf_generic;
+#define NLP_SIN_(k, i) sin[(i) * SIN_N + (k)]
+#define NLP_SF_(k, i) sf[(i) * SF_N + (k)]
+  auto nlp_load_node = [&](int i, NlpNodeIn &n) {
+#pragma unroll
+    for (int k = 0; k < SIN_N; ++k) n.v[k] = NLP_SIN_(k, i);
+  };
+  double Lp[6], yp[3];                         // factor of the previous node's diagonal block (reciprocal diagonal), its y
+#pragma unroll
+  for (int k = 0; k < 6; ++k) Lp[k] = 0.0;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) yp[c] = 0.0;
+  bool ok = true;
+  // Ring of four node buffers, the loop unrolled by four: node i+3 is requested before node i is processed (one node's arithmetic
+  // is shorter than an L2 round trip), and no buffer is ever copied.
+  NlpNodeIn buf[4];
+  nlp_load_node(0, buf[0]); nlp_load_node(N > 1 ? 1 : N - 1, buf[1]); nlp_load_node(N > 2 ? 2 : N - 1, buf[2]);
+  // vmcnt(0) before the loop: the wait at the loop head has to serve both ways in; coming from here with the first nodes still
+  // in flight it would be stricter than the back edge needs, and on the back edge it would then also wait for stores
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  for (int i0 = 0; i0 < N; i0 += 4) {
+#pragma unroll
+   for (int u = 0; u < 4; ++u) {
+    const int i = i0 + u;
+    if (i >= N) break;
+    nlp_load_node(i + 3 < N ? i + 3 : N - 1, buf[(u + 3) & 3]);
+    const NlpNodeIn &cur = buf[u];
+    double Lo[3][3], t[3], D[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        double v = cur.v[SIN_E + a * 3 + c];
+#pragma unroll
+        for (int k = 0; k < c; ++k) v -= Lp[c * (c + 1) / 2 + k] * Lo[a][k];
+        Lo[a][c] = v * Lp[c * (c + 1) / 2 + c];           // (the diagonal slots hold 1 / L_cc; node 0: Lp = 0 -> Lo = 0)
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+      for (int c = 0; c <= a; ++c) D[a][c] = cur.v[SIN_D + a * (a + 1) / 2 + c] - (Lo[a][0] * Lo[c][0] + Lo[a][1] * Lo[c][1] + Lo[a][2] * Lo[c][2]);
+      t[a] = cur.v[SIN_T + a] - (Lo[a][0] * yp[0] + Lo[a][1] * yp[1] + Lo[a][2] * yp[2]);
+    }
+    double L[6];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
 #pragma unroll
       for (int c = 0; c <= a; ++c) {
         double v = D[a][c];
@@ -314,145 +491,193 @@ __device__ bool nlp_factor(const NlpDims &d, const NlpScen &s, const double *__r
         for (int k = 0; k < c; ++k) v -= L[a * (a + 1) / 2 + k] * L[c * (c + 1) / 2 + k];
         if (a == c) {
           if (!(v > 0.0)) { ok = false; v = 1.0; }
-          L[a * (a + 1) / 2 + a] = sqrt(v);
+          L[a * (a + 1) / 2 + a] = nlp_rsqrt(v);           // the factor keeps the RECIPROCAL diagonal: every later use divides by it
         } else {
-          L[a * (a + 1) / 2 + c] = v / L[c * (c + 1) / 2 + c];
+          L[a * (a + 1) / 2 + c] = v * L[c * (c + 1) / 2 + c];
         }
       }
     }
-    double y[NLP_NV];
+    double y[3];
 #pragma unroll
-    for (int a = 0; a < NLP_NV; ++a) {
+    for (int a = 0; a < 3; ++a) {
       double v = t[a];
 #pragma unroll
       for (int k = 0; k < a; ++k) v -= L[a * (a + 1) / 2 + k] * y[k];
-      y[a] = v / L[a * (a + 1) / 2 + a];
+      y[a] = v * L[a * (a + 1) / 2 + a];
     }
+    // (every lane stores the same values to the same address: a store under `if (lane == 0)` sits behind a branch, and the wait
+    // for the next node's loads then also waits for these stores -- vmcnt counts in order and the compiler cannot count them)
 #pragma unroll
-    for (int k = 0; k < 15; ++k) NLP_AT(u.fac, NLP_FAC, i, k) = L[k];
+    for (int k = 0; k < 6; ++k) NLP_SF_(SF_L + k, i) = L[k];
 #pragma unroll
-    for (int a = 0; a < NLP_NV; ++a)
+    for (int a = 0; a < 3; ++a)
 #pragma unroll
-      for (int c = 0; c < NLP_NV; ++c) NLP_AT(u.fac, NLP_FAC, i, 15 + a * NLP_NV + c) = Lo[a][c];
+      for (int c = 0; c < 3; ++c) NLP_SF_(SF_LO + a * 3 + c, i) = Lo[a][c];
 #pragma unroll
-    for (int a = 0; a < NLP_NV; ++a) NLP_AT(u.fac, NLP_FAC, i, 40 + a) = y[a];
-    // slide the window
+    for (int a = 0; a < 3; ++a) NLP_SF_(SF_Y + a, i) = y[a];
 #pragma unroll
-    for (int k = 0; k < 15; ++k) Lp[k] = L[k];
+    for (int k = 0; k < 6; ++k) Lp[k] = L[k];
 #pragma unroll
-    for (int a = 0; a < NLP_NV; ++a) yp[a] = y[a];
-    wp[0] = wc[0]; wp[1] = wc[1]; wp[2] = wc[2];
-#pragma unroll
-    for (int c = 0; c < NLP_NV; ++c) wc[c] = wn[c];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) cc[k] = cn[k];
+    for (int a = 0; a < 3; ++a) yp[a] = y[a];
+   }
   }
-  (void)wp;
-  *err_out = err;
   return ok;
 }
 
-// Sweep 2 (backward): dw_i = L_i^-T (y_i - Lo_{i+1}^T dw_{i+1}); directional derivative of the merit function, largest primal
-// step (fraction to the boundary), and the dual steps' largest fraction.
-__device__ void nlp_backsolve(const NlpDims &d, const NlpScen &s, const NlpBuf &u, int b, double mub, double tau, double *dphi_out,
-                              double *amax_out, double *az_out) {
-  const int B = d.B, N = d.N;
-  double dn[NLP_NV] = {0, 0, 0, 0, 0}, Lon[NLP_NV][NLP_NV];
-  double dphi = 0.0, amax = 1.0, az = 1.0;
-  for (int i = N - 1; i >= 0; --i) {
-    double L[15], t[NLP_NV], dw[NLP_NV];
+// Serial recursion 2 (backward): ds_i = L_i^-T (y_i - Lo_{i+1}^T ds_{i+1}).
+__device__ __attribute__((noinline)) void nlp_backsolve(double *sf_generic, double *ds_generic, int N) {
+  const gdouble *sf = (const gdouble *)sf_generic;
+  gdouble *dsv = (gdouble *)ds_generic;
+  double dn[3] = {0, 0, 0}, Lon[3][3];
 #pragma unroll
-    for (int k = 0; k < 15; ++k) L[k] = NLP_AT(u.fac, NLP_FAC, i, k);
+  for (int a = 0; a < 3; ++a)
 #pragma unroll
-    for (int a = 0; a < NLP_NV; ++a) t[a] = NLP_AT(u.fac, NLP_FAC, i, 40 + a);
-    if (i + 1 < N) {
+    for (int c = 0; c < 3; ++c) Lon[a][c] = 0.0;
+  auto load = [&](int i, NlpNodeIn &n) {
 #pragma unroll
-      for (int a = 0; a < NLP_NV; ++a) {
-        double v = 0.0;
+    for (int k = 0; k < SF_N; ++k) n.v[k] = NLP_SF_(k, i);
+  };
+  NlpNodeIn buf[4];                                                    // ring of four, unrolled by four (see nlp_factor)
+  load(N - 1, buf[0]); load(N > 1 ? N - 2 : 0, buf[1]); load(N > 2 ? N - 3 : 0, buf[2]);
+  __builtin_amdgcn_s_waitcnt(0x0F70);                                  // (vmcnt(0), see nlp_factor)
+  for (int i0 = N - 1; i0 >= 0; i0 -= 4) {
 #pragma unroll
-        for (int k = 0; k < NLP_NV; ++k) v += Lon[k][a] * dn[k];
-        t[a] -= v;
-      }
-    }
+   for (int u = 0; u < 4; ++u) {
+    const int i = i0 - u;
+    if (i < 0) break;
+    load(i >= 3 ? i - 3 : 0, buf[(u + 3) & 3]);
+    const NlpNodeIn &cur = buf[u];
+    double t[3], ds[3];
 #pragma unroll
-    for (int a = NLP_NV - 1; a >= 0; --a) {
+    for (int a = 0; a < 3; ++a) t[a] = cur.v[SF_Y + a] - (Lon[0][a] * dn[0] + Lon[1][a] * dn[1] + Lon[2][a] * dn[2]);
+#pragma unroll
+    for (int a = 2; a >= 0; --a) {
       double v = t[a];
 #pragma unroll
-      for (int k = a + 1; k < NLP_NV; ++k) v -= L[k * (k + 1) / 2 + a] * dw[k];
-      dw[a] = v / L[a * (a + 1) / 2 + a];
+      for (int k = a + 1; k < 3; ++k) v -= cur.v[SF_L + k * (k + 1) / 2 + a] * ds[k];
+      ds[a] = v * cur.v[SF_L + a * (a + 1) / 2 + a];
     }
 #pragma unroll
-    for (int c = 0; c < NLP_NV; ++c) {
-      const bool fx = nlp_fixed(i, N, c);
-      if (fx) dw[c] = 0.0;
-      NLP_AT(u.dw, NLP_NV, i, c) = dw[c];
-      dphi -= NLP_AT(u.rhs, NLP_NV, i, c) * dw[c];
-      if (fx) continue;
-      const double w = NLP_AT(u.W, NLP_NV, i, c);
-      if (s.lo[c] > -1e299) {
-        const double sl = w - s.lo[c], z = NLP_AT(u.zL, NLP_NV, i, c);
-        if (dw[c] < 0.0) amax = fmin(amax, -tau * sl / dw[c]);
-        const double dz = mub / sl - z - z / sl * dw[c];
-        if (dz < 0.0) az = fmin(az, -tau * z / dz);
-      }
-      if (s.hi[c] < 1e299) {
-        const double su = s.hi[c] - w, z = NLP_AT(u.zU, NLP_NV, i, c);
-        if (dw[c] > 0.0) amax = fmin(amax, tau * su / dw[c]);
-        const double dz = mub / su - z + z / su * dw[c];
-        if (dz < 0.0) az = fmin(az, -tau * z / dz);
-      }
+    for (int c = 0; c < 3; ++c) {
+      if (nlp_fixed(i, N, c)) ds[c] = 0.0;
+      dn[c] = ds[c];
     }
 #pragma unroll
-    for (int a = 0; a < NLP_NV; ++a) {
-      dn[a] = dw[a];
+    for (int a = 0; a < 3; ++a)
 #pragma unroll
-      for (int c = 0; c < NLP_NV; ++c) Lon[a][c] = NLP_AT(u.fac, NLP_FAC, i, 15 + a * NLP_NV + c);
-    }
+      for (int c = 0; c < 3; ++c) Lon[a][c] = cur.v[SF_LO + a * 3 + c];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) dsv[i * 3 + c] = ds[c];            // (uniform store, see nlp_factor)
+   }
   }
-  *dphi_out = dphi; *amax_out = amax; *az_out = az;
 }
 
-// Sweep 4: take the step -- W += a dw, duals += az dz (dz from the step's dw), duals kept near the central path.
-__device__ void nlp_apply(const NlpDims &d, const NlpScen &s, const NlpBuf &u, int b, double a, double az, double mub) {
-  const int B = d.B, N = d.N;
-  for (int i = 0; i < N; ++i) {
+// Recovery of the eliminated (phi, v) steps + step statistics (node-parallel): d(phi, v)_i = LP^-T (tt - Qt ds_i - Rt ds_{i-1});
+// directional derivative of the merit function, largest primal step (fraction to the boundary) and the dual steps' largest
+// fraction.  Wave-uniform results.
+__device__ void nlp_recover_stats(const NlpProb &pb, const NlpScen &s, int lane, double mub, double tau, double *dphi_out,
+                                  double *amax_out, double *az_out) {
+  const int N = pb.N;
+  double dphi = 0.0, amax = 1.0, az = 1.0;
+  for (int i0 = 0; i0 < N; i0 += 64) {
+    const int i = i0 + lane;
+    if (i >= N) continue;
+    double dwv[NLP_NV], dsp[3] = {0, 0, 0};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) dwv[c] = NLP_DS(c, i);
+    if (i >= 1) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) dsp[c] = NLP_DS(c, i - 1);
+    }
+    double z0 = NLP_EL(EL_T + 0, i), z1 = NLP_EL(EL_T + 1, i);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      z0 -= NLP_EL(EL_Q + k, i) * dwv[k] + NLP_EL(EL_R + k, i) * dsp[k];
+      z1 -= NLP_EL(EL_Q + 3 + k, i) * dwv[k] + NLP_EL(EL_R + 3 + k, i) * dsp[k];
+    }
+    dwv[4] = z1 * NLP_EL(EL_LP + 2, i);
+    dwv[3] = (z0 - NLP_EL(EL_LP + 1, i) * dwv[4]) * NLP_EL(EL_LP + 0, i);
+#pragma unroll
+    for (int c = 0; c < NLP_NV; ++c) {
+      const double dw = dwv[c];
+      NLP_DW(c, i) = dw;
+      dphi -= NLP_RAW(RAW_RHS + c, i) * dw;
+      if (nlp_fixed(i, N, c)) continue;
+      const double w = NLP_W(c, i);
+      if (s.lo[c] > -1e299) {
+        const double sl = w - s.lo[c], z = NLP_P(WS_ZL + c, i);
+        if (-dw * amax > tau * sl) amax = -tau * sl / dw;          // (divide only when the bound is the binding one so far)
+        const double dz = (mub - z * dw) / sl - z;
+        if (-dz * az > tau * z) az = -tau * z / dz;
+      }
+      if (s.hi[c] < 1e299) {
+        const double su = s.hi[c] - w, z = NLP_P(WS_ZU + c, i);
+        if (dw * amax > tau * su) amax = tau * su / dw;
+        const double dz = (mub + z * dw) / su - z;
+        if (-dz * az > tau * z) az = -tau * z / dz;
+      }
+    }
+  }
+  *dphi_out = wave_sum(dphi); *amax_out = wave_min(amax); *az_out = wave_min(az);
+}
+
+// Take the step (node-parallel): W += a dw, duals += az dz (dz from the step's dw), duals kept near the central path.
+__device__ void nlp_apply(const NlpProb &pb, const NlpScen &s, int lane, double a, double az, double mub) {
+  const int N = pb.N;
+  for (int i0 = 0; i0 < N; i0 += 64) {
+    const int i = i0 + lane;
+    if (i >= N) continue;
 #pragma unroll
     for (int c = 0; c < NLP_NV; ++c) {
       if (nlp_fixed(i, N, c)) continue;
-      const double w = NLP_AT(u.W, NLP_NV, i, c), dw = NLP_AT(u.dw, NLP_NV, i, c);
+      const double w = NLP_W(c, i), dw = NLP_DW(c, i);
       const double wn = w + a * dw;
-      NLP_AT(u.W, NLP_NV, i, c) = wn;
+      NLP_W(c, i) = wn;
       if (s.lo[c] > -1e299) {
-        const double sl = w - s.lo[c], z = NLP_AT(u.zL, NLP_NV, i, c), sn = wn - s.lo[c];
-        double zn = z + az * (mub / sl - z - z / sl * dw);
-        zn = fmin(fmax(zn, mub / (1e10 * sn)), 1e10 * mub / sn);
-        NLP_AT(u.zL, NLP_NV, i, c) = zn;
+        const double sl = w - s.lo[c], z = NLP_P(WS_ZL + c, i), mn = mub / (wn - s.lo[c]);
+        double zn = z + az * ((mub - z * dw) / sl - z);
+        zn = fmin(fmax(zn, 1e-10 * mn), 1e10 * mn);
+        NLP_P(WS_ZL + c, i) = zn;
       }
       if (s.hi[c] < 1e299) {
-        const double su = s.hi[c] - w, z = NLP_AT(u.zU, NLP_NV, i, c), sn = s.hi[c] - wn;
-        double zn = z + az * (mub / su - z + z / su * dw);
-        zn = fmin(fmax(zn, mub / (1e10 * sn)), 1e10 * mub / sn);
-        NLP_AT(u.zU, NLP_NV, i, c) = zn;
+        const double su = s.hi[c] - w, z = NLP_P(WS_ZU + c, i), mn = mub / (s.hi[c] - wn);
+        double zn = z + az * ((mub + z * dw) / su - z);
+        zn = fmin(fmax(zn, 1e-10 * mn), 1e10 * mn);
+        NLP_P(WS_ZU + c, i) = zn;
       }
     }
   }
 }
 
+// One wavefront per problem.  Node-parallel phases (merit, assembly, step statistics, update) run with lane = node; the two
+// block recursions are serial in the nodes and run wave-uniform.  Control flow is uniform: no lane waits for another problem.
 __global__ void __launch_bounds__(64)
-nlp_solve_kernel(NlpDims d, d2d_nlp_opts o, const double *__restrict__ scen, const double *__restrict__ partner, NlpBuf u,
-                 double *__restrict__ cost_out, double *__restrict__ feas_out, int32_t *__restrict__ iters_out,
-                 int32_t *__restrict__ status_out) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= d.B) return;
-  const int B = d.B, N = d.N;
+nlp_solve_kernel(int B, int N, double h, d2d_nlp_opts o, const double *__restrict__ scen, const double *partner, double *W,
+                 double *work, double *mult, double *__restrict__ cost_out, double *__restrict__ feas_out,
+                 int32_t *__restrict__ iters_out, int32_t *__restrict__ status_out, unsigned long long *stamps) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  if (b >= B) return;
+  // diagnostics (D2D_NLP_STAMPS): cycles of problem 0 per phase -- merit, assembly, factorisation, back substitution, ratio tests, update
+  unsigned long long st_t = 0, st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const bool st_on = stamps != nullptr && b == 0;
+#define NLP_STAMP(k) if (st_on) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[k] += t_ - st_t; st_t = t_; }
+  if (st_on) st_t = __builtin_amdgcn_s_memtime();
   const double *sc = scen + (size_t)b * D2D_SCEN_STRIDE;
   const NlpScen s = nlp_load_scen(sc, o);
+  NlpProb pb;
+  pb.N = N; pb.h = h;
+  pb.W = W + (size_t)b * NLP_NV * N;
+  pb.ws = work + (size_t)b * WS_TOTAL * N;
+  pb.mu = mult ? mult + (size_t)b * 3 * N : pb.ws + (size_t)WS_MU * N;
+  pb.partner = partner ? partner + (size_t)b * 2 * N : nullptr;
   // ---- start: end conditions in place, everything else pushed strictly inside the box; duals on the central path
   double mub = o.mub0;
-  for (int i = 0; i < N; ++i) {
+  for (int i0 = 0; i0 < N; i0 += 64) {
+    const int i = i0 + lane;
+    if (i >= N) continue;
 #pragma unroll
     for (int c = 0; c < NLP_NV; ++c) {
-      double w = NLP_AT(u.W, NLP_NV, i, c);
+      double w = NLP_W(c, i);
       double zl = 0.0, zu = 0.0;
       if (nlp_fixed(i, N, c)) {
         w = (i == 0) ? s.p0[c] : s.p1[c];
@@ -465,87 +690,120 @@ nlp_solve_kernel(NlpDims d, d2d_nlp_opts o, const double *__restrict__ scen, con
         if (hl) zl = mub / (w - s.lo[c]);
         if (hu) zu = mub / (s.hi[c] - w);
       }
-      NLP_AT(u.W, NLP_NV, i, c) = w;
-      NLP_AT(u.zL, NLP_NV, i, c) = zl; NLP_AT(u.zU, NLP_NV, i, c) = zu;
-      NLP_AT(u.dw, NLP_NV, i, c) = 0.0;
+      NLP_W(c, i) = w;
+      NLP_P(WS_ZL + c, i) = zl; NLP_P(WS_ZU + c, i) = zu;
+      NLP_DW(c, i) = 0.0;
     }
 #pragma unroll
-    for (int k = 0; k < 3; ++k) NLP_AT(u.mu, 3, i, k) = 0.0;
+    for (int k = 0; k < 3; ++k) NLP_MU(k, i) = 0.0;
   }
+  nlp_phase_sync();
   double rho = o.rho0, lam = D2D_LM_LAMBDA0, feas_prev = INFINITY;
   int total_inner = 0, status = D2D_ST_MAXITER;
   double err = 0.0, cost_ref = 0.0, feas = 0.0;
   int n_stalled = 0;                        // outer iterations in a row at the largest penalty without feasibility progress
   for (int outer = 1; outer <= o.outer_max; ++outer) {
     const double tol_in = fmax(fmax(o.opt_tol, fmin(1e-1, 10.0 * mub)), D2D_NLP_GRAD_FLOOR * rho);
-    // merit value of the current point for this (mub, rho, mu): one sweep here, afterwards the accepted trial's value
-    double phi0 = nlp_merit(d, s, sc, partner, u, b, 0.0, rho, mub, nullptr, nullptr);
+    // merit value of the current point for this (mub, rho, mu): one pass here, afterwards the accepted trial's value
+    NLP_STAMP(7)
+    double phi0 = nlp_merit(pb, s, sc, lane, 0.0, rho, mub, nullptr, nullptr);
+    NLP_STAMP(0)
     for (int it = 0; it < o.inner_max; ++it) {
       ++total_inner;
       bool accepted = false, converged = false;
+      err = nlp_assemble(pb, s, sc, lane, rho, mub);
+      nlp_phase_sync();
+      NLP_STAMP(1)
+      if (err <= tol_in) break;
       for (int tr = 0; tr < 30; ++tr) {
-        const bool pd = nlp_factor(d, s, sc, partner, u, b, rho, mub, lam, &err);
-        if (err <= tol_in) { converged = true; break; }      // (the error does not depend on the damping)
+        bool pd = nlp_eliminate_a(pb, lane, lam);
+        nlp_phase_sync();
+        if (pd) {
+          nlp_eliminate_b(pb, lane, lam);
+          nlp_phase_sync();
+          NLP_STAMP(6)
+          pd = nlp_factor(pb.ws + (size_t)WS_SIN * N, pb.ws + (size_t)WS_SF * N, N);
+        }
+        NLP_STAMP(2)
         if (!pd) { lam = fmin(lam * 8.0, D2D_LM_LAMBDA_MAX); continue; }
+        nlp_phase_sync();
+        nlp_backsolve(pb.ws + (size_t)WS_SF * N, pb.ws + (size_t)WS_DS * N, N);
+        nlp_phase_sync();
+        NLP_STAMP(3)
         const double tau = fmax(0.99, 1.0 - mub);
         double dphi, amax, az;
-        nlp_backsolve(d, s, u, b, mub, tau, &dphi, &amax, &az);
+        nlp_recover_stats(pb, s, lane, mub, tau, &dphi, &amax, &az);
+        nlp_phase_sync();
+        NLP_STAMP(4)
         if (!(dphi < 0.0)) { lam = fmin(lam * 8.0, D2D_LM_LAMBDA_MAX); continue; }
         double a = amax, pt = 0.0;
         bool ok = false;
         for (int ls = 0; ls < 8; ++ls) {
-          pt = nlp_merit(d, s, sc, partner, u, b, a, rho, mub, nullptr, nullptr);
+          pt = nlp_merit(pb, s, sc, lane, a, rho, mub, nullptr, nullptr);
           if (pt <= phi0 + 1e-4 * a * dphi) { ok = true; break; }
           a *= 0.5;
         }
+        NLP_STAMP(0)
         if (ok) {
           phi0 = pt;
-          nlp_apply(d, s, u, b, a, az, mub);
+          nlp_apply(pb, s, lane, a, az, mub);
+          nlp_phase_sync();
+          NLP_STAMP(5)
           if (a == amax) lam = fmax(lam / 3.0, D2D_LM_LAMBDA_MIN);
           accepted = true;
           break;
         }
         lam = fmin(lam * 4.0, D2D_LM_LAMBDA_MAX);
       }
-      if (converged || !accepted) break;
+      (void)converged;
+      if (!accepted) break;
     }
-    (void)nlp_merit(d, s, sc, partner, u, b, 0.0, rho, mub, &cost_ref, &feas);
+    (void)nlp_merit(pb, s, sc, lane, 0.0, rho, mub, &cost_ref, &feas);
     if (feas <= o.feas_tol && mub <= o.mub_min * 1.0001 && err <= tol_in) { status = D2D_ST_CONVERGED; break; }
     // an infeasible problem (e.g. end points too far apart for v_max) sits at the largest penalty with its constraint violation
-    // no longer shrinking: give up instead of holding the whole batch for outer_max x inner_max steps
+    // no longer shrinking: give up instead of running outer_max x inner_max steps
     n_stalled = (rho >= D2D_NLP_RHO_MAX && feas > 0.5 * feas_prev && feas > 1e3 * o.feas_tol) ? n_stalled + 1 : 0;
     if (n_stalled >= 3) { status = D2D_ST_STALLED; break; }
     // first-order multiplier update (lambda = 2 rho mu); the penalty grows when feasibility stalls
     const bool grow = feas > 0.25 * feas_prev && rho < D2D_NLP_RHO_MAX;
-    {
-      double wp[3] = {NLP_AT(u.W, NLP_NV, 0, 0), NLP_AT(u.W, NLP_NV, 0, 1), NLP_AT(u.W, NLP_NV, 0, 2)};
-      for (int i = 1; i < N; ++i) {
-        double w[NLP_NV], c3[3];
+    for (int i0 = 0; i0 < N; i0 += 64) {
+      const int i = i0 + lane;
+      if (i < 1 || i >= N) continue;
+      double wp[3], w[NLP_NV], c3[3];
 #pragma unroll
-        for (int c = 0; c < NLP_NV; ++c) w[c] = NLP_AT(u.W, NLP_NV, i, c);
-        nlp_constraint(s, d.h, wp, w, c3);
+      for (int c = 0; c < 3; ++c) wp[c] = NLP_W(c, i - 1);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          const double m = NLP_AT(u.mu, 3, i, k) + c3[k];
-          NLP_AT(u.mu, 3, i, k) = grow ? m / D2D_NLP_RHO_GROW : m;
-        }
-        wp[0] = w[0]; wp[1] = w[1]; wp[2] = w[2];
+      for (int c = 0; c < NLP_NV; ++c) w[c] = NLP_W(c, i);
+      nlp_constraint(s, h, wp, w, c3);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const double m = NLP_MU(k, i) + c3[k];
+        NLP_MU(k, i) = grow ? m / D2D_NLP_RHO_GROW : m;
       }
     }
+    nlp_phase_sync();
     if (grow) rho *= D2D_NLP_RHO_GROW;
     feas_prev = feas;
     mub = fmax(o.mub_min, fmin(0.2 * mub, mub * sqrt(mub)));
   }
-  (void)nlp_merit(d, s, sc, partner, u, b, 0.0, rho, mub, &cost_ref, &feas);
-  cost_out[b] = cost_ref;
-  feas_out[b] = feas;
-  if (iters_out) iters_out[b] = total_inner;
-  if (status_out) status_out[b] = status;
+  (void)nlp_merit(pb, s, sc, lane, 0.0, rho, mub, &cost_ref, &feas);
+  if (lane == 0) {
+    cost_out[b] = cost_ref;
+    feas_out[b] = feas;
+    if (iters_out) iters_out[b] = total_inner;
+    if (status_out) status_out[b] = status;
+    if (st_on) {
+      NLP_STAMP(7)
+      for (int k = 0; k < 8; ++k) stamps[k] = st_acc[k];
+      stamps[8] = (unsigned long long)total_inner;
+    }
+  }
+#undef NLP_STAMP
 }
 
 extern "C" {
 
-int d2d_nlp_workspace_doubles(int N) { return N * (3 * NLP_NV + 3 + NLP_FAC + NLP_NV); }
+int d2d_nlp_workspace_doubles(int N) { return N * WS_TOTAL; }
 
 int d2d_nlp_solve(d2d_ctx *ctx, int B, int N, double h, const double *scen, const d2d_nlp_opts *opts, double *W,
                   const double *partner, double *work, double *mult, double *cost, double *feas, int32_t *iters, int32_t *status) {
@@ -554,15 +812,21 @@ int d2d_nlp_solve(d2d_ctx *ctx, int B, int N, double h, const double *scen, cons
   d2d_nlp_opts o = {D2D_NLP_RHO0, D2D_NLP_MUB0, D2D_NLP_MUB_MIN, 1e-9, 1e-7, 60, 40};
   if (opts) o = *opts;
   D2D_REQUIRE(o.inner_max >= 1 && o.outer_max >= 1 && o.rho0 > 0 && o.mub0 > 0 && o.mub_min > 0, "d2d_nlp_solve: bad options");
-  NlpBuf u;
-  const size_t nb = (size_t)N * B;
-  u.W = W;
-  u.zL = work; u.zU = u.zL + NLP_NV * nb; u.dw = u.zU + NLP_NV * nb; u.rhs = u.dw + NLP_NV * nb;
-  u.fac = u.rhs + NLP_NV * nb;
-  u.mu = mult ? mult : u.fac + NLP_FAC * nb;
-  const NlpDims d{B, N, h};
-  hipLaunchKernelGGL(nlp_solve_kernel, dim3((B + 63) / 64), dim3(64), 0, ctx->stream, d, o, scen, partner, u, cost, feas, iters, status);
+  unsigned long long *stamps = nullptr;
+  if (getenv("D2D_NLP_STAMPS")) D2D_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&stamps), 16 * sizeof(unsigned long long)));
+  hipLaunchKernelGGL(nlp_solve_kernel, dim3(B), dim3(64), 0, ctx->stream, B, N, h, o, scen, partner, W, work, mult, cost, feas, iters,
+                     status, stamps);
   D2D_LAUNCH_CHECK();
+  if (stamps) {                                            // diagnostics: synchronous
+    unsigned long long hs[9];
+    D2D_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    D2D_CHECK_HIP(hipMemcpy(hs, stamps, sizeof(hs), hipMemcpyDeviceToHost));
+    D2D_CHECK_HIP(hipFree(stamps));
+    static const char *nm[8] = {"merit", "assemble", "factor", "backsolve", "recover+ratio tests", "update", "eliminate", "other"};
+    fprintf(stderr, "[nlp] problem 0: %llu Newton steps; shader clocks per phase:", hs[8]);
+    for (int k = 0; k < 8; ++k) fprintf(stderr, " %s %llu", nm[k], hs[k]);
+    fprintf(stderr, "\n");
+  }
   return D2D_OK;
 }
 

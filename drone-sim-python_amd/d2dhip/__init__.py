@@ -326,14 +326,15 @@ class Context:
 
     def nlp_solve(self, scen, W, h, partner=None, rho0=10.0, mub0=0.1, mub_min=1e-9, feas_tol=1e-9, opt_tol=1e-7, inner_max=60,
                   outer_max=40, want_mult=False):
-        """Direct-collocation NLP in node variables (d2d_nlp_solve): scen dev [B][SCEN_STRIDE], W dev [N][5][B] in/out (initial
-        guess -> solution), partner dev [N][2][B] or None.  Returns dict(cost, feas, iters, status[, mult]) of device tensors."""
+        """Direct-collocation NLP in node variables (d2d_nlp_solve): scen dev [B][SCEN_STRIDE], W dev [B][5][N] in/out (initial
+        guess -> solution), partner dev [B][2][N] or None.  Returns dict(cost, feas, iters, status[, mult [B][3][N]]) of device tensors."""
         torch = _torch()
-        N, _, B = W.shape
+        B, _, N = W.shape
+        assert W.is_contiguous() and scen.shape[0] == B and (partner is None or (partner.is_contiguous() and partner.shape == (B, 2, N)))
         work = self.empty(self.lib.d2d_nlp_workspace_doubles(N) * B)
         cost, feas = self.empty(B), self.empty(B)
         iters = torch.empty(B, dtype=torch.int32, device=self.device); status = torch.empty(B, dtype=torch.int32, device=self.device)
-        mult = self.zeros(N, 3, B) if want_mult else None
+        mult = self.zeros(B, 3, N) if want_mult else None
         o = NlpOpts(rho0, mub0, mub_min, feas_tol, opt_tol, inner_max, outer_max)
         _check(self.lib.d2d_nlp_solve(self.h, B, N, float(h), _ptr(scen), C.byref(o), _ptr(W), _ptr(partner), _ptr(work), _ptr(mult),
                                       _ptr(cost), _ptr(feas), _ptr(iters), _ptr(status)))

@@ -119,7 +119,7 @@ class Problem:
         single = not isinstance(sl._slice_x, (list, tuple))
         get = (lambda s, a: x0[s]) if single else (lambda s, a: x0[s[a]])
         W = np.stack([np.stack([get(sl._slice_x, a), get(sl._slice_y, a), get(sl._slice_psi, a), get(sl._slice_phi, a),
-                                get(sl._slice_v, a)], 1) for a in range(n)], 2)                       # (N, 5, n)
+                                get(sl._slice_v, a)], 0) for a in range(n)], 0)                       # (n, 5, N)
         rows, coupled = self._rows()
         # IPOPT's max_iter counts Newton steps; here they are grouped as outer (multiplier / barrier updates) x inner (<= 60)
         kw = dict(inner_max=60, outer_max=int(min(max(self.options.get('max_iter', 3000) // 60, 12), 60)))
@@ -133,22 +133,22 @@ class Problem:
             rows_nc = rows.copy(); rows_nc[:, d2dhip.SC_KCOL] = 0.0
             out = ctx.nlp_solve(ctx.dev(rows_nc), dW, self.time_step, **kw)                          # uncoupled start for everybody
             for sweeps in range(1, 13):
-                prev = dW[:, :2, :2].clone()
+                prev = dW[:2, :2].clone()
                 for a, o in ((0, 1), (1, 0)):
-                    Wa = dW[:, :, a:a + 1].contiguous()
-                    partner = dW[:, :2, o:o + 1].contiguous()
+                    Wa = dW[a:a + 1].contiguous()
+                    partner = dW[o:o + 1, :2].contiguous()
                     oa = ctx.nlp_solve(dsc[a:a + 1].contiguous(), Wa, self.time_step, partner=partner, **kw)
-                    dW[:, :, a] = Wa[:, :, 0]
+                    dW[a] = Wa[0]
                     for k in ('cost', 'feas', 'iters', 'status'):
                         out[k][a] = oa[k][0]
-                if float((dW[:, :2, :2] - prev).abs().max().item()) <= 1e-7:
+                if float((dW[:2, :2] - prev).abs().max().item()) <= 1e-7:
                     break
         ctx.sync()
         Wh = dW.cpu().numpy()
         sol = np.zeros(self.num_free)
         for a in range(n):
             for c, s in enumerate((sl._slice_x, sl._slice_y, sl._slice_psi, sl._slice_phi, sl._slice_v)):
-                sol[s if single else s[a]] = Wh[:, c, a]
+                sol[s if single else s[a]] = Wh[a, c]
         st = out['status'].cpu().numpy()
         info = {'status': int(st.max()) if single else st.tolist(), 'feas': float(out['feas'].max().item()),
                 'iters': out['iters'].cpu().numpy().tolist(), 'sweeps': sweeps,

@@ -28,7 +28,7 @@ def test_header_symbols_exported():
     # the binding declares exactly the header's functions
     assert sorted(d2dhip.EXPORTS) == names
     lib.d2d_version.restype = ctypes.c_int
-    assert lib.d2d_version() == 102
+    assert lib.d2d_version() == 103
 
 
 def test_struct_layouts_match_header():

@@ -39,11 +39,13 @@ def _row(pb, obstacles=(), kobs=0.0, okind=0):
 
 
 def _solve(ctx, pbs, W0s, rows, **kw):
-    N = pbs[0].N
-    W = ctx.dev(np.ascontiguousarray(np.stack(W0s, 2)))               # (N, 5, B)
+    """W0s: (N, 5) node values per problem -> device [B][5][N]; returns the solution as (N, 5, B) and mult as (N, 3, B)."""
+    W = ctx.dev(np.ascontiguousarray(np.stack([w.T for w in W0s], 0)))               # (B, 5, N)
     out = ctx.nlp_solve(ctx.dev(np.stack(rows)), W, pbs[0].h, want_mult=True, **kw)
     ctx.sync()
-    return W.cpu().numpy(), {k: v.cpu().numpy() for k, v in out.items() if k != 'work'}
+    res = {k: v.cpu().numpy() for k, v in out.items() if k != 'work'}
+    res['mult'] = np.ascontiguousarray(res['mult'].transpose(2, 1, 0))
+    return np.ascontiguousarray(W.cpu().numpy().transpose(2, 1, 0)), res
 
 
 def test_exp14_reproduces_the_reference_ipopt_cost(ctx, gold):
@@ -78,7 +80,7 @@ def test_exp14_reproduces_the_reference_ipopt_cost(ctx, gold):
 
 
 def test_batch_with_obstacles_wind_and_boxes_vs_oracle(ctx):
-    """A ragged batch of different problems in one launch (each lane its own scenario): obstacles of both kinds, wind, a
+    """A ragged batch of different problems in one launch (each wavefront its own scenario): obstacles of both kinds, wind, a
     binding y box; every one against the oracle's solve and against the KKT conditions."""
     N, h = 41, 0.1
     pbs, rows, W0s, obs = [], [], [], []

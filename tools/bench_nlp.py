@@ -12,7 +12,7 @@ def problems(B, N=121, seed=0):
     import d2dhip as D
     import d2d.opty_utils as d2ou
     rng = np.random.default_rng(seed)
-    rows = np.zeros((B, D.SCEN_STRIDE)); W = np.zeros((N, 5, B))
+    rows = np.zeros((B, D.SCEN_STRIDE)); W = np.zeros((B, 5, N))
     for b in range(B):
         p0 = np.array([-49.98, -58.14, 2.22]) + rng.normal(0, [3., 3., 0.1]); p1 = np.array([75., 40., 0.]) + rng.normal(0, [3., 3., 0.1])
         r = rows[b]
@@ -22,7 +22,7 @@ def problems(B, N=121, seed=0):
         r[D.SC_XMIN], r[D.SC_XMAX], r[D.SC_YMIN], r[D.SC_YMAX] = -150, 150, -150, 150
         import contextlib, io
         x, y, psi, phi, v = d2ou.triangle(p0[:2], p1[:2], 12., 12.0, N, go_left=-1.)
-        W[:, :, b] = np.stack([x, y, psi, phi, v], 1)
+        W[b] = np.stack([x, y, psi, phi, v], 0)
     return rows, W
 
 
