@@ -24,6 +24,8 @@ Besides the contract fields the line carries
   config3           BASELINE configs[3]: 32 768 fits per rank (256 k at N = 8), same solve, barrier + max over ranks
   parity            the SAME scenarios the cpu_baseline leg solved with scipy: fraction agreeing to 1e-6 (cost, coefficients)
   sim               BASELINE configs[4] (65 536 drones x 10 000 steps GVF loop) and the tracking loop, with roofline + cpu_baseline
+  nlp               SURVEY 8 f-1: the collocation-NLP backend on 4096 perturbed copies of the reference's exp_14 (one wavefront per problem),
+                    with the oracle's solver timed beside it and the cost agreement on the problems both solved
   cpu_baseline      scipy.optimize.least_squares (method 'lm', analytic Jacobian) on the oracle's residual function over a
                     process pool, bounded sample
 """
@@ -154,6 +156,50 @@ def cpu_polish(keep, q_gpu, n_polish=256):
     return np.array([r[0] for r in res]), np.array([r[1] for r in res])
 
 
+def cpu_baseline_nlp(n=3):
+    """cpu_baseline leg of the collocation record: the oracle's solver (numpy + banded LAPACK, the same algorithm as the kernel)
+    on the first n problems of the batch, one core."""
+    from oracle import nlp as ON               # the oracle is the thing timed in this leg only
+    import d2dhip
+    from d2dhip import synth
+    rows, W0, h = synth.nlp_problems(n)
+    t0 = time.perf_counter()
+    costs, steps = [], []
+    for b in range(n):
+        r = rows[b]
+        pb = ON.Problem(W0.shape[2], h, r[d2dhip.SC_X0:d2dhip.SC_X0 + 3], r[d2dhip.SC_X1:d2dhip.SC_X1 + 3], vsp=12., kv=1., kphi=0., obj_scale=1.,
+                        phi_max=np.deg2rad(40.), v_min=9., v_max=15., x_box=(-150, 150), y_box=(-150, 150))
+        _, info = ON.solve(pb, W0[b].T.copy())
+        costs.append(info['cost']); steps.append(info['inner'])
+    dt = time.perf_counter() - t0
+    return {'value': n / dt, 'unit': 'problems/s', 'cores': 1, 'kind': 'port', 'seconds': dt,
+            'sample': f'oracle/nlp.py solve() on the first {n} problems of the batch', 'cost': costs, 'newton_steps': steps}
+
+
+def nlp_record(ctx, torch, cpu, B=4096):
+    """the collocation-NLP backend (d2d_nlp_solve, what opty.direct_collocation.Problem(...).solve runs) on B perturbed
+    copies of the reference's exp_14, one launch, one wavefront per problem."""
+    from d2dhip import synth
+    rows, W0, h = synth.nlp_problems(B)
+    dsc = ctx.dev(rows)
+    best, out = 1e30, None
+    for rep in range(2):
+        W = ctx.dev(np.ascontiguousarray(W0))
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        out = ctx.nlp_solve(dsc, W, h)
+        torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
+    st, it, cost = out['status'].cpu().numpy(), out['iters'].cpu().numpy(), out['cost'].cpu().numpy()
+    rec = {'metric': 'collocation problems/sec (121 nodes x 5 node variables, hard bounds)', 'value': B / best, 'unit': 'problems/s',
+           'workload': f'{B} perturbed copies of optyplan_scenarios.exp_14 (end poses moved by N(0, [3 m, 3 m, 0.1 rad])), tri initial guess',
+           'seconds': best, 'dtype': 'f64', 'converged_frac': float((st == 1).mean()), 'mean_newton_steps': float(it.mean()),
+           'max_newton_steps': int(it.max()), 'cpu_baseline': cpu}
+    if cpu is not None:
+        n = len(cpu['cost'])
+        rec['parity'] = {'n': n, 'max_rel_cost_diff_vs_oracle': float(np.max(np.abs(cost[:n] - np.array(cpu['cost'])) / np.array(cpu['cost']))),
+                         'newton_steps_gpu': it[:n].tolist(), 'newton_steps_oracle': cpu['newton_steps']}
+    return rec
+
+
 def cpu_baseline_sim_gvf(n_steps=300):
     """cpu_baseline leg of the simulation records (BASELINE configs[4]): the oracle's restatement of
     the reference's phase-1 loop body (DCF + GVF + scipy odeint) on one core."""
@@ -267,6 +313,7 @@ def main():
     ap.add_argument('--config3-batch', type=int, default=32768, help='fits per rank of the config3 record (0 = skip)')
     ap.add_argument('--config3-steps', type=int, default=3)
     ap.add_argument('--no-sim', action='store_true', help='skip the simulation records (BASELINE configs[4])')
+    ap.add_argument('--no-nlp', action='store_true', help='skip the collocation-NLP record (SURVEY 8 f-1)')
     ap.add_argument('--no-groups', action='store_true', help='skip the coupled-groups record (BASELINE configs[2])')
     ap.add_argument('--no-order', action='store_true',
                     help='hand the fits out in index order instead of longest-first by the previous solve\'s iteration counts')
@@ -280,11 +327,13 @@ def main():
         print(json.dumps({'rank': rank, 'world': world, 'local_rank': local_rank, 'gpus': a.gpus}), flush=True)
         return
     B = a.batch
-    cpu = keep = cpu_g = cpu_t = None
+    cpu = keep = cpu_g = cpu_t = cpu_n = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu, keep = cpu_baseline(B, a.cpu_sample)
         if not a.no_sim:
             cpu_g, cpu_t = cpu_baseline_sim_gvf(), cpu_baseline_sim_track()
+        if not a.no_nlp:
+            cpu_n = cpu_baseline_nlp()
 
     import torch
     import d2dhip
@@ -496,6 +545,10 @@ def main():
         del dsc, q0, q, cost, iters, status
         torch.cuda.empty_cache()
         sim = sim_records(ctx, torch, cpu_g, cpu_t)
+    nlp = None
+    if rank == 0 and world == 1 and not a.no_nlp:
+        torch.cuda.empty_cache()
+        nlp = nlp_record(ctx, torch, cpu_n)
 
     if rank == 0:
         line = {
@@ -511,7 +564,7 @@ def main():
             'converged_frac': headline['converged_frac'], 'mean_iters': headline['mean_iters'],
             'evals_per_fit': headline['evals_per_fit'],          # Gauss-Newton units (200 rows); second-order evaluations count 1.5
             'mean_cost': headline['mean_cost'],
-            'roofline': roof, 'roofline_isolated': roof_iso, 'config2': config2, 'config3': config3, 'parity': parity, 'sim': sim, 'cpu_baseline': cpu,
+            'roofline': roof, 'roofline_isolated': roof_iso, 'config2': config2, 'config3': config3, 'parity': parity, 'sim': sim, 'nlp': nlp, 'cpu_baseline': cpu,
         }
         print(json.dumps(line))
     if dist is not None:

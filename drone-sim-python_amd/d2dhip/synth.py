@@ -5,7 +5,7 @@ import numpy as np
 
 from . import (SCEN_STRIDE, SC_X0, SC_Y0, SC_PSI0, SC_X1, SC_Y1, SC_PSI1, SC_VREF, SC_VSP, SC_KV, SC_KPHI,
                SC_KOBS, SC_S, SC_WWP, SC_GOLEFT, SC_O0X, SC_O0Y, SC_O0R, SC_O1X, SC_O1Y, SC_O1R, SC_WBND,
-               SC_PHIMAX, SC_VMIN, SC_VMAX, SC_KCOL, SC_RCOL, SC_SCOL, SC_PMASK)
+               SC_PHIMAX, SC_VMIN, SC_VMAX, SC_KCOL, SC_RCOL, SC_SCOL, SC_PMASK, SC_XMIN, SC_XMAX, SC_YMIN, SC_YMAX)
 
 G_ACC = 9.81
 
@@ -74,3 +74,21 @@ def circle_group_scenarios(n_ac, R, duration, K=50, seed=0, sigma=2.0, pair01_on
     else:
         sc[..., SC_PMASK] = (1 << n_ac) - 1
     return sc
+
+
+def nlp_problems(B, N=121, seed=0):
+    """B perturbed copies of the reference's exp_14 (src/d2d/optyplan_scenarios.py:219-253: 121 nodes, 12 s, CostAirVel(12), phi in
+    +-40 deg, v in [9, 15], boxes +-150) for the collocation backend: end poses moved by N(0, [3 m, 3 m, 0.1 rad]), the
+    reference's 'tri' initial guess.  -> scenario rows [B][SCEN_STRIDE], node values W0 [B][5][N], time step."""
+    from d2d.opty_utils import triangle
+    rng = np.random.default_rng(seed)
+    rows = np.zeros((B, SCEN_STRIDE)); W = np.zeros((B, 5, N))
+    for b in range(B):
+        p0 = np.array([-49.98, -58.14, 2.22]) + rng.normal(0, [3., 3., 0.1]); p1 = np.array([75., 40., 0.]) + rng.normal(0, [3., 3., 0.1])
+        r = rows[b]
+        r[SC_X0:SC_X0 + 3] = p0; r[SC_X1:SC_X1 + 3] = p1
+        r[SC_VSP], r[SC_KV], r[SC_KPHI], r[SC_S] = 12., 1., 0., 1. / N
+        r[SC_PHIMAX] = np.deg2rad(40.); r[SC_VMIN], r[SC_VMAX] = 9., 15.
+        r[SC_XMIN], r[SC_XMAX], r[SC_YMIN], r[SC_YMAX] = -150, 150, -150, 150
+        W[b] = np.stack(triangle(p0[:2], p1[:2], 12., 12.0, N, go_left=-1.), 0)
+    return rows, W, 12.0 / (N - 1)
