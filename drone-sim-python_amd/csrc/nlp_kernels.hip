@@ -1,11 +1,12 @@
 // Direct-collocation NLP of the reference's planners in its own parameterisation -- node values (x, y, psi, phi, v)(t_i),
 // backward-Euler collocation equalities, end conditions, HARD box bounds -- solved on the device: the backend that stands
 // where the reference builds `opty.direct_collocation.Problem(...)` and calls `.solve(x0)` (IPOPT)
-// (src/single_opt_planner.py:62-71,124; src/multi_opt_planner.py:69-78,86).  Restates oracle/nlp.py line by line:
+// (src/single_opt_planner.py:62-71,124; src/multi_opt_planner.py:69-78,86).  The algorithm is oracle/nlp.py's, step for step:
 //   equalities  -> augmented Lagrangian (scaled multiplier estimate mu, penalty rho)
 //   bounds      -> primal-dual log barrier (parameter mub, duals zL / zU), fraction-to-the-boundary rule
 //   inner step  -> damped Newton on the block-tridiagonal system  H/2 + Sigma/2 + lam |diag|  (Lagrangian Hessian incl. the
-//                  constraint curvature, 5x5 blocks, block Cholesky), backtracking line search on the barrier-AL merit function
+//                  constraint curvature), backtracking line search on the barrier-AL merit function
+// (the oracle solves that system with banded LAPACK; here: per-node elimination of phi, v + 3x3 block Cholesky, see below).
 // One problem per WAVEFRONT.  Everything that is independent from node to node -- merit function, assembly of the Hessian
 // blocks, ratio tests, the update -- runs with lane = node (chunks of 64, DPP reductions); only the two block recursions
 // (Cholesky + forward substitution, back substitution) are serial in the nodes and run wave-uniform with the next node's
