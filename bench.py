@@ -191,7 +191,9 @@ def nlp_record(ctx, torch, cpu, B=4096):
     st, it, cost = out['status'].cpu().numpy(), out['iters'].cpu().numpy(), out['cost'].cpu().numpy()
     rec = {'metric': 'collocation problems/sec (121 nodes x 5 node variables, hard bounds)', 'value': B / best, 'unit': 'problems/s',
            'workload': f'{B} perturbed copies of optyplan_scenarios.exp_14 (end poses moved by N(0, [3 m, 3 m, 0.1 rad])), tri initial guess',
-           'seconds': best, 'dtype': 'f64', 'converged_frac': float((st == 1).mean()), 'mean_newton_steps': float(it.mean()),
+           'seconds': best, 'dtype': 'f64', 'converged_frac': float((st == 1).mean()),
+           'infeasible_frac': float((st == 4).mean()),     # D2D_ST_STALLED: perturbed end poses that no v <= 15 path joins in 12 s (the oracle agrees)
+           'mean_newton_steps': float(it.mean()),
            'max_newton_steps': int(it.max()), 'cpu_baseline': cpu}
     if cpu is not None:
         n = len(cpu['cost'])

@@ -114,6 +114,39 @@ def test_batch_with_obstacles_wind_and_boxes_vs_oracle(ctx):
         assert kkt <= 1e-5 and feas <= 1e-8, (i, kkt)
 
 
+@pytest.mark.parametrize('N', [3, 5, 63, 64, 65, 129, 200])
+def test_ragged_node_counts_vs_oracle(ctx, N):
+    """Node counts around the chunk size of the node-parallel phases (64) and the unroll of the serial recursions (4), down to the
+    smallest problem the entry point takes (3 nodes: one free position): a side-step at 12 m/s, against the oracle's solve."""
+    h = 0.1
+    # (cost of order one: with obj_scale = 1 the 1/N-scaled cost of a gentle 200-node leg is 1e-3 and its minimiser is not
+    # determined to the solver's tolerances -- the oracle itself moves by 0.5 m when the guess moves by 1e-9)
+    p0 = (0., 0., 0., 0., 12.); p1 = (12. * h * (N - 1) * 0.995, (0.01 if N <= 5 else 0.15) * (N - 1), 0., 0., 12.)
+    pb = nlp.Problem(N, h, p0, p1, vsp=12., kv=1., kphi=5., obj_scale=float(N), phi_max=np.deg2rad(30.), v_min=9., v_max=15.)
+    W0 = np.stack([np.linspace(p0[0], p1[0], N), np.linspace(p0[1], p1[1], N), np.zeros(N), np.zeros(N), np.full(N, 12.)], 1)
+    W, out = _solve(ctx, [pb], [W0], [_row(pb)])
+    W = W[:, :, 0]
+    Wo, info = nlp.solve(pb, W0)
+    assert info['status'] == 1 and out['status'][0] == 1, (info['status'], out['status'])
+    assert out['feas'][0] <= 1e-8 and np.abs(nlp.constraints(pb, W)).max() <= 1e-8
+    assert abs(info['cost'] - out['cost'][0]) <= 1e-7 * max(info['cost'], 1e-6) and np.abs(W - Wo).max() <= 1e-5
+    np.testing.assert_allclose(W[0, :3], p0[:3], atol=0); np.testing.assert_allclose(W[-1, :3], p1[:3], atol=0)
+
+
+def test_infeasible_problem_gives_up_like_the_oracle(ctx):
+    """Three nodes and a side-step that needs 39 deg of bank against a 30 deg bound: no feasible point.  Kernel and oracle both stop
+    with status 4 (stalled at the largest penalty) instead of running outer_max x inner_max steps, bounds never violated."""
+    N, h = 3, 0.1
+    p0 = (0., 0., 0., 0., 12.); p1 = (12. * h * 2 * 0.995, 0.08, 0., 0., 12.)
+    pb = nlp.Problem(N, h, p0, p1, vsp=12., kv=1., kphi=0.5, obj_scale=1., phi_max=np.deg2rad(30.), v_min=9., v_max=15.)
+    W0 = np.stack([np.linspace(p0[0], p1[0], N), np.linspace(p0[1], p1[1], N), np.zeros(N), np.zeros(N), np.full(N, 12.)], 1)
+    W, out = _solve(ctx, [pb], [W0], [_row(pb)])
+    Wo, info = nlp.solve(pb, W0)
+    assert info['status'] == 4 and out['status'][0] == 4, (info['status'], out['status'])
+    assert out['feas'][0] > 1e-3 and (np.abs(W[:, 3, 0]) <= np.deg2rad(30.)).all()
+    assert abs(int(out['iters'][0]) - info['inner']) <= 5
+
+
 def _feas(sol_x, sol_y, sol_psi, sol_phi, sol_v, h, wind=(0., 0.)):
     free = np.concatenate([sol_x, sol_y, sol_psi, sol_phi, sol_v])
     return np.abs(C.collocation_residual(free, len(sol_x), h, wind)).max()
