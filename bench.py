@@ -57,10 +57,10 @@ JTJ_BYTES_PER_UNIT = 4 * K * 16 + 6 * 1024                  # contraction-only k
 
 def pmc_traffic(kernel):
     """HBM bytes per launch of a hot kernel from the committed rocprofv3 PMC passes of THIS command (tools/profile_bench.sh ->
-    tools/condense_profile.py -> profiles/r02/04_bench_final_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate passes,
+    tools/condense_profile.py -> profiles/r02/06_bench_final_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate passes,
     corrected as MI355X_MICROARCH.md prescribes).  bench.py cannot read hardware counters itself; None when the file is absent."""
     try:
-        t = json.load(open(os.path.join(ROOT, 'profiles', 'r02', '04_bench_final_traffic.json')))[kernel][0]
+        t = json.load(open(os.path.join(ROOT, 'profiles', 'r02', '06_bench_final_traffic.json')))[kernel][0]
     except (OSError, KeyError, IndexError, ValueError):
         return None, None
     return t['fetch_bytes_per_launch'] + t['write_bytes_per_launch'], t
@@ -194,7 +194,7 @@ def nlp_record(ctx, torch, cpu, B=4096):
            'seconds': best, 'dtype': 'f64', 'converged_frac': float((st == 1).mean()),
            'infeasible_frac': float((st == 4).mean()),     # D2D_ST_STALLED: perturbed end poses that no v <= 15 path joins in 12 s (the oracle agrees)
            'mean_newton_steps': float(it.mean()),
-           'max_newton_steps': int(it.max()), 'cpu_baseline': cpu}
+           'max_newton_steps': int(it.max()), 'hbm_traffic_per_launch': pmc_traffic('nlp_solve_kernel')[0], 'cpu_baseline': cpu}
     if cpu is not None:
         n = len(cpu['cost'])
         rec['parity'] = {'n': n, 'max_rel_cost_diff_vs_oracle': float(np.max(np.abs(cost[:n] - np.array(cpu['cost'])) / np.array(cpu['cost']))),
@@ -270,7 +270,7 @@ def sim_records(ctx, torch, cpu_g, cpu_t, drones=65536, steps=10000, track_steps
                    'unit': 'drone-steps/s', 'drones': N, 'steps': steps, 'launch_s': dte, 'dtype': 'f64',
                    'workload': 'BASELINE configs[4]: full_sim_case1 guidance loop, 65k drones x 10k plant steps, per-step controller evaluation',
                    'roofline': {'bound': 'hbm', 'kernel': 'gvf_run_kernel', 'achieved': n_steps * 56 / dte / 1e9, 'peak': HBM_PEAK_GBS,
-                                'unit': 'GB/s', 'frac': n_steps * 56 / dte / 1e9 / HBM_PEAK_GBS, 'traffic': None, 'alg_bytes_per_unit': 56,
+                                'unit': 'GB/s', 'frac': n_steps * 56 / dte / 1e9 / HBM_PEAK_GBS, 'traffic': pmc_traffic('gvf_run_kernel')[0], 'alg_bytes_per_unit': 56,
                                 'note': 'integration-bound (fp64 VALU); HBM GB/s reported as BASELINE configs[4] asks; PMC WRITE_SIZE = '
                                         'algorithmic to 0.03 % (profiles/)'},
                    'cpu_baseline': cpu_g}
@@ -288,7 +288,7 @@ def sim_records(ctx, torch, cpu_g, cpu_t, drones=65536, steps=10000, track_steps
                      'unit': 'drone-steps/s', 'drones': N, 'steps': track_steps, 'launch_s': dte, 'dtype': 'f64',
                      'workload': 'implement_controller loop of 11_full_sim_case1.py (:272-290) for 65k independent drones',
                      'roofline': {'bound': 'hbm', 'kernel': 'gradient_kernel x4 + track_run_kernel', 'achieved': n_steps * 104 / dte / 1e9,
-                                  'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': n_steps * 104 / dte / 1e9 / HBM_PEAK_GBS, 'traffic': None,
+                                  'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': n_steps * 104 / dte / 1e9 / HBM_PEAK_GBS, 'traffic': pmc_traffic('track_run_kernel')[0],
                                   'alg_bytes_per_unit': 104, 'note': 'CARE-bound (fp64 VALU); HBM GB/s as configs[4] asks'},
                      'cpu_baseline': cpu_t}
     del o

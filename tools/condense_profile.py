@@ -6,7 +6,7 @@
                                    MI355X_MICROARCH.md prescribes (separate passes; the counters are in KiB; FETCH_SIZE of wide
                                    coalesced streaming reads reports half the bytes on gfx950: doubled for the kernel whose
                                    reads are 16-B-per-lane streams, left as is -- and flagged uncalibrated -- elsewhere)
-  python tools/condense_profile.py gpurun_out/r2_prof profiles/r02/04_bench_final"""
+  python tools/condense_profile.py gpurun_out/r2_prof profiles/r02/06_bench_final"""
 import collections
 import csv
 import glob
@@ -34,7 +34,7 @@ with open(prefix + '_pmc_summary.txt', 'w') as out:
 traffic = {}
 for k, cs in acc.items():
     if 'FETCH_SIZE' in cs and 'WRITE_SIZE' in cs:
-        name = 'fit_lm_kernel' if 'fit_lm_kernel' in k else ('fit_jtj_kernel' if 'fit_jtj_kernel' in k else None)
+        name = next((n for n in ('fit_lm_kernel', 'fit_jtj_kernel', 'gvf_run_kernel', 'track_run_kernel', 'nlp_solve_kernel') if n in k), None)
         if name is None:
             continue
         fetch_kib = sum(cs['FETCH_SIZE']) / len(cs['FETCH_SIZE'])
