@@ -112,14 +112,13 @@ enum {
   WS_ZL = 0, WS_ZU = 5,                  // bound duals (5 + 5 planes)
   WS_MU = 10,                            // scaled multiplier estimates (3 planes) unless the caller wants them (mult)
   WS_DW = 13,                            // step (5 planes)
-  WS_RAW = 18,                           // assembled node, undamped (35 planes): rhs (5), D lower triangle by rows (15), E [a][k] (15)
-  WS_EL = 53,                            // local elimination of (phi, v) (17 planes): 1/l00, l10, 1/l11; Qt [j][k] (6); Rt [j][k] (6); tt (2)
-  WS_UP = 70,                            // what node i hands to node i-1 (9 planes): Rt^T Rt lower triangle (6), Rt^T tt (3)
-  WS_SIN = 79,                           // reduced node [N][18]: D' lower triangle (6), E' [a][k] (9), t' (3)
-  WS_SF = 97,                            // factor of the reduced system [N][18]: L (6, RECIPROCAL diagonal), Lo [a][k] (9), y (3)
-  WS_DS = 115,                           // reduced step [N][3]
-  WS_TOTAL = 118,
-  RAW_RHS = 0, RAW_D = 5, RAW_E = 20,
+  WS_RHS = 18,                           // right-hand side (5 planes)
+  WS_EL = 23,                            // local elimination of (phi, v) (17 planes): 1/l00, l10, 1/l11; Qt [j][k] (6); Rt [j][k] (6); tt (2)
+  WS_UP = 40,                            // what node i hands to node i-1 (9 planes): Rt^T Rt lower triangle (6), Rt^T tt (3)
+  WS_SIN = 49,                           // reduced node [N][18]: D' lower triangle (6), E' [a][k] (9), t' (3)
+  WS_SF = 67,                            // factor of the reduced system [N][18]: L (6, RECIPROCAL diagonal), Lo [a][k] (9), y (3)
+  WS_DS = 85,                            // reduced step [N][3]
+  WS_TOTAL = 88,
   EL_LP = 0, EL_Q = 3, EL_R = 9, EL_T = 15,
   UP_RR = 0, UP_RT = 6,
   SIN_D = 0, SIN_E = 6, SIN_T = 15, SIN_N = 18,
@@ -138,7 +137,7 @@ struct NlpProb {
 #define NLP_P(plane, i) pb.ws[(plane) * pb.N + (i)]
 #define NLP_MU(k, i) pb.mu[(k) * pb.N + (i)]
 #define NLP_DW(c, i) NLP_P(WS_DW + (c), i)
-#define NLP_RAW(k, i) NLP_P(WS_RAW + (k), i)
+#define NLP_RHS(c, i) NLP_P(WS_RHS + (c), i)
 #define NLP_EL(k, i) NLP_P(WS_EL + (k), i)
 #define NLP_UP(k, i) NLP_P(WS_UP + (k), i)
 #define NLP_SIN(k, i) pb.ws[(size_t)WS_SIN * pb.N + (i) * SIN_N + (k)]
@@ -215,17 +214,31 @@ __device__ double nlp_merit(const NlpProb &pb, const NlpScen &s, const double *_
   return val - mub * bar;
 }
 
-// Assembly (node-parallel): half gradient g, half Hessian blocks D (diagonal) and E (i, i-1) of the barrier-AL Lagrangian incl.
-// the constraint curvature, barrier diagonal, right-hand side; barrier KKT error of the inner problem (wave-uniform return).
-// The damping is NOT in D: the factorisation adds it (a retry with a larger damping needs no re-assembly).
-__device__ double nlp_assemble(const NlpProb &pb, const NlpScen &s, const double *__restrict__ sc, int lane, double rho, double mub) {
+// 1/sqrt(v), v > 0 (normal range): hardware estimate + two Newton steps (the pivots of the serial recursion are a dependent
+// chain -- the library's sqrt followed by a division is four times as long)
+__device__ __forceinline__ double nlp_rsqrt(double v) {
+  double y = __builtin_amdgcn_rsq(v);
+  const double hv = 0.5 * v;
+  y = fma(y, fma(-hv * y, y, 0.5), y);
+  y = fma(y, fma(-hv * y, y, 0.5), y);
+  return y;
+}
+
+// Assembly + local elimination (node-parallel, one pass, the 5x5 blocks never leave the registers): half gradient g, half Hessian
+// blocks D (diagonal) and E (i, i-1) of the barrier-AL Lagrangian incl. the constraint curvature, barrier diagonal, damping,
+// right-hand side; then the elimination of (phi, v) described below.  Returns the barrier KKT error of the inner problem
+// (wave-uniform; it does not depend on the damping); *pd_out = false if a 2x2 pivot is not positive.
+__device__ double nlp_assemble(const NlpProb &pb, const NlpScen &s, const double *__restrict__ sc, int lane, double rho, double mub,
+                               double lam, bool *pd_out) {
   const int N = pb.N;
   const double h = pb.h, ih = 1.0 / h;
   double err = 0.0;
+  int bad = 0;
   for (int i0 = 0; i0 < N; i0 += 64) {
     const int i = i0 + lane;
     if (i >= N) continue;
     const bool has_next = i + 1 < N;
+    double rhsv[NLP_NV];
     double wp[3] = {0, 0, 0}, wc[NLP_NV], wn[NLP_NV] = {0, 0, 0, 0, 1};
     double cc[3] = {0, 0, 0}, cn[3] = {0, 0, 0};     // (c + mu) of the constraint that ends at this node / at the next one
 #pragma unroll
@@ -310,8 +323,10 @@ __device__ double nlp_assemble(const NlpProb &pb, const NlpScen &s, const double
         err = fmax(err, fabs(z * su - mub));
       }
       if (!fx) err = fmax(err, fabs(st));
-      NLP_RAW(RAW_RHS + c, i) = fx ? 0.0 : r;
+      rhsv[c] = fx ? 0.0 : r;
+      NLP_RHS(c, i) = rhsv[c];
       D[c][c] += 0.5 * sig;
+      if (!fx) D[c][c] += lam * fmax(fabs(D[c][c]), 1e-12);
       if (fx) {
 #pragma unroll
         for (int a = 0; a < NLP_NV; ++a) { D[c][a] = 0.0; D[a][c] = 0.0; }
@@ -324,25 +339,44 @@ __device__ double nlp_assemble(const NlpProb &pb, const NlpScen &s, const double
 #pragma unroll
       for (int a = 0; a < NLP_NV; ++a) { E[a][0] = 0.0; E[a][1] = 0.0; E[a][2] = 0.0; }
     }
+    // ---- elimination of (phi, v) of this node: P = LP LP^T, Qt = LP^-1 M[pv, s_i], Rt = LP^-1 M[pv, s_{i-1}], tt = LP^-1 rhs_pv / 2
+    double P00 = D[3][3], v11;
+    if (!(P00 > 0.0)) { bad = 1; P00 = 1.0; }
+    const double i00 = nlp_rsqrt(P00), l10 = D[4][3] * i00;
+    v11 = D[4][4] - l10 * l10;
+    if (!(v11 > 0.0)) { bad = 1; v11 = 1.0; }
+    const double i11 = nlp_rsqrt(v11);
+    NLP_EL(EL_LP + 0, i) = i00; NLP_EL(EL_LP + 1, i) = l10; NLP_EL(EL_LP + 2, i) = i11;
+    double Qt[2][3], Rt[2][3], tt[2];
 #pragma unroll
-    for (int a = 0; a < NLP_NV; ++a) {
+    for (int k = 0; k < 3; ++k) {
+      Qt[0][k] = D[3][k] * i00; Qt[1][k] = (D[4][k] - l10 * Qt[0][k]) * i11;
+      Rt[0][k] = E[3][k] * i00; Rt[1][k] = (E[4][k] - l10 * Rt[0][k]) * i11;
+    }
+    tt[0] = 0.5 * rhsv[3] * i00;
+    tt[1] = (0.5 * rhsv[4] - l10 * tt[0]) * i11;
 #pragma unroll
-      for (int c = 0; c <= a; ++c) NLP_RAW(RAW_D + a * (a + 1) / 2 + c, i) = D[a][c];
+    for (int j = 0; j < 2; ++j) {
 #pragma unroll
-      for (int k = 0; k < 3; ++k) NLP_RAW(RAW_E + a * 3 + k, i) = E[a][k];
+      for (int k = 0; k < 3; ++k) { NLP_EL(EL_Q + j * 3 + k, i) = Qt[j][k]; NLP_EL(EL_R + j * 3 + k, i) = Rt[j][k]; }
+      NLP_EL(EL_T + j, i) = tt[j];
+    }
+    // what node i-1 gets from this node's elimination, and this node's own part of the reduced node (node-major)
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+      for (int c = 0; c <= a; ++c) {
+        NLP_UP(UP_RR + a * (a + 1) / 2 + c, i) = Rt[0][a] * Rt[0][c] + Rt[1][a] * Rt[1][c];
+        NLP_SIN(SIN_D + a * (a + 1) / 2 + c, i) = D[a][c] - (Qt[0][a] * Qt[0][c] + Qt[1][a] * Qt[1][c]);
+      }
+      NLP_UP(UP_RT + a, i) = Rt[0][a] * tt[0] + Rt[1][a] * tt[1];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) NLP_SIN(SIN_E + a * 3 + k, i) = E[a][k] - (Qt[0][a] * Rt[0][k] + Qt[1][a] * Rt[1][k]);
+      NLP_SIN(SIN_T + a, i) = 0.5 * rhsv[a] - (Qt[0][a] * tt[0] + Qt[1][a] * tt[1]);
     }
   }
+  *pd_out = __builtin_amdgcn_ballot_w64(bad != 0) == 0ull;
   return wave_max(err);
-}
-
-// 1/sqrt(v), v > 0 (normal range): hardware estimate + two Newton steps (the pivots of the serial recursion are a dependent
-// chain -- the library's sqrt followed by a division is four times as long)
-__device__ __forceinline__ double nlp_rsqrt(double v) {
-  double y = __builtin_amdgcn_rsq(v);
-  const double hv = 0.5 * v;
-  y = fma(y, fma(-hv * y, y, 0.5), y);
-  y = fma(y, fma(-hv * y, y, 0.5), y);
-  return y;
 }
 
 // The Newton system  M dw = rhs / 2  (M: block tridiagonal, 5x5 blocks D_i + damping, sub-diagonal blocks E_i whose only
@@ -350,79 +384,17 @@ __device__ __forceinline__ double nlp_rsqrt(double v) {
 // other node's phi, v: they are eliminated NODE BY NODE IN PARALLEL (2x2 Cholesky + Schur complement), which leaves a block
 // tridiagonal system with 3x3 blocks in (x, y, psi) for the serial recursion -- 80 instead of 280 fp64 operations per node on
 // the serial chain.
-// Pass A (lane = node): P = LP LP^T, Qt = LP^-1 M[pv, s_i], Rt = LP^-1 M[pv, s_{i-1}], tt = LP^-1 rhs_pv / 2; what node i-1 gets.
-// Returns false (wave-uniform) if a 2x2 pivot is not positive.
-__device__ bool nlp_eliminate_a(const NlpProb &pb, int lane, double lam) {
-  const int N = pb.N;
-  int bad = 0;
-  for (int i0 = 0; i0 < N; i0 += 64) {
-    const int i = i0 + lane;
-    if (i >= N) continue;
-    double P00 = NLP_RAW(RAW_D + 9, i), P10 = NLP_RAW(RAW_D + 13, i), P11 = NLP_RAW(RAW_D + 14, i);     // (3,3), (4,3), (4,4)
-    P00 += lam * fmax(fabs(P00), 1e-12);
-    P11 += lam * fmax(fabs(P11), 1e-12);
-    if (!(P00 > 0.0)) { bad = 1; P00 = 1.0; }
-    const double i00 = nlp_rsqrt(P00), l10 = P10 * i00;
-    double v11 = P11 - l10 * l10;
-    if (!(v11 > 0.0)) { bad = 1; v11 = 1.0; }
-    const double i11 = nlp_rsqrt(v11);
-    NLP_EL(EL_LP + 0, i) = i00; NLP_EL(EL_LP + 1, i) = l10; NLP_EL(EL_LP + 2, i) = i11;
-    double Qt[2][3], Rt[2][3], tt[2];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const double q0 = NLP_RAW(RAW_D + 6 + k, i), q1 = NLP_RAW(RAW_D + 10 + k, i);      // rows 3 and 4 of the lower triangle
-      Qt[0][k] = q0 * i00; Qt[1][k] = (q1 - l10 * Qt[0][k]) * i11;
-      const double r0 = NLP_RAW(RAW_E + 9 + k, i), r1 = NLP_RAW(RAW_E + 12 + k, i);      // E[3][k], E[4][k]
-      Rt[0][k] = r0 * i00; Rt[1][k] = (r1 - l10 * Rt[0][k]) * i11;
-    }
-    tt[0] = 0.5 * NLP_RAW(RAW_RHS + 3, i) * i00;
-    tt[1] = (0.5 * NLP_RAW(RAW_RHS + 4, i) - l10 * tt[0]) * i11;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-#pragma unroll
-      for (int k = 0; k < 3; ++k) { NLP_EL(EL_Q + j * 3 + k, i) = Qt[j][k]; NLP_EL(EL_R + j * 3 + k, i) = Rt[j][k]; }
-      NLP_EL(EL_T + j, i) = tt[j];
-    }
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-#pragma unroll
-      for (int c = 0; c <= a; ++c) NLP_UP(UP_RR + a * (a + 1) / 2 + c, i) = Rt[0][a] * Rt[0][c] + Rt[1][a] * Rt[1][c];
-      NLP_UP(UP_RT + a, i) = Rt[0][a] * tt[0] + Rt[1][a] * tt[1];
-    }
-  }
-  return __builtin_amdgcn_ballot_w64(bad != 0) == 0ull;
-}
-// Pass B (lane = node): the reduced node  D' = D_ss + damping - Qt^T Qt - (Rt^T Rt)_{i+1},  E' = E_ss - Qt^T Rt,
-// t' = rhs_s / 2 - Qt^T tt - (Rt^T tt)_{i+1}  -> node-major input of the serial recursion.
-__device__ void nlp_eliminate_b(const NlpProb &pb, int lane, double lam) {
+// The elimination itself is the tail of nlp_assemble (the blocks are in registers there); what remains is the hand-over between
+// neighbours (lane = node):  D'_i -= (Rt^T Rt)_{i+1},  t'_i -= (Rt^T tt)_{i+1}.
+__device__ void nlp_eliminate_b(const NlpProb &pb, int lane) {
   const int N = pb.N;
   for (int i0 = 0; i0 < N; i0 += 64) {
     const int i = i0 + lane;
-    if (i >= N) continue;
-    const bool has_next = i + 1 < N;
-    double Qt[2][3], Rt[2][3], tt[2];
+    if (i + 1 >= N) continue;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int k = 0; k < 6; ++k) NLP_SIN(SIN_D + k, i) -= NLP_UP(UP_RR + k, i + 1);
 #pragma unroll
-      for (int k = 0; k < 3; ++k) { Qt[j][k] = NLP_EL(EL_Q + j * 3 + k, i); Rt[j][k] = NLP_EL(EL_R + j * 3 + k, i); }
-      tt[j] = NLP_EL(EL_T + j, i);
-    }
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-#pragma unroll
-      for (int c = 0; c <= a; ++c) {
-        double d = NLP_RAW(RAW_D + a * (a + 1) / 2 + c, i);
-        if (a == c && !nlp_fixed(i, N, a)) d += lam * fmax(fabs(d), 1e-12);
-        d -= Qt[0][a] * Qt[0][c] + Qt[1][a] * Qt[1][c];
-        if (has_next) d -= NLP_UP(UP_RR + a * (a + 1) / 2 + c, i + 1);
-        NLP_SIN(SIN_D + a * (a + 1) / 2 + c, i) = d;
-      }
-#pragma unroll
-      for (int k = 0; k < 3; ++k) NLP_SIN(SIN_E + a * 3 + k, i) = NLP_RAW(RAW_E + a * 3 + k, i) - (Qt[0][a] * Rt[0][k] + Qt[1][a] * Rt[1][k]);
-      double t = 0.5 * NLP_RAW(RAW_RHS + a, i) - (Qt[0][a] * tt[0] + Qt[1][a] * tt[1]);
-      if (has_next) t -= NLP_UP(UP_RT + a, i + 1);
-      NLP_SIN(SIN_T + a, i) = t;
-    }
+    for (int a = 0; a < 3; ++a) NLP_SIN(SIN_T + a, i) -= NLP_UP(UP_RT + a, i + 1);
   }
 }
 
@@ -602,7 +574,7 @@ __device__ void nlp_recover_stats(const NlpProb &pb, const NlpScen &s, int lane,
     for (int c = 0; c < NLP_NV; ++c) {
       const double dw = dwv[c];
       NLP_DW(c, i) = dw;
-      dphi -= NLP_RAW(RAW_RHS + c, i) * dw;
+      dphi -= NLP_RHS(c, i) * dw;
       if (nlp_fixed(i, N, c)) continue;
       const double w = NLP_W(c, i);
       if (s.lo[c] > -1e299) {
@@ -652,7 +624,9 @@ __device__ void nlp_apply(const NlpProb &pb, const NlpScen &s, int lane, double 
 
 // One wavefront per problem.  Node-parallel phases (merit, assembly, step statistics, update) run with lane = node; the two
 // block recursions are serial in the nodes and run wave-uniform.  Control flow is uniform: no lane waits for another problem.
-__global__ void __launch_bounds__(64)
+// Two waves per SIMD (the assembly spills ~280 registers for it, once per Newton step; the serial recursions are separate functions
+// and do not): measured +12 % problems/s at 4096 and 65 536 problems for +6 % latency of a lone one.
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 nlp_solve_kernel(int B, int N, double h, d2d_nlp_opts o, const double *__restrict__ scen, const double *partner, double *W,
                  double *work, double *mult, double *__restrict__ cost_out, double *__restrict__ feas_out,
                  int32_t *__restrict__ iters_out, int32_t *__restrict__ status_out, unsigned long long *stamps) {
@@ -712,15 +686,14 @@ nlp_solve_kernel(int B, int N, double h, d2d_nlp_opts o, const double *__restric
     for (int it = 0; it < o.inner_max; ++it) {
       ++total_inner;
       bool accepted = false, converged = false;
-      err = nlp_assemble(pb, s, sc, lane, rho, mub);
-      nlp_phase_sync();
-      NLP_STAMP(1)
-      if (err <= tol_in) break;
       for (int tr = 0; tr < 30; ++tr) {
-        bool pd = nlp_eliminate_a(pb, lane, lam);
+        bool pd;
+        err = nlp_assemble(pb, s, sc, lane, rho, mub, lam, &pd);        // (a retry with another damping assembles again: rare)
         nlp_phase_sync();
+        NLP_STAMP(1)
+        if (tr == 0 && err <= tol_in) { converged = true; break; }
         if (pd) {
-          nlp_eliminate_b(pb, lane, lam);
+          nlp_eliminate_b(pb, lane);
           nlp_phase_sync();
           NLP_STAMP(6)
           pd = nlp_factor(pb.ws + (size_t)WS_SIN * N, pb.ws + (size_t)WS_SF * N, N);
@@ -756,8 +729,7 @@ nlp_solve_kernel(int B, int N, double h, d2d_nlp_opts o, const double *__restric
         }
         lam = fmin(lam * 4.0, D2D_LM_LAMBDA_MAX);
       }
-      (void)converged;
-      if (!accepted) break;
+      if (converged || !accepted) break;
     }
     (void)nlp_merit(pb, s, sc, lane, 0.0, rho, mub, &cost_ref, &feas);
     if (feas <= o.feas_tol && mub <= o.mub_min * 1.0001 && err <= tol_in) { status = D2D_ST_CONVERGED; break; }
