@@ -398,149 +398,251 @@ __device__ void nlp_eliminate_b(const NlpProb &pb, int lane) {
   }
 }
 
-// Serial recursion 1 (forward over the nodes; every lane computes and stores the same values): block Cholesky of the reduced
-// block-tridiagonal matrix and the forward substitution.  Lo = E' Lp^-T, S = D' - Lo Lo^T, L = chol(S), y = L^-1 (t' - Lo yp).
-// The inputs of node i+1 are requested before node i is processed (nothing else hides the memory latency: one wave per SIMD).
+// The two serial recursions, TWISTED: the block Cholesky runs from both ends of the horizon towards the middle node m = N/2 at
+// the same time -- lanes 0..31 eliminate nodes 0, 1, .. m-1, lanes 32..63 nodes N-1, N-2, .. m+1, one instruction stream (inside a
+// half every lane computes and stores the same values) -- and the back substitution runs from the middle outwards the same way:
+// the dependent chain is N/2 nodes long instead of N.
+//   step of a half:  Lo = C Lp^-T,  S = D' - Lo Lo^T,  L = chol(S),  y = L^-1 (t' - Lo yp)
+//   C = block (this node, node eliminated before it): E'_i for the lower half, E'_{i+1}^T for the upper half
+//   middle:          S_m = D'_m - Lo Lo^T (from m-1) - Uo Uo^T (from m+1),  y_m = L_m^-1 (t'_m - Lo y_{m-1} - Uo y_{m+1})
+//   back:            d_m = L_m^-T y_m;  d_i = L_i^-T (y_i - Lon^T dn)  with Lon, dn of the node next to i on the middle's side
+// Own functions, not inlined (inside the solver's loop nest the compiler spilled a dozen scalar registers around every node);
+// global address space stated explicitly (through a generic pointer the loads would be FLAT ones, whose waits also wait for the
+// stores); a ring of four node buffers with the loop unrolled by four (the node three steps ahead is requested before a node is
+// processed: one node's arithmetic is shorter than an L2 round trip, and no buffer is ever copied); every lane of a half stores the
+// same values to the same address (a store under `if (lane == 0)` sits behind a branch, and the wait for the next loads then
+// also waits for the stores: vmcnt counts in order and the compiler cannot count through a branch); a full wait before each
+// loop so that the loop-head wait is the back edge's.
 struct NlpNodeIn {
   double v[SIN_N];
 };
-// (own functions, not inlined: inside the solver's loop nest the compiler spilled a dozen scalar registers around every node of
-// the recursion; global address space stated explicitly: through a generic pointer the loads would be FLAT ones, whose waits
-// also wait for the stores)
 typedef __attribute__((address_space(1))) double gdouble;
-__device__ __attribute__((noinline)) bool nlp_factor(double *sin_generic, double *sf_generic, int N) {
+
+__device__ __forceinline__ double nlp_other_half(double v) {              // the value the lane 32 places away holds
+  return __hiloint2double(__builtin_amdgcn_ds_bpermute(((threadIdx.x ^ 32) & 63) << 2, __double2hiint(v)),
+                          __builtin_amdgcn_ds_bpermute(((threadIdx.x ^ 32) & 63) << 2, __double2loint(v)));
+}
+
+// one elimination step from the reduced node `in` (D' 6, C 9 row-major, t' 3) and the factor (Lp, yp) of the node before it
+__device__ __forceinline__ void nlp_block_lo(const double (&C)[3][3], const double (&Lp)[6], double (&Lo)[3][3]) {
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      double v = C[a][c];
+#pragma unroll
+      for (int k = 0; k < c; ++k) v -= Lp[c * (c + 1) / 2 + k] * Lo[a][k];
+      Lo[a][c] = v * Lp[c * (c + 1) / 2 + c];             // (the diagonal slots hold 1 / L_cc; first node of a half: Lp = 0 -> Lo = 0)
+    }
+  }
+}
+__device__ __forceinline__ bool nlp_block_chol(const double (&S)[6], const double (&t)[3], double (&L)[6], double (&y)[3]) {
+  bool ok = true;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+#pragma unroll
+    for (int c = 0; c <= a; ++c) {
+      double v = S[a * (a + 1) / 2 + c];
+#pragma unroll
+      for (int k = 0; k < c; ++k) v -= L[a * (a + 1) / 2 + k] * L[c * (c + 1) / 2 + k];
+      if (a == c) {
+        if (!(v > 0.0)) { ok = false; v = 1.0; }
+        L[a * (a + 1) / 2 + a] = nlp_rsqrt(v);             // the factor keeps the RECIPROCAL diagonal: every later use divides by it
+      } else {
+        L[a * (a + 1) / 2 + c] = v * L[c * (c + 1) / 2 + c];
+      }
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    double v = t[a];
+#pragma unroll
+    for (int k = 0; k < a; ++k) v -= L[a * (a + 1) / 2 + k] * y[k];
+    y[a] = v * L[a * (a + 1) / 2 + a];
+  }
+  return ok;
+}
+
+// mid: 9 doubles of scratch for the second coupling block of the middle node (its coupling to node m+1)
+__device__ __attribute__((noinline)) bool nlp_factor(double *sin_generic, double *sf_generic, double *mid_generic, int N) {
   const gdouble *sin = (const gdouble *)sin_generic;
   gdouble *sf = (gdouble *)sf_generic;
-#define NLP_SIN_(k, i) sin[(i) * SIN_N + (k)]
-#define NLP_SF_(k, i) sf[(i) * SF_N + (k)]
-  auto nlp_load_node = [&](int i, NlpNodeIn &n) {
+  gdouble *mid = (gdouble *)mid_generic;
+  const bool up = (threadIdx.x & 32) != 0;                   // upper half: nodes N-1 down to m+1
+  const int m = N >> 1, nlo = m, cnt = up ? N - 1 - m : m;   // (cnt >= 1 for N >= 3; the upper half has nlo or nlo - 1 nodes)
+  // inputs of step k of this lane's half: D', t' of its node i; C from E' of node i (lower) / E'^T of node i+1 (upper)
+  auto load = [&](int k, NlpNodeIn &n) {
+    const int kk = k < cnt ? k : cnt - 1;
+    const int i = up ? N - 1 - kk : kk;
+    const int ie = up ? (i + 1 < N ? i + 1 : i) : i;
+    const gdouble *pd = sin + (long)i * SIN_N, *pe = sin + (long)ie * SIN_N;
 #pragma unroll
-    for (int k = 0; k < SIN_N; ++k) n.v[k] = NLP_SIN_(k, i);
+    for (int q = 0; q < 6; ++q) n.v[SIN_D + q] = pd[SIN_D + q];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) n.v[SIN_E + q] = pe[SIN_E + q];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) n.v[SIN_T + q] = pd[SIN_T + q];
   };
-  double Lp[6], yp[3];                         // factor of the previous node's diagonal block (reciprocal diagonal), its y
+  auto coupling = [&](const NlpNodeIn &n, bool zero, double (&C)[3][3]) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const double v = up ? n.v[SIN_E + c * 3 + a] : n.v[SIN_E + a * 3 + c];
+        C[a][c] = zero ? 0.0 : v;
+      }
+  };
+  double Lp[6], yp[3];                         // factor of the node eliminated before (reciprocal diagonal), its y
 #pragma unroll
   for (int k = 0; k < 6; ++k) Lp[k] = 0.0;
 #pragma unroll
   for (int c = 0; c < 3; ++c) yp[c] = 0.0;
   bool ok = true;
-  // Ring of four node buffers, the loop unrolled by four: node i+3 is requested before node i is processed (one node's arithmetic
-  // is shorter than an L2 round trip), and no buffer is ever copied.
   NlpNodeIn buf[4];
-  nlp_load_node(0, buf[0]); nlp_load_node(N > 1 ? 1 : N - 1, buf[1]); nlp_load_node(N > 2 ? 2 : N - 1, buf[2]);
-  // vmcnt(0) before the loop: the wait at the loop head has to serve both ways in; coming from here with the first nodes still
-  // in flight it would be stricter than the back edge needs, and on the back edge it would then also wait for stores
-  __builtin_amdgcn_s_waitcnt(0x0F70);
-  for (int i0 = 0; i0 < N; i0 += 4) {
+  load(0, buf[0]); load(1, buf[1]); load(2, buf[2]);
+  __builtin_amdgcn_s_waitcnt(0x0F70);                        // vmcnt(0)
+  for (int k0 = 0; k0 < nlo; k0 += 4) {
 #pragma unroll
    for (int u = 0; u < 4; ++u) {
-    const int i = i0 + u;
-    if (i >= N) break;
-    nlp_load_node(i + 3 < N ? i + 3 : N - 1, buf[(u + 3) & 3]);
+    const int k = k0 + u;
+    if (k >= nlo) break;
+    load(k + 3, buf[(u + 3) & 3]);
     const NlpNodeIn &cur = buf[u];
-    double Lo[3][3], t[3], D[3][3];
+    if (k < cnt) {                                           // (the upper half may be one node shorter)
+      const int i = up ? N - 1 - k : k;
+      double C[3][3], Lo[3][3], S[6], t[3], L[6], y[3];
+      coupling(cur, k == 0, C);                              // (first node of a half: nothing before it)
+      nlp_block_lo(C, Lp, Lo);
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
+      for (int a = 0; a < 3; ++a) {
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        double v = cur.v[SIN_E + a * 3 + c];
-#pragma unroll
-        for (int k = 0; k < c; ++k) v -= Lp[c * (c + 1) / 2 + k] * Lo[a][k];
-        Lo[a][c] = v * Lp[c * (c + 1) / 2 + c];           // (the diagonal slots hold 1 / L_cc; node 0: Lp = 0 -> Lo = 0)
+        for (int c = 0; c <= a; ++c)
+          S[a * (a + 1) / 2 + c] = cur.v[SIN_D + a * (a + 1) / 2 + c] - (Lo[a][0] * Lo[c][0] + Lo[a][1] * Lo[c][1] + Lo[a][2] * Lo[c][2]);
+        t[a] = cur.v[SIN_T + a] - (Lo[a][0] * yp[0] + Lo[a][1] * yp[1] + Lo[a][2] * yp[2]);
       }
-    }
+      ok = nlp_block_chol(S, t, L, y) && ok;
+      gdouble *o = sf + (long)i * SF_N;
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
+      for (int q = 0; q < 6; ++q) o[SF_L + q] = L[q];
 #pragma unroll
-      for (int c = 0; c <= a; ++c) D[a][c] = cur.v[SIN_D + a * (a + 1) / 2 + c] - (Lo[a][0] * Lo[c][0] + Lo[a][1] * Lo[c][1] + Lo[a][2] * Lo[c][2]);
-      t[a] = cur.v[SIN_T + a] - (Lo[a][0] * yp[0] + Lo[a][1] * yp[1] + Lo[a][2] * yp[2]);
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o[SF_LO + a * 3 + c] = Lo[a][c];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) o[SF_Y + a] = y[a];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) Lp[q] = L[q];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) yp[a] = y[a];
     }
-    double L[6];
+   }
+  }
+  // ---- the middle node: both halves hand in their Schur complement
+  {
+    NlpNodeIn md;
+    const int ie = up ? m + 1 : m;
+    const gdouble *pd = sin + (long)m * SIN_N, *pe = sin + (long)ie * SIN_N;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) md.v[SIN_D + q] = pd[SIN_D + q];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) md.v[SIN_E + q] = pe[SIN_E + q];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) md.v[SIN_T + q] = pd[SIN_T + q];
+    double C[3][3], Lo[3][3], S[6], t[3], L[6], y[3];
+    coupling(md, false, C);
+    nlp_block_lo(C, Lp, Lo);
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
 #pragma unroll
       for (int c = 0; c <= a; ++c) {
-        double v = D[a][c];
-#pragma unroll
-        for (int k = 0; k < c; ++k) v -= L[a * (a + 1) / 2 + k] * L[c * (c + 1) / 2 + k];
-        if (a == c) {
-          if (!(v > 0.0)) { ok = false; v = 1.0; }
-          L[a * (a + 1) / 2 + a] = nlp_rsqrt(v);           // the factor keeps the RECIPROCAL diagonal: every later use divides by it
-        } else {
-          L[a * (a + 1) / 2 + c] = v * L[c * (c + 1) / 2 + c];
-        }
+        const double p = Lo[a][0] * Lo[c][0] + Lo[a][1] * Lo[c][1] + Lo[a][2] * Lo[c][2];
+        S[a * (a + 1) / 2 + c] = md.v[SIN_D + a * (a + 1) / 2 + c] - (p + nlp_other_half(p));
       }
+      const double q = Lo[a][0] * yp[0] + Lo[a][1] * yp[1] + Lo[a][2] * yp[2];
+      t[a] = md.v[SIN_T + a] - (q + nlp_other_half(q));
     }
-    double y[3];
+    ok = nlp_block_chol(S, t, L, y) && ok;
+    gdouble *o = sf + (long)m * SF_N;
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      double v = t[a];
+    for (int q = 0; q < 6; ++q) o[SF_L + q] = L[q];
 #pragma unroll
-      for (int k = 0; k < a; ++k) v -= L[a * (a + 1) / 2 + k] * y[k];
-      y[a] = v * L[a * (a + 1) / 2 + a];
-    }
-    // (every lane stores the same values to the same address: a store under `if (lane == 0)` sits behind a branch, and the wait
-    // for the next node's loads then also waits for these stores -- vmcnt counts in order and the compiler cannot count them)
-#pragma unroll
-    for (int k = 0; k < 6; ++k) NLP_SF_(SF_L + k, i) = L[k];
+    for (int a = 0; a < 3; ++a) o[SF_Y + a] = y[a];
+    gdouble *oc = up ? mid : o + SF_LO;                      // coupling to m-1 with the node, coupling to m+1 in the scratch
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
-      for (int c = 0; c < 3; ++c) NLP_SF_(SF_LO + a * 3 + c, i) = Lo[a][c];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) NLP_SF_(SF_Y + a, i) = y[a];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) Lp[k] = L[k];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) yp[a] = y[a];
-   }
+      for (int c = 0; c < 3; ++c) oc[a * 3 + c] = Lo[a][c];
   }
-  return ok;
+  return __builtin_amdgcn_ballot_w64(!ok) == 0ull;
 }
 
-// Serial recursion 2 (backward): ds_i = L_i^-T (y_i - Lo_{i+1}^T ds_{i+1}).
-__device__ __attribute__((noinline)) void nlp_backsolve(double *sf_generic, double *ds_generic, int N) {
+// Serial recursion 2, from the middle outwards in both halves: ds_m = L_m^-T y_m;  ds_i = L_i^-T (y_i - Lon^T dn).
+__device__ __attribute__((noinline)) void nlp_backsolve(double *sf_generic, double *mid_generic, double *ds_generic, int N) {
   const gdouble *sf = (const gdouble *)sf_generic;
+  const gdouble *mid = (const gdouble *)mid_generic;
   gdouble *dsv = (gdouble *)ds_generic;
-  double dn[3] = {0, 0, 0}, Lon[3][3];
+  const bool up = (threadIdx.x & 32) != 0;
+  const int m = N >> 1, nlo = m, cnt = up ? N - 1 - m : m;
+  auto node_of = [&](int k) { const int kk = k < cnt ? k : cnt - 1; return up ? m + 1 + kk : m - 1 - kk; };
+  auto load = [&](int k, NlpNodeIn &n) {
+    const gdouble *p = sf + (long)node_of(k) * SF_N;
 #pragma unroll
-  for (int a = 0; a < 3; ++a)
-#pragma unroll
-    for (int c = 0; c < 3; ++c) Lon[a][c] = 0.0;
-  auto load = [&](int i, NlpNodeIn &n) {
-#pragma unroll
-    for (int k = 0; k < SF_N; ++k) n.v[k] = NLP_SF_(k, i);
+    for (int q = 0; q < SF_N; ++q) n.v[q] = p[q];
   };
-  NlpNodeIn buf[4];                                                    // ring of four, unrolled by four (see nlp_factor)
-  load(N - 1, buf[0]); load(N > 1 ? N - 2 : 0, buf[1]); load(N > 2 ? N - 3 : 0, buf[2]);
-  __builtin_amdgcn_s_waitcnt(0x0F70);                                  // (vmcnt(0), see nlp_factor)
-  for (int i0 = N - 1; i0 >= 0; i0 -= 4) {
-#pragma unroll
-   for (int u = 0; u < 4; ++u) {
-    const int i = i0 - u;
-    if (i < 0) break;
-    load(i >= 3 ? i - 3 : 0, buf[(u + 3) & 3]);
-    const NlpNodeIn &cur = buf[u];
-    double t[3], ds[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) t[a] = cur.v[SF_Y + a] - (Lon[0][a] * dn[0] + Lon[1][a] * dn[1] + Lon[2][a] * dn[2]);
+  auto subst = [&](const double *v, const double (&t)[3], double (&ds)[3]) {       // ds = L^-T t (v: the node's factor record)
 #pragma unroll
     for (int a = 2; a >= 0; --a) {
-      double v = t[a];
+      double x = t[a];
 #pragma unroll
-      for (int k = a + 1; k < 3; ++k) v -= cur.v[SF_L + k * (k + 1) / 2 + a] * ds[k];
-      ds[a] = v * cur.v[SF_L + a * (a + 1) / 2 + a];
+      for (int k = a + 1; k < 3; ++k) x -= v[SF_L + k * (k + 1) / 2 + a] * ds[k];
+      ds[a] = x * v[SF_L + a * (a + 1) / 2 + a];
     }
+  };
+  NlpNodeIn buf[4];
+  load(0, buf[0]); load(1, buf[1]); load(2, buf[2]);
+  double dn[3], Lon[3][3];
+  {
+    NlpNodeIn md;
+    const gdouble *p = sf + (long)m * SF_N;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      if (nlp_fixed(i, N, c)) ds[c] = 0.0;
-      dn[c] = ds[c];
-    }
+    for (int q = 0; q < SF_N; ++q) md.v[q] = p[q];
+    const gdouble *pc = up ? mid : p + SF_LO;
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
-      for (int c = 0; c < 3; ++c) Lon[a][c] = cur.v[SF_LO + a * 3 + c];
+      for (int c = 0; c < 3; ++c) Lon[a][c] = pc[a * 3 + c];
+    __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0)
+    double t[3] = {md.v[SF_Y], md.v[SF_Y + 1], md.v[SF_Y + 2]};
+    subst(md.v, t, dn);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) dsv[i * 3 + c] = ds[c];            // (uniform store, see nlp_factor)
+    for (int c = 0; c < 3; ++c) dsv[(long)m * 3 + c] = dn[c];
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  for (int k0 = 0; k0 < nlo; k0 += 4) {
+#pragma unroll
+   for (int u = 0; u < 4; ++u) {
+    const int k = k0 + u;
+    if (k >= nlo) break;
+    load(k + 3, buf[(u + 3) & 3]);
+    const NlpNodeIn &cur = buf[u];
+    if (k < cnt) {
+      const int i = up ? m + 1 + k : m - 1 - k;
+      double t[3], ds[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) t[a] = cur.v[SF_Y + a] - (Lon[0][a] * dn[0] + Lon[1][a] * dn[1] + Lon[2][a] * dn[2]);
+      subst(cur.v, t, ds);
+      const bool fx = i == 0 || i == N - 1;                 // end conditions: fixed variables
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        if (fx) ds[c] = 0.0;
+        dn[c] = ds[c];
+        dsv[(long)i * 3 + c] = ds[c];
+      }
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) Lon[a][c] = cur.v[SF_LO + a * 3 + c];
+    }
    }
   }
 }
@@ -696,12 +798,12 @@ nlp_solve_kernel(int B, int N, double h, d2d_nlp_opts o, const double *__restric
           nlp_eliminate_b(pb, lane);
           nlp_phase_sync();
           NLP_STAMP(6)
-          pd = nlp_factor(pb.ws + (size_t)WS_SIN * N, pb.ws + (size_t)WS_SF * N, N);
+          pd = nlp_factor(pb.ws + (size_t)WS_SIN * N, pb.ws + (size_t)WS_SF * N, pb.ws + (size_t)WS_UP * N, N);   // (UP is free by now)
         }
         NLP_STAMP(2)
         if (!pd) { lam = fmin(lam * 8.0, D2D_LM_LAMBDA_MAX); continue; }
         nlp_phase_sync();
-        nlp_backsolve(pb.ws + (size_t)WS_SF * N, pb.ws + (size_t)WS_DS * N, N);
+        nlp_backsolve(pb.ws + (size_t)WS_SF * N, pb.ws + (size_t)WS_UP * N, pb.ws + (size_t)WS_DS * N, N);
         nlp_phase_sync();
         NLP_STAMP(3)
         const double tau = fmax(0.99, 1.0 - mub);
