@@ -405,13 +405,15 @@ int d2d_fit_sample(d2d_ctx *ctx, const d2d_fit_plan *plan, int B, const double *
  *                minimises the objective whose gradient that is; the cost REPORTED is the reference's cost()).
  * Solver (oracle/nlp.py is its CPU statement): equalities by an augmented Lagrangian, bounds by a primal-dual log barrier,
  * damped Newton steps on the block-tridiagonal (5x5 blocks) Lagrangian Hessian.  One problem per wavefront: merit function,
- * assembly, ratio tests and updates run with lane = node, the two block recursions are serial in the nodes.
+ * assembly, the elimination of (phi, v), ratio tests and updates run with lane = node; the 3x3 block recursion that remains is
+ * serial in the nodes and runs from both ends of the horizon towards the middle in the two halves of the wave.
  * scen dev [B][D2D_SCEN_STRIDE]: the fit's scenario rows (end poses, VSP, KV, KPHI, KOBS, S, wind, obstacles + OKIND, PHIMAX,
  * VMIN/VMAX, the x/y box, KCOL/RCOL/SCOL); W dev [B][5][N] node values (problem, component, node), in: the initial guess (e.g.
  * Planner.get_initial_guess), out: the solution; partner dev [B][2][N] frozen positions of the CostCollision partner or NULL;
  * work dev double[d2d_nlp_workspace_doubles(N) * B]; mult dev [B][3][N] or NULL: out, scaled multiplier estimates (node 0 unused;
  * Lagrange multiplier = 2 rho mu);  cost dev [B] (the reference's cost() at the solution), feas dev [B] (largest collocation
- * residual, in the reference's form), iters / status dev int32 [B] or NULL (Newton steps; D2D_ST_CONVERGED / D2D_ST_MAXITER).
+ * residual, in the reference's form), iters / status dev int32 [B] or NULL (Newton steps; D2D_ST_CONVERGED / D2D_ST_MAXITER /
+ * D2D_ST_STALLED: no feasible point found -- the violation stopped shrinking at the largest penalty).
  * Asynchronous on the context's stream. */
 #define D2D_NLP_RHO0 10.0
 #define D2D_NLP_RHO_MAX 1e8
