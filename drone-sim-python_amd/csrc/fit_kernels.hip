@@ -437,7 +437,7 @@ static FusedLds fused_lds_layout(int K, int nq, int N, int wpb, int nds = 0) {
   if ((N + 3) * (N + 4) * 4 > big) big = (N + 3) * (N + 4) * 4;
   w = align16(w + big);
   L.wave_stride = w;
-  L.total = o + wpb * w;
+  L.total = o + wpb * w + 64;                   // + one flag word per wave (fit_lm_kernel: exclusive SIMDs for the longest fits)
   return L;
 }
 static bool pick_fused_layout(int K, int nq, int N, int *wpb, int nds = 0) {
@@ -455,7 +455,8 @@ fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_budget,
               const double *__restrict__ prep, double *__restrict__ q_io, double *__restrict__ cost_io,
               double *__restrict__ g_io, double *__restrict__ lm, int32_t *__restrict__ flags,
               int32_t *__restrict__ queue, unsigned long long *__restrict__ stamps,
-              const int32_t *__restrict__ order, int prio_at) {
+              const int32_t *__restrict__ order, int prio_pack) {
+  // prio_pack = prio_at | excl << 16.
   // order != NULL: hand-out position i takes trajectory order[i] (d2d_fit_plan_set_order: the longest fits of a previous solve
   // first, so that the tail of the launch is not one long fit that was drawn late).  prio_at: a fit that has used this many
   // iterations raises its wave's priority (s_setprio): the stragglers that decide when the launch ends get the SIMD's issue
@@ -474,6 +475,8 @@ fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_budget,
   stage(G64, gG64, 3 * g.K * g.gstr * 8);
   stage(lds + L.G32, gG32, (3 * g.K + 1) * g.nq * 4);
   stage(lds + L.Wt, gWt, NT * 256 * 4);
+#define WFLAG(w) (*reinterpret_cast<volatile int *>(lds + L.wave0 + (blockDim.x >> 6) * L.wave_stride + 4 * (w)))
+  if (threadIdx.x < 16) WFLAG(threadIdx.x) = 0;
   __syncthreads();
   const float *Wt = reinterpret_cast<const float *>(lds + L.Wt);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -494,16 +497,30 @@ fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_budget,
   // them (iteration counts range from 20 to 150).  queue[1] counts the waves that have left the loop: the last
   // one zeroes both for the next launch (d2d_fit_begin zeroes them too).  queue == NULL: static striding.
   const int stride = gridDim.x * (blockDim.x >> 6);
+  // Exclusive SIMDs for the longest fits (order hint only, prio_pack >> 16 = excl <= gridDim.x): waves w and w + 4 of a workgroup
+  // share a SIMD; wave 4 of the first `excl` workgroups -- the SIMD-mate of the wave that starts on one of the `excl` longest
+  // fits -- gives its static position to the queue (counter values below excl) and stays off the SIMD (s_sleep) until that fit is
+  // done, then pulls from the queue like everybody: the fit that decides when the launch ends iterates at the speed of a lone
+  // wave.  The wait is bounded (the flag is also raised on every way out of the mate's loop).
   auto next_index = [&](int b) -> int {
     if (queue == nullptr) return b + stride;
     int t = 0;
-    if (lane == 0) t = stride + atomicAdd(queue, 1);
+    if (lane == 0) {
+      const int excl = (order != nullptr) ? (prio_pack >> 16) : 0;
+      t = atomicAdd(queue, 1);
+      t = t < excl ? 4 * (int)gridDim.x + t : stride + t - excl;
+    }
     return __builtin_amdgcn_readfirstlane(t);
   };
   if (STAMPS) st_last = __builtin_amdgcn_s_memtime();
-  for (int bi = blockIdx.x + gridDim.x * wave; (unsigned)bi < (unsigned)B; bi = next_index(bi)) {
+  int bi = blockIdx.x + gridDim.x * wave;
+  if (order != nullptr && queue != nullptr && wave == 4 && (int)blockIdx.x < (prio_pack >> 16)) {
+    for (int spin = 0; spin < 40000 && __builtin_amdgcn_readfirstlane(WFLAG(0)) == 0; ++spin) __builtin_amdgcn_s_sleep(16);
+    bi = next_index(bi);
+  }
+  for (; (unsigned)bi < (unsigned)B; bi = next_index(bi)) {
     const int b = order ? __builtin_amdgcn_readfirstlane(order[bi]) : bi;
-    if (flags[4 * b + FL_STATUS] != D2D_ST_RUNNING) continue;
+    if (flags[4 * b + FL_STATUS] != D2D_ST_RUNNING) { if (lane == 0) WFLAG(wave) = 1; continue; }
     const double *prow = prep + (size_t)b * FIT_PREP_STRIDE;
     const double *pkb = pk + (size_t)b * FIT_PK * g.K;
     double qi = act ? q_io[(size_t)b * n + lane] : 0.0;
@@ -558,7 +575,7 @@ fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_budget,
       if (local >= iter_budget || iters >= opts.max_iter) break;
       const double gmax = uniform_d(wave_max(fabs(gi)));
       if (gmax <= opts.gtol) { status = D2D_ST_CONVERGED; break; }
-      if (iters >= prio_at) __builtin_amdgcn_s_setprio(2);
+      if (iters >= (prio_pack & 0xffff)) __builtin_amdgcn_s_setprio(2);
       float dgi, dl;
       LM_STAMP(6)
       const int ok = uniform_i(damped_solve<N>(hrow, lam, act, lane, big, dgi, dl, STAMPS ? st_solve : nullptr) ? 1 : 0);
@@ -615,8 +632,11 @@ fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_budget,
       flags[4 * b + FL_NEVAL] += nev;
     }
     __builtin_amdgcn_s_setprio(0);
+    if (lane == 0) WFLAG(wave) = 1;
     LM_STAMP(0)
   }
+  if (lane == 0) WFLAG(wave) = 1;
+#undef WFLAG
   if (queue != nullptr && lane == 0) {
     if (atomicAdd(queue + 1, 1) == stride - 1) { queue[0] = 0; queue[1] = 0; }     // every wave has stopped pulling
   }
@@ -1330,7 +1350,10 @@ static int launch_lm(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, double *q, con
   const int blocks = B < pl->n_cu ? B : pl->n_cu;     // persistent: one workgroup per CU
   static const bool no_queue = getenv("D2D_LM_STATIC") != nullptr;      // A/B switch: static striding instead of the work queue
   int32_t *queue = no_queue ? nullptr : ctx->counter_dev + 8;
-  static const int prio_at = getenv("D2D_LM_PRIO_AT") ? atoi(getenv("D2D_LM_PRIO_AT")) : 48;     // (A/B switch; 1 << 30 = never)
+  static const int prio_only = getenv("D2D_LM_PRIO_AT") ? atoi(getenv("D2D_LM_PRIO_AT")) : 48;     // (A/B switch; 0xffff = never)
+  static const int excl = getenv("D2D_LM_EXCL") ? atoi(getenv("D2D_LM_EXCL")) : 4;                 // exclusive SIMDs for the first `excl` hand-out positions (A/B switch; measured: tools/rank_spread.py)
+  const int excl_eff = (pl->wpb_lm == 8 && queue != nullptr) ? (excl < blocks ? excl : blocks) : 0;
+  const int prio_at = (prio_only > 0xffff ? 0xffff : prio_only) | (excl_eff << 16);
   const int32_t *order = (pl->order_B == B) ? pl->d_order : nullptr;
   if (want_stamps)
     hipLaunchKernelGGL((fit_lm_kernel<3, 24, true>), dim3(blocks), dim3(64 * pl->wpb_lm), L.total, ctx->stream, B, gm, L, o, budget,

@@ -1,6 +1,8 @@
 """How much do the per-rank batches of the weak-scaling bench differ? (one GPU, ranks' seeds one after the other)"""
 import sys, time, json
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/drone-sim-python_amd')
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'drone-sim-python_amd'))
 import numpy as np, torch, d2dhip
 from d2dhip import synth
 ctx = d2dhip.Context(0); K = 50
@@ -9,7 +11,9 @@ B = 4096
 MAX_ITER = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 for rank in range(8):
     sc = ctx.dev(synth.synth_scenarios(B, seed=20241008, rank=rank, obj_scale=0.1, K=K)); q0 = plan.init(sc)
-    plan.solve(sc, q0.clone(), check_every=200, max_iter=MAX_ITER)
+    plan.clear_order()
+    _, it0, _, _ = plan.solve(sc, q0.clone(), check_every=200, max_iter=MAX_ITER)
+    plan.order_from_iters(it0)                       # as bench.py: longest-first hand-out from the warm-up solve
     torch.cuda.synchronize(); t0 = time.perf_counter(); n = 5
     for _ in range(n):
         cost, iters, status, stats = plan.solve(sc, q0.clone(), check_every=200, max_iter=MAX_ITER)
