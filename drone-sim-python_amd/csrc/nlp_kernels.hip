@@ -784,10 +784,13 @@ nlp_solve_kernel(int B, int N, double h, d2d_nlp_opts o, const double *__restric
     // merit value of the current point for this (mub, rho, mu): one pass here, afterwards the accepted trial's value
     NLP_STAMP(7)
     double phi0 = nlp_merit(pb, s, sc, lane, 0.0, rho, mub, nullptr, nullptr);
+    const double phi_first = phi0;
     NLP_STAMP(0)
+    bool accepted = false;
     for (int it = 0; it < o.inner_max; ++it) {
       ++total_inner;
-      bool accepted = false, converged = false;
+      bool converged = false;
+      accepted = false;
       for (int tr = 0; tr < 30; ++tr) {
         bool pd;
         err = nlp_assemble(pb, s, sc, lane, rho, mub, lam, &pd);        // (a retry with another damping assembles again: rare)
@@ -835,10 +838,14 @@ nlp_solve_kernel(int B, int N, double h, d2d_nlp_opts o, const double *__restric
     }
     (void)nlp_merit(pb, s, sc, lane, 0.0, rho, mub, &cost_ref, &feas);
     if (feas <= o.feas_tol && mub <= o.mub_min * 1.0001 && err <= tol_in) { status = D2D_ST_CONVERGED; break; }
-    // an infeasible problem (e.g. end points too far apart for v_max) sits at the largest penalty with its constraint violation
-    // no longer shrinking: give up instead of running outer_max x inner_max steps
-    n_stalled = (rho >= D2D_NLP_RHO_MAX && feas > 0.5 * feas_prev && feas > 1e3 * o.feas_tol) ? n_stalled + 1 : 0;
-    if (n_stalled >= 3) { status = D2D_ST_STALLED; break; }
+    // the inner problem is not solved yet and the batch still lowered the merit function by more than rounding: same multipliers,
+    // penalty and barrier parameter, another batch of steps -- the schedule must not run ahead of the iterate
+    if (err > tol_in && accepted && (phi_first - phi0) > D2D_NLP_GATE_PROGRESS * (1.0 + fabs(phi0))) continue;
+    // an infeasible problem (e.g. end points too far apart for v_max) or an infeasible stationary point of the violation: the
+    // penalty grows tenfold per solved inner problem and the violation no longer halves -- give up instead of running
+    // outer_max x inner_max steps
+    n_stalled = (feas > 0.5 * feas_prev && feas > 1e3 * o.feas_tol) ? n_stalled + 1 : 0;
+    if (n_stalled >= (rho >= D2D_NLP_RHO_MAX ? 3 : D2D_NLP_STALL_OUTERS)) { status = D2D_ST_STALLED; break; }
     // first-order multiplier update (lambda = 2 rho mu); the penalty grows when feasibility stalls
     const bool grow = feas > 0.25 * feas_prev && rho < D2D_NLP_RHO_MAX;
     for (int i0 = 0; i0 < N; i0 += 64) {

@@ -1,7 +1,7 @@
 """ORACLE (test infrastructure, CPU, numpy/scipy): the reference's direct-collocation NLP in its own parameterisation --
 node values (x, y, psi, phi, v)(t_i), backward-Euler collocation equalities, end conditions, hard box bounds -- and the
-solver the HIP kernel csrc/nlp_kernels.hip implements: bound-constrained augmented Lagrangian, inner problem by projected
-Levenberg-Marquardt on block-tridiagonal normal equations.  Only tests/, __graft_entry__.smoke() and bench.py's
+solver the HIP kernel csrc/nlp_kernels.hip implements: augmented Lagrangian for the equalities, primal-dual log barrier for the
+bounds, damped Newton steps on the block-tridiagonal Lagrangian Hessian (solve() below).  Only tests/, __graft_entry__.smoke() and bench.py's
 cpu_baseline leg may import this.
 
 What is restated, with the reference lines (relative to the reference's repository root):
@@ -34,6 +34,8 @@ LAM0, LAM_MIN, LAM_MAX = 1e-3, 1e-12, 1e12
 FEAS_TOL, OPT_TOL = 1e-9, 1e-7
 INNER_MAX, OUTER_MAX = 60, 40
 MUB0, MUB_MIN = 1e-1, 1e-9   # barrier parameter: start, floor
+GATE_PROGRESS = 1e-9      # relative decrease of the merit function over a batch of inner_max steps below which an unsolved inner problem is left
+STALL_OUTERS = 5          # solved inner problems in a row (each with a tenfold penalty) that did not halve the violation: give up
 GRAD_FLOOR = 1e-11        # x rho: rounding floor of the penalty gradient (|x|/h ~ 1e3 at fp64, times rho)
 
 
@@ -59,6 +61,26 @@ class Problem:
         lo[0, :3] = hi[0, :3] = self.p0                 # end conditions: fixed variables
         lo[-1, :3] = hi[-1, :3] = self.p1
         self.lo, self.hi = lo, hi
+
+
+def problem_from_row(row, N, h):
+    """The Problem a d2dhip scenario row describes (what d2d_nlp_solve reads from it: csrc/nlp_kernels.hip nlp_load_scen)."""
+    import d2dhip as D
+    r = np.asarray(row, float)
+    obs = []
+    for i in range(D.MAX_OBS):
+        c = D.SC_O0X + 3 * i if i < 2 else D.SC_OEXT + 3 * (i - 2)
+        if r[c + 2] > 0.0:
+            obs.append((r[c], r[c + 1], r[c + 2]))
+    okind = int(r[D.SC_OKIND])
+    kinds = {(okind >> i) & 1 for i in range(len(obs))}
+    assert len(kinds) <= 1, 'mixed obstacle kinds: not expressible as one oracle Problem'
+    pb = Problem(N, h, r[D.SC_X0:D.SC_X0 + 3], r[D.SC_X1:D.SC_X1 + 3], vsp=r[D.SC_VSP], kv=r[D.SC_KV], kphi=r[D.SC_KPHI],
+                 obj_scale=r[D.SC_S] * N, wind=(-r[D.SC_WX], -r[D.SC_WY]), phi_max=r[D.SC_PHIMAX], v_min=r[D.SC_VMIN], v_max=r[D.SC_VMAX],
+                 x_box=(r[D.SC_XMIN], r[D.SC_XMAX]) if r[D.SC_XMIN] < r[D.SC_XMAX] else None,
+                 y_box=(r[D.SC_YMIN], r[D.SC_YMAX]) if r[D.SC_YMIN] < r[D.SC_YMAX] else None,
+                 obstacles=obs, kobs=r[D.SC_KOBS], obs_kind=0 if (kinds and 1 in kinds) else 1)
+    return pb
 
 
 def from_free(free, N):
@@ -250,6 +272,7 @@ def solve(pb, W0, verbose=False, rho0=RHO0, inner_max=INNER_MAX, outer_max=OUTER
     n_stalled = 0
     for outer in range(1, outer_max + 1):
         tol_in = max(opt_tol, min(1e-1, 10.0 * mub), GRAD_FLOOR * rho)
+        phi_first = phi_last = None
         for it in range(inner_max):
             total_inner += 1
             sl = np.where(hasL, W - pb.lo, 1.0); su = np.where(hasU, pb.hi - W, 1.0)
@@ -267,6 +290,8 @@ def solve(pb, W0, verbose=False, rho0=RHO0, inner_max=INNER_MAX, outer_max=OUTER
             idx = np.arange(NV)
             Dh[:, idx, idx] += 0.5 * sig                        # (half convention: D holds H / 2)
             phi0 = _merit(pb, W, mu, rho, mub, hasL, hasU)
+            if phi_first is None:
+                phi_first = phi_last = phi0
             accepted = False
             for _ in range(30):
                 try:
@@ -299,6 +324,7 @@ def solve(pb, W0, verbose=False, rho0=RHO0, inner_max=INNER_MAX, outer_max=OUTER
                         azU = np.where(hasU & (dzU < 0), -tau * zU / dzU, np.inf)
                     az = min(1.0, float(azL.min()), float(azU.min()))
                     W = Wt
+                    phi_last = pt
                     zL = zL + az * dzL; zU = zU + az * dzU
                     # keep the duals in a neighbourhood of the central path (IPOPT's kappa_sigma safeguard)
                     slp = np.where(hasL, W - pb.lo, 1.0); sup = np.where(hasU, pb.hi - W, 1.0)
@@ -317,9 +343,14 @@ def solve(pb, W0, verbose=False, rho0=RHO0, inner_max=INNER_MAX, outer_max=OUTER
         if feas <= feas_tol and mub <= MUB_MIN * 1.0001 and err <= tol_in:
             status = 1
             break
-        # an infeasible problem sits at the largest penalty with its violation no longer shrinking: give up (status 4)
-        n_stalled = n_stalled + 1 if (rho >= RHO_MAX and feas > 0.5 * feas_prev and feas > 1e3 * feas_tol) else 0
-        if n_stalled >= 3:
+        # the inner problem is not solved yet and the batch still lowered the merit function by more than rounding: same
+        # multipliers, penalty and barrier parameter, another batch of steps -- the schedule must not run ahead of the iterate
+        if err > tol_in and accepted and (phi_first - phi_last) > GATE_PROGRESS * (1.0 + abs(phi_last)):
+            continue
+        # an infeasible problem (or an infeasible stationary point of the violation): the penalty grows tenfold per solved inner problem
+        # and the violation no longer shrinks: give up (status 4)
+        n_stalled = n_stalled + 1 if (feas > 0.5 * feas_prev and feas > 1e3 * feas_tol) else 0
+        if n_stalled >= (3 if rho >= RHO_MAX else STALL_OUTERS):
             status = 4
             break
         mu = mu + c                                          # first-order multiplier update (lambda = 2 rho mu)
