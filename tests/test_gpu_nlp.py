@@ -221,3 +221,29 @@ def test_multi_planner_on_the_collocation_backend_like_11_full_sim():
         assert c_coupled <= keep.cost(_q.solution, _q) + 1e-6
     finally:
         scen.cost = keep
+
+
+def test_catalogue_scenarios_on_the_collocation_backend():
+    """A cross-section of the reference's single-aircraft catalogue (src/d2d/optyplan_scenarios.py) through
+    Planner(scen, backend='nlp'): turn-around (exp_0), its 5 m/s wind case (exp_0_2[3]), bank/velocity composite (exp_2), obstacle
+    (exp_4_1), rendez-vous (exp_6[0]).  Converged, collocation feasible to 1e-8, hard bounds held, end conditions exact.
+    (tools/nlp_catalogue.py surveys all 33 cases: 28 converge; the others are listed in DESIGN.md 8.)"""
+    import d2d.optyplan_scenarios as sc
+    import single_opt_planner as sop
+    keep = {k: getattr(sc.exp_0, k) for k in ('t1', 'wind', 'p0', 'p1')}
+    try:
+        for s, case in ((sc.exp_0, 0), (sc.exp_0_2, 3), (sc.exp_2, 0), (sc.exp_4_1, 0), (sc.exp_6, 0)):
+            for k, v in keep.items():
+                setattr(sc.exp_0, k, v)
+            s.set_case(case)
+            p = sop.Planner(s, initialize=True, backend='nlp')
+            p.run(p.get_initial_guess('tri'))
+            assert p.info['status'] == 1, (s.__name__, p.info)
+            w = tuple(np.asarray(s.wind.w, float)[:2])
+            assert _feas(p.sol_x, p.sol_y, p.sol_psi, p.sol_phi, p.sol_v, p.time_step, w) <= 1e-8, s.__name__
+            assert np.abs(p.sol_phi).max() <= s.phi_constraint[1] and p.sol_v.min() >= s.v_constraint[0] and p.sol_v.max() <= s.v_constraint[1]
+            np.testing.assert_allclose([p.sol_x[0], p.sol_y[0], p.sol_psi[0], p.sol_x[-1], p.sol_y[-1], p.sol_psi[-1]],
+                                       list(s.p0[:3]) + list(s.p1[:3]), atol=0)
+    finally:
+        for k, v in keep.items():
+            setattr(sc.exp_0, k, v)
