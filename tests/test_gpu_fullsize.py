@@ -171,3 +171,40 @@ def test_65536_drones_10000_steps_gvf(ctx):
     rad = np.hypot(xf[0] - centres[:, 0], xf[1] - centres[:, 1])
     assert np.abs(rad - 60.0).max() < 8.0 and np.abs(xf[4] - 15.0).max() < 1e-6
     assert np.array_equal(X[-1], xf)                  # row 10000 is the final state
+
+
+def test_collocation_batch_16384_properties(ctx):
+    """SURVEY 8 f-1 at batch scale: 16 384 perturbed copies of the reference's exp_14 (121 nodes, hard bounds) in one launch.
+    Every problem ends CONVERGED or STALLED (infeasible end poses); the converged ones satisfy the collocation equations to 1e-8
+    (recomputed on the host in the reference's form), hold every bound and end condition exactly and report the reference's
+    cost() of their own node values; identical problems give identical answers; a seeded sample equals the oracle's solve."""
+    import d2dhip
+    from d2dhip import synth
+    from oracle import nlp as ON
+    B, N = 16384, 121
+    rows, W0, h = synth.nlp_problems(B)
+    rows[1] = rows[0]; W0[1] = W0[0]                                    # two identical problems
+    W = ctx.dev(np.ascontiguousarray(W0))
+    out = ctx.nlp_solve(ctx.dev(rows), W, h)
+    ctx.sync()
+    st, feas, cost = out['status'].cpu().numpy(), out['feas'].cpu().numpy(), out['cost'].cpu().numpy()
+    Wh = W.cpu().numpy()                                               # (B, 5, N)
+    assert set(np.unique(st)) <= {1, 4}, np.unique(st)
+    ok = st == 1
+    assert 0.93 < ok.mean() < 0.98                                     # (the rest: end poses more than 15 m/s x 12 s apart along any flyable path)
+    x, y, psi, phi, v = (Wh[:, c, :] for c in range(5))
+    c1 = (x[:, 1:] - x[:, :-1]) / h - v[:, 1:] * np.cos(psi[:, 1:])
+    c2 = (y[:, 1:] - y[:, :-1]) / h - v[:, 1:] * np.sin(psi[:, 1:])
+    c3 = (psi[:, 1:] - psi[:, :-1]) / h - 9.81 / v[:, 1:] * np.tan(phi[:, 1:])
+    viol = np.maximum(np.abs(c1).max(1), np.maximum(np.abs(c2).max(1), np.abs(c3).max(1)))
+    assert np.abs(viol - feas).max() <= 1e-12 * max(1.0, viol.max())   # the kernel's feasibility number is this one
+    assert viol[ok].max() <= 1e-8 and viol[~ok].min() > 1e-6
+    assert np.abs(phi).max() <= np.deg2rad(40.) and v.min() >= 9. and v.max() <= 15. and np.abs(x).max() <= 150. and np.abs(y).max() <= 150.
+    for c, col in ((0, d2dhip.SC_X0), (1, d2dhip.SC_Y0), (2, d2dhip.SC_PSI0)):
+        np.testing.assert_array_equal(Wh[:, c, 0], rows[:, col]); np.testing.assert_array_equal(Wh[:, c, -1], rows[:, col + (d2dhip.SC_X1 - d2dhip.SC_X0)])
+    np.testing.assert_allclose(cost, ((v - 12.0) ** 2).sum(1) / N, rtol=1e-12)
+    np.testing.assert_array_equal(Wh[0], Wh[1])
+    for b in np.random.default_rng(5).choice(np.nonzero(ok)[0], 3, replace=False):
+        pb = ON.problem_from_row(rows[b], N, h)
+        Wo, info = ON.solve(pb, W0[b].T.copy())
+        assert info['status'] == 1 and abs(info['cost'] - cost[b]) <= 1e-7 * cost[b], (b, info['cost'], cost[b])
