@@ -49,7 +49,7 @@ static inline int align16(int v) { return (v + 15) & ~15; }
 static FitLds eval_lds_layout(int K, int nq, bool g32_lds, int wpb, int nds = 0) {
   FitLds L;
   const int gstr = nq + 1;
-  int o = 0;
+  int o = 64;                                   // the first 64 bytes: one flag word per wave (fit_lm_kernel: exclusive SIMDs for the longest fits)
   L.G64 = o; o = align16(o + 3 * K * gstr * 8);
   L.G32 = o; o = align16(o + (g32_lds ? (3 * K + 1) * nq * 4 : 0));   // + one padded sample row
   L.wave0 = o;
@@ -284,7 +284,7 @@ struct StepLds {
 static StepLds step_lds_layout(int K, int nq, int N, int wpb) {
   StepLds L;
   const int gstr = nq + 1;
-  int o = 0;
+  int o = 64;                                   // the first 64 bytes: one flag word per wave (fit_lm_kernel: exclusive SIMDs for the longest fits)
   L.G64 = o; o = align16(o + 3 * K * gstr * 8);
   L.wave0 = o;
   int w = 0;
@@ -420,7 +420,7 @@ struct FusedLds {
 static FusedLds fused_lds_layout(int K, int nq, int N, int wpb, int nds = 0) {
   FusedLds L;
   const int gstr = nq + 1;
-  int o = 0;
+  int o = 64;                                   // the first 64 bytes: one flag word per wave (fit_lm_kernel: exclusive SIMDs for the longest fits)
   L.G64 = o; o = align16(o + 3 * K * gstr * 8);
   L.G32 = o; o = align16(o + (3 * K + 1) * nq * 4);
   L.Wt = o; o = align16(o + (N / 16) * (N / 16 + 1) / 2 * 256 * 4);      // waypoint rows' constant block, tile-major
@@ -437,7 +437,7 @@ static FusedLds fused_lds_layout(int K, int nq, int N, int wpb, int nds = 0) {
   if ((N + 3) * (N + 4) * 4 > big) big = (N + 3) * (N + 4) * 4;
   w = align16(w + big);
   L.wave_stride = w;
-  L.total = o + wpb * w + 64;                   // + one flag word per wave (fit_lm_kernel: exclusive SIMDs for the longest fits)
+  L.total = o + wpb * w;
   return L;
 }
 static bool pick_fused_layout(int K, int nq, int N, int *wpb, int nds = 0) {
@@ -475,7 +475,7 @@ fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_budget,
   stage(G64, gG64, 3 * g.K * g.gstr * 8);
   stage(lds + L.G32, gG32, (3 * g.K + 1) * g.nq * 4);
   stage(lds + L.Wt, gWt, NT * 256 * 4);
-#define WFLAG(w) (*reinterpret_cast<volatile int *>(lds + L.wave0 + (blockDim.x >> 6) * L.wave_stride + 4 * (w)))
+#define WFLAG(w) (*reinterpret_cast<volatile int *>(lds + 4 * (w)))
   if (threadIdx.x < 16) WFLAG(threadIdx.x) = 0;
   __syncthreads();
   const float *Wt = reinterpret_cast<const float *>(lds + L.Wt);
