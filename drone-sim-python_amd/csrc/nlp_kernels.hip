@@ -72,19 +72,22 @@ __device__ __forceinline__ void nlp_exp_terms(const NlpScen &s, const double *__
     nlp_obs(sc, i, cx, cy, r);
     if (!(r > 0.0)) continue;
     const double dx = x - cx, dy = y - cy;
-    double k2, w, e;
-    if ((s.okind >> i) & 1) {       // kind 0: e = clip(exp(r^2 - d^2), 0, 1e3); cost_grad ignores the clip (src/d2d/opty_utils.py:108-127)
-      k2 = 1.0; w = s.wobs;
-      e = exp(fmin(r * r - (dx * dx + dy * dy), 6.907755278982137));
+    double k2, w, e, f;
+    if ((s.okind >> i) & 1) {       // kind 0: e = clip(exp(r^2 - d^2), 0, 1e3) in cost AND in cost_grad = -2 dx e (src/d2d/opty_utils.py:108-131):
+      k2 = 1.0; w = s.wobs;         // on the clip that is the gradient of 1e3 (1 + arg - log 1e3), not of the constant cost -- the
+      const double arg = r * r - (dx * dx + dy * dy);      // objective minimised continues the term that way (oracle/nlp.py _obst_terms)
+      e = exp(fmin(arg, 6.907755278982137));
+      f = arg > 6.907755278982137 ? 1e3 * (1.0 + arg - 6.907755278982137) : e;
       cost_ref += w * e;
     } else {                        // kind 1: e = exp(-|k (p - c) / r|^2); cost_grad omits (k/r)^2 (:118-131)
       k2 = (FIT_OBS_K / r) * (FIT_OBS_K / r);
       e = exp(-(dx * dx + dy * dy) * k2);
       cost_ref += s.wobs * e;
       w = s.wobs / k2;
+      f = e;
     }
     const double we = w * e;
-    obj += we;
+    obj += w * f;
     if (gx) {
       *gx += -k2 * we * dx; *gy += -k2 * we * dy;
       *dxx += k2 * k2 * we * dx * dx; *dxy += k2 * k2 * we * dx * dy; *dyy += k2 * k2 * we * dy * dy;

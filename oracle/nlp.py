@@ -102,24 +102,30 @@ def constraints(pb, W):
     return np.stack([c1, c2, c3], 1)
 
 
+LOG_CLIP = float(np.log(1e3))
+
+
 def _obst_terms(pb, W, quirk):
-    """Per node: list of (weight, e, dx, dy, k2) of the position-dependent exp terms: cost = sum w*e, de/dx = -2 k2 dx e."""
+    """Per node: list of (weight, e, dx, dy, k2, f) of the position-dependent exp terms: cost = sum w*e, cost_grad = -2 k2 w dx e,
+    and f = the function of the node position whose gradient that is (f = e except on the clip of a kind-0 obstacle)."""
     out = []
     x, y = W[:, 0], W[:, 1]
     for (cx, cy, r) in pb.obstacles:
         dx, dy = x - cx, y - cy
-        if pb.obs_kind == 0:           # e = clip(exp(r^2 - d^2), 0, 1e3); cost_grad ignores the clip (src/d2d/opty_utils.py:108-127)
-            e = np.exp(np.minimum(r * r - (dx * dx + dy * dy), np.log(1e3)))
-            out.append((pb.s * pb.kobs, e, dx, dy, 1.0))
+        if pb.obs_kind == 0:           # e = clip(exp(r^2 - d^2), 0, 1e3) in cost AND in cost_grad = -2 dx e (src/d2d/opty_utils.py:108-131):
+            arg = r * r - (dx * dx + dy * dy)      # on the clip that is the gradient of 1e3 (1 + arg - log 1e3), not of the constant cost
+            e = np.exp(np.minimum(arg, LOG_CLIP))
+            f = np.where(arg > LOG_CLIP, 1e3 * (1.0 + arg - LOG_CLIP), e)
+            out.append((pb.s * pb.kobs, e, dx, dy, 1.0, f))
         else:                          # e = exp(-((dx k/r)^2 + (dy k/r)^2)); cost_grad = -2 s dx e (no (k/r)^2)
             k2 = (OBS_K / r) ** 2
             e = np.exp(-(dx * dx + dy * dy) * k2)
-            out.append((pb.s * pb.kobs * ((1.0 / k2) if quirk else 1.0), e, dx, dy, k2))
+            out.append((pb.s * pb.kobs * ((1.0 / k2) if quirk else 1.0), e, dx, dy, k2, e))
     if pb.partner is not None and pb.kcol > 0.0:      # CostCollision against a frozen partner (src/d2d/multiopty_utils.py:120-153)
         dx, dy = x - pb.partner[:, 0], y - pb.partner[:, 1]
         k2 = (OBS_K / pb.rcol) ** 2
         e = np.exp(-(dx * dx + dy * dy) * k2)
-        out.append((pb.s * pb.kcol * ((1.0 / k2) if quirk else 1.0), e, dx, dy, k2))
+        out.append((pb.s * pb.kcol * ((1.0 / k2) if quirk else 1.0), e, dx, dy, k2, e))
     return out
 
 
@@ -132,10 +138,11 @@ def cost(pb, W):
 
 
 def objective(pb, W):
-    """The objective whose gradient is the reference's cost_grad (obstacle terms scaled by (r/k)^2, see the header)."""
+    """The objective whose gradient is the reference's cost_grad (kind-1 obstacle terms scaled by (r/k)^2; kind-0 terms continued
+    over their clip by the paraboloid whose gradient cost_grad returns there -- see the header and _obst_terms)."""
     c = pb.s * (pb.kv * np.sum((W[:, 4] - pb.vsp) ** 2) + pb.kphi * np.sum(W[:, 3] ** 2))
-    for w, e, *_ in _obst_terms(pb, W, quirk=True):
-        c += w * np.sum(e)
+    for w, e, dx, dy, k2, f in _obst_terms(pb, W, quirk=True):
+        c += w * np.sum(f)
     return float(c)
 
 
@@ -144,7 +151,7 @@ def cost_grad(pb, W):
     g = np.zeros_like(W)
     g[:, 4] = 2 * pb.s * pb.kv * (W[:, 4] - pb.vsp)
     g[:, 3] = 2 * pb.s * pb.kphi * W[:, 3]
-    for w, e, dx, dy, k2 in _obst_terms(pb, W, quirk=True):
+    for w, e, dx, dy, k2, _f in _obst_terms(pb, W, quirk=True):
         g[:, 0] += -2 * w * k2 * dx * e
         g[:, 1] += -2 * w * k2 * dy * e
     return g
@@ -168,7 +175,7 @@ def _normal_equations(pb, W, mu, rho, second_order=True):
     D[:, 4, 4] += pb.s * pb.kv; g[:, 4] += pb.s * pb.kv * (v - pb.vsp)
     D[:, 3, 3] += pb.s * pb.kphi; g[:, 3] += pb.s * pb.kphi * phi
     # exp rows r = sqrt(w e):  dr = -k2 (dx, dy) r   ->  J^T r = -k2 w e (dx, dy),  J^T J = k2^2 w e (dx, dy)(dx, dy)^T
-    for w, e, dx, dy, k2 in _obst_terms(pb, W, quirk=True):
+    for w, e, dx, dy, k2, _f in _obst_terms(pb, W, quirk=True):
         we = w * e
         g[:, 0] += -k2 * we * dx; g[:, 1] += -k2 * we * dy
         D[:, 0, 0] += k2 * k2 * we * dx * dx; D[:, 0, 1] += k2 * k2 * we * dx * dy

@@ -225,14 +225,15 @@ def test_multi_planner_on_the_collocation_backend_like_11_full_sim():
 
 def test_catalogue_scenarios_on_the_collocation_backend():
     """A cross-section of the reference's single-aircraft catalogue (src/d2d/optyplan_scenarios.py) through
-    Planner(scen, backend='nlp'): turn-around (exp_0), its 5 m/s wind case (exp_0_2[3]), bank/velocity composite (exp_2), obstacle
-    (exp_4_1), rendez-vous (exp_6[0]).  Converged, collocation feasible to 1e-8, hard bounds held, end conditions exact.
-    (tools/nlp_catalogue.py surveys all 33 cases: 28 converge; the others are listed in DESIGN.md 8.)"""
+    Planner(scen, backend='nlp'): turn-around (exp_0), its 5 m/s wind case (exp_0_2[3]), bank/velocity composite (exp_2), kind-0
+    obstacles whose clip region the path has to cross or skirt (exp_4: a 6.5 s leg that needs a detour; exp_5: 12-disc checkerboard),
+    exp_4_1, rendez-vous (exp_6[0]).  Converged, collocation feasible to 1e-8, hard bounds held, end conditions exact.
+    (tools/nlp_catalogue.py surveys all 33 cases: 30 converge; the others are listed in DESIGN.md 5.8.)"""
     import d2d.optyplan_scenarios as sc
     import single_opt_planner as sop
     keep = {k: getattr(sc.exp_0, k) for k in ('t1', 'wind', 'p0', 'p1')}
     try:
-        for s, case in ((sc.exp_0, 0), (sc.exp_0_2, 3), (sc.exp_2, 0), (sc.exp_4_1, 0), (sc.exp_6, 0)):
+        for s, case in ((sc.exp_0, 0), (sc.exp_0_2, 3), (sc.exp_2, 0), (sc.exp_4, 0), (sc.exp_4_1, 0), (sc.exp_5, 0), (sc.exp_6, 0)):
             for k, v in keep.items():
                 setattr(sc.exp_0, k, v)
             s.set_case(case)
