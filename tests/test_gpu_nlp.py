@@ -89,8 +89,8 @@ def test_batch_with_obstacles_wind_and_boxes_vs_oracle(ctx):
         p0 = (0., 0., rng.uniform(-0.5, 0.5), 0., 12.); p1 = (48. + rng.uniform(-4, 4), rng.uniform(-6, 6), rng.uniform(-0.4, 0.4), 0., 12.)
         ob = [(24. + rng.uniform(-3, 3), rng.uniform(-2, 2), rng.uniform(4, 7))] if i % 2 else []
         kind = 0 if i == 3 else 1
-        if kind == 0:                                      # exp(r^2 - d^2) stays below its 1e3 clip (on the clip the reference's
-            ob = [(ob[0][0], ob[0][1], 2.2)]               # cost_grad is not the gradient of its cost: no stationary point to find)
+        # (i == 3: a kind-0 disc of 4-7 m radius ON the straight line: the dog-leg guess starts inside its 1e3 clip, where the
+        # reference's cost_grad is the gradient of the paraboloid the solver continues the term with)
         pb = nlp.Problem(N, h, p0, p1, vsp=12., kv=5., kphi=1., obj_scale=0.1 if i < 4 else 1.0, wind=(1.0, -0.5) if i == 2 else (0., 0.),
                          phi_max=np.deg2rad(35.), v_min=9., v_max=15., y_box=(-6.5, 9.) if i == 5 else None, obstacles=ob,
                          kobs=1.0 if ob else 0.0, obs_kind=kind)
