@@ -1,5 +1,7 @@
 import sys, os, time
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/drone-sim-python_amd')
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'drone-sim-python_amd')]
 import numpy as np, torch
 import d2dhip
 from d2dhip import synth

@@ -1,6 +1,8 @@
 """Throughput of the fused LM solve against the batch size (one GPU): shows where the 4096-fit tail stops mattering."""
 import sys, time, json
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/drone-sim-python_amd')
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'drone-sim-python_amd')]
 import numpy as np, torch, d2dhip
 from d2dhip import synth
 ctx = d2dhip.Context(0); K = 50

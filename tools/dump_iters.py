@@ -1,5 +1,7 @@
 import sys, os
-sys.path[:0]=['/root/repo','/root/repo/drone-sim-python_amd']
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'drone-sim-python_amd')]
 import numpy as np, bench, d2dhip
 ctx=d2dhip.Context(0)
 dur,wref=bench._plan_consts()
