@@ -24,6 +24,7 @@ Besides the contract fields the line carries
   config3           BASELINE configs[3]: 32 768 fits per rank (256 k at N = 8), same solve, barrier + max over ranks
   parity            the SAME scenarios the cpu_baseline leg solved with scipy: fraction agreeing to 1e-6 (cost, coefficients)
   sim               BASELINE configs[4] (65 536 drones x 10 000 steps GVF loop) and the tracking loop, with roofline + cpu_baseline
+  long_horizon      the same fit at the reference's own horizon (121 nodes, exp_14): 4096 fits on the chunked kernel fit_lm_long_kernel
   nlp               SURVEY 8 f-1: the collocation-NLP backend on 4096 perturbed copies of the reference's exp_14 (one wavefront per problem),
                     with the oracle's solver timed beside it and the cost agreement on the problems both solved
   cpu_baseline      scipy.optimize.least_squares (method 'lm', analytic Jacobian) on the oracle's residual function over a
@@ -199,6 +200,31 @@ def nlp_record(ctx, torch, cpu, B=4096):
         n = len(cpu['cost'])
         rec['parity'] = {'n': n, 'max_rel_cost_diff_vs_oracle': float(np.max(np.abs(cost[:n] - np.array(cpu['cost'])) / np.array(cpu['cost']))),
                          'newton_steps_gpu': it[:n].tolist(), 'newton_steps_oracle': cpu['newton_steps']}
+    return rec
+
+
+def long_horizon_record(ctx, torch, d2dhip, B=4096, K=121, t1=12.0):
+    """The reference's own planner horizons (101 .. 151 nodes at 10 Hz: exp_14 = 121) on the chunked persistent kernel
+    (fit_lm_long_kernel, K > 64): B independent fits of K nodes, same solver as the headline."""
+    from d2dhip import synth
+    dur = synth.planner_timing(0, t1, 10)[2]
+    plan = d2dhip.FitPlan(ctx, S_, K, dur, synth.default_wref(OBJ_SCALE, K))
+    dsc = ctx.dev(synth.synth_scenarios(B, seed=SEED, obj_scale=OBJ_SCALE, K=K, dist_range=(100., 150.)))
+    q0 = plan.init(dsc)
+    cost, iters, status, stats = plan.solve(dsc, q0.clone(), max_iter=200)
+    plan.order_from_iters(iters)
+    best = 1e30
+    for _ in range(3):
+        q = q0.clone()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        cost, iters, status, stats = plan.solve(dsc, q, max_iter=200)
+        torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
+    st = status.cpu().numpy()
+    rec = {'metric': f'trajectory-optimisations/sec (6-seg poly, {K} nodes)', 'value': B / best, 'unit': 'trajectory-optimisations/s',
+           'workload': f'{B} independent fits, {K} nodes over {t1:g} s, end poses 100-150 m apart (the horizon of optyplan_scenarios.exp_14)',
+           'kernel': plan.kernel, 'ms_per_step': 1e3 * best, 'converged_frac': float((st == 1).mean()), 'mean_iters': float(iters.float().mean().item()),
+           'evals_per_fit': float(stats[3]) / B}
+    plan.close()
     return rec
 
 
@@ -547,10 +573,11 @@ def main():
         del dsc, q0, q, cost, iters, status
         torch.cuda.empty_cache()
         sim = sim_records(ctx, torch, cpu_g, cpu_t)
-    nlp = None
+    nlp = longh = None
     if rank == 0 and world == 1 and not a.no_nlp:
         torch.cuda.empty_cache()
         nlp = nlp_record(ctx, torch, cpu_n)
+        longh = long_horizon_record(ctx, torch, d2dhip)
 
     if rank == 0:
         line = {
@@ -566,7 +593,7 @@ def main():
             'converged_frac': headline['converged_frac'], 'mean_iters': headline['mean_iters'],
             'evals_per_fit': headline['evals_per_fit'],          # Gauss-Newton units (200 rows); second-order evaluations count 1.5
             'mean_cost': headline['mean_cost'],
-            'roofline': roof, 'roofline_isolated': roof_iso, 'config2': config2, 'config3': config3, 'parity': parity, 'sim': sim, 'nlp': nlp, 'cpu_baseline': cpu,
+            'roofline': roof, 'roofline_isolated': roof_iso, 'config2': config2, 'config3': config3, 'parity': parity, 'sim': sim, 'nlp': nlp, 'long_horizon': longh, 'cpu_baseline': cpu,
         }
         print(json.dumps(line))
     if dist is not None:

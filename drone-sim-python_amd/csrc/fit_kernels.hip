@@ -848,12 +848,18 @@ fit_groups_kernel(int R, int n_ac, int nds, FitGeom g, FusedLds L, d2d_fit_opts 
 // for every chunk: rows (phase 1) -> J^T r (phase 2) -> MFMA pass accumulating into the same six tiles.  Trial points
 // are cost-only passes (no row records are kept across chunks), an accepted step is followed by a full evaluation.
 struct LongLds {
-  int Wt, wave0, wave_stride, qs, sp, big, cf, cfp, total;
+  int Wt, G64, G32, wave0, wave_stride, qs, sp, big, cf, cfp, total;      // G64 / G32: only with the tables in the LDS
 };
-static LongLds long_lds_layout(int N, int wpb) {
+// tables: the fp64 basis block [3][K][nq+1] and the fp32 planes [(3K+1)][nq] live in the LDS too (K, nq > 0), otherwise in global memory
+static LongLds long_lds_layout(int N, int wpb, int K = 0, int nq = 0, bool g32 = true) {
   LongLds L;
   int o = 0;
   L.Wt = o; o = align16(o + (N / 16) * (N / 16 + 1) / 2 * 256 * 4);
+  L.G64 = L.G32 = 0;
+  if (K > 0) {
+    L.G64 = o; o = align16(o + 3 * K * (nq + 1) * 8);
+    if (g32) { L.G32 = o; o = align16(o + (3 * K + 1) * nq * 4); }
+  }
   L.wave0 = o;
   int w = 0;
   L.qs = w; w = align16(w + N * 8);
@@ -869,11 +875,22 @@ static LongLds long_lds_layout(int N, int wpb) {
   L.total = o + wpb * w;
   return L;
 }
+// Waves per workgroup of the long-horizon kernel with its tables in the LDS (0: they do not fit beside at least FIT_LONG_TL_MIN_WAVES
+// per-wave blocks -- the kernel then reads them from global memory / L2 with FIT_LM_WPB_MAX waves)
+#define FIT_LONG_TL_MIN_WAVES 3
+static int long_tables_waves(int K, int nq, int N, bool g32) {
+  for (int w = FIT_LM_WPB_MAX; w >= FIT_LONG_TL_MIN_WAVES; --w)
+    if (long_lds_layout(N, w, K, nq, g32).total <= FIT_LDS_BYTES) return w;
+  return 0;
+}
 
-template <int NB, int NQ>
+// TL: the basis tables are staged into the LDS once per workgroup (they fit beside >= 3 per-wave blocks: K <= 121 at nq = 24) and
+// the phases read them there like the K <= 64 kernel does -- from global memory every phase of every chunk is a chain of L2
+// round trips (measured at K = 121: 287 us per LM iteration and wave with 8 waves per CU against 40 us with 3).
+template <int NB, int NQ, bool TL, bool TL32 = TL>
 __global__ void __launch_bounds__(64 * FIT_LM_WPB_MAX)
 fit_lm_long_kernel(int B, FitGeom g, LongLds L, d2d_fit_opts opts, int iter_budget,
-                   const double *__restrict__ GT, const double *__restrict__ G64g, const double *__restrict__ pk,
+                   const double *__restrict__ GTg, const double *__restrict__ G64gl, const double *__restrict__ pk,
                    const float *__restrict__ gG32, const float *__restrict__ gWt, const double *__restrict__ prep,
                    double *__restrict__ q_io, double *__restrict__ cost_io, double *__restrict__ g_io,
                    double *__restrict__ lm, int32_t *__restrict__ flags, int32_t *__restrict__ queue,
@@ -881,8 +898,15 @@ fit_lm_long_kernel(int B, FitGeom g, LongLds L, d2d_fit_opts opts, int iter_budg
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   constexpr int N = 16 * NB, NT = NB * (NB + 1) / 2;
   stage(lds + L.Wt, gWt, NT * 256 * 4);
+  if (TL) {
+    stage(lds + L.G64, G64gl, 3 * g.K * g.gstr * 8);
+    if (TL32) stage(lds + L.G32, gG32, (3 * g.K + 1) * g.nq * 4);
+  }
   __syncthreads();
   const float *Wt = reinterpret_cast<const float *>(lds + L.Wt);
+  // phase 1 table / phase 2 table: the LDS copy of the row-major block, or the transposed / row-major global tables
+  const double *GT = TL ? reinterpret_cast<const double *>(lds + L.G64) : GTg;
+  const double *G64g = TL ? reinterpret_cast<const double *>(lds + L.G64) : G64gl;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int woff = L.wave0 + wave * L.wave_stride;
   unsigned char *wl = lds + woff;
@@ -921,27 +945,28 @@ fit_lm_long_kernel(int B, FitGeom g, LongLds L, d2d_fit_opts opts, int iter_budg
     auto cost_at = [&](double alpha, double delta) -> double {
       if (act) qs[q_slot(lane, nq)] = qi + alpha * delta;
       wave_lds_sync();
-      const int kbank = long_bank_argmax<NQ>(g, GT, pkb, qs, load_scenp(sp), lane);
+      const int kbank = long_bank_argmax<NQ, TL>(g, GT, pkb, qs, load_scenp(sp), lane);
       double ca = 0.0;
-      for (int k0 = 0; k0 < g.K; k0 += 64) ca += long_phase1<NQ, false>(g, GT, pkb, sp, qs, us, cf, cfp, false, kbank, k0, lane);
+      for (int k0 = 0; k0 < g.K; k0 += 64) ca += long_phase1<NQ, false, TL>(g, GT, pkb, sp, qs, us, cf, cfp, false, kbank, k0, lane);
       return uniform_d(ca);
     };
     // full evaluation at qi: c, gi, and (want_H) hrow = this lane's row of J^T J (+ the waypoint block) with -g as row N
     auto eval_full = [&](bool so, bool want_H) {
       if (act) qs[q_slot(lane, nq)] = qi;
       wave_lds_sync();
-      const int kbank = long_bank_argmax<NQ>(g, GT, pkb, qs, load_scenp(sp), lane);
+      const int kbank = long_bank_argmax<NQ, TL>(g, GT, pkb, qs, load_scenp(sp), lane);
       f32x4 acc[NT];
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
       double ca = 0.0, ga = 0.0;
       for (int k0 = 0; k0 < g.K; k0 += 64) {
         const int kn = g.K - k0 < 64 ? g.K - k0 : 64;
-        ca += long_phase1<NQ, true>(g, GT, pkb, sp, qs, us, cf, cfp, so, kbank, k0, lane);
+        ca += long_phase1<NQ, true, TL>(g, GT, pkb, sp, qs, us, cf, cfp, so, kbank, k0, lane);
         ga += long_phase2<NQ>(g, G64g, us, k0, kn, lane);
         if (want_H) {
-          if (so) jtj_mfma_so<NB, NQ, false>(g, lds, 0, woff + L.cf, woff + L.cfp, lane, acc, gG32 + (size_t)k0 * nq, kn, true);
-          else jtj_mfma<NB, NQ, false>(g, lds, 0, gG32 + (size_t)k0 * nq, woff + L.cf, lane, kn, acc, 0, 0, true);
+          const int toff = L.G32 + 4 * k0 * nq;                            // this chunk's first row of the fp32 planes (LDS copy)
+          if (so) jtj_mfma_so<NB, NQ, TL32>(g, lds, toff, woff + L.cf, woff + L.cfp, lane, acc, gG32 + (size_t)k0 * nq, kn, true);
+          else jtj_mfma<NB, NQ, TL32>(g, lds, toff, gG32 + (size_t)k0 * nq, woff + L.cf, lane, kn, acc, 0, 0, true);
         }
         wave_lds_sync();                              // every lane is done with this chunk's records
       }
@@ -1385,18 +1410,29 @@ static int launch_lm(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, double *q, con
 static int launch_lm_long(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, double *q, const d2d_fit_opts &o, int budget) {
   const FitGeom gm = geom_of(pl);
   const int NB = (2 * pl->nq + 15) / 16;
-  const LongLds L = long_lds_layout(16 * NB, pl->wpb_lm);
+  // D2D_FIT_LONG_TABLES (A/B switch): 0 = both tables from global memory, 1 = fp64 block in the LDS and the fp32 planes from global
+  // memory, 2 = both in the LDS.  Default: both if they fit beside >= 3 per-wave blocks (K <= 121 at nq = 24; measured at K = 121,
+  // 4096 fits: 251 k fits/s from global memory with 8 waves per CU, 416 k with the fp64 block in the LDS and 6 waves, 542 k with
+  // both tables and 3 waves; converting the MFMA operands from the fp64 block instead -- 6 waves -- gave 409 k), else the fp64 block alone
+  static const int force = getenv("D2D_FIT_LONG_TABLES") ? atoi(getenv("D2D_FIT_LONG_TABLES")) : -1;
+  const int w2 = long_tables_waves(pl->K, pl->nq, 16 * NB, true), w1 = long_tables_waves(pl->K, pl->nq, 16 * NB, false);
+  int mode = force >= 0 ? force : (w2 ? 2 : (w1 ? 1 : 0));
+  if ((mode == 2 && !w2) || (mode == 1 && !w1) || mode > 2) mode = 0;
+  const int wpb = mode == 2 ? w2 : (mode ? w1 : pl->wpb_lm);
+  const LongLds L = mode ? long_lds_layout(16 * NB, wpb, pl->K, pl->nq, mode == 2) : long_lds_layout(16 * NB, wpb);
   const int blocks = B < pl->n_cu ? B : pl->n_cu;
   static const bool no_queue = getenv("D2D_LM_STATIC") != nullptr;
   int32_t *queue = no_queue ? nullptr : ctx->counter_dev + 8;
   const int32_t *order = (pl->order_B == B) ? pl->d_order : nullptr;
-#define LAUNCH_LONG(NBV, NQV)                                                                                          \
-  hipLaunchKernelGGL((fit_lm_long_kernel<NBV, NQV>), dim3(blocks), dim3(64 * pl->wpb_lm), L.total, ctx->stream, B, gm, L, o, budget, \
+#define LAUNCH_LONG_(NBV, NQV, TLV, TL32V)                                                                             \
+  hipLaunchKernelGGL((fit_lm_long_kernel<NBV, NQV, TLV, TL32V>), dim3(blocks), dim3(64 * wpb), L.total, ctx->stream, B, gm, L, o, budget, \
                      pl->d_GT, pl->d_G, pl->d_pk, pl->d_G32, pl->d_W32, pl->d_prep, q, pl->d_cost, pl->d_g, pl->d_lm, pl->d_flags, queue, order)
+#define LAUNCH_LONG(NBV, NQV) do { if (mode == 2) LAUNCH_LONG_(NBV, NQV, true, true); else if (mode == 1) LAUNCH_LONG_(NBV, NQV, true, false); else LAUNCH_LONG_(NBV, NQV, false, false); } while (0)
   if (pl->nq == 24) LAUNCH_LONG(3, 24);
   else if (NB == 1) LAUNCH_LONG(1, 0);
   else if (NB == 2) LAUNCH_LONG(2, 0);
   else LAUNCH_LONG(3, 0);
+#undef LAUNCH_LONG_
 #undef LAUNCH_LONG
   D2D_LAUNCH_CHECK();
   return D2D_OK;
@@ -1480,7 +1516,9 @@ int d2d_fit_plan_create(d2d_ctx *ctx, int S, int K, double duration, const doubl
   allow_big_lds(&fit_eval_kernel<1, 0, false>); allow_big_lds(&fit_eval_kernel<2, 0, false>); allow_big_lds(&fit_eval_kernel<3, 0, false>);
   allow_big_lds(&fit_eval_kernel<3, 24, true>); allow_big_lds(&fit_eval_kernel<3, 24, false>);
   allow_big_lds(&fit_jtj_kernel<1, 0>); allow_big_lds(&fit_jtj_kernel<2, 0>); allow_big_lds(&fit_jtj_kernel<3, 0>); allow_big_lds(&fit_jtj_kernel<3, 24>);
-  allow_big_lds(&fit_lm_long_kernel<3, 24>); allow_big_lds(&fit_lm_long_kernel<3, 0>); allow_big_lds(&fit_lm_long_kernel<2, 0>); allow_big_lds(&fit_lm_long_kernel<1, 0>);
+  allow_big_lds(&fit_lm_long_kernel<3, 24, false>); allow_big_lds(&fit_lm_long_kernel<3, 0, false>); allow_big_lds(&fit_lm_long_kernel<2, 0, false>); allow_big_lds(&fit_lm_long_kernel<1, 0, false>);
+  allow_big_lds(&fit_lm_long_kernel<3, 24, true>); allow_big_lds(&fit_lm_long_kernel<3, 0, true>); allow_big_lds(&fit_lm_long_kernel<2, 0, true>); allow_big_lds(&fit_lm_long_kernel<1, 0, true>);
+  allow_big_lds(&fit_lm_long_kernel<3, 24, true, false>); allow_big_lds(&fit_lm_long_kernel<3, 0, true, false>); allow_big_lds(&fit_lm_long_kernel<2, 0, true, false>); allow_big_lds(&fit_lm_long_kernel<1, 0, true, false>);
   allow_big_lds(&fit_groups_kernel<3, 24>);
   allow_big_lds(&fit_lm_kernel<3, 24, false>);
   allow_big_lds(&fit_lm_kernel<3, 24, true>);

@@ -190,8 +190,10 @@ __device__ __forceinline__ void flat_outputs_gt(const FitGeom &g, const double *
 }
 
 // CostBank max mode over a long horizon: index of the sample with the largest |phi| (first on ties); -1 in mean mode.
-template <int NQ>
-__device__ __forceinline__ int long_bank_argmax(const FitGeom &g, const double *__restrict__ GT, const double *__restrict__ pkb,
+// TL: GT is the row-major table [3][K][gstr] in the LDS (plans whose tables fit beside the per-wave blocks), otherwise the
+// transposed table [3][nq][K] in global memory.
+template <int NQ, bool TL = false>
+__device__ __forceinline__ int long_bank_argmax(const FitGeom &g, const double *GT, const double *__restrict__ pkb,
                                                 const double *qs, const ScenP &s, int lane) {
   if (!(s.cphimax > 0.0)) return -1;
   double best = -1.0;
@@ -203,7 +205,7 @@ __device__ __forceinline__ int long_bank_argmax(const FitGeom &g, const double *
       double pk[FIT_PK], Y[6];
 #pragma unroll
       for (int c = 0; c < FIT_PK; ++c) pk[c] = pkb[(size_t)c * g.K + k];
-      flat_outputs_gt<NQ>(g, GT, qs, pk, k, Y);
+      if (TL) flat_outputs_pk<NQ>(g, GT, qs, pk, k, Y); else flat_outputs_gt<NQ>(g, GT, qs, pk, k, Y);
       aw = sample_absw(s, Y);
     }
     const double m = wave_max(aw);
@@ -216,8 +218,8 @@ __device__ __forceinline__ int long_bank_argmax(const FitGeom &g, const double *
 // second-order mode), chunk-local indices; a lane beyond the horizon writes zero records (the MFMA passes read the
 // whole chunk up to its last sample and one padded sample).  Returns the chunk's sum r^2 (wave-uniform).
 // WANT_JAC = false: the cost alone (trial points).
-template <int NQ, bool WANT_JAC>
-__device__ __forceinline__ double long_phase1(const FitGeom &g, const double *__restrict__ GT, const double *__restrict__ pkb,
+template <int NQ, bool WANT_JAC, bool TL = false>
+__device__ __forceinline__ double long_phase1(const FitGeom &g, const double *GT, const double *__restrict__ pkb,
                                               const double *sp, const double *qs, double *us, f32x4 *cf, float2 *cfp,
                                               bool so, int kbank, int k0, int lane) {
   LAUNDER(lane);
@@ -228,7 +230,7 @@ __device__ __forceinline__ double long_phase1(const FitGeom &g, const double *__
     f32x4 coef[4];
 #pragma unroll
     for (int c = 0; c < FIT_PK; ++c) pk[c] = pkb[(size_t)c * g.K + k];
-    flat_outputs_gt<NQ>(g, GT, qs, pk, k, Y);
+    if (TL) flat_outputs_pk<NQ>(g, GT, qs, pk, k, Y); else flat_outputs_gt<NQ>(g, GT, qs, pk, k, Y);
     const ScenP s = load_scenp(sp);
     if (!WANT_JAC) {
       cacc = sample_terms<false>(s, Y, pk[6], pk[7], nullptr, nullptr, k == kbank);
@@ -264,7 +266,7 @@ __device__ __forceinline__ double long_phase1(const FitGeom &g, const double *__
 
 // Phase 2 of one chunk (lane = unknown): sum over the chunk's samples of G_k^T u_k, basis rows from the row-major global table.
 template <int NQ>
-__device__ __forceinline__ double long_phase2(const FitGeom &g, const double *__restrict__ G64g, const double *us, int k0,
+__device__ __forceinline__ double long_phase2(const FitGeom &g, const double *G64g, const double *us, int k0,
                                               int kn, int lane) {
   const int nq = NQ ? NQ : g.nq, gstr = nq + 1;
   double g_lane = 0.0;
@@ -318,7 +320,9 @@ __device__ __forceinline__ void jtj_mfma(const FitGeom &g, const unsigned char *
   const int rho = lane >> 4, ci = lane & 15;
   const int nq = NQ ? NQ : g.nq;
   const int n = 2 * nq;
-  const int plane = g.K * nq;
+  // byte geometry of the fp32 basis planes: element size, row step (one sample), plane step (one derivative order)
+  constexpr int TE = 4;
+  const int tstep = nq * 4, plane = g.K * tstep;
   bool jok[NB], ayc[NB];
   int oc[NB], oa[NB], ob[NB], jj[NB];     // byte offsets: (cA,cB) pair, TA entry, TB entry
 #pragma unroll
@@ -328,8 +332,8 @@ __device__ __forceinline__ void jtj_mfma(const FitGeom &g, const unsigned char *
     ayc[c] = col >= nq;
     jj[c] = jok[c] ? col - (ayc[c] ? nq : 0) : 0;
     oc[c] = cf_off + rho * 16 + (ayc[c] ? 8 : 0);
-    oa[c] = 4 * (((rho < 2) ? plane : 0) + jj[c]);
-    ob[c] = 4 * (2 * plane + jj[c]);
+    oa[c] = ((rho < 2) ? plane : 0) + TE * jj[c];
+    ob[c] = 2 * plane + TE * jj[c];
   }
 #define LDS_F(off) lds_get<float>(lds_base + (off))
 #define LDS_F2(off) lds_get<float2>(lds_base + (off))
@@ -357,7 +361,7 @@ __device__ __forceinline__ void jtj_mfma(const FitGeom &g, const unsigned char *
     }                                                                                          \
     _Pragma("unroll") for (int c = 0; c < NB; ++c) {                                           \
       cc[c] = LDS_F2(oc[c] + ((KK) + 1) * 64);                                                 \
-      ta[c] = T32_AT(oa[c] + ((KK) + 1) * nq * 4); tb[c] = T32_AT(ob[c] + ((KK) + 1) * nq * 4); \
+      ta[c] = T32_AT(oa[c] + ((KK) + 1) * tstep); tb[c] = T32_AT(ob[c] + ((KK) + 1) * tstep);     \
     }                                                                                          \
     int t = 0;                                                                                 \
     _Pragma("unroll") for (int I = 0; I < NB; ++I)                                             \
@@ -377,12 +381,12 @@ __device__ __forceinline__ void jtj_mfma(const FitGeom &g, const unsigned char *
   for (; k + 5 <= Kmf; k += 5) {
     JTJ_KSTEP(0) JTJ_KSTEP(1) JTJ_KSTEP(2) JTJ_KSTEP(3) JTJ_KSTEP(4)
 #pragma unroll
-    for (int c = 0; c < NB; ++c) { oc[c] += 5 * 64; oa[c] += 5 * nq * 4; ob[c] += 5 * nq * 4; }
+    for (int c = 0; c < NB; ++c) { oc[c] += 5 * 64; oa[c] += 5 * tstep; ob[c] += 5 * tstep; }
   }
   for (; k < Kmf; ++k) {
     JTJ_KSTEP(0)
 #pragma unroll
-    for (int c = 0; c < NB; ++c) { oc[c] += 64; oa[c] += nq * 4; ob[c] += nq * 4; }
+    for (int c = 0; c < NB; ++c) { oc[c] += 64; oa[c] += tstep; ob[c] += tstep; }
   }
 #undef JTJ_KSTEP
   // collision rows of a coupled group: further k-steps of four rows each, all of the form c * G0[k][j]
@@ -392,7 +396,7 @@ __device__ __forceinline__ void jtj_mfma(const FitGeom &g, const unsigned char *
       float v[NB];
 #pragma unroll
       for (int c = 0; c < NB; ++c) {
-        const float val = (ayc[c] ? c2.y : c2.x) * T32_AT(4 * (kk * nq + jj[c]));
+        const float val = (ayc[c] ? c2.y : c2.x) * T32_AT(kk * tstep + TE * jj[c]);
         v[c] = (2 * nq == 16 * NB || jok[c]) ? val : 0.f;
       }
       int t = 0;

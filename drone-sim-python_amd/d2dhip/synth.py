@@ -24,14 +24,14 @@ def default_wref(obj_scale, K, kv=5.0, kphi=1.0, wwp=0.02):
     return (wwp ** 2, s * kv, s * kphi / G_ACC ** 2)
 
 
-def synth_scenarios(B, seed=20241008, rank=0, n_obs=2, wbnd=1.0, wwp=0.02, obj_scale=0.1, K=50):
-    """B scenario rows (float64 [B][24]): start/end poses 30-55 m apart with random
+def synth_scenarios(B, seed=20241008, rank=0, n_obs=2, wbnd=1.0, wwp=0.02, obj_scale=0.1, K=50, dist_range=(30., 55.)):
+    """B scenario rows (float64 [B][SCEN_STRIDE]): start/end poses dist_range (30-55 m) apart with random
     headings, vref = vsp = 12, kv = 5, kphi = 1 (src/multi_opt_planner.py:187-188), two
     circular obstacles beside the straight line, soft bounds phi in +-40 deg, v in [9,15]."""
     rng = np.random.default_rng(seed + rank)
     sc = np.zeros((B, SCEN_STRIDE))
     p0 = rng.uniform(-100, 100, (B, 2)); psi0 = rng.uniform(-np.pi, np.pi, B)
-    dist = rng.uniform(30, 55, B); beta = rng.uniform(-np.pi, np.pi, B)
+    dist = rng.uniform(dist_range[0], dist_range[1], B); beta = rng.uniform(-np.pi, np.pi, B)
     p1 = p0 + dist[:, None] * np.stack([np.cos(beta), np.sin(beta)], 1)
     psi1 = rng.uniform(-np.pi, np.pi, B)
     sc[:, SC_X0], sc[:, SC_Y0], sc[:, SC_PSI0] = p0[:, 0], p0[:, 1], psi0
