@@ -7,7 +7,7 @@ import numpy as np, torch, d2dhip
 from d2dhip import synth
 ctx = d2dhip.Context(0); K = 50
 plan = d2dhip.FitPlan(ctx, 6, K, synth.planner_timing(0, 4.9, 10)[2], synth.default_wref(0.1, K))
-B = 4096
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 MAX_ITER = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 for rank in range(8):
     sc = ctx.dev(synth.synth_scenarios(B, seed=20241008, rank=rank, obj_scale=0.1, K=K)); q0 = plan.init(sc)
