@@ -106,6 +106,27 @@ def test_32768_fits_properties_and_order_invariance(ctx, plan, obasis):
     assert torch.equal(q, q2) and torch.equal(iters, iters2) and torch.equal(cost, cost2) and torch.equal(status, status2)
 
 
+@pytest.mark.parametrize('B', [1, 3, 5, 300, 1027, 2049])
+def test_order_hint_small_and_ragged_batches(ctx, plan, B):
+    """The ordered hand-out with its exclusive SIMDs (fit_lm_kernel: wave 4 of the first workgroups gives its position to the queue
+    and waits for its SIMD-mate) on batches smaller than the grid, around the first queue positions (1024 + excl) and just past
+    one round of static positions (2048): same bits as the index-order solve, every fit handled exactly once."""
+    import torch
+    from d2dhip import synth
+    sc = synth.synth_scenarios(B, seed=77, obj_scale=0.1, K=K)
+    dsc = ctx.dev(sc)
+    q0 = plan.init(dsc)
+    plan.clear_order()
+    qa = q0.clone()
+    ca, ia, sa, _ = plan.solve(dsc, qa)
+    plan.order_from_iters(ia)
+    qb = q0.clone()
+    cb, ib, sb, _ = plan.solve(dsc, qb)
+    plan.clear_order()
+    assert torch.equal(qa, qb) and torch.equal(ia, ib) and torch.equal(ca, cb) and torch.equal(sa, sb)
+    assert (sa.cpu().numpy() != 0).all()                    # nobody left RUNNING
+
+
 def test_8x8192_groups_properties(ctx, obasis):
     """BASELINE configs[2]: 8-drone circular formation x 8192 replicas with collision rows (block Gauss-Seidel)."""
     import d2dhip
