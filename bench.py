@@ -196,6 +196,12 @@ def nlp_record(ctx, torch, cpu, B=4096):
            'infeasible_frac': float((st == 4).mean()),     # D2D_ST_STALLED: perturbed end poses that no v <= 15 path joins in 12 s (the oracle agrees)
            'mean_newton_steps': float(it.mean()),
            'max_newton_steps': int(it.max()), 'hbm_traffic_per_launch': pmc_traffic('nlp_solve_kernel')[0], 'cpu_baseline': cpu}
+    # algorithmic HBM bytes: per problem and Newton step the 88 N doubles of workspace are read and written about once per phase
+    # (~100 kB read + ~96 kB written at N = 121); the kernel is bound by its serial block recursion, not by HBM
+    alg = float(it.sum()) * (100e3 + 96e3) * (W0.shape[2] / 121.0)
+    rec['roofline'] = {'bound': 'hbm', 'kernel': 'nlp_solve_kernel', 'achieved': alg / best / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                       'frac': alg / best / 1e9 / HBM_PEAK_GBS, 'traffic': rec['hbm_traffic_per_launch'], 'alg_bytes_per_launch': alg,
+                       'note': 'latency-bound on the twisted 3x3 block recursion (one wavefront per problem, two waves per SIMD); traffic = FETCH_SIZE + WRITE_SIZE of the committed PMC passes'}
     if cpu is not None:
         n = len(cpu['cost'])
         rec['parity'] = {'n': n, 'max_rel_cost_diff_vs_oracle': float(np.max(np.abs(cost[:n] - np.array(cpu['cost'])) / np.array(cpu['cost']))),
