@@ -86,6 +86,13 @@ class Problem:
         self.options[k] = v
     add_option = addOption
 
+    # opty's plotting helpers (called by the reference's `if plot:` branches, src/06_optyplan.py:159-161, src/07_multioptyplan.py:
+    # 90-92): plotting is out of scope -- refuse by name instead of failing with an AttributeError
+    def _no_plot(self, *_a, **_k):
+        raise NotImplementedError('opty.direct_collocation.Problem plotting helpers are not part of this backend: plot Planner.sol_* '
+                                  '(x, y, psi, phi, v over sol_time) with your own matplotlib code')
+    plot_objective_value = plot_trajectories = plot_constraint_violations = _no_plot
+
     def _rows(self):
         import single_opt_planner as sop
         low = sop.lower_cost(self.cost)
