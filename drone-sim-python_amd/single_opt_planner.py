@@ -140,6 +140,11 @@ class _FitProblem:
     def solve(self, x0):
         return self._p._solve(np.asarray(x0, dtype=np.float64))
 
+    # opty's plotting helpers (the reference's `if plot:` branches): out of scope, refused by name
+    def _no_plot(self, *_a, **_k):
+        raise NotImplementedError('the opty plotting helpers are not part of this backend: plot Planner.sol_* with your own matplotlib code')
+    plot_objective_value = plot_trajectories = plot_constraint_violations = _no_plot
+
 
 class Planner:
     def __init__(self, exp, initialize=True, backend=None):
