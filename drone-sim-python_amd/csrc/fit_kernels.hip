@@ -26,8 +26,11 @@
 #define FIT_THREADS (64 * FIT_WPB_MAX)
 #define FIT_LDS_BYTES (160 * 1024)
 
-// flags[b][4] = status, iters, need_eval, evaluations (half-units: 2 per Gauss-Newton, 3 per second-order one); lm[b][4] = lambda, nu, gmax, second-order mode of the pending evaluation
+// flags[b][4] = status, iters, need_eval, evaluations (half-units: 2 per Gauss-Newton, 3 per second-order one); lm[b][LM_STRIDE], below
 enum { FL_STATUS = 0, FL_ITERS = 1, FL_NEED = 2, FL_NEVAL = 3 };
+// lm[b][LM_STRIDE]: 0 lambda, 1 nu, 2 gmax, 3 second-order mode of the pending evaluation; MINPACK mode: 4 par, 5 trust-region radius,
+// 6 phase | first << 1 | calm << 2, 7 factorisations so far
+#define LM_STRIDE 8
 
 struct FitLds {
   // byte offsets into dynamic LDS
@@ -326,14 +329,14 @@ fit_step_kernel(int B, FitGeom g, StepLds L, d2d_fit_opts opts, GroupArgs ga,
   double *qt = reinterpret_cast<double *>(wl + L.qt);     // trial point
   const int n = 2 * g.nq;
 
-  const double lam = lm[4 * b + 0], nu = lm[4 * b + 1];
+  const double lam = lm[LM_STRIDE * b + 0], nu = lm[LM_STRIDE * b + 1];
   const double c = cost_io[b];
   const int iters = flags[4 * b + FL_ITERS];
   const bool act = lane < n;
   const double gi = act ? g_in[(size_t)b * n + lane] : 0.0;
   const double qi = act ? q_io[(size_t)b * n + lane] : 0.0;
   const double gmax = wave_max(fabs(gi));
-  if (lane == 0) lm[4 * b + 2] = gmax;
+  if (lane == 0) lm[LM_STRIDE * b + 2] = gmax;
   if (gmax <= opts.gtol) {                                 // wave-uniform
     if (lane == 0) flags[4 * b + FL_STATUS] = D2D_ST_CONVERGED;
     return;
@@ -397,8 +400,8 @@ fit_step_kernel(int B, FitGeom g, StepLds L, d2d_fit_opts opts, GroupArgs ga,
     }
   }
   if (lane == 0) {
-    lm[4 * b + 0] = lam_n;
-    lm[4 * b + 1] = nu_n;
+    lm[LM_STRIDE * b + 0] = lam_n;
+    lm[LM_STRIDE * b + 1] = nu_n;
     flags[4 * b + FL_ITERS] = iters + 1;
     if (status == D2D_ST_RUNNING && iters + 1 >= opts.max_iter) status = D2D_ST_MAXITER;
     flags[4 * b + FL_STATUS] = status;
@@ -447,20 +450,35 @@ static bool pick_fused_layout(int K, int nq, int N, int *wpb, int nds = 0) {
   return false;
 }
 
-template <int NB, int NQ, bool STAMPS>
+// Loads of per-fit state that another wavefront of the same launch may have written (a fit that yielded its wavefront is
+// resumed by whoever pops it from the ring, possibly on another XCD): device-scope atomic loads, after an acquire fence.
+__device__ __forceinline__ double ld_dev(const double *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int ld_dev(const int32_t *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_dev(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_dev(int32_t *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// MODE = D2D_LM_MODE_MINPACK: phase 0 is MINPACK's lmder (fit_phases.h mp_*; Gauss-Newton rows, trust region), phase 1 the
+// second-order loop that finishes it; D2D_LM_MODE_FAST: the second-order loop alone, from the start, with the so_lambda rule.
+// One pass of the inner loop = at most one factorisation and at most one trial point, whatever the phase: ONE inlined copy of
+// damped_solve and ONE of the trial's phase 1 serve lmpar's Gauss-Newton and damped solves, lmder's trial, the finish's
+// damped solve and its full and shortened trials (the loop nest is ~35 kB of code as it is; the instruction cache holds 64).
+template <int NB, int NQ, bool STAMPS, int MODE>
 __global__ void __launch_bounds__(64 * FIT_LM_WPB_MAX)
-fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_budget,
+fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_cap,
               const double *__restrict__ gG64, const double *__restrict__ pk,
               const float *__restrict__ gG32, const float *__restrict__ gWt,
-              const double *__restrict__ prep, double *__restrict__ q_io, double *__restrict__ cost_io,
-              double *__restrict__ g_io, double *__restrict__ lm, int32_t *__restrict__ flags,
-              int32_t *__restrict__ queue, unsigned long long *__restrict__ stamps,
-              const int32_t *__restrict__ order, int prio_pack) {
-  // prio_pack = prio_at | excl << 16.
-  // order != NULL: hand-out position i takes trajectory order[i] (d2d_fit_plan_set_order: the longest fits of a previous solve
-  // first, so that the tail of the launch is not one long fit that was drawn late).  prio_at: a fit that has used this many
-  // iterations raises its wave's priority (s_setprio): the stragglers that decide when the launch ends get the SIMD's issue
-  // slots ahead of the co-resident wave instead of sharing them.
+              const double *__restrict__ prep, double *q_io, double *cost_io,
+              double *g_io, double *lm, int32_t *flags,
+              int32_t *queue, int32_t *ring, int ring_mask, unsigned long long *__restrict__ stamps,
+              const int32_t *__restrict__ order, int prio_at) {
+  // iter_cap: a fit stops (state saved, still D2D_ST_RUNNING) once it has used this many iterations in total (the host's
+  // convergence poll, d2d_fit_iterate).  order != NULL: hand-out position i takes trajectory order[i] (d2d_fit_plan_set_order).
+  // prio_at: a fit that has used this many iterations raises its wave's priority (s_setprio): the stragglers that decide when
+  // the launch ends get the SIMD's issue slots ahead of the co-resident wave instead of sharing them.
   // stamps != NULL (D2D_LM_STAMPS=1, diagnostics only): per-phase wave-cycle totals, see launch_lm
   unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = 0, st_solve[5] = {0, 0, 0, 0, 0};
 #define LM_STAMP(i)                                                     \
@@ -475,8 +493,6 @@ fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_budget,
   stage(G64, gG64, 3 * g.K * g.gstr * 8);
   stage(lds + L.G32, gG32, (3 * g.K + 1) * g.nq * 4);
   stage(lds + L.Wt, gWt, NT * 256 * 4);
-#define WFLAG(w) (*reinterpret_cast<volatile int *>(lds + 4 * (w)))
-  if (threadIdx.x < 16) WFLAG(threadIdx.x) = 0;
   __syncthreads();
   const float *Wt = reinterpret_cast<const float *>(lds + L.Wt);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -490,161 +506,401 @@ fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_budget,
   const int n = 2 * g.nq;
   const bool act = lane < n;
 
-  // Work distribution: the first trajectory of a wave is static and workgroup-major (wave w of workgroup g
-  // takes g + gridDim*w: a batch smaller than the grid's wave count spreads over all CUs, and over the four
-  // SIMDs of a CU -- consecutive waves of a workgroup sit on different SIMDs); every further one is pulled
-  // from a device-wide counter (queue[0], zero at launch), so that a wave that drew short fits takes more of
-  // them (iteration counts range from 20 to 150).  queue[1] counts the waves that have left the loop: the last
-  // one zeroes both for the next launch (d2d_fit_begin zeroes them too).  queue == NULL: static striding.
+  // Work distribution.  The first trajectory of a wave is static and workgroup-major (wave w of workgroup g takes hand-out
+  // position g + gridDim*w: a batch smaller than the grid's wave count spreads over all CUs, and over the four SIMDs of a CU);
+  // the positions beyond come from a device-wide counter (queue[0]).  A fit that has run opts.slice iterations while others
+  // are waiting -- positions not yet handed out, or fits in the ring -- saves its state, goes to the back of the ring
+  // (queue[2] = head, queue[3] = tail, queue[4] = entries ready to be taken, ring[] = trajectory indices, -1 = empty slot) and its wave takes the next waiting
+  // fit: every fit of the batch advances at the same rate (processor sharing), so the launch ends when the work is done or
+  // when its longest fit is, whichever is later, without knowing the lengths in advance.  A wave leaves when nothing waits;
+  // a wave only pushes when something waits and pops right after, so no entry is left behind.  queue[1] counts the waves that
+  // have left: the last one zeroes the counters for the next launch.  queue == NULL: static striding, no yields.
   const int stride = gridDim.x * (blockDim.x >> 6);
-  // Exclusive SIMDs for the longest fits (order hint only, prio_pack >> 16 = excl <= gridDim.x): waves w and w + 4 of a workgroup
-  // share a SIMD; wave 4 of the first `excl` workgroups -- the SIMD-mate of the wave that starts on one of the `excl` longest
-  // fits -- gives its static position to the queue (counter values below excl) and stays off the SIMD (s_sleep) until that fit is
-  // done, then pulls from the queue like everybody: the fit that decides when the launch ends iterates at the speed of a lone
-  // wave.  The wait is bounded (the flag is also raised on every way out of the mate's loop).
-  auto next_index = [&](int b) -> int {
-    if (queue == nullptr) return b + stride;
-    int t = 0;
+  auto take = [&](bool first) -> int {          // trajectory index, or -1: nothing waits
+    if (first) {
+      const int bi = blockIdx.x + gridDim.x * wave;
+      if (bi >= B) return -1;
+      return order ? __builtin_amdgcn_readfirstlane(order[bi]) : bi;
+    }
+    if (queue == nullptr) return -1;
+    int t = -1;
     if (lane == 0) {
-      const int excl = (order != nullptr) ? (prio_pack >> 16) : 0;
-      t = atomicAdd(queue, 1);
-      t = t < excl ? 4 * (int)gridDim.x + t : stride + t - excl;
+      if (stride + __hip_atomic_load(queue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < B) {
+        const int p = stride + atomicAdd(queue, 1);
+        if (p < B) t = order ? order[p] : p;
+      }
+      if (t < 0) {
+        // (fetch-adds only: a compare-and-swap on the head under 2048 waves that reach their slice boundary together is quadratic)
+        const int a = atomicAdd(queue + 4, -1);
+        if (a <= 0) atomicAdd(queue + 4, 1);                 // nothing there (or a concurrent taker's undo made it look so: harmless)
+        else {
+          const int h = atomicAdd(queue + 2, 1);              // an entry is ours: completed pushes >= successful takes
+          int32_t *slot = ring + (h & ring_mask);
+          int v;
+          while ((v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < 0) __builtin_amdgcn_s_sleep(1);
+          __hip_atomic_store(slot, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          t = v | 0x40000000;                                 // (bit 30: resumed from the ring)
+        }
+      }
     }
     return __builtin_amdgcn_readfirstlane(t);
   };
+  auto others_waiting = [&]() -> bool {
+    int w = 0;
+    if (lane == 0) {
+      w = (stride + __hip_atomic_load(queue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < B) ||
+          __hip_atomic_load(queue + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0;
+    }
+    return __builtin_amdgcn_readfirstlane(w) != 0;
+  };
   if (STAMPS) st_last = __builtin_amdgcn_s_memtime();
-  int bi = blockIdx.x + gridDim.x * wave;
-  if (order != nullptr && queue != nullptr && wave == 4 && (int)blockIdx.x < (prio_pack >> 16)) {
-    for (int spin = 0; spin < 40000 && __builtin_amdgcn_readfirstlane(WFLAG(0)) == 0; ++spin) __builtin_amdgcn_s_sleep(16);
-    bi = next_index(bi);
-  }
-  for (; (unsigned)bi < (unsigned)B; bi = next_index(bi)) {
-    const int b = order ? __builtin_amdgcn_readfirstlane(order[bi]) : bi;
-    if (flags[4 * b + FL_STATUS] != D2D_ST_RUNNING) { if (lane == 0) WFLAG(wave) = 1; continue; }
+  bool first_take = true;
+  for (;;) {
+    int b = take(first_take);
+    first_take = false;
+    if (b < 0) break;
+    const bool resumed = (b & 0x40000000) != 0;
+    b &= 0x3fffffff;
+    if (!resumed && flags[4 * b + FL_STATUS] != D2D_ST_RUNNING) continue;      // (a resumed fit's state is read with device-scope loads below)
     const double *prow = prep + (size_t)b * FIT_PREP_STRIDE;
     const double *pkb = pk + (size_t)b * FIT_PK * g.K;
-    double qi = act ? q_io[(size_t)b * n + lane] : 0.0;
-    double lam = lm[4 * b + 0], nu = lm[4 * b + 1];          // scalar loads: uniform
-    int iters = flags[4 * b + FL_ITERS];
+    double *lmb = lm + (size_t)b * LM_STRIDE;
+    double qi = act ? ld_dev(q_io + (size_t)b * n + lane) : 0.0;
+    // Wave-uniform state lives in scalar registers, of which there are ~100: values that are never live together share one.
+    //   s0, s1       phase 1: V_lam, V_nu (damping, Nielsen's growth factor); phase 0: V_par, the trust-region radius
+    //   u0 .. u7     scratch of one iteration: phase 0 (lmpar + lmder) V_parl, V_paru, V_fp, V_pn, V_gnrm, V_gnorm, V_par;
+    //                phase 1 V_pred, V_dmax, V_qmax, V_ct, V_pred_s, V_bt_a, V_bt_b, V_alpha
+    double s0 = 0.0, s1 = 0.0, u0 = 0.0, u1 = 0.0, u2 = 0.0, u3 = 0.0, u4 = 0.0, u5 = 0.0, u6 = 0.0, u7 = 1.0;
+#define V_lam s0
+#define V_nu s1
+#define V_mp_par s0
+#define V_mp_delta s1
+#define V_parl u0
+#define V_paru u1
+#define V_fp u2
+#define V_pn u3
+#define V_gnrm u4
+#define V_gnorm u5
+#define V_par u6
+#define V_pred u0
+#define V_dmax u1
+#define V_qmax u2
+#define V_ct u3
+#define V_pred_s u4
+#define V_bt_a u5
+#define V_bt_b u6
+#define V_alpha u7
+    int iters = uniform_i(ld_dev(flags + 4 * b + FL_ITERS));
     int nev = 0, local = 0, status = D2D_ST_RUNNING;
+    bool so_rows = uniform_i(ld_dev(lmb + 3) != 0.0 ? 1 : 0) != 0;      // mode of the rows in us / cf (and of hrow after the MFMA pass)
+    int phase = 1;
+    MpState mp;
+    mp.dx_gn = 0.0; mp.t2_gn = 0.0; mp.p_gn = 0.f; mp.gn_valid = 0; mp.gn_ok = 0; mp.first = 0; mp.calm = 0; mp.nfac = 0;
+    if (MODE == D2D_LM_MODE_MINPACK) {
+      const int pw = uniform_i((int)ld_dev(lmb + 6));                   // phase | first << 1 | calm << 2
+      phase = pw & 1; mp.first = (pw >> 1) & 1; mp.calm = pw >> 2;
+    }
+    if (phase == 0) { V_mp_par = uniform_d(ld_dev(lmb + 4)); V_mp_delta = uniform_d(ld_dev(lmb + 5)); }
+    else { V_lam = uniform_d(ld_dev(lmb + 0)); V_nu = uniform_d(ld_dev(lmb + 1)); }
     double c = 0.0, gi = 0.0;
+    float hdiag = 0.f;
     f32x2 hrow[N / 2];
 #pragma unroll
     for (int m = 0; m < N / 2; ++m) hrow[m] = f32x2{0.f, 0.f};
-    // Every value that steers the loop below is made scalar (uniform_*): the control flow is
-    // wave-uniform by construction and must compile to scalar branches.
-    // Invariant at the top of the loop: us / cf hold phase 1 at the point qs (= qi) whose cost is c;
-    // `fresh` says they still need phase 2 + MFMA (J^T r, J^T J) before the next damped solve.
     if (act) qs[q_slot(lane, g.nq)] = qi;
     for (int i = lane; i < FIT_PREP_STRIDE; i += 64) sp[i] = prow[i];
     double pkr[FIT_PK];
 #pragma unroll
     for (int cc = 0; cc < FIT_PK; ++cc) pkr[cc] = lane < g.K ? pkb[(size_t)cc * g.K + lane] : 0.0;
     wave_lds_sync();
+    if (MODE == D2D_LM_MODE_MINPACK && phase == 0 && mp.first && V_mp_delta <= 0.0) {   // lmder's first radius: factor * ||x||
+      const double xn = sqrt(uniform_d(wave_sum(qi * qi)));
+      V_mp_delta = xn > 0.0 ? 100.0 * xn : 100.0;
+    }
     LM_STAMP(0)
-    // mode of the rows in us / cf (and of hrow after the MFMA pass); kept in lm[.][3] between launches
-    bool so_rows = uniform_i(lm[4 * b + 3] != 0.0 ? 1 : 0) != 0;
-    c = uniform_d(eval_phase1_reg<NQ>(g, G64, pkr, pkb, sp, qs, us, cf, cfp, so_rows, lane));
-    LM_STAMP(1)
-    bool fresh = true;
-    if (!(fabs(c) <= 1.79e308)) { status = D2D_ST_NONFINITE; fresh = false; }
-    while (status == D2D_ST_RUNNING || fresh) {
-      if (fresh) {
-        gi = eval_phase2<NQ>(g, G64, us, lane, 0);
-        LM_STAMP(2)
-        fresh = false;
-        if (status != D2D_ST_RUNNING) break;             // accepted + converged: J^T r refreshed, done
-        f32x4 acc[NT];
-        if (so_rows) jtj_mfma_so<NB, NQ>(g, lds, L.G32, L.wave0 + wave * L.wave_stride + L.cf, L.wave0 + wave * L.wave_stride + L.cfp, lane, acc);
-        else jtj_mfma<NB, NQ, true>(g, lds, L.G32, gG32, L.wave0 + wave * L.wave_stride + L.cf, lane, g.K, acc);
-        nev += so_rows ? 3 : 2;                          // contracted rows in units of 100 (the roofline unit is 200 rows)
-        wave_lds_sync();                                 // every lane is done with us / cf before they are overwritten
-        LM_STAMP(3)
-        const float ww = (float)(sp[PR_WWP] * sp[PR_WWP]);
+    bool yield = false;
+    // Invariant at the top of a pass with sub == 0: us / cf hold phase 1 (rows in mode so_rows) at the point qs (= qi) whose
+    // cost is c; `fresh` says they still need phase 2 + MFMA (J^T r, J^T J) before the next factorisation.
+    for (bool reenter = true; reenter;) {
+      reenter = false;
+      c = uniform_d(eval_phase1_reg<NQ>(g, G64, pkr, pkb, sp, qs, us, cf, cfp, so_rows, lane));
+      LM_STAMP(1)
+      bool fresh = true;
+      if (!(fabs(c) <= 1.79e308)) { status = D2D_ST_NONFINITE; fresh = false; }
+      // sub-state of an iteration that needs further passes: 1 = lmpar's damped solves (phase 0), 2 = shortened trials (phase 1)
+      int sub = 0, lp_it = 0, att = 0;
+      V_alpha = 1.0;
+      float dl = 0.f, dgi = 0.f;
+      bool fin = false, accept = false, so_next = false;
+      while (status == D2D_ST_RUNNING || fresh) {
+        bool do_solve = false, is_gn = false, do_trial = false;
+        double solve_lam = 0.0;
+        int isq_mode = 0;
+        if (sub == 0) {
+          if (fresh) {
+            gi = eval_phase2<NQ>(g, G64, us, lane, 0);
+            LM_STAMP(2)
+            fresh = false;
+            if (status != D2D_ST_RUNNING) break;             // accepted + converged: J^T r refreshed, done
+            f32x4 acc[NT];
+            if (so_rows) jtj_mfma_so<NB, NQ>(g, lds, L.G32, L.wave0 + wave * L.wave_stride + L.cf, L.wave0 + wave * L.wave_stride + L.cfp, lane, acc);
+            else jtj_mfma<NB, NQ, true>(g, lds, L.G32, gG32, L.wave0 + wave * L.wave_stride + L.cf, lane, g.K, acc);
+            nev += so_rows ? 3 : 2;                          // contracted rows in units of 100 (the roofline unit is 200 rows)
+            wave_lds_sync();                                 // every lane is done with us / cf before they are overwritten
+            LM_STAMP(3)
+            const float ww = (float)(sp[PR_WWP] * sp[PR_WWP]);
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) acc[t][r] = fmaf(ww, Wt[(t * 4 + r) * 64 + lane], acc[t][r]);
-        tiles_to_image<N>(acc, big, lane);
-        image_put_rhs<N>(big, lane, gi);
-        wave_lds_sync();
-        image_row<N>(big, lane, hrow);
-        wave_lds_sync();
-        LM_STAMP(4)
-      }
-      if (local >= iter_budget || iters >= opts.max_iter) break;
-      const double gmax = uniform_d(wave_max(fabs(gi)));
-      if (gmax <= opts.gtol) { status = D2D_ST_CONVERGED; break; }
-      if (iters >= (prio_pack & 0xffff)) __builtin_amdgcn_s_setprio(2);
-      float dgi, dl;
-      LM_STAMP(6)
-      const int ok = uniform_i(damped_solve<N>(hrow, lam, act, lane, big, dgi, dl, STAMPS ? st_solve : nullptr) ? 1 : 0);
-      const double delta = (double)dl;
-      LM_STAMP(5)
-      // Trial points: the full step (att 0) and, if its gain ratio is not positive, up to two shortened steps along it.
-      // Every trial is a full phase 1: if a step is accepted its rows are the next evaluation -- with the second-order
-      // blocks once the damping (before this step's update) has fallen to so_lambda.  One copy of phase 1 in the loop.
-      const bool so_next = opts.so_lambda > 0.0 && lam <= opts.so_lambda;
-      const double pred = uniform_d(wave_sum(delta * (lam * (double)dgi * delta - gi)));
-      const double dmax = uniform_d(wave_max(fabs(delta))), qmax = uniform_d(wave_max(fabs(qi)));
-      double ct = 0.0, pred_s = pred, alpha = 1.0, bt_a = 0.0, bt_b = 0.0;
-      bool fin = false, accept = false;
-      if (ok) {
-        for (int att = 0; att < 3; ++att) {
-          if (act) qs[q_slot(lane, g.nq)] = qi + alpha * delta;
-          wave_lds_sync();
-          const double ca = uniform_d(eval_phase1_reg<NQ>(g, G64, pkr, pkb, sp, qs, us, cf, cfp, so_next, lane));
-          LM_STAMP(1)
-          if (att == 0) {
-            ct = ca;
-            fin = (fabs(ct) <= 1.79e308) && (pred > 0.0);
-            if (fin && (c - ct) / pred > 0.0) { accept = true; break; }
-            if (!fin) break;
-            bt_a = uniform_d(-2.0 * wave_sum(gi * delta)); bt_b = bt_a - pred;
-            alpha = bt_first_alpha(bt_a, c, ct);
+              for (int r = 0; r < 4; ++r) acc[t][r] = fmaf(ww, Wt[(t * 4 + r) * 64 + lane], acc[t][r]);
+            tiles_to_image<N>(acc, big, lane);
+            image_put_rhs<N>(big, lane, gi);
+            wave_lds_sync();
+            image_row<N>(big, lane, hrow);
+            if (MODE == D2D_LM_MODE_MINPACK) hdiag = big[(lane < N ? lane : 0) * CHOL_LS + (lane < N ? lane : 0)];
+            wave_lds_sync();
+            LM_STAMP(4)
+          }
+          if (iters >= iter_cap || iters >= opts.max_iter) break;
+          if (opts.slice > 0 && queue != nullptr && local >= opts.slice && ((local - opts.slice) & 3) == 0 && others_waiting()) { yield = true; break; }
+          if (iters >= prio_at) __builtin_amdgcn_s_setprio(2);
+          LM_STAMP(6)
+          if (MODE == D2D_LM_MODE_MINPACK && phase == 0) {
+            // lmder's test on the scaled gradient, then lmpar
+            const double fnorm = sqrt(c);
+            double gl = 0.0;
+            if (act && hdiag > 0.f && fnorm > 0.0) gl = fabs(gi) / (sqrt((double)hdiag) * fnorm);
+            V_gnorm = uniform_d(wave_max(gl));
+            if (V_gnorm <= opts.mp_gtol) { status = D2D_ST_CONVERGED; break; }
+            V_gnrm = sqrt(uniform_d(wave_sum(gi * gi)));
+            V_par = V_mp_par; V_parl = 0.0; V_paru = 0.0; V_fp = 0.0; lp_it = 0; V_alpha = 1.0;
+            if (!mp.gn_valid) { do_solve = true; is_gn = true; solve_lam = 0.0; isq_mode = 1; }
+            else sub = 3;                                     // (cached Gauss-Newton step: straight to its post-processing)
           } else {
-            if ((fabs(ca) <= 1.79e308) && ca < c) { accept = true; ct = ca; pred_s = bt_a * alpha - bt_b * alpha * alpha; break; }
-            alpha = fmax(D2D_LM_BT_SHRINK * alpha, D2D_LM_BT_FLOOR);
+            const double gmax = uniform_d(wave_max(fabs(gi)));
+            if (gmax <= opts.gtol) { status = D2D_ST_CONVERGED; break; }
+            do_solve = true; solve_lam = V_lam;
+          }
+        } else if (sub == 1) {                                // lmpar: the next damped solve
+          if (V_par == 0.0) V_par = fmax(MP_DWARF, 0.001 * V_paru);
+          do_solve = true; solve_lam = V_par; isq_mode = lp_it + 1 < 10 ? 2 : 0;
+        } else if (sub == 2) {
+          do_trial = true;                                    // a shortened step along the rejected direction
+        }
+        // ---- at most one factorisation per pass ----
+        bool ok = true;
+        if (do_solve) {
+          double dxn = 0.0, t2 = 0.0;
+          float dls;
+          const bool unit = MODE == D2D_LM_MODE_MINPACK && phase == 0;
+          ok = uniform_i(damped_solve<N, MODE == D2D_LM_MODE_MINPACK>(hrow, solve_lam, act, lane, big, dgi, dls, STAMPS ? st_solve : nullptr,
+                                                                    unit, isq_mode, V_mp_delta, &dxn, &t2) ? 1 : 0) != 0;
+          LM_STAMP(5)
+          if (MODE == D2D_LM_MODE_MINPACK && phase == 0) {
+            ++mp.nfac;
+            if (is_gn) {
+              mp.gn_ok = ok ? 1 : 0; mp.p_gn = dls; mp.dx_gn = dxn; mp.t2_gn = t2; mp.gn_valid = 1;
+              sub = 3;
+            } else {
+              ++lp_it;
+              if (!ok) {                                      // cannot happen in exact arithmetic (V_par > 0): raise the damping
+                V_parl = fmax(V_parl, V_par); V_par = fmax(2.0 * V_par, 0.001 * V_paru);
+                if (lp_it >= 10) { dl = 0.f; V_pn = 0.0; do_trial = true; }
+              } else {
+                const double temp = V_fp;
+                V_fp = dxn - V_mp_delta;
+                if (fabs(V_fp) <= 0.1 * V_mp_delta || (V_parl == 0.0 && V_fp <= temp && temp < 0.0) || lp_it == 10) { dl = dls; V_pn = dxn; do_trial = true; }
+                else {
+                  const double parc = (V_fp / V_mp_delta) / t2;
+                  if (V_fp > 0.0) V_parl = fmax(V_parl, V_par);
+                  if (V_fp < 0.0) V_paru = fmin(V_paru, V_par);
+                  V_par = fmax(V_parl, V_par + parc);
+                }
+              }
+            }
+          } else {
+            // second-order / FAST loop: the full step first (att 0), then up to two shortened ones along it
+            dl = dls;
+            const double delta = (double)dl;
+            so_next = MODE == D2D_LM_MODE_MINPACK ? true : (opts.so_lambda > 0.0 && V_lam <= opts.so_lambda);
+            V_pred = uniform_d(wave_sum(delta * (V_lam * (double)dgi * delta - gi)));
+            V_dmax = uniform_d(wave_max(fabs(delta))); V_qmax = uniform_d(wave_max(fabs(qi)));
+            V_ct = 0.0; V_pred_s = V_pred; V_alpha = 1.0; V_bt_a = 0.0; V_bt_b = 0.0; fin = false; accept = false; att = 0;
+            if (ok) do_trial = true;
           }
         }
+        if (MODE == D2D_LM_MODE_MINPACK && sub == 3) {        // lmpar after the Gauss-Newton step (fresh or cached)
+          if (mp.gn_ok && mp.dx_gn - V_mp_delta <= 0.1 * V_mp_delta) { dl = mp.p_gn; V_pn = mp.dx_gn; V_par = 0.0; do_trial = true; }
+          else {
+            V_fp = mp.gn_ok ? mp.dx_gn - V_mp_delta : 1.79e308;
+            V_parl = (mp.gn_ok && mp.t2_gn > 0.0) ? (V_fp / V_mp_delta) / mp.t2_gn : 0.0;
+            V_paru = V_gnrm / V_mp_delta;
+            if (V_paru == 0.0) V_paru = MP_DWARF / fmin(V_mp_delta, 0.1);
+            V_par = fmin(fmax(V_par, V_parl), V_paru);
+            if (V_par == 0.0) V_par = mp.gn_ok ? V_gnrm / mp.dx_gn : 0.0;
+            sub = 1;
+          }
+        }
+        if (!do_trial) {
+          if (MODE == D2D_LM_MODE_MINPACK && phase == 0) continue;      // lmpar goes on
+          if (sub == 0 && !ok) {                                        // failed factorisation: no trial, the damping grows
+            const StepOutcome so = lm_update(false, false, false, 1.0, c, 0.0, V_pred, V_pred, V_dmax, V_qmax, V_lam, V_nu, opts);
+            ++iters; ++local;
+            V_lam = so.lam; V_nu = so.nu; status = so.status;
+            LM_STAMP(6)
+          }
+          continue;
+        }
+        // ---- at most one trial point per pass: a full phase 1 (if the step is accepted its rows are the next evaluation) ----
+        if (MODE == D2D_LM_MODE_MINPACK && phase == 0 && mp.first) { V_mp_delta = fmin(V_mp_delta, V_pn); mp.first = 0; }
+        const bool so_trial = (MODE == D2D_LM_MODE_MINPACK && phase == 0) ? false : so_next;
+        if (act) qs[q_slot(lane, g.nq)] = qi + V_alpha * (double)dl;
+        wave_lds_sync();
+        const double ca = uniform_d(eval_phase1_reg<NQ>(g, G64, pkr, pkb, sp, qs, us, cf, cfp, so_trial, lane));
+        LM_STAMP(1)
+        if (MODE == D2D_LM_MODE_MINPACK && phase == 0) {
+          // lmder: actual against predicted reduction, radius and damping updates, convergence tests
+          const double fnorm = sqrt(c);
+          const bool ctfin = fabs(ca) <= 1.79e308;
+          const double fnorm1 = ctfin ? sqrt(ca) : 1.79e308;
+          double actred = -1.0;
+          if (0.1 * fnorm1 < fnorm) actred = 1.0 - ca / c;
+          const double pg = -uniform_d(wave_sum((double)dl * gi));         // p^T J^T f with p = -dl
+          const double jp2 = fmax(pg - V_par * V_pn * V_pn, 0.0);                // ||J p||^2 = p^T g - V_par p^T p
+          const double t1 = jp2 / c, t2v = V_par * V_pn * V_pn / c;
+          const double prered = t1 + t2v / 0.5, dirder = -(t1 + t2v);
+          const double ratio = prered != 0.0 ? actred / prered : 0.0;
+          if (ratio <= 0.25) {
+            double temp = actred >= 0.0 ? 0.5 : 0.5 * dirder / (dirder + 0.5 * actred);
+            if (0.1 * fnorm1 >= fnorm || temp < 0.1) temp = 0.1;
+            V_mp_delta = temp * fmin(V_mp_delta, V_pn / 0.1);
+            V_par = V_par / temp;
+          } else if (V_par == 0.0 || ratio >= 0.75) {
+            V_mp_delta = V_pn / 0.5;
+            V_par = 0.5 * V_par;
+          }
+          V_mp_par = V_par;
+          const bool taken = ratio >= 1e-4;
+          if (taken) {
+            qi += (double)dl; c = ca;
+            mp.gn_valid = 0;
+            mp.calm = (V_par == 0.0 && ratio >= 0.75) ? mp.calm + 1 : 0;
+            fresh = true;
+          }
+          ++iters; ++local;
+          sub = 0;
+          const double xnorm = sqrt(uniform_d(wave_sum(qi * qi)));
+          int info = 0;
+          if (fabs(actred) <= opts.mp_ftol && prered <= opts.mp_ftol && 0.5 * ratio <= 1.0) info = 1;
+          if (V_mp_delta <= opts.mp_xtol * xnorm) info = 2;
+          if (info == 0) {
+            if (fabs(actred) <= MP_EPSMCH && prered <= MP_EPSMCH && 0.5 * ratio <= 1.0) info = 6;
+            else if (V_mp_delta <= MP_EPSMCH * xnorm) info = 7;
+            else if (V_gnorm <= MP_EPSMCH) info = 8;
+          }
+          if (info != 0) status = D2D_ST_CONVERGED;
+          if (taken && status == D2D_ST_RUNNING && opts.mp_finish > 0 && mp.calm >= opts.mp_finish) {
+            // the trust region has been inactive for mp_finish steps: second-order finish from here (rows of this point in that mode)
+            phase = 1; V_lam = D2D_LM_LAMBDA0; V_nu = 2.0; so_rows = true;
+            reenter = true;
+            break;
+          }
+          LM_STAMP(6)
+          continue;
+        }
+        // second-order / FAST loop
+        bool decided = false;
+        if (att == 0) {
+          V_ct = ca;
+          fin = (fabs(V_ct) <= 1.79e308) && (V_pred > 0.0);
+          if (fin && (c - V_ct) / V_pred > 0.0) { accept = true; decided = true; }
+          else if (!fin) decided = true;
+          else {
+            V_bt_a = uniform_d(-2.0 * wave_sum(gi * (double)dl)); V_bt_b = V_bt_a - V_pred;
+            V_alpha = bt_first_alpha(V_bt_a, c, V_ct);
+          }
+        } else {
+          if ((fabs(ca) <= 1.79e308) && ca < c) { accept = true; V_ct = ca; V_pred_s = V_bt_a * V_alpha - V_bt_b * V_alpha * V_alpha; decided = true; }
+          else V_alpha = fmax(D2D_LM_BT_SHRINK * V_alpha, D2D_LM_BT_FLOOR);
+        }
+        ++att;
+        if (!decided && att < 3) { sub = 2; continue; }
+        sub = 0;
+        const StepOutcome so = lm_update(true, fin, accept, accept ? V_alpha : 1.0, c, V_ct, V_pred, V_pred_s, V_dmax, V_qmax, V_lam, V_nu, opts);
+        ++iters; ++local;
+        V_lam = so.lam; V_nu = so.nu; status = so.status;
+        if (so.accept) {
+          qi += V_alpha * (double)dl; c = V_ct;
+          fresh = true;                                    // also when converged: refresh J^T r
+          so_rows = so_next;
+        }
+        V_alpha = 1.0;
+        LM_STAMP(6)
       }
-      const StepOutcome so = lm_update(ok != 0, fin, accept, accept ? alpha : 1.0, c, ct, pred, pred_s, dmax, qmax, lam, nu, opts);
-      ++iters; ++local;
-      lam = so.lam; nu = so.nu; status = so.status;
-      if (so.accept) {
-        qi += alpha * delta; c = ct;
-        fresh = true;                                    // also when converged: refresh J^T r
-        so_rows = so_next;
-      }
-      LM_STAMP(6)
     }
     if (status == D2D_ST_RUNNING && iters >= opts.max_iter) status = D2D_ST_MAXITER;
     const double gmax = uniform_d(wave_max(fabs(gi)));
+    // The state a resuming wave reads (q, the lm words, the iteration / evaluation counters) is stored with device-scope
+    // atomic stores: they go through to memory on their own (the eight XCDs have separate L2s), so handing a fit over needs no
+    // L2 write-back / invalidate -- a device-scope fence per yield flushed the L2 under 2048 waves and cost 30x the solve.
     {
       int lane_io = lane;      // (laundered: the per-lane output addresses are not worth two VGPR pairs held across the whole LM loop)
       LAUNDER(lane_io);
-      if (act) { q_io[(size_t)b * n + lane_io] = qi; g_io[(size_t)b * n + lane_io] = gi; }
+      if (act) {
+        st_dev(q_io + (size_t)b * n + lane_io, qi);
+        if (!yield) g_io[(size_t)b * n + lane_io] = gi;
+      }
     }
     if (lane == 0) {
-      cost_io[b] = c;
-      lm[4 * b + 0] = lam; lm[4 * b + 1] = nu; lm[4 * b + 2] = gmax; lm[4 * b + 3] = so_rows ? 1.0 : 0.0;
-      flags[4 * b + FL_STATUS] = status; flags[4 * b + FL_ITERS] = iters; flags[4 * b + FL_NEED] = 1;
-      flags[4 * b + FL_NEVAL] += nev;
+      if (!yield) cost_io[b] = c;
+      st_dev(lmb + 2, gmax); st_dev(lmb + 3, so_rows ? 1.0 : 0.0);
+      if (phase == 0) { st_dev(lmb + 4, V_mp_par); st_dev(lmb + 5, V_mp_delta); } else { st_dev(lmb + 0, V_lam); st_dev(lmb + 1, V_nu); }
+      if (MODE == D2D_LM_MODE_MINPACK) { st_dev(lmb + 6, (double)(phase | (mp.first << 1) | (mp.calm << 2))); st_dev(lmb + 7, ld_dev(lmb + 7) + (double)mp.nfac); }
+      st_dev(flags + 4 * b + FL_STATUS, status); st_dev(flags + 4 * b + FL_ITERS, iters); st_dev(flags + 4 * b + FL_NEED, 1);
+      st_dev(flags + 4 * b + FL_NEVAL, ld_dev(flags + 4 * b + FL_NEVAL) + nev);
     }
     __builtin_amdgcn_s_setprio(0);
-    if (lane == 0) WFLAG(wave) = 1;
+    if (yield) {                                 // to the back of the ring: the stores above have completed before the index is published
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_s_waitcnt(0);
+      if (lane == 0) {
+        const int tl = atomicAdd(queue + 3, 1);
+        int32_t *slot = ring + (tl & ring_mask);
+        while (__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 0) __builtin_amdgcn_s_sleep(1);
+        __hip_atomic_store(slot, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_s_waitcnt(0);
+        atomicAdd(queue + 4, 1);                              // the entry is in its slot: one more to take
+      }
+    }
     LM_STAMP(0)
   }
-  if (lane == 0) WFLAG(wave) = 1;
-#undef WFLAG
   if (queue != nullptr && lane == 0) {
-    if (atomicAdd(queue + 1, 1) == stride - 1) { queue[0] = 0; queue[1] = 0; }     // every wave has stopped pulling
+    if (atomicAdd(queue + 1, 1) == stride - 1) { queue[0] = 0; queue[1] = 0; queue[2] = 0; queue[3] = 0; queue[4] = 0; }     // every wave has stopped pulling
   }
   if (STAMPS && lane == 0) {
     for (int i = 0; i < 8; ++i) atomicAdd(&stamps[i], st_acc[i]);
     for (int i = 0; i < 5; ++i) atomicAdd(&stamps[8 + i], st_solve[i]);
   }
 #undef LM_STAMP
+#undef V_lam
+#undef V_nu
+#undef V_mp_par
+#undef V_mp_delta
+#undef V_parl
+#undef V_paru
+#undef V_fp
+#undef V_pn
+#undef V_gnrm
+#undef V_gnorm
+#undef V_par
+#undef V_pred
+#undef V_dmax
+#undef V_qmax
+#undef V_ct
+#undef V_pred_s
+#undef V_bt_a
+#undef V_bt_b
+#undef V_alpha
 }
 
 // ------------------------------------------------------------------------------------
@@ -887,7 +1143,8 @@ static int long_tables_waves(int K, int nq, int N, bool g32) {
 // TL: the basis tables are staged into the LDS once per workgroup (they fit beside >= 3 per-wave blocks: K <= 121 at nq = 24) and
 // the phases read them there like the K <= 64 kernel does -- from global memory every phase of every chunk is a chain of L2
 // round trips (measured at K = 121: 287 us per LM iteration and wave with 8 waves per CU against 40 us with 3).
-template <int NB, int NQ, bool TL, bool TL32 = TL>
+// MODE: as fit_lm_kernel (D2D_LM_MODE_MINPACK: lmder's trials through mp_trial, then the second-order loop)
+template <int NB, int NQ, bool TL, bool TL32, int MODE>
 __global__ void __launch_bounds__(64 * FIT_LM_WPB_MAX)
 fit_lm_long_kernel(int B, FitGeom g, LongLds L, d2d_fit_opts opts, int iter_budget,
                    const double *__restrict__ GTg, const double *__restrict__ G64gl, const double *__restrict__ pk,
@@ -930,11 +1187,24 @@ fit_lm_long_kernel(int B, FitGeom g, LongLds L, d2d_fit_opts opts, int iter_budg
     if (flags[4 * b + FL_STATUS] != D2D_ST_RUNNING) continue;
     const double *pkb = pk + (size_t)b * FIT_PK * g.K;
     double qi = act ? q_io[(size_t)b * n + lane] : 0.0;
-    double lam = lm[4 * b + 0], nu = lm[4 * b + 1];
+    double lam = lm[LM_STRIDE * b + 0], nu = lm[LM_STRIDE * b + 1];
     int iters = flags[4 * b + FL_ITERS];
     int nev = 0, local = 0, status = D2D_ST_RUNNING;
-    bool so_rows = uniform_i(lm[4 * b + 3] != 0.0 ? 1 : 0) != 0;
+    bool so_rows = uniform_i(lm[LM_STRIDE * b + 3] != 0.0 ? 1 : 0) != 0;
+    int phase = 1;
+    MpState mp;
+    mp.par = 0.0; mp.delta = 0.0; mp.dx_gn = 0.0; mp.t2_gn = 0.0; mp.p_gn = 0.f; mp.gn_valid = 0; mp.gn_ok = 0; mp.first = 0; mp.calm = 0; mp.nfac = 0;
+    if (MODE == D2D_LM_MODE_MINPACK) {
+      const int pw = uniform_i((int)lm[LM_STRIDE * b + 6]);            // phase | first << 1 | calm << 2
+      phase = pw & 1; mp.first = (pw >> 1) & 1; mp.calm = pw >> 2;
+      mp.par = uniform_d(lm[LM_STRIDE * b + 4]); mp.delta = uniform_d(lm[LM_STRIDE * b + 5]);
+      if (phase == 0 && mp.first && mp.delta <= 0.0) {                   // lmder's first radius: factor * ||x||
+        const double xn = sqrt(uniform_d(wave_sum(qi * qi)));
+        mp.delta = xn > 0.0 ? 100.0 * xn : 100.0;
+      }
+    }
     double c = 0.0, gi = 0.0;
+    float hdiag = 0.f;
     f32x2 hrow[N / 2];
 #pragma unroll
     for (int m = 0; m < N / 2; ++m) hrow[m] = f32x2{0.f, 0.f};
@@ -981,6 +1251,7 @@ fit_lm_long_kernel(int B, FitGeom g, LongLds L, d2d_fit_opts opts, int iter_budg
         image_put_rhs<N>(big, lane, gi);
         wave_lds_sync();
         image_row<N>(big, lane, hrow);
+        if (MODE == D2D_LM_MODE_MINPACK) hdiag = big[(lane < N ? lane : 0) * CHOL_LS + (lane < N ? lane : 0)];
         wave_lds_sync();
         nev += (so ? 3 : 2) * ((g.K + 49) / 50);      // contracted rows in units of 100 (FL_NEVAL; one unit = 200 rows)
       }
@@ -995,12 +1266,27 @@ fit_lm_long_kernel(int B, FitGeom g, LongLds L, d2d_fit_opts opts, int iter_budg
       }
       if (status != D2D_ST_RUNNING) break;
       if (local >= iter_budget || iters >= opts.max_iter) break;
+      if (MODE == D2D_LM_MODE_MINPACK && phase == 0) {
+        bool taken = false;
+        status = mp_trial(mp, opts, c, qi, gi, hdiag, act, iters,
+                          [&](double lamv, int isq_mode, double trd, float &dls, double &dxn, double &t2) -> bool {
+                            float dgi_;
+                            return uniform_i(damped_solve<N, true>(hrow, lamv, act, lane, big, dgi_, dls, nullptr, true, isq_mode, trd, &dxn, &t2) ? 1 : 0) != 0;
+                          },
+                          [&](float dls) -> double { return cost_at(1.0, (double)dls); }, taken);
+        ++iters; ++local;
+        if (taken) {
+          need_eval = true;                                // (also when converged: cost and J^T r at the final point)
+          if (status == D2D_ST_RUNNING && opts.mp_finish > 0 && mp.calm >= opts.mp_finish) { phase = 1; lam = D2D_LM_LAMBDA0; nu = 2.0; so_rows = true; }
+        }
+        continue;
+      }
       const double gmax = uniform_d(wave_max(fabs(gi)));
       if (gmax <= opts.gtol) { status = D2D_ST_CONVERGED; break; }
       float dgi, dl;
       const int ok = uniform_i(damped_solve<N>(hrow, lam, act, lane, big, dgi, dl) ? 1 : 0);
       const double delta = (double)dl;
-      const bool so_next = opts.so_lambda > 0.0 && lam <= opts.so_lambda;
+      const bool so_next = MODE == D2D_LM_MODE_MINPACK ? true : (opts.so_lambda > 0.0 && lam <= opts.so_lambda);
       const double pred = uniform_d(wave_sum(delta * (lam * (double)dgi * delta - gi)));
       const double dmax = uniform_d(wave_max(fabs(delta))), qmax = uniform_d(wave_max(fabs(qi)));
       double ct = 0.0, pred_s = pred, alpha = 1.0, bt_a = 0.0, bt_b = 0.0;
@@ -1039,7 +1325,11 @@ fit_lm_long_kernel(int B, FitGeom g, LongLds L, d2d_fit_opts opts, int iter_budg
     }
     if (lane == 0) {
       cost_io[b] = c;
-      lm[4 * b + 0] = lam; lm[4 * b + 1] = nu; lm[4 * b + 2] = gmax; lm[4 * b + 3] = so_rows ? 1.0 : 0.0;
+      lm[LM_STRIDE * b + 0] = lam; lm[LM_STRIDE * b + 1] = nu; lm[LM_STRIDE * b + 2] = gmax; lm[LM_STRIDE * b + 3] = so_rows ? 1.0 : 0.0;
+      if (MODE == D2D_LM_MODE_MINPACK) {
+        lm[LM_STRIDE * b + 4] = mp.par; lm[LM_STRIDE * b + 5] = mp.delta;
+        lm[LM_STRIDE * b + 6] = (double)(phase | (mp.first << 1) | (mp.calm << 2)); lm[LM_STRIDE * b + 7] += (double)mp.nfac;
+      }
       flags[4 * b + FL_STATUS] = status; flags[4 * b + FL_ITERS] = iters; flags[4 * b + FL_NEED] = 1;
       flags[4 * b + FL_NEVAL] += nev;
     }
@@ -1054,10 +1344,12 @@ __global__ void __launch_bounds__(256)
 fit_state_init_kernel(int B, int off, int stride, double *__restrict__ lm, int32_t *__restrict__ flags,
                       int32_t *__restrict__ queue) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == 0 && queue) { queue[0] = 0; queue[1] = 0; }     // work queue of the persistent LM kernel (fit_lm_kernel)
+  if (i == 0 && queue) { queue[0] = 0; queue[1] = 0; queue[2] = 0; queue[3] = 0; queue[4] = 0; }     // work queue + ring counters of the persistent LM kernel (fit_lm_kernel)
   if (i >= B) return;
   const int b = off + i * stride;
-  lm[4 * b + 0] = D2D_LM_LAMBDA0; lm[4 * b + 1] = 2.0; lm[4 * b + 2] = 0.0; lm[4 * b + 3] = 0.0;
+  lm[LM_STRIDE * b + 0] = D2D_LM_LAMBDA0; lm[LM_STRIDE * b + 1] = 2.0; lm[LM_STRIDE * b + 2] = 0.0; lm[LM_STRIDE * b + 3] = 0.0;
+  // MINPACK mode: par = 0, radius not yet set (factor * ||x|| on the first visit), phase 0 with the `first` flag, no factorisations
+  lm[LM_STRIDE * b + 4] = 0.0; lm[LM_STRIDE * b + 5] = -1.0; lm[LM_STRIDE * b + 6] = 2.0; lm[LM_STRIDE * b + 7] = 0.0;
   flags[4 * b + FL_STATUS] = D2D_ST_RUNNING; flags[4 * b + FL_ITERS] = 0; flags[4 * b + FL_NEED] = 1;
   if (stride == 1) flags[4 * b + FL_NEVAL] = 0;       // group sweeps keep counting across visits
 }
@@ -1264,13 +1556,14 @@ static FitGeom geom_of(const d2d_fit_plan *pl) { return FitGeom{pl->K, pl->nq, p
 static void free_scratch(d2d_fit_plan *pl) {
   void **ptrs[] = {(void **)&pl->d_g, (void **)&pl->d_H, (void **)&pl->d_cost, (void **)&pl->d_lm, (void **)&pl->d_flags,
                    (void **)&pl->d_prep, (void **)&pl->d_pos, (void **)&pl->d_qprev, (void **)&pl->d_pk, (void **)&pl->d_rows,
-                   (void **)&pl->d_order};
+                   (void **)&pl->d_order, (void **)&pl->d_ring};
   for (void **p : ptrs) {
     if (*p) (void)hipFree(*p);
     *p = nullptr;
   }
-  pl->cap_B = 0;
+  pl->cap_B = 0; pl->ring_cap = 0;
   pl->order_B = 0; pl->gorder_R = 0; pl->gsweeps_R = 0;
+  pl->rows_B = 0;            // (the row records of d2d_fit_rows lived in the freed scratch)
 }
 
 // Scratch of a plan grows on demand.  A failed regrow leaves the plan with NO scratch (every pointer null, cap_B = 0):
@@ -1297,8 +1590,14 @@ static int ensure_scratch(d2d_fit_plan *pl, int B) {
   }
   SCRATCH_ALLOC(d_rows, (size_t)B * 4 * (pl->K + 1) * 4 * sizeof(float))
   SCRATCH_ALLOC(d_order, (size_t)B * sizeof(int32_t))
+  {
+    int cap = 64;
+    while (cap < B) cap <<= 1;
+    SCRATCH_ALLOC(d_ring, (size_t)cap * sizeof(int32_t))      // ring of yielded fits (fit_lm_kernel), -1 = empty slot
+    pl->ring_cap = cap;
+  }
   SCRATCH_ALLOC(d_cost, (size_t)B * sizeof(double))
-  SCRATCH_ALLOC(d_lm, (size_t)B * 4 * sizeof(double))
+  SCRATCH_ALLOC(d_lm, (size_t)B * LM_STRIDE * sizeof(double))
   SCRATCH_ALLOC(d_flags, (size_t)B * 4 * sizeof(int32_t))
 #undef SCRATCH_ALLOC
   pl->cap_B = B;
@@ -1306,6 +1605,8 @@ static int ensure_scratch(d2d_fit_plan *pl, int B) {
 }
 
 static int launch_prep(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, const double *scen) {
+  // (d_prep is about to describe other scenarios: the row records of an earlier d2d_fit_rows no longer pair with it)
+  const_cast<d2d_fit_plan *>(pl)->rows_B = 0;
   hipLaunchKernelGGL(fit_prep_kernel, dim3((B + 255) / 256), dim3(256), 0, ctx->stream, B, pl->K, pl->duration, scen, pl->d_prep);
   hipLaunchKernelGGL(fit_prepk_kernel, dim3(((long)B * pl->K + 255) / 256), dim3(256), 0, ctx->stream, B, pl->K, pl->d_prep, pl->d_Gp, pl->d_pk);
   D2D_LAUNCH_CHECK();
@@ -1363,7 +1664,7 @@ static int launch_step(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, double *q, c
   return D2D_OK;
 }
 
-static int launch_lm(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, double *q, const d2d_fit_opts &o, int budget) {
+static int launch_lm(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, double *q, const d2d_fit_opts &o, int iter_cap) {
   const FitGeom gm = geom_of(pl);
   const FusedLds L = fused_lds_layout(pl->K, pl->nq, 48, pl->wpb_lm);
   static const bool want_stamps = getenv("D2D_LM_STAMPS") != nullptr;
@@ -1375,22 +1676,23 @@ static int launch_lm(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, double *q, con
   const int blocks = B < pl->n_cu ? B : pl->n_cu;     // persistent: one workgroup per CU
   static const bool no_queue = getenv("D2D_LM_STATIC") != nullptr;      // A/B switch: static striding instead of the work queue
   int32_t *queue = no_queue ? nullptr : ctx->counter_dev + 8;
-  static const int prio_only = getenv("D2D_LM_PRIO_AT") ? atoi(getenv("D2D_LM_PRIO_AT")) : 48;     // (A/B switch; 0xffff = never)
-  static const int excl = getenv("D2D_LM_EXCL") ? atoi(getenv("D2D_LM_EXCL")) : 4;                 // exclusive SIMDs for the first `excl` hand-out positions (A/B switch; measured: tools/rank_spread.py)
-  const int excl_eff = (pl->wpb_lm == 8 && queue != nullptr) ? (excl < blocks ? excl : blocks) : 0;
-  const int prio_at = (prio_only > 0xffff ? 0xffff : prio_only) | (excl_eff << 16);
+  static const int prio_only = getenv("D2D_LM_PRIO_AT") ? atoi(getenv("D2D_LM_PRIO_AT")) : 48;     // (A/B switch; large = never)
+  static const int slice_env = getenv("D2D_LM_SLICE") ? atoi(getenv("D2D_LM_SLICE")) : -1;         // (A/B switch: overrides opts.slice)
+  d2d_fit_opts oo = o;
+  if (slice_env >= 0) oo.slice = slice_env;
   const int32_t *order = (pl->order_B == B) ? pl->d_order : nullptr;
-  if (want_stamps)
-    hipLaunchKernelGGL((fit_lm_kernel<3, 24, true>), dim3(blocks), dim3(64 * pl->wpb_lm), L.total, ctx->stream, B, gm, L, o, budget,
-                       pl->d_G, pl->d_pk, pl->d_G32, pl->d_W32, pl->d_prep, q, pl->d_cost, pl->d_g, pl->d_lm, pl->d_flags, queue, stamps, order, prio_at);
-  else
-    hipLaunchKernelGGL((fit_lm_kernel<3, 24, false>), dim3(blocks), dim3(64 * pl->wpb_lm), L.total, ctx->stream, B, gm, L, o, budget,
-                       pl->d_G, pl->d_pk, pl->d_G32, pl->d_W32, pl->d_prep, q, pl->d_cost, pl->d_g, pl->d_lm, pl->d_flags, queue, stamps, order, prio_at);
+#define LAUNCH_LM(STAMPSV, MODEV)                                                                                                  \
+  hipLaunchKernelGGL((fit_lm_kernel<3, 24, STAMPSV, MODEV>), dim3(blocks), dim3(64 * pl->wpb_lm), L.total, ctx->stream, B, gm, L, oo, iter_cap, \
+                     pl->d_G, pl->d_pk, pl->d_G32, pl->d_W32, pl->d_prep, q, pl->d_cost, pl->d_g, pl->d_lm, pl->d_flags, queue,   \
+                     pl->d_ring, pl->ring_cap - 1, stamps, order, prio_only)
+  if (oo.mode == D2D_LM_MODE_FAST) { if (want_stamps) LAUNCH_LM(true, D2D_LM_MODE_FAST); else LAUNCH_LM(false, D2D_LM_MODE_FAST); }
+  else { if (want_stamps) LAUNCH_LM(true, D2D_LM_MODE_MINPACK); else LAUNCH_LM(false, D2D_LM_MODE_MINPACK); }
+#undef LAUNCH_LM
   D2D_LAUNCH_CHECK();
   if (want_times) {
     D2D_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-    fprintf(stderr, "[fit_lm launch] B=%d budget=%d blocks=%d wpb=%d: %.1f us\n", B, budget, blocks, pl->wpb_lm, us);
+    fprintf(stderr, "[fit_lm launch] B=%d iter_cap=%d blocks=%d wpb=%d: %.1f us\n", B, iter_cap, blocks, pl->wpb_lm, us);
   }
   if (want_stamps) {
     unsigned long long h[13];
@@ -1399,7 +1701,7 @@ static int launch_lm(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, double *q, con
     static const char *nm[8] = {"io/loop", "phase1", "phase2", "mfma", "image", "solve", "reduce+judge", "-"};
     double tot = 0;
     for (int i = 0; i < 7; ++i) tot += (double)h[i];
-    fprintf(stderr, "[fit_lm stamps] wave-cycles (s_memtime ticks), B=%d budget=%d:", B, budget);
+    fprintf(stderr, "[fit_lm stamps] wave-cycles (s_memtime ticks), B=%d iter_cap=%d:", B, iter_cap);
     for (int i = 0; i < 7; ++i) fprintf(stderr, " %s=%.1f%%", nm[i], 100.0 * (double)h[i] / tot);
     fprintf(stderr, " total=%.3e | solve split: setup=%.1f%% steps0-15=%.1f%% 16-31=%.1f%% 32-47=%.1f%% subst=%.1f%%\n", tot,
             100.0 * h[8] / tot, 100.0 * h[9] / tot, 100.0 * h[10] / tot, 100.0 * h[11] / tot, 100.0 * h[12] / tot);
@@ -1424,14 +1726,16 @@ static int launch_lm_long(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, double *q
   static const bool no_queue = getenv("D2D_LM_STATIC") != nullptr;
   int32_t *queue = no_queue ? nullptr : ctx->counter_dev + 8;
   const int32_t *order = (pl->order_B == B) ? pl->d_order : nullptr;
-#define LAUNCH_LONG_(NBV, NQV, TLV, TL32V)                                                                             \
-  hipLaunchKernelGGL((fit_lm_long_kernel<NBV, NQV, TLV, TL32V>), dim3(blocks), dim3(64 * wpb), L.total, ctx->stream, B, gm, L, o, budget, \
+#define LAUNCH_LONG__(NBV, NQV, TLV, TL32V, MODEV)                                                                     \
+  hipLaunchKernelGGL((fit_lm_long_kernel<NBV, NQV, TLV, TL32V, MODEV>), dim3(blocks), dim3(64 * wpb), L.total, ctx->stream, B, gm, L, o, budget, \
                      pl->d_GT, pl->d_G, pl->d_pk, pl->d_G32, pl->d_W32, pl->d_prep, q, pl->d_cost, pl->d_g, pl->d_lm, pl->d_flags, queue, order)
+#define LAUNCH_LONG_(NBV, NQV, TLV, TL32V) do { if (o.mode == D2D_LM_MODE_FAST) LAUNCH_LONG__(NBV, NQV, TLV, TL32V, D2D_LM_MODE_FAST); else LAUNCH_LONG__(NBV, NQV, TLV, TL32V, D2D_LM_MODE_MINPACK); } while (0)
 #define LAUNCH_LONG(NBV, NQV) do { if (mode == 2) LAUNCH_LONG_(NBV, NQV, true, true); else if (mode == 1) LAUNCH_LONG_(NBV, NQV, true, false); else LAUNCH_LONG_(NBV, NQV, false, false); } while (0)
   if (pl->nq == 24) LAUNCH_LONG(3, 24);
   else if (NB == 1) LAUNCH_LONG(1, 0);
   else if (NB == 2) LAUNCH_LONG(2, 0);
   else LAUNCH_LONG(3, 0);
+#undef LAUNCH_LONG__
 #undef LAUNCH_LONG_
 #undef LAUNCH_LONG
   D2D_LAUNCH_CHECK();
@@ -1516,12 +1820,17 @@ int d2d_fit_plan_create(d2d_ctx *ctx, int S, int K, double duration, const doubl
   allow_big_lds(&fit_eval_kernel<1, 0, false>); allow_big_lds(&fit_eval_kernel<2, 0, false>); allow_big_lds(&fit_eval_kernel<3, 0, false>);
   allow_big_lds(&fit_eval_kernel<3, 24, true>); allow_big_lds(&fit_eval_kernel<3, 24, false>);
   allow_big_lds(&fit_jtj_kernel<1, 0>); allow_big_lds(&fit_jtj_kernel<2, 0>); allow_big_lds(&fit_jtj_kernel<3, 0>); allow_big_lds(&fit_jtj_kernel<3, 24>);
-  allow_big_lds(&fit_lm_long_kernel<3, 24, false>); allow_big_lds(&fit_lm_long_kernel<3, 0, false>); allow_big_lds(&fit_lm_long_kernel<2, 0, false>); allow_big_lds(&fit_lm_long_kernel<1, 0, false>);
-  allow_big_lds(&fit_lm_long_kernel<3, 24, true>); allow_big_lds(&fit_lm_long_kernel<3, 0, true>); allow_big_lds(&fit_lm_long_kernel<2, 0, true>); allow_big_lds(&fit_lm_long_kernel<1, 0, true>);
-  allow_big_lds(&fit_lm_long_kernel<3, 24, true, false>); allow_big_lds(&fit_lm_long_kernel<3, 0, true, false>); allow_big_lds(&fit_lm_long_kernel<2, 0, true, false>); allow_big_lds(&fit_lm_long_kernel<1, 0, true, false>);
+  allow_big_lds(&fit_lm_long_kernel<3, 24, false, false, D2D_LM_MODE_MINPACK>); allow_big_lds(&fit_lm_long_kernel<3, 0, false, false, D2D_LM_MODE_MINPACK>); allow_big_lds(&fit_lm_long_kernel<2, 0, false, false, D2D_LM_MODE_MINPACK>); allow_big_lds(&fit_lm_long_kernel<1, 0, false, false, D2D_LM_MODE_MINPACK>);
+  allow_big_lds(&fit_lm_long_kernel<3, 24, false, false, D2D_LM_MODE_FAST>); allow_big_lds(&fit_lm_long_kernel<3, 0, false, false, D2D_LM_MODE_FAST>); allow_big_lds(&fit_lm_long_kernel<2, 0, false, false, D2D_LM_MODE_FAST>); allow_big_lds(&fit_lm_long_kernel<1, 0, false, false, D2D_LM_MODE_FAST>);
+  allow_big_lds(&fit_lm_long_kernel<3, 24, true, true, D2D_LM_MODE_MINPACK>); allow_big_lds(&fit_lm_long_kernel<3, 0, true, true, D2D_LM_MODE_MINPACK>); allow_big_lds(&fit_lm_long_kernel<2, 0, true, true, D2D_LM_MODE_MINPACK>); allow_big_lds(&fit_lm_long_kernel<1, 0, true, true, D2D_LM_MODE_MINPACK>);
+  allow_big_lds(&fit_lm_long_kernel<3, 24, true, true, D2D_LM_MODE_FAST>); allow_big_lds(&fit_lm_long_kernel<3, 0, true, true, D2D_LM_MODE_FAST>); allow_big_lds(&fit_lm_long_kernel<2, 0, true, true, D2D_LM_MODE_FAST>); allow_big_lds(&fit_lm_long_kernel<1, 0, true, true, D2D_LM_MODE_FAST>);
+  allow_big_lds(&fit_lm_long_kernel<3, 24, true, false, D2D_LM_MODE_MINPACK>); allow_big_lds(&fit_lm_long_kernel<3, 0, true, false, D2D_LM_MODE_MINPACK>); allow_big_lds(&fit_lm_long_kernel<2, 0, true, false, D2D_LM_MODE_MINPACK>); allow_big_lds(&fit_lm_long_kernel<1, 0, true, false, D2D_LM_MODE_MINPACK>);
+  allow_big_lds(&fit_lm_long_kernel<3, 24, true, false, D2D_LM_MODE_FAST>); allow_big_lds(&fit_lm_long_kernel<3, 0, true, false, D2D_LM_MODE_FAST>); allow_big_lds(&fit_lm_long_kernel<2, 0, true, false, D2D_LM_MODE_FAST>); allow_big_lds(&fit_lm_long_kernel<1, 0, true, false, D2D_LM_MODE_FAST>);
   allow_big_lds(&fit_groups_kernel<3, 24>);
-  allow_big_lds(&fit_lm_kernel<3, 24, false>);
-  allow_big_lds(&fit_lm_kernel<3, 24, true>);
+  allow_big_lds(&fit_lm_kernel<3, 24, false, D2D_LM_MODE_MINPACK>);
+  allow_big_lds(&fit_lm_kernel<3, 24, true, D2D_LM_MODE_MINPACK>);
+  allow_big_lds(&fit_lm_kernel<3, 24, false, D2D_LM_MODE_FAST>);
+  allow_big_lds(&fit_lm_kernel<3, 24, true, D2D_LM_MODE_FAST>);
   allow_big_lds(&fit_step_kernel<16>); allow_big_lds(&fit_step_kernel<32>); allow_big_lds(&fit_step_kernel<48>);
   (void)hipGetLastError();
   *out = pl;
@@ -1700,7 +2009,7 @@ int d2d_fit_profile_read(d2d_fit_plan *pl, double *out) {
 }
 
 static d2d_fit_opts opts_or_default(const d2d_fit_opts *opts) {
-  d2d_fit_opts o = {200, 8, 1e-14, 1e-9, 1e-11, D2D_LM_SO_LAMBDA};
+  d2d_fit_opts o = {200, 8, 1e-14, 1e-9, 1e-11, D2D_LM_SO_LAMBDA, D2D_LM_MODE_MINPACK, D2D_LM_MP_FINISH, 1e-15, 1e-15, 1e-15, D2D_LM_SLICE, 0};
   if (opts) o = *opts;
   return o;
 }
@@ -1715,9 +2024,11 @@ int d2d_fit_begin(d2d_ctx *ctx, d2d_fit_plan *pl, int B) {
   if (int rc = ensure_scratch(pl, B)) return rc;
   hipLaunchKernelGGL(fit_state_init_kernel, dim3((B + 255) / 256), dim3(256), 0, ctx->stream, B, 0, 1, pl->d_lm, pl->d_flags, ctx->counter_dev + 8);
   D2D_LAUNCH_CHECK();
+  D2D_CHECK_HIP(hipMemsetAsync(pl->d_ring, 0xff, (size_t)pl->ring_cap * sizeof(int32_t), ctx->stream));
   pl->it_done = 0;
   pl->active_B = B;
   pl->prep_valid_for = nullptr;
+  pl->rows_B = 0;              // (a solve rewrites d_prep and, on the launch-pair path, d_H)
   return D2D_OK;
 }
 
@@ -1737,7 +2048,7 @@ int d2d_fit_iterate(d2d_ctx *ctx, d2d_fit_plan *pl, int B, const double *scen, d
     if (budget > n_iters) budget = n_iters;
     if (budget > 0) {
       if (int rc = prof_begin(ctx, pl, 2)) return rc;
-      if (int rc = pl->use_lm ? launch_lm(ctx, pl, B, q, o, budget) : launch_lm_long(ctx, pl, B, q, o, budget)) return rc;
+      if (int rc = pl->use_lm ? launch_lm(ctx, pl, B, q, o, pl->it_done + budget) : launch_lm_long(ctx, pl, B, q, o, budget)) return rc;
       if (int rc = prof_end(ctx, pl)) return rc;
       pl->it_done += budget;
     }

@@ -545,9 +545,15 @@ __device__ __forceinline__ float lane_value(float v, int l) {
 // makes its entries the forward substitution L y = b; the back substitution reads the columns of Lm.
 // A non-positive pivot is not clamped: it turns the step into NaN, which the gain-ratio test rejects
 // like any failed step.  Returns false if a pivot is not positive.
-template <int N>
+// MP (the MINPACK mode, mp_trial below): `unit` (wave-uniform) damps with lam * I instead of lam * diag; dxnorm = ||delta||_2;
+// isq_mode 1 (always) / 2 (only when | ||delta|| - tr_delta | > 0.1 tr_delta): isq = || L^-1 (delta / ||delta||) ||^2 -- the
+// quantity lmpar's Newton correction of the damping needs -- by a forward substitution through the rows of the factor,
+// which every lane still holds in registers (right-looking: z_j = w_j / L_jj, w_i -= L_ij z_j).
+template <int N, bool MP = false>
 __device__ __forceinline__ bool damped_solve(const f32x2 (&hrow)[N / 2], double lam, bool act, int lane,
-                                             float *Lm, float &dgi, float &delta, unsigned long long *tt = nullptr) {
+                                             float *Lm, float &dgi, float &delta, unsigned long long *tt = nullptr,
+                                             bool unit = false, int isq_mode = 0, double tr_delta = 0.0,
+                                             double *dxnorm = nullptr, double *isq = nullptr) {
   constexpr int LS = CHOL_LS;
   // tt (diagnostics, fused kernel with D2D_LM_STAMPS): cycles of setup, steps [0,N/3), [N/3,2N/3), [2N/3,N), substitution
   unsigned long long tl = 0;
@@ -567,7 +573,7 @@ __device__ __forceinline__ bool damped_solve(const f32x2 (&hrow)[N / 2], double 
   }
   if (!act) d = 1.f;
   dgi = fmaxf(fabsf(d), (float)D2D_LM_DIAG_FLOOR);      // (|.|: the second-order Hessian may have a negative diagonal)
-  const float dd = act ? d + (float)(lam * (double)dgi) : 1.f;
+  const float dd = act ? d + ((MP && unit) ? (float)lam : (float)(lam * (double)dgi)) : 1.f;
 #pragma unroll
   for (int m = 0; m < N / 2; ++m) {
     if (2 * m == lane) row[m].x = dd;
@@ -633,6 +639,24 @@ __device__ __forceinline__ bool damped_solve(const f32x2 (&hrow)[N / 2], double 
 #pragma unroll
   for (int i = N - 1; i >= 1; --i) dl = fmaf(-col[i * LS] * myinv, lane_value(dl, i), dl);   // L[i][lane] = 0 for i <= lane
   delta = act ? dl : 0.f;
+  if (MP) {
+    const double dn2 = uniform_d(wave_sum((double)delta * (double)delta));
+    const double dn = sqrt(dn2);
+    *dxnorm = dn;
+    *isq = 0.0;
+    const bool want = isq_mode == 1 || (isq_mode == 2 && fabs(dn - tr_delta) > 0.1 * tr_delta);
+    if (want && dn > 0.0 && pivmin > 0) {
+      float wcur = delta * (float)(1.0 / dn);
+#pragma unroll
+      for (int j = 0; j < N - 1; ++j) {
+        const float zj = lane_value(wcur * myinv, j);
+        const float lj = (j & 1) ? row[j >> 1].y : row[j >> 1].x;      // L[lane][j], zero on and above the diagonal
+        wcur = fmaf(-lj, zj, wcur);
+      }
+      const float z = act ? wcur * myinv : 0.f;
+      *isq = uniform_d(wave_sum((double)z * (double)z));
+    }
+  }
   DS_STAMP(4)
 #undef DS_STAMP
   return pivmin > 0;
@@ -686,4 +710,117 @@ __device__ __forceinline__ StepOutcome lm_update(bool ok, bool fin, bool accept,
     if (r.status == D2D_ST_RUNNING && r.lam > D2D_LM_LAMBDA_MAX) r.status = D2D_ST_STALLED;
   }
   return r;
+}
+
+// ---- MINPACK's lmder on the normal equations (oracle/fit.py lmder_solve, lmpar_normal) -------------------------------
+// The path scipy.optimize.least_squares(method='lm') follows: a trust region ||p|| <= Delta on the Gauss-Newton model (unit
+// scaling: scipy's x_scale = 1 is MINPACK's mode 2), lmpar's safeguarded Newton iteration on the damping `par` until
+// | ||p(par)|| - Delta | <= 0.1 Delta, the ratio test of actual against predicted reduction, Delta and par updated by lmder's rules.
+// lmder / lmpar take every decision from quantities that are functions of J^T J and J^T f alone, so they are taken here from
+// the Cholesky factor of J^T J + par I (damped_solve<N, true>) instead of the QR factors of J.
+struct MpState {
+  double par, delta;        // damping of the last lmpar, trust-region radius
+  double dx_gn, t2_gn;      // cached Gauss-Newton step of the current point: its norm, || L^-1 (p / ||p||) ||^2
+  float p_gn;               // ... and the step itself (this lane's entry)
+  int gn_valid, gn_ok;      // the cache holds the step of the current J^T J / it could be factorised
+  int first, calm, nfac;    // first trial of the fit (Delta = min(Delta, ||p||)); accepted steps in a row with par = 0 and ratio >= 0.75
+};
+#define MP_DWARF 2.2250738585072014e-308
+#define MP_EPSMCH 2.220446049250313e-16
+
+// One trial of lmder at the point qi (cost c = ||f||^2, gi = (J^T f)[lane], hdiag = (J^T J)[lane][lane]): lmpar, the trial point,
+// the ratio test and the updates of Delta / par.  solve(lam, isq_mode, tr_delta, dl, dxn, t2) -> bool factorises J^T J + lam I
+// and returns the step dl = -(J^T J + lam I)^-1 J^T f of this lane, its norm and (see damped_solve) t2; trial(dl) -> the cost at
+// qi + dl.  Every decision is wave-uniform.  On acceptance qi and c are updated.  Returns the new status; accepted reports
+// whether the trial point was taken; on D2D_ST_RUNNING the caller goes on (re-evaluating J^T f, J^T J after an accepted step).
+template <class Solve, class Trial>
+__device__ __forceinline__ int mp_trial(MpState &s, const d2d_fit_opts &o, double &c, double &qi, double gi, float hdiag, bool act,
+                                        int nfev, Solve solve, Trial trial, bool &accepted) {
+  accepted = false;
+  const double fnorm = sqrt(c);
+  double gl = 0.0;
+  if (act && hdiag > 0.f && fnorm > 0.0) gl = fabs(gi) / (sqrt((double)hdiag) * fnorm);
+  const double gnorm = uniform_d(wave_max(gl));
+  if (gnorm <= o.mp_gtol) return D2D_ST_CONVERGED;
+  const double gnrm = sqrt(uniform_d(wave_sum(gi * gi)));
+  // ---- lmpar ----
+  double par = s.par, parl = 0.0, paru = 0.0, fp = 0.0, pn = 0.0;
+  float dl = 0.f;
+  int it = 0;
+  bool done = false;
+  auto gn_post = [&]() -> bool {
+    if (s.gn_ok && s.dx_gn - s.delta <= 0.1 * s.delta) { dl = s.p_gn; pn = s.dx_gn; par = 0.0; return true; }
+    fp = s.gn_ok ? s.dx_gn - s.delta : 1.79e308;
+    parl = (s.gn_ok && s.t2_gn > 0.0) ? (fp / s.delta) / s.t2_gn : 0.0;
+    paru = gnrm / s.delta;
+    if (paru == 0.0) paru = MP_DWARF / fmin(s.delta, 0.1);
+    par = fmin(fmax(par, parl), paru);
+    if (par == 0.0) par = s.gn_ok ? gnrm / s.dx_gn : 0.0;
+    return false;
+  };
+  if (s.gn_valid) done = gn_post();
+  while (!done) {
+    const bool gn = !s.gn_valid;
+    if (!gn && par == 0.0) par = fmax(MP_DWARF, 0.001 * paru);
+    float dls;
+    double dxn, t2;
+    const bool ok = solve(gn ? 0.0 : par, gn ? 1 : (it + 1 < 10 ? 2 : 0), s.delta, dls, dxn, t2);
+    ++s.nfac;
+    if (gn) {
+      s.gn_ok = ok ? 1 : 0; s.p_gn = dls; s.dx_gn = dxn; s.t2_gn = t2; s.gn_valid = 1;
+      done = gn_post();
+      continue;
+    }
+    ++it;
+    if (!ok) {                                   // cannot happen in exact arithmetic (par > 0): raise the damping
+      parl = fmax(parl, par); par = fmax(2.0 * par, 0.001 * paru);
+      if (it >= 10) { dl = 0.f; pn = 0.0; done = true; }
+      continue;
+    }
+    const double temp = fp;
+    fp = dxn - s.delta;
+    if (fabs(fp) <= 0.1 * s.delta || (parl == 0.0 && fp <= temp && temp < 0.0) || it == 10) { dl = dls; pn = dxn; done = true; continue; }
+    const double parc = (fp / s.delta) / t2;
+    if (fp > 0.0) parl = fmax(parl, par);
+    if (fp < 0.0) paru = fmin(paru, par);
+    par = fmax(parl, par + parc);
+  }
+  // ---- the trial point and lmder's updates ----
+  if (s.first) { s.delta = fmin(s.delta, pn); s.first = 0; }
+  const double ct = trial(dl);
+  const bool ctfin = fabs(ct) <= 1.79e308;
+  const double fnorm1 = ctfin ? sqrt(ct) : 1.79e308;
+  double actred = -1.0;
+  if (0.1 * fnorm1 < fnorm) actred = 1.0 - ct / c;
+  const double pg = -uniform_d(wave_sum((double)dl * gi));           // p^T J^T f with p = -dl
+  const double jp2 = fmax(pg - par * pn * pn, 0.0);                  // ||J p||^2 = p^T g - par p^T p
+  const double t1 = jp2 / c, t2v = par * pn * pn / c;
+  const double prered = t1 + t2v / 0.5, dirder = -(t1 + t2v);
+  const double ratio = prered != 0.0 ? actred / prered : 0.0;
+  if (ratio <= 0.25) {
+    double temp = actred >= 0.0 ? 0.5 : 0.5 * dirder / (dirder + 0.5 * actred);
+    if (0.1 * fnorm1 >= fnorm || temp < 0.1) temp = 0.1;
+    s.delta = temp * fmin(s.delta, pn / 0.1);
+    par = par / temp;
+  } else if (par == 0.0 || ratio >= 0.75) {
+    s.delta = pn / 0.5;
+    par = 0.5 * par;
+  }
+  s.par = par;
+  accepted = ratio >= 1e-4;
+  if (accepted) {
+    qi += (double)dl; c = ct;
+    s.gn_valid = 0;
+    s.calm = (par == 0.0 && ratio >= 0.75) ? s.calm + 1 : 0;
+  }
+  const double xnorm = sqrt(uniform_d(wave_sum(qi * qi)));
+  int info = 0;
+  if (fabs(actred) <= o.mp_ftol && prered <= o.mp_ftol && 0.5 * ratio <= 1.0) info = 1;
+  if (s.delta <= o.mp_xtol * xnorm) info = 2;
+  if (info == 0) {
+    if (fabs(actred) <= MP_EPSMCH && prered <= MP_EPSMCH && 0.5 * ratio <= 1.0) info = 6;
+    else if (s.delta <= MP_EPSMCH * xnorm) info = 7;
+    else if (gnorm <= MP_EPSMCH) info = 8;
+  }
+  return info != 0 ? D2D_ST_CONVERGED : D2D_ST_RUNNING;
 }

@@ -25,7 +25,7 @@ struct d2d_fit_plan {
   double *d_g = nullptr;     // [B][2nq]
   float *d_H = nullptr;      // [B][2nq][2nq]
   double *d_cost = nullptr;  // [B]
-  double *d_lm = nullptr;    // [B][4] lambda, nu, gmax, pad
+  double *d_lm = nullptr;    // [B][8] per-trajectory solver state (fit_kernels.hip LM_STRIDE)
   int32_t *d_flags = nullptr;  // [B][4] status, iters, need_eval, nevals
   double *d_prep = nullptr;    // [B][FIT_PREP_STRIDE] derived scenario rows (fit_prep_kernel)
   double *d_pk = nullptr;      // [B][FIT_PK][K] per-sample constants (fit_prepk_kernel)
@@ -35,6 +35,8 @@ struct d2d_fit_plan {
   int rows_B = 0;              // trajectories whose records d_rows holds
   int32_t *d_order = nullptr;  // [B] hand-out order of the persistent LM kernel (longest fits of the previous solve first)
   int order_B = 0;             // batch size the order was built for (0: none)
+  int32_t *d_ring = nullptr;   // [ring_cap] ring of yielded fits of the persistent LM kernel (-1 = empty slot)
+  int ring_cap = 0;            // power of two >= cap_B
   int gorder_R = 0, gsweeps_R = 0;   // coupled groups: d_order[0, R) holds a scenario order / d_order[R, 2R) the sweeps of the last solve
   int n_group = 1, nds = 0;    // aircraft per coupled group and padded collision-row slots per sample
   const double *prep_valid_for = nullptr;   // scen pointer d_prep was derived from

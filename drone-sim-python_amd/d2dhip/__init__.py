@@ -57,10 +57,21 @@ class NlpOpts(C.Structure):
 
 class FitOpts(C.Structure):
     _fields_ = [('max_iter', C.c_int32), ('check_every', C.c_int32), ('ftol', C.c_double),
-                ('gtol', C.c_double), ('xtol', C.c_double), ('so_lambda', C.c_double)]
+                ('gtol', C.c_double), ('xtol', C.c_double), ('so_lambda', C.c_double),
+                ('mode', C.c_int32), ('mp_finish', C.c_int32), ('mp_ftol', C.c_double), ('mp_xtol', C.c_double),
+                ('mp_gtol', C.c_double), ('slice', C.c_int32), ('reserved', C.c_int32)]
 
 
-SO_LAMBDA = 1e-4          # D2D_LM_SO_LAMBDA: damping below which the evaluations carry the second-order term
+SO_LAMBDA = 1e-4          # D2D_LM_SO_LAMBDA: damping below which the evaluations carry the second-order term (FAST mode)
+MODE_MINPACK, MODE_FAST = 0, 1     # D2D_LM_MODE_*: MINPACK's lmder path (what scipy least_squares('lm') follows) / rounds 1-2's loop
+MP_FINISH = 3             # D2D_LM_MP_FINISH: calm lmder steps before the second-order finish (0 = pure lmder)
+SLICE = 0                 # D2D_LM_SLICE: iterations a fit runs before it yields its wavefront to waiting fits (0 = never)
+
+
+def fit_opts(max_iter=200, check_every=8, ftol=1e-14, gtol=1e-9, xtol=1e-11, so_lambda=SO_LAMBDA, mode=MODE_MINPACK,
+             mp_finish=MP_FINISH, mp_tol=1e-15, slice=SLICE):
+    """d2d_fit_opts with the library's defaults (include/d2d.h)."""
+    return FitOpts(max_iter, check_every, ftol, gtol, xtol, so_lambda, mode, mp_finish, mp_tol, mp_tol, mp_tol, slice, 0)
 
 
 _P = C.c_void_p
@@ -423,15 +434,16 @@ class FitPlan:
         _check(self.ctx.lib.d2d_fit_eval(self.ctx.h, self.h, B, _ptr(scen), _ptr(q), _ptr(cost), _ptr(g), _ptr(H)))
         return cost, g, H
 
-    def solve(self, scen, q, max_iter=200, check_every=8, ftol=1e-14, gtol=1e-9, xtol=1e-11, so_lambda=SO_LAMBDA):
-        """In-place LM solve of q.  Returns cost, iters, status (device) and stats (numpy[4])."""
+    def solve(self, scen, q, max_iter=200, check_every=8, ftol=1e-14, gtol=1e-9, xtol=1e-11, so_lambda=SO_LAMBDA, **mode_kw):
+        """In-place LM solve of q.  Returns cost, iters, status (device) and stats (numpy[4]).
+        mode_kw: mode (MODE_MINPACK default / MODE_FAST), mp_finish, mp_tol, slice (fit_opts)."""
         torch = _torch()
         B = scen.shape[0]
         cost = self.ctx.empty(B)
         iters = torch.empty(B, dtype=torch.int32, device=self.ctx.device)
         status = torch.empty(B, dtype=torch.int32, device=self.ctx.device)
         stats = np.zeros(4)
-        o = FitOpts(max_iter, check_every, ftol, gtol, xtol, so_lambda)
+        o = fit_opts(max_iter, check_every, ftol, gtol, xtol, so_lambda, **mode_kw)
         _check(self.ctx.lib.d2d_fit_solve(self.ctx.h, self.h, B, _ptr(scen), _ptr(q), C.byref(o), _ptr(cost),
                                           _ptr(iters), _ptr(status), _hptr(stats)))
         return cost, iters, status, stats
@@ -440,9 +452,9 @@ class FitPlan:
     def begin(self, B):
         _check(self.ctx.lib.d2d_fit_begin(self.ctx.h, self.h, B))
 
-    def iterate(self, scen, q, n_iters, max_iter=200, ftol=1e-14, gtol=1e-9, xtol=1e-11, so_lambda=SO_LAMBDA):
+    def iterate(self, scen, q, n_iters, max_iter=200, ftol=1e-14, gtol=1e-9, xtol=1e-11, so_lambda=SO_LAMBDA, **mode_kw):
         """Run n_iters more damped solves; returns the number of trajectories still running."""
-        o = FitOpts(max_iter, n_iters, ftol, gtol, xtol, so_lambda)
+        o = fit_opts(max_iter, n_iters, ftol, gtol, xtol, so_lambda, **mode_kw)
         running = C.c_int32(0)
         _check(self.ctx.lib.d2d_fit_iterate(self.ctx.h, self.h, scen.shape[0], _ptr(scen), _ptr(q), C.byref(o), n_iters,
                                             C.byref(running)))
@@ -484,7 +496,7 @@ class FitPlan:
         B = scen.shape[0]
         assert B % n_ac == 0
         cost = self.ctx.empty(B)
-        o = FitOpts(inner_iters, 1, ftol, gtol, xtol, 0.0)
+        o = fit_opts(inner_iters, 1, ftol, gtol, xtol, 0.0)
         sw = C.c_int32(0)
         stats = np.zeros(4)
         _check(self.ctx.lib.d2d_fit_solve_groups(self.ctx.h, self.h, B // n_ac, _ptr(scen), _ptr(q), C.byref(o), max_sweeps,

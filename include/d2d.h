@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define D2D_VERSION 103
+#define D2D_VERSION 104
 
 /* error codes */
 #define D2D_OK 0
@@ -273,15 +273,40 @@ enum {
 #define D2D_GS_PRIO_AT 40
 enum { D2D_ST_RUNNING = 0, D2D_ST_CONVERGED = 1, D2D_ST_MAXITER = 2, D2D_ST_NONFINITE = 3, D2D_ST_STALLED = 4 };
 
+/* Solver of d2d_fit_solve / d2d_fit_iterate (persistent LM kernel; oracle/fit.py states both on the CPU):
+ *  D2D_LM_MODE_MINPACK (default)  MINPACK's lmder restated on the normal equations -- the path the CPU arbiter
+ *      scipy.optimize.least_squares(method='lm') follows (unit scaling, factor 100; trust region on the Gauss-Newton model,
+ *      lmpar's Newton iteration on the damping, lmder's ratio test and radius update), every decision taken from the Cholesky
+ *      factor of J^T J + par I instead of the QR factors of J.  Once the trust region has been inactive for mp_finish accepted
+ *      steps in a row (par = 0 and ratio >= 0.75: the basin is decided and Gauss-Newton crawls at its linear rate) the fit is
+ *      handed to the second-order loop below, started at lambda0, for the quadratic finish; mp_finish = 0 never hands over
+ *      (pure lmder, stopping on mp_ftol / mp_xtol / mp_gtol exactly as MINPACK does).
+ *  D2D_LM_MODE_FAST  Nielsen's gain-ratio damping on (H + lam diag|H|) with shortened steps along a rejected direction and
+ *      the second-order term once lam <= so_lambda (rounds 1-2): fewer factorisations per fit, but it reaches another local
+ *      minimum than scipy on ~13 % of the synthetic bench scenarios. */
+enum { D2D_LM_MODE_MINPACK = 0, D2D_LM_MODE_FAST = 1 };
+#define D2D_LM_MP_FINISH 3       /* default of d2d_fit_opts.mp_finish */
+#define D2D_LM_SLICE 0           /* default of d2d_fit_opts.slice */
 typedef struct {
-  int32_t max_iter;     /* damped solves per trajectory (default 200)                  */
+  int32_t max_iter;     /* trial points (damped solves in FAST mode) per trajectory (default 200)      */
   int32_t check_every;  /* host convergence poll period in iterations (default 8)      */
-  double ftol, gtol, xtol;   /* defaults 1e-14, 1e-9, 1e-11                            */
-  double so_lambda;     /* once the damping has fallen to this value the next evaluation carries the
+  double ftol, gtol, xtol;   /* second-order / FAST loop: defaults 1e-14, 1e-9, 1e-11                  */
+  double so_lambda;     /* FAST mode: once the damping has fallen to this value the next evaluation carries the
                            second-order term sum_i r_i Hessian(r_i) (exact Hessian of 0.5 sum r^2) beside
                            J^T J: Gauss-Newton's linear rate on these large-residual fits becomes
                            quadratic.  0 = Gauss-Newton only; default D2D_LM_SO_LAMBDA.  Persistent LM
-                           kernel only (6-segment plans); the launch-pair path ignores it.            */
+                           kernels only; the launch-pair path ignores it.  (The finish of MINPACK mode always
+                           carries the term.)                                                          */
+  int32_t mode;         /* D2D_LM_MODE_*; persistent K <= 64 kernel (the other paths run FAST)         */
+  int32_t mp_finish;    /* MINPACK mode: calm steps before the second-order finish (default D2D_LM_MP_FINISH; 0 = never) */
+  double mp_ftol, mp_xtol, mp_gtol;   /* lmder's ftol / xtol / gtol (default 1e-15 each: what bench.py's scipy leg uses) */
+  int32_t slice;        /* scheduling of the persistent kernel, > 0: a fit that has run this many iterations while other fits
+                           are waiting for a wavefront goes to the back of a device-wide ring (its state is saved, another
+                           wavefront resumes it), so that every fit of a batch advances at the same rate whatever the order
+                           they were handed out in.  Results are bit-identical.  Measured: equal shares end
+                           a 4096-fit launch at (longest fit) + (the excess of the first rounds) -- 1.5 % sooner than running
+                           every fit to its end in index order, 4 % later at 32 768 fits -- so the default is 0 = off     */
+  int32_t reserved;
 } d2d_fit_opts;
 
 /* Build the shared basis block on the host (fp64) and upload it.  wref[3] = weights of the

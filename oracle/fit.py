@@ -505,7 +505,7 @@ ST_RUNNING, ST_CONVERGED, ST_MAXITER, ST_NONFINITE, ST_STALLED = 0, 1, 2, 3, 4
 
 
 def lm_solve(basis, sc, q0=None, max_iter=200, ftol=1e-14, gtol=1e-9, xtol=1e-11,
-             hess_dtype=np.float64, chol_dtype=np.float64, others=None, so_lambda=None, backtrack=True):
+             hess_dtype=np.float64, chol_dtype=np.float64, others=None, so_lambda=None, backtrack=True, lam0=LM_LAMBDA0):
     """(H + lam*diag|H|) delta = -J^T r with Nielsen's gain-ratio damping, H = J^T J (Gauss-Newton) or, once the
     damping has fallen to so_lambda, J^T J + sum_i r_i Hessian(r_i) (the exact Hessian of 0.5*sum r^2).
 
@@ -525,9 +525,9 @@ def lm_solve(basis, sc, q0=None, max_iter=200, ftol=1e-14, gtol=1e-9, xtol=1e-11
         so_lambda = LM_SO_LAMBDA if others is None else 0.0
     wp = waypoints(sc, basis.K, basis.duration)
     q = initial_guess(basis, sc, wp) if q0 is None else np.array(q0, float)
-    lam, nu = LM_LAMBDA0, 2.0
+    lam, nu = lam0, 2.0
     status = ST_MAXITER
-    c, g, H = eval_normal(basis, sc, q, wp, others)
+    c, g, H = eval_normal(basis, sc, q, wp, others, second_order=(so_lambda > 0 and lam0 <= so_lambda))
     H = H.astype(hess_dtype).astype(np.float64)
     it = 0
     if not np.isfinite(c):
@@ -709,3 +709,197 @@ def synth_scenarios(B, seed=20241008, rank=0, n_obs=2, wbnd=1.0, wwp=0.02):
 def set_scale(sc, obj_scale, K):
     sc[..., SC_S] = obj_scale / K
     return sc
+
+
+# ----------------------------------------------------------------------------------
+# MINPACK lmder restated on the normal equations -- the path scipy.optimize.least_squares(method='lm')
+# follows (scipy/optimize/_lsq/least_squares.py call_minpack: diag = 1/x_scale = 1 -> mode 2, factor = 100,
+# maxfev = 100 n).  lmder / lmpar work on the QR factors of J; every quantity they use is a function of
+# J^T J and J^T f alone (the norms ||R^-T w|| of lmpar's Newton correction are w^T (J^T J + par I)^-1 w, the
+# predicted reduction is p^T J^T J p + 2 par p^T p), so the same decisions can be taken from the Cholesky
+# factor of J^T J + par I.  This is the `mode = D2D_LM_MINPACK` algorithm of the HIP path.
+# ----------------------------------------------------------------------------------
+MP_FACTOR = 100.0
+MP_P1, MP_P5, MP_P25, MP_P75, MP_P0001 = 0.1, 0.5, 0.25, 0.75, 1e-4
+MP_DWARF = 2.2250738585072014e-308
+MP_EPS = 2.220446049250313e-16
+
+
+def _chol_solve(A, b, dtype):
+    """p with A p = b and w |-> ||L^-1 w||^2 for the Cholesky factor L of A (in `dtype`); None when A is not positive definite."""
+    try:
+        L = np.linalg.cholesky(A.astype(dtype))
+    except np.linalg.LinAlgError:
+        return None, None
+    import scipy.linalg as sl
+    y = sl.solve_triangular(L, b.astype(dtype), lower=True)
+    p = sl.solve_triangular(L.T, y, lower=False).astype(np.float64)
+    return p, (lambda w: float(np.sum(sl.solve_triangular(L, w.astype(dtype), lower=True).astype(np.float64) ** 2)))
+
+
+def lmpar_normal(H, g, delta, par, chol_dtype=np.float64):
+    """MINPACK lmpar on the normal equations: p (the step is -p) and par with | ||p|| - delta | <= 0.1 delta, or par = 0 and the
+    Gauss-Newton direction when that one is inside the region.  Returns p, par, number of factorisations."""
+    n = len(g)
+    I = np.eye(n)
+    nfac = 1
+    p, isq = _chol_solve(H, g, chol_dtype)
+    it = 0
+    if p is not None:
+        dxnorm = float(np.linalg.norm(p))
+        fp = dxnorm - delta
+        if fp <= MP_P1 * delta:
+            return p, 0.0, nfac
+        temp2 = isq(p / dxnorm)                  # ||R^-T (D^2 p / ||D p||)||^2
+        parl = (fp / delta) / temp2 if temp2 > 0.0 else 0.0
+    else:                                        # rank-deficient (not positive definite to working precision): no lower bound
+        dxnorm, fp, parl = np.inf, np.inf, 0.0
+    gnorm = float(np.linalg.norm(g))
+    paru = gnorm / delta
+    if paru == 0.0:
+        paru = MP_DWARF / min(delta, MP_P1)
+    par = min(max(par, parl), paru)
+    if par == 0.0:
+        par = gnorm / dxnorm
+    while True:
+        it += 1
+        if par == 0.0:
+            par = max(MP_DWARF, 0.001 * paru)
+        p, isq = _chol_solve(H + par * I, g, chol_dtype)
+        nfac += 1
+        if p is None:                            # cannot happen in exact arithmetic (par > 0): raise the damping
+            parl = max(parl, par); par = max(2.0 * par, 0.001 * paru)
+            if it >= 10:
+                return np.zeros(n), par, nfac
+            continue
+        dxnorm = float(np.linalg.norm(p))
+        temp = fp
+        fp = dxnorm - delta
+        if abs(fp) <= MP_P1 * delta or (parl == 0.0 and fp <= temp and temp < 0.0) or it == 10:
+            break
+        temp2 = isq(p / dxnorm)
+        parc = (fp / delta) / temp2
+        if fp > 0.0:
+            parl = max(parl, par)
+        if fp < 0.0:
+            paru = min(paru, par)
+        par = max(parl, par + parc)
+    return p, par, nfac
+
+
+def lmder_solve(basis, sc, q0=None, ftol=1e-15, xtol=1e-15, gtol=1e-15, max_nfev=None, hess_dtype=np.float64,
+                chol_dtype=np.float64, finish=None, trace=None):
+    """MINPACK's lmder (the solver behind scipy least_squares(method='lm')) on the normal equations, unit scaling (mode 2).
+    f = the residual vector (cost c = ||f||^2), J its Jacobian.  One "iteration" here = one trial point (one nfev).
+    finish = (n_ok, ...) see lm_finish_rule: hand over to the second-order loop once the trust region has been inactive
+    (par = 0, ratio >= 0.75) for n_ok consecutive steps -- None: pure lmder.
+    Returns q, cost, nfev, status (ST_*), info dict."""
+    wp = waypoints(sc, basis.K, basis.duration)
+    x = initial_guess(basis, sc, wp) if q0 is None else np.array(q0, float)
+    n = len(x)
+    if max_nfev is None:
+        max_nfev = 100 * n
+    c, g, H = eval_normal(basis, sc, x, wp)
+    H = H.astype(hess_dtype).astype(np.float64)
+    nfev, nfac = 1, 0
+    if not np.isfinite(c):
+        return x, c, nfev, ST_NONFINITE, {}
+    fnorm = math.sqrt(c)
+    par = 0.0
+    xnorm = float(np.linalg.norm(x))
+    delta = MP_FACTOR * xnorm if xnorm > 0 else MP_FACTOR
+    first = True
+    info = 0
+    calm = 0
+    while True:
+        acn = np.sqrt(np.maximum(np.diag(H), 0.0))
+        gnorm = 0.0
+        if fnorm != 0.0:
+            ok = acn > 0
+            gnorm = float(np.max(np.abs(g[ok]) / (acn[ok] * fnorm))) if ok.any() else 0.0
+        if gnorm <= gtol:
+            info = 4
+            break
+        while True:                               # inner loop: until a step is accepted
+            p, par, nf = lmpar_normal(H, g, delta, par, chol_dtype)
+            nfac += nf
+            step = -p
+            pnorm = float(np.linalg.norm(step))
+            if first:
+                delta = min(delta, pnorm)
+                first = False
+            xt = x + step
+            ct = cost(basis, sc, xt, wp)
+            nfev += 1
+            fnorm1 = math.sqrt(ct) if np.isfinite(ct) else np.inf
+            actred = -1.0
+            if MP_P1 * fnorm1 < fnorm:
+                actred = 1.0 - ct / c             # 1 - (fnorm1 / fnorm)^2
+            # ||J p||^2 = p^T H p = p^T g - par p^T p  (H p = g - par p)
+            jp2 = max(float(p @ g) - par * pnorm * pnorm, 0.0)
+            t1 = jp2 / c                          # (||J p|| / fnorm)^2
+            t2 = par * pnorm * pnorm / c          # (sqrt(par) ||p|| / fnorm)^2
+            prered = t1 + t2 / MP_P5
+            dirder = -(t1 + t2)
+            ratio = actred / prered if prered != 0.0 else 0.0
+            if ratio <= MP_P25:
+                temp = MP_P5 if actred >= 0.0 else MP_P5 * dirder / (dirder + MP_P5 * actred)
+                if MP_P1 * fnorm1 >= fnorm or temp < MP_P1:
+                    temp = MP_P1
+                delta = temp * min(delta, pnorm / MP_P1)
+                par = par / temp
+            elif par == 0.0 or ratio >= MP_P75:
+                delta = pnorm / MP_P5
+                par = MP_P5 * par
+            if trace is not None:
+                trace.append((nfev, c, ct, par, delta, ratio))
+            accepted = ratio >= MP_P0001
+            if accepted:
+                x = xt
+                xnorm = float(np.linalg.norm(x))
+                c, fnorm = ct, fnorm1
+            if abs(actred) <= ftol and prered <= ftol and MP_P5 * ratio <= 1.0:
+                info = 1
+            if delta <= xtol * xnorm:
+                info = 2 if info == 0 else 3
+            if info == 0:
+                if nfev >= max_nfev:
+                    info = 5
+                elif abs(actred) <= MP_EPS and prered <= MP_EPS and MP_P5 * ratio <= 1.0:
+                    info = 6
+                elif delta <= MP_EPS * xnorm:
+                    info = 7
+                elif gnorm <= MP_EPS:
+                    info = 8
+            if accepted:
+                calm = calm + 1 if (par == 0.0 and ratio >= MP_P75) else 0
+            if info != 0 or accepted:
+                break
+        if info != 0:
+            break
+        if finish is not None and calm >= finish:
+            break
+        c, g, H = eval_normal(basis, sc, x, wp)
+        H = H.astype(hess_dtype).astype(np.float64)
+    status = ST_CONVERGED if info in (1, 2, 3, 4, 6, 7, 8) else ST_MAXITER
+    return x, c, nfev, status, {'info': info, 'nfac': nfac, 'handover': info == 0}
+
+
+MP_FINISH = 3          # include/d2d.h D2D_LM_MP_FINISH
+
+
+def solve_minpack(basis, sc, q0=None, finish=MP_FINISH, max_iter=200, mp_tol=1e-15, ftol=1e-14, gtol=1e-9, xtol=1e-11,
+                  hess_dtype=np.float64, chol_dtype=np.float64):
+    """The default solver of the HIP path (d2d_fit_opts.mode = D2D_LM_MODE_MINPACK): lmder until the trust region has been
+    inactive for `finish` accepted steps in a row, then the second-order loop of lm_solve (every evaluation with the exact
+    Hessian, damping restarted at LM_LAMBDA0) to the end; finish = 0: lmder alone.  max_iter bounds the trial points of both
+    phases together.  Returns q, cost, iterations (trial points), status, info (factorisations of the lmder phase, its trials)."""
+    q, c, nfev, st, info = lmder_solve(basis, sc, q0, ftol=mp_tol, xtol=mp_tol, gtol=mp_tol, max_nfev=max_iter + 1,
+                                       hess_dtype=hess_dtype, chol_dtype=chol_dtype, finish=finish if finish > 0 else None)
+    it = nfev - 1
+    out = {'nfac': info['nfac'], 'mp_trials': it, 'handover': info['handover']}
+    if info['handover'] and it < max_iter:
+        q, c, it2, st = lm_solve(basis, sc, q0=q, max_iter=max_iter - it, ftol=ftol, gtol=gtol, xtol=xtol, hess_dtype=hess_dtype,
+                                 chol_dtype=chol_dtype, so_lambda=1e300)
+        it += it2
+    return q, c, it, st, out

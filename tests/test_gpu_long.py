@@ -51,10 +51,13 @@ def _scen(B, K, dur, seed):
     return sc
 
 
+@pytest.mark.parametrize('mode', ['minpack', 'fast'])
 @pytest.mark.parametrize('K', [121, 151, 65, 128])
-def test_long_kernel_vs_oracle_lm(ctx, K):
-    """Chunk boundaries: K = 65 (one sample in the second chunk), 128 (two full chunks), 121 / 151 (the reference's scenarios)."""
+def test_long_kernel_vs_oracle_lm(ctx, K, mode):
+    """Chunk boundaries: K = 65 (one sample in the second chunk), 128 (two full chunks), 121 / 151 (the reference's scenarios).
+    Both solvers: the default (lmder's path + second-order finish, oracle solve_minpack) and the FAST loop (oracle lm_solve)."""
     import d2dhip
+    kw = {'minpack': {}, 'fast': {'mode': d2dhip.MODE_FAST}}[mode]
     plan, dur = _plan(ctx, K)
     try:
         assert plan.kernel == 'long'
@@ -67,7 +70,7 @@ def test_long_kernel_vs_oracle_lm(ctx, K):
         dsc = ctx.dev(sc)
         q0 = plan.init(dsc)
         q = q0.clone()
-        cost, iters, status, stats = plan.solve(dsc, q)
+        cost, iters, status, stats = plan.solve(dsc, q, **kw)
         qh, ch, ih = q.cpu().numpy(), cost.cpu().numpy(), iters.cpu().numpy()
         st = status.cpu().numpy()
         assert np.isin(st, (d2dhip.ST_CONVERGED, d2dhip.ST_STALLED)).all(), st
@@ -78,7 +81,10 @@ def test_long_kernel_vs_oracle_lm(ctx, K):
             assert co <= F.cost(ob, sc[i], q0.cpu().numpy()[i]) * (1 + 1e-12)
             if i < 9:
                 # fp32 Hessian + fp32 Cholesky on the GPU, mimicked by the oracle: the same minimum in about as many iterations
-                qo, c_or, it_or, _ = F.lm_solve(ob, sc[i], hess_dtype=np.float32, chol_dtype=np.float32)
+                if mode == 'fast':
+                    qo, c_or, it_or, _ = F.lm_solve(ob, sc[i], hess_dtype=np.float32, chol_dtype=np.float32)
+                else:
+                    qo, c_or, it_or, _, _ = F.solve_minpack(ob, sc[i], hess_dtype=np.float32, chol_dtype=np.float32)
                 ok = abs(c_or - ch[i]) <= 1e-6 * c_or and np.abs(qo - qh[i]).max() <= 1e-5 * np.abs(qo).max()
                 same += int(ok)
                 if ok:
