@@ -505,7 +505,7 @@ ST_RUNNING, ST_CONVERGED, ST_MAXITER, ST_NONFINITE, ST_STALLED = 0, 1, 2, 3, 4
 
 
 def lm_solve(basis, sc, q0=None, max_iter=200, ftol=1e-14, gtol=1e-9, xtol=1e-11,
-             hess_dtype=np.float64, chol_dtype=np.float64, others=None, so_lambda=None, backtrack=True, lam0=LM_LAMBDA0):
+             hess_dtype=np.float64, chol_dtype=np.float64, others=None, so_lambda=None, backtrack=True, lam0=LM_LAMBDA0, fail_floor=0.0, stats=None):
     """(H + lam*diag|H|) delta = -J^T r with Nielsen's gain-ratio damping, H = J^T J (Gauss-Newton) or, once the
     damping has fallen to so_lambda, J^T J + sum_i r_i Hessian(r_i) (the exact Hessian of 0.5*sum r^2).
 
@@ -526,6 +526,7 @@ def lm_solve(basis, sc, q0=None, max_iter=200, ftol=1e-14, gtol=1e-9, xtol=1e-11
     wp = waypoints(sc, basis.K, basis.duration)
     q = initial_guess(basis, sc, wp) if q0 is None else np.array(q0, float)
     lam, nu = lam0, 2.0
+    lam_fail = 0.0
     status = ST_MAXITER
     c, g, H = eval_normal(basis, sc, q, wp, others, second_order=(so_lambda > 0 and lam0 <= so_lambda))
     H = H.astype(hess_dtype).astype(np.float64)
@@ -576,6 +577,9 @@ def lm_solve(basis, sc, q0=None, max_iter=200, ftol=1e-14, gtol=1e-9, xtol=1e-11
             small_x = np.max(np.abs(step)) <= xtol * (np.max(np.abs(q)) + xtol)
             q = q + step
             lam, nu = lam_new, 2.0
+            if fail_floor > 0.0:
+                lam = max(lam, fail_floor * lam_fail)
+                lam_fail *= 0.5
             small_f = (c - ct) <= ftol * c and pred_s <= ftol * c
             c, g, H = eval_normal(basis, sc, q, wp, others, second_order=so_next)
             H = H.astype(hess_dtype).astype(np.float64)
@@ -589,6 +593,9 @@ def lm_solve(basis, sc, q0=None, max_iter=200, ftol=1e-14, gtol=1e-9, xtol=1e-11
             if ok or not backtrack:
                 lam *= nu; nu *= 2.0
             else:
+                lam_fail = max(lam_fail, lam)
+                if stats is not None:
+                    stats['fails'] = stats.get('fails', 0) + 1
                 lam *= LM_FAIL_MULT
             if lam > LM_LAMBDA_MAX:
                 status = ST_STALLED
