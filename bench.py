@@ -366,6 +366,7 @@ def main():
                     help='solver of the headline: minpack = the library default (MINPACK lmder path + second-order finish: the path scipy follows), '
                          'fast = rounds 1-2\'s loop (reported beside it in any case)')
     ap.add_argument('--no-extra-modes', action='store_true', help='skip the fast_mode / minpack_pure / order-hint records')
+    ap.add_argument('--dump-costs', default=None, help='(tests) every rank writes the costs / iteration counts of its last headline solve to <prefix>_rank<r>.npz')
     a = ap.parse_args()
 
     if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -469,6 +470,8 @@ def main():
     ev_ms, ev_n, stp_ms, stp_n, lm_ms, lm_n = prof[:6]
     total = B * world
     headline = summary(B, a.steps, dt, glob, prof, n_evals)
+    if a.dump_costs:
+        np.savez(f'{a.dump_costs}_rank{rank}.npz', cost=cost.cpu().numpy(), iters=iters.cpu().numpy(), status=status.cpu().numpy(), q=q.cpu().numpy())
     q_head = q[:a.cpu_sample].clone() if keep is not None else None
     z_head = plan.coeffs(dsc[:a.cpu_sample], q[:a.cpu_sample]).cpu().numpy() if keep is not None else None
     c_head = cost[:a.cpu_sample].cpu().numpy() if keep is not None else None

@@ -14,35 +14,45 @@ def shard_bounds(total, rank, world):
 
 
 class StatsReducer:
-    """All-reduce of the three convergence scalars.  `device` is where the backend wants the
-    buffer (cuda:<local_rank> for nccl, cpu for gloo)."""
+    """The convergence exchange.  `device` is where the backend wants its buffers (cuda:<local_rank> for nccl / RCCL, cpu for
+    gloo).  Everything is allocated once: a pinned host staging tensor, the device send buffer and the gathered [world, 3]
+    tensor; a call is one host write, one collective, one read-back -- no tensors are built per call."""
 
     def __init__(self, dist=None, device='cpu'):
         self.dist = dist
         if dist is not None:
             import torch
-            self.sum_buf = torch.zeros(2, dtype=torch.float64, device=device)
-            self.mine = torch.zeros(3, dtype=torch.float64, device=device)
-            self.all = [torch.zeros(3, dtype=torch.float64, device=device) for _ in range(dist.get_world_size())]
+            self.torch = torch
+            on_gpu = str(device).startswith('cuda')
+            self.host = torch.zeros(3, dtype=torch.float64, pin_memory=on_gpu)
+            self.send = torch.zeros(3, dtype=torch.float64, device=device)
+            self.all = torch.zeros(dist.get_world_size(), 3, dtype=torch.float64, device=device)
+            self.all_rows = list(self.all.unbind(0))      # views: all_gather fills the rows of self.all (gloo has no all_gather_into_tensor)
+            self.all_host = torch.zeros(dist.get_world_size(), 3, dtype=torch.float64, pin_memory=on_gpu)
+            self.run_host = torch.zeros(1, dtype=torch.float64, pin_memory=on_gpu)
+            self.run_dev = torch.zeros(1, dtype=torch.float64, device=device)
 
     def __call__(self, cost_sum, gmax, running):
-        """(sum of costs, max |J^T r|, trajectories not converged) over all ranks: ONE collective (an
-        all-gather of the three scalars; sum and max are then taken locally)."""
+        """(sum of costs, max |J^T r|, trajectories not converged) over all ranks: ONE collective (an all-gather of the three
+        scalars; sum and max are then taken locally)."""
         if self.dist is None:
             return float(cost_sum), float(gmax), int(running)
-        import torch
-        self.mine.copy_(torch.tensor([float(cost_sum), float(gmax), float(running)], dtype=torch.float64))
-        self.dist.all_gather(self.all, self.mine)
-        t = torch.stack(self.all).cpu()
+        self.host[0] = float(cost_sum); self.host[1] = float(gmax); self.host[2] = float(running)
+        self.send.copy_(self.host, non_blocking=True)
+        self.dist.all_gather(self.all_rows, self.send)
+        self.all_host.copy_(self.all)              # (synchronises: the host needs the numbers)
+        t = self.all_host
         return float(t[:, 0].sum()), float(t[:, 1].max()), int(round(float(t[:, 2].sum())))
 
     def running_only(self, running):
-        """The per-check exchange inside the iteration loop (one all-reduce)."""
+        """The per-check exchange inside the iteration loop: one all-reduce of one scalar."""
         if self.dist is None:
             return int(running)
-        self.sum_buf[0] = 0.0; self.sum_buf[1] = float(running)
-        self.dist.all_reduce(self.sum_buf, op=self.dist.ReduceOp.SUM)
-        return int(round(self.sum_buf[1].item()))
+        self.run_host[0] = float(running)
+        self.run_dev.copy_(self.run_host, non_blocking=True)
+        self.dist.all_reduce(self.run_dev, op=self.dist.ReduceOp.SUM)
+        self.run_host.copy_(self.run_dev)          # (synchronises: the host decides whether another launch is needed)
+        return int(round(float(self.run_host[0])))
 
 
 def solve_sharded(plan, scen, q, reducer, check_every=8, max_iter=200, **tol):
