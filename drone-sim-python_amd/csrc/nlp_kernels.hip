@@ -727,29 +727,34 @@ __device__ void nlp_apply(const NlpProb &pb, const NlpScen &s, int lane, double 
   }
 }
 
-// One wavefront per problem.  Node-parallel phases (merit, assembly, step statistics, update) run with lane = node; the two
-// block recursions are serial in the nodes and run wave-uniform.  Control flow is uniform: no lane waits for another problem.
-// Two waves per SIMD (the assembly spills ~280 registers for it, once per Newton step; the serial recursions are separate functions
-// and do not): measured +12 % problems/s at 4096 and 65 536 problems for +6 % latency of a lone one.
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
-nlp_solve_kernel(int B, int N, double h, d2d_nlp_opts o, const double *__restrict__ scen, const double *partner, double *W,
-                 double *work, double *mult, double *__restrict__ cost_out, double *__restrict__ feas_out,
-                 int32_t *__restrict__ iters_out, int32_t *__restrict__ status_out, unsigned long long *stamps) {
-  const int b = blockIdx.x, lane = threadIdx.x;
-  if (b >= B) return;
-  // diagnostics (D2D_NLP_STAMPS): cycles of problem 0 per phase -- merit, assembly, factorisation, back substitution, ratio tests, update
+struct NlpOut { double cost, feas; int iters, status; };
+
+// The solve of ONE problem by one wavefront (lane = threadIdx.x & 63): sc its scenario row, Wb [5][N] in/out, wsb its workspace,
+// multb [3][N] or null, partner [2][N] frozen positions of the CostCollision partner or null.  Wave-uniform control flow.
+__device__ __forceinline__ void nlp_solve_one(int N, double h, const d2d_nlp_opts &o, const double *__restrict__ sc, const double *partner,
+                                              double *Wb, double *wsb, double *multb, int lane, NlpOut &out, unsigned long long *stamps) {
+  // diagnostics (D2D_NLP_STAMPS): cycles per phase -- merit, assembly, factorisation, back substitution, ratio tests, update
   unsigned long long st_t = 0, st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  const bool st_on = stamps != nullptr && b == 0;
 #define NLP_STAMP(k) if (st_on) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[k] += t_ - st_t; st_t = t_; }
+  const bool st_on = stamps != nullptr;
   if (st_on) st_t = __builtin_amdgcn_s_memtime();
-  const double *sc = scen + (size_t)b * D2D_SCEN_STRIDE;
   const NlpScen s = nlp_load_scen(sc, o);
   NlpProb pb;
   pb.N = N; pb.h = h;
-  pb.W = W + (size_t)b * NLP_NV * N;
-  pb.ws = work + (size_t)b * WS_TOTAL * N;
-  pb.mu = mult ? mult + (size_t)b * 3 * N : pb.ws + (size_t)WS_MU * N;
-  pb.partner = partner ? partner + (size_t)b * 2 * N : nullptr;
+  pb.W = Wb;
+  pb.ws = wsb;
+  pb.mu = multb ? multb : pb.ws + (size_t)WS_MU * N;
+  pb.partner = partner;
+  // (a row whose bounds are unset or inverted would give a zero-width box, infinite duals and NaN pivots for
+  // outer_max x 30 assemblies -- refuse it at once)
+  {
+    bool bad = !(s.hi[3] > s.lo[3]) || !(s.hi[4] > s.lo[4]) || !(s.lo[4] > 0.0) || !(s.hi[0] > s.lo[0]) || !(s.hi[1] > s.lo[1]);
+    for (int c = 0; c < 3; ++c) bad = bad || !(fabs(s.p0[c]) <= 1.79e308) || !(fabs(s.p1[c]) <= 1.79e308);
+    if (bad) {
+      out.cost = out.feas = __builtin_nan(""); out.iters = 0; out.status = D2D_ST_NONFINITE;
+      return;
+    }
+  }
   // ---- start: end conditions in place, everything else pushed strictly inside the box; duals on the central path
   double mub = o.mub0;
   for (int i0 = 0; i0 < N; i0 += 64) {
@@ -840,6 +845,7 @@ nlp_solve_kernel(int B, int N, double h, d2d_nlp_opts o, const double *__restric
       if (converged || !accepted) break;
     }
     (void)nlp_merit(pb, s, sc, lane, 0.0, rho, mub, &cost_ref, &feas);
+    if (!(fabs(phi0) <= 1.79e308) || !(fabs(err) <= 1.79e308)) { status = D2D_ST_NONFINITE; break; }
     if (feas <= o.feas_tol && mub <= o.mub_min * 1.0001 && err <= tol_in) { status = D2D_ST_CONVERGED; break; }
     // the inner problem is not solved yet and the batch still lowered the merit function by more than rounding: same multipliers,
     // penalty and barrier parameter, another batch of steps -- the schedule must not run ahead of the iterate
@@ -872,18 +878,100 @@ nlp_solve_kernel(int B, int N, double h, d2d_nlp_opts o, const double *__restric
     mub = fmax(o.mub_min, fmin(0.2 * mub, mub * sqrt(mub)));
   }
   (void)nlp_merit(pb, s, sc, lane, 0.0, rho, mub, &cost_ref, &feas);
-  if (lane == 0) {
-    cost_out[b] = cost_ref;
-    feas_out[b] = feas;
-    if (iters_out) iters_out[b] = total_inner;
-    if (status_out) status_out[b] = status;
-    if (st_on) {
-      NLP_STAMP(7)
-      for (int k = 0; k < 8; ++k) stamps[k] = st_acc[k];
-      stamps[8] = (unsigned long long)total_inner;
-    }
+  out.cost = cost_ref; out.feas = feas; out.iters = total_inner; out.status = status;
+  if (lane == 0 && st_on) {
+    NLP_STAMP(7)
+    for (int k = 0; k < 8; ++k) stamps[k] = st_acc[k];
+    stamps[8] = (unsigned long long)total_inner;
   }
 #undef NLP_STAMP
+}
+
+// One wavefront per problem.  Node-parallel phases (merit, assembly, step statistics, update) run with lane = node; the two
+// block recursions are serial in the nodes and run wave-uniform.  Control flow is uniform: no lane waits for another problem.
+// Two waves per SIMD (the assembly spills ~280 registers for it, once per Newton step; the serial recursions are separate functions
+// and do not): measured +12 % problems/s at 4096 and 65 536 problems for +6 % latency of a lone one.
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+nlp_solve_kernel(int B, int N, double h, d2d_nlp_opts o, const double *__restrict__ scen, const double *partner, double *W,
+                 double *work, double *mult, double *__restrict__ cost_out, double *__restrict__ feas_out,
+                 int32_t *__restrict__ iters_out, int32_t *__restrict__ status_out, unsigned long long *stamps) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  if (b >= B) return;
+  NlpOut out;
+  nlp_solve_one(N, h, o, scen + (size_t)b * D2D_SCEN_STRIDE, partner ? partner + (size_t)b * 2 * N : nullptr, W + (size_t)b * NLP_NV * N,
+                work + (size_t)b * WS_TOTAL * N, mult ? mult + (size_t)b * 3 * N : nullptr, lane, out, b == 0 ? stamps : nullptr);
+  if (lane == 0) {
+    cost_out[b] = out.cost;
+    feas_out[b] = out.feas;
+    if (iters_out) iters_out[b] = out.iters;
+    if (status_out) status_out[b] = out.status;
+  }
+}
+
+// The reference's multi-aircraft Problem (src/multi_opt_planner.py:69-78,86) in ONE launch: a workgroup takes a scenario, wavefront
+// a its aircraft a.  The aircraft are coupled through the objective only -- CostCollision on the pair (0, 1), src/d2d/
+// multiopty_utils.py:120-153; every constraint is per aircraft -- so a fixed point of block Gauss-Seidel over the aircraft (each
+// block = the full collocation solve of one aircraft against its partner's frozen node positions) is a KKT point of the joint
+// problem.  Sweep 0 solves every aircraft uncoupled, concurrently; then aircraft 0 and 1 take turns (workgroup barriers between
+// the turns; the partner's positions are read from its W in global memory, which its wave does not touch meanwhile) until neither
+// moved by more than tol in a sweep, or max_sweeps.  No host round trips.  prev [R][2][N] scratch.
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+nlp_groups_kernel(int R, int n_ac, int N, double h, d2d_nlp_opts o, int max_sweeps, double tol, const double *__restrict__ scen, double *W,
+                  double *work, double *mult, double *prev, double *__restrict__ cost_out, double *__restrict__ feas_out,
+                  int32_t *__restrict__ iters_out, int32_t *__restrict__ status_out, int32_t *__restrict__ sweeps_out,
+                  double *__restrict__ moved_out) {
+  __shared__ double moved_s[2];
+  const int r = blockIdx.x, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int b = r * n_ac + wave;
+  const double *sc = scen + (size_t)b * D2D_SCEN_STRIDE;
+  double *Wb = W + (size_t)b * NLP_NV * N;
+  double *wsb = work + (size_t)b * WS_TOTAL * N;
+  double *mb = mult ? mult + (size_t)b * 3 * N : nullptr;
+  const bool coupled = n_ac >= 2 && scen[(size_t)(r * n_ac) * D2D_SCEN_STRIDE + D2D_SC_KCOL] > 0.0;       // wave-uniform for the whole group
+  NlpOut out;
+  int iters_total = 0;
+  nlp_solve_one(N, h, o, sc, nullptr, Wb, wsb, mb, lane, out, nullptr);
+  iters_total += out.iters;
+  if (threadIdx.x < 2) moved_s[threadIdx.x] = 0.0;
+  __threadfence_block();
+  __syncthreads();
+  int sweep = 0;
+  double moved = 0.0;
+  if (coupled) {
+    double *pv = prev + (size_t)r * 2 * N;
+    for (sweep = 1; sweep <= max_sweeps; ++sweep) {
+      for (int turn = 0; turn < 2; ++turn) {
+        if (wave == turn) {
+          const double *pw = W + (size_t)(r * n_ac + (1 - turn)) * NLP_NV * N;      // the partner's x and y planes
+          for (int i = lane; i < 2 * N; i += 64) pv[i] = Wb[i];
+          nlp_solve_one(N, h, o, sc, pw, Wb, wsb, mb, lane, out, nullptr);
+          iters_total += out.iters;
+          double m = 0.0;
+          for (int i = lane; i < 2 * N; i += 64) m = fmax(m, fabs(Wb[i] - pv[i]));
+          m = wave_max(m);
+          if (lane == 0) moved_s[turn] = m;
+        }
+        __threadfence_block();
+        __syncthreads();
+      }
+      moved = fmax(moved_s[0], moved_s[1]);
+      __syncthreads();
+      if (moved <= tol) break;
+    }
+    if (sweep > max_sweeps) sweep = max_sweeps;
+    // not settled after the last sweep: the pair is reported as such (the inner solves each converged, the alternation did not)
+    if (moved > tol && wave < 2 && out.status == D2D_ST_CONVERGED) out.status = D2D_ST_MAXITER;
+  }
+  if (lane == 0) {
+    cost_out[b] = out.cost;
+    feas_out[b] = out.feas;
+    if (iters_out) iters_out[b] = iters_total;
+    if (status_out) status_out[b] = out.status;
+    if (wave == 0) {
+      if (sweeps_out) sweeps_out[r] = sweep;
+      if (moved_out) moved_out[r] = moved;
+    }
+  }
 }
 
 extern "C" {
@@ -912,6 +1000,23 @@ int d2d_nlp_solve(d2d_ctx *ctx, int B, int N, double h, const double *scen, cons
     for (int k = 0; k < 8; ++k) fprintf(stderr, " %s %llu", nm[k], hs[k]);
     fprintf(stderr, "\n");
   }
+  return D2D_OK;
+}
+
+int d2d_nlp_solve_groups(d2d_ctx *ctx, int R, int n_ac, int N, double h, const double *scen, const d2d_nlp_opts *opts, int max_sweeps,
+                         double tol, double *W, double *work, double *mult, double *cost, double *feas, int32_t *iters, int32_t *status,
+                         int32_t *sweeps, double *moved) {
+  D2D_REQUIRE(ctx && scen && W && work && cost && feas, "d2d_nlp_solve_groups: null argument");
+  D2D_REQUIRE(R >= 1 && n_ac >= 1 && n_ac <= 8 && N >= 3 && h > 0, "d2d_nlp_solve_groups: R >= 1, 1 <= n_ac <= 8, N >= 3, h > 0 required (R=%d n_ac=%d N=%d h=%g)", R, n_ac, N, h);
+  D2D_REQUIRE(max_sweeps >= 1 && tol >= 0, "d2d_nlp_solve_groups: max_sweeps >= 1 and tol >= 0 required");
+  d2d_nlp_opts o = {D2D_NLP_RHO0, D2D_NLP_MUB0, D2D_NLP_MUB_MIN, 1e-9, 1e-7, 60, 40};
+  if (opts) o = *opts;
+  D2D_REQUIRE(o.inner_max >= 1 && o.outer_max >= 1 && o.rho0 > 0 && o.mub0 > 0 && o.mub_min > 0, "d2d_nlp_solve_groups: bad options");
+  // scratch for the positions before a turn: the tail of aircraft 0's workspace is not free, so it lives behind the workspaces
+  double *prev = work + (size_t)R * n_ac * WS_TOTAL * N;
+  hipLaunchKernelGGL(nlp_groups_kernel, dim3(R), dim3(64 * n_ac), 0, ctx->stream, R, n_ac, N, h, o, max_sweeps, tol, scen, W, work, mult, prev,
+                     cost, feas, iters, status, sweeps, moved);
+  D2D_LAUNCH_CHECK();
   return D2D_OK;
 }
 

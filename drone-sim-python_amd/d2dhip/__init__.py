@@ -95,6 +95,7 @@ _SIGS = {
     'd2d_lqr': (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P]),
     'd2d_nlp_workspace_doubles': (C.c_int, [C.c_int]),
     'd2d_nlp_solve': (C.c_int, [_P, C.c_int, C.c_int, C.c_double, _P, C.POINTER(NlpOpts)] + [_P] * 8),
+    'd2d_nlp_solve_groups': (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_double, _P, C.POINTER(NlpOpts), C.c_int, C.c_double] + [_P] * 9),
     'd2d_fit_plan_create': (C.c_int, [_P, C.c_int, C.c_int, C.c_double, _P, C.POINTER(_P)]),
     'd2d_fit_plan_destroy': (C.c_int, [_P]),
     'd2d_fit_plan_get': (C.c_int, [_P] * 6),
@@ -353,6 +354,24 @@ class Context:
         if want_mult:
             out['mult'] = mult
         return out
+
+    def nlp_solve_groups(self, scen, W, h, n_ac, max_sweeps=12, tol=1e-7, rho0=10.0, mub0=0.1, mub_min=1e-9, feas_tol=1e-9, opt_tol=1e-7,
+                         inner_max=60, outer_max=40):
+        """The reference's multi-aircraft Problem for R scenarios in one launch (d2d_nlp_solve_groups): scen dev [R*n_ac][SCEN_STRIDE],
+        W dev [R*n_ac][5][N] in/out, the aircraft of a scenario consecutive; CostCollision couples aircraft 0 and 1 (rows' KCOL > 0).
+        Returns dict(cost, feas, iters, status per aircraft; sweeps, moved per scenario) of device tensors."""
+        torch = _torch()
+        B, _, N = W.shape
+        assert W.is_contiguous() and scen.shape[0] == B and B % n_ac == 0
+        R = B // n_ac
+        work = self.empty((self.lib.d2d_nlp_workspace_doubles(N) * n_ac + 2 * N) * R)
+        cost, feas, moved = self.empty(B), self.empty(B), self.empty(R)
+        iters = torch.empty(B, dtype=torch.int32, device=self.device); status = torch.empty(B, dtype=torch.int32, device=self.device)
+        sweeps = torch.empty(R, dtype=torch.int32, device=self.device)
+        o = NlpOpts(rho0, mub0, mub_min, feas_tol, opt_tol, inner_max, outer_max)
+        _check(self.lib.d2d_nlp_solve_groups(self.h, R, n_ac, N, float(h), _ptr(scen), C.byref(o), int(max_sweeps), float(tol), _ptr(W), _ptr(work),
+                                             None, _ptr(cost), _ptr(feas), _ptr(iters), _ptr(status), _ptr(sweeps), _ptr(moved)))
+        return dict(cost=cost, feas=feas, iters=iters, status=status, sweeps=sweeps, moved=moved, work=work)
 
     def track_run(self, x_ref, y_ref, X0, dt, record=('X', 'U', 'Xr', 'dX', 'Yd', 'Ydd'), out=None, **kw):
         """x_ref, y_ref dev [T][n]; X0 dev [5][n] -> dict of device histories (out: reuse the buffers of an earlier

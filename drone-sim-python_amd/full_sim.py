@@ -179,11 +179,22 @@ def implement_controller(n_ac, time, x_ref, y_ref, v, w, X0s):
     return t('X'), t('U'), t('Xr'), t('Yd'), t('Ydd'), t('dX')
 
 
-def plan_batch(scen_rows, K, duration, obj_scale_over_n, q0=None, **solve_kw):
+def plan_batch(scen_rows, K, duration, obj_scale_over_n, q0=None, backend='fit', W0=None, h=None, n_ac=1, **solve_kw):
     """Batched planning entry point: scen_rows (B, d2dhip.SCEN_STRIDE) in the d2dhip layout -> dict with device
-    tensors q, cost, iters, status and host stats."""
+    tensors q, cost, iters, status and host stats (polynomial fit, backend='fit').
+    backend='nlp': the reference's direct-collocation Problem (hard bounds) for B / n_ac scenarios of n_ac aircraft in one launch
+    (d2d_nlp_solve_groups; CostCollision couples aircraft 0 and 1 of a scenario whose rows carry KCOL > 0): W0 (B, 5, K) node
+    values of the initial guess, h the time step -> dict with device tensors W (the solution), cost, feas, iters, status per
+    aircraft and sweeps, moved per scenario."""
     import single_opt_planner as sop
     ctx = d2dhip.default_context()
+    if backend == 'nlp':
+        dsc = ctx.dev(np.ascontiguousarray(scen_rows, dtype=np.float64))
+        W = ctx.dev(np.ascontiguousarray(W0, dtype=np.float64))
+        assert W.shape == (dsc.shape[0], 5, K) and h is not None
+        out = ctx.nlp_solve_groups(dsc, W, float(h), int(n_ac), **solve_kw)
+        out.update(W=W, scen=dsc)
+        return out
     plan = sop.get_plan(K, duration, obj_scale_over_n)
     dsc = ctx.dev(np.ascontiguousarray(scen_rows, dtype=np.float64))
     q = plan.init(dsc) if q0 is None else q0

@@ -15,8 +15,11 @@ What is interpreted instead of compiled:
                             `cost=` / `planner=` keywords) and lowered structurally (single_opt_planner.lower_cost): the known
                             classes of d2d.opty_utils / d2d.multiopty_utils have a kernel, anything else raises NotImplementedError.
                             The gradient the solver follows is the plug-in's cost_grad (reference quirks included, oracle/nlp.py).
-Collision coupling (CostCollision acts on the pair of aircraft 0 and 1 only, src/d2d/multiopty_utils.py:124-125) is resolved by
-alternating solves of the two aircraft against each other's frozen positions until they stop moving."""
+The whole Problem is ONE launch (d2d_nlp_solve_groups): wavefront a of a workgroup solves aircraft a.  The aircraft are coupled
+through the objective only -- CostCollision acts on the pair of aircraft 0 and 1, src/d2d/multiopty_utils.py:124-125 -- so the
+pair alternates on the device (each turn a full solve against the partner's frozen node positions) until neither moves by more than
+options['sweep_tol'] (1e-7 m) or options['max_sweeps'] (12): a fixed point of that alternation is a KKT point of the joint NLP.  A
+pair that has not settled is reported 'max_iter'."""
 import numpy as np
 
 import d2dhip
@@ -130,26 +133,21 @@ class Problem:
         rows, coupled = self._rows()
         # IPOPT's max_iter counts Newton steps; here they are grouped as outer (multiplier / barrier updates) x inner (<= 60)
         kw = dict(inner_max=60, outer_max=int(min(max(self.options.get('max_iter', 3000) // 60, 12), 60)))
+        # IPOPT's `tol` (the reference sets 1e-5 .. 1e-8) bounds its scaled KKT error.  This backend's own tolerances -- barrier KKT
+        # error of the last inner problem 1e-7, collocation residual 1e-9 -- are at least as tight as every value the reference
+        # uses, so a looser `tol` changes nothing; a tighter one tightens them with it.
+        tol = float(self.options.get('tol', 1e-8))
+        kw.update(opt_tol=min(tol, 1e-7), feas_tol=min(1e-2 * tol, 1e-9))
         dsc = ctx.dev(rows)
         dW = ctx.dev(np.ascontiguousarray(W))
-        sweeps = 1
+        # one launch for the whole Problem: wavefront a of a workgroup solves aircraft a; the pair coupled by CostCollision
+        # alternates on the device (block Gauss-Seidel, d2d_nlp_solve_groups) until neither aircraft moves
         if not coupled:
-            out = ctx.nlp_solve(dsc, dW, self.time_step, **kw)
-        else:
-            # aircraft 0 and 1 repel each other: alternate (others are independent and solved in the first pass)
-            rows_nc = rows.copy(); rows_nc[:, d2dhip.SC_KCOL] = 0.0
-            out = ctx.nlp_solve(ctx.dev(rows_nc), dW, self.time_step, **kw)                          # uncoupled start for everybody
-            for sweeps in range(1, 13):
-                prev = dW[:2, :2].clone()
-                for a, o in ((0, 1), (1, 0)):
-                    Wa = dW[a:a + 1].contiguous()
-                    partner = dW[o:o + 1, :2].contiguous()
-                    oa = ctx.nlp_solve(dsc[a:a + 1].contiguous(), Wa, self.time_step, partner=partner, **kw)
-                    dW[a] = Wa[0]
-                    for k in ('cost', 'feas', 'iters', 'status'):
-                        out[k][a] = oa[k][0]
-                if float((dW[:2, :2] - prev).abs().max().item()) <= 1e-7:
-                    break
+            dsc[:, d2dhip.SC_KCOL] = 0.0
+        out = ctx.nlp_solve_groups(dsc, dW, self.time_step, n, max_sweeps=int(self.options.get('max_sweeps', 12)),
+                                   tol=float(self.options.get('sweep_tol', 1e-7)), **kw)
+        sweeps = int(out['sweeps'][0].item())
+        moved = float(out['moved'][0].item())
         ctx.sync()
         Wh = dW.cpu().numpy()
         sol = np.zeros(self.num_free)
@@ -158,7 +156,7 @@ class Problem:
                 sol[s if single else s[a]] = Wh[a, c]
         st = out['status'].cpu().numpy()
         info = {'status': int(st.max()) if single else st.tolist(), 'feas': float(out['feas'].max().item()),
-                'iters': out['iters'].cpu().numpy().tolist(), 'sweeps': sweeps,
+                'iters': out['iters'].cpu().numpy().tolist(), 'sweeps': sweeps, 'moved': moved,
                 'obj_val': float(self.obj(sol)), 'status_msg': 'converged' if (st == 1).all() else 'max_iter',
                 'box_violation': 0.0, 'phi_violation': 0.0, 'v_violation': 0.0}       # hard bounds: an interior-point iterate never leaves its box
         return sol, info

@@ -458,9 +458,25 @@ typedef struct {
   int32_t outer_max; /* outer iterations: multiplier / barrier updates (default 40)                           */
 } d2d_nlp_opts;
 int d2d_nlp_workspace_doubles(int N);
+/* A problem whose row is unusable -- PHIMAX <= 0, VMIN <= 0 or VMIN >= VMAX (the model divides by v and the barrier needs an
+ * interior), an inverted position box, non-finite end poses -- is refused at once: status D2D_ST_NONFINITE, cost = feas = NaN. */
 int d2d_nlp_solve(d2d_ctx *ctx, int B, int N, double h, const double *scen, const d2d_nlp_opts *opts, double *W,
                   const double *partner, double *work, double *mult, double *cost, double *feas, int32_t *iters,
                   int32_t *status);
+
+/* The reference's multi-aircraft Problem (src/multi_opt_planner.py:41-78,86: one NLP over the n_ac aircraft of a scenario) for R
+ * scenarios in ONE launch: problems r*n_ac .. r*n_ac + n_ac - 1 (rows of scen, W, cost, ...) are the aircraft of scenario r.  The
+ * aircraft are coupled through the objective only -- CostCollision on the pair (0, 1), src/d2d/multiopty_utils.py:120-153
+ * (D2D_SC_KCOL / RCOL / SCOL of rows 0 and 1; KCOL = 0 on the scenario's first row: uncoupled) -- so a fixed point of block
+ * Gauss-Seidel over the aircraft, each block the full collocation solve of one aircraft against the partner's frozen node
+ * positions, is a KKT point of the joint problem.  A workgroup takes a scenario, wavefront a its aircraft a: every aircraft is solved
+ * uncoupled first (concurrently), then aircraft 0 and 1 take turns until neither moved by more than tol (metres) in a sweep or
+ * max_sweeps; no host round trips.  A pair that has not settled reports D2D_ST_MAXITER.
+ * work dev double[(d2d_nlp_workspace_doubles(N) * n_ac + 2 * N) * R]; sweeps dev int32 [R], moved dev [R] (largest move of the last sweep)
+ * or NULL; the other arguments as d2d_nlp_solve with B = R * n_ac.  Asynchronous on the context's stream. */
+int d2d_nlp_solve_groups(d2d_ctx *ctx, int R, int n_ac, int N, double h, const double *scen, const d2d_nlp_opts *opts, int max_sweeps,
+                         double tol, double *W, double *work, double *mult, double *cost, double *feas, int32_t *iters, int32_t *status,
+                         int32_t *sweeps, double *moved);
 
 #ifdef __cplusplus
 }

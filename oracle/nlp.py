@@ -80,6 +80,8 @@ def problem_from_row(row, N, h):
                  x_box=(r[D.SC_XMIN], r[D.SC_XMAX]) if r[D.SC_XMIN] < r[D.SC_XMAX] else None,
                  y_box=(r[D.SC_YMIN], r[D.SC_YMAX]) if r[D.SC_YMIN] < r[D.SC_YMAX] else None,
                  obstacles=obs, kobs=r[D.SC_KOBS], obs_kind=0 if (kinds and 1 in kinds) else 1)
+    if r[D.SC_KCOL] > 0.0 and r[D.SC_RCOL] > 0.0:        # CostCollision: scale SCOL * KCOL (no 1 / n_ac, src/d2d/multiopty_utils.py:132); set pb.partner
+        pb.kcol, pb.rcol = r[D.SC_KCOL] * r[D.SC_SCOL] / r[D.SC_S], r[D.SC_RCOL]
     return pb
 
 

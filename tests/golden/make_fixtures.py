@@ -379,6 +379,33 @@ def fx_planner_goldens():
     out['stline_free'] = fm; out['stline_time'] = np.array(df['time'])
     out['stline_cost'] = cc.cost(fm, pm); out['stline_grad_norm'] = np.linalg.norm(cc.cost_grad(fm, pm))
     np.savez(os.path.join(OUT, 'planner_goldens.npz'), **out)
+    # the other committed solver outputs: values only, with the reference's cost on them -- feasibility fixtures
+    # (every one satisfies the backward-Euler collocation of the symbolic model to <= 4e-6) and known-answer costs
+    feas = {}
+    for tag, fn in (('exp0', 'optyplan_exp0.npz'), ('exp0_1_0', 'optyplan_exp0_1_0.npz'), ('exp0_1_1', 'optyplan_exp0_1_1.npz'),
+                    ('exp0_1_2', 'optyplan_exp0_1_2.npz'), ('exp0_1_3', 'optyplan_exp0_1_3.npz'), ('exp0_1_4', 'optyplan_exp0_1_4.npz'),
+                    ('exp13', 'optyplan_exp13 - some traj.npz')):
+        d = np.load(os.path.join(REF, 'cache', fn))
+        N = len(d['sol_time'])
+        free = np.concatenate([d['sol_x'], d['sol_y'], d['sol_psi'], d['sol_phi'], d['sol_v']])
+        feas[tag + '_W'] = np.stack([d['sol_x'], d['sol_y'], d['sol_psi'], d['sol_phi'], d['sol_v']])     # (5, N)
+        feas[tag + '_time'] = d['sol_time']; feas[tag + '_wind'] = d['wind']
+        feas[tag + '_cost_airvel12'] = d2ou.CostAirVel(12.0).cost(free, _FakeSingle(N, 1.0))
+    for tag, fn in (('st_line', 'opt_states_st_line.csv'), ('simple_traj', 'opt_states_simple_traj.csv'), ('inf_traj_10s', 'inf_traj_10s.csv'),
+                    ('opt_states', 'opt_states.csv'), ('opt_states_hf', 'opt_states_hf.csv')):
+        df = pd.read_csv(os.path.join(REF, fn))
+        n, N = 4, len(df)
+        pm = _FakeMulti(N, n, 1.0)
+        fm = np.zeros(5 * n * N)
+        W = np.zeros((n, 5, N))
+        for i in range(n):
+            for c, nm in enumerate(('x', 'y', 'psi', 'phi', 'v')):
+                W[i, c] = df[f'{nm}_{i + 1}']
+            fm[pm._slice_x[i]] = W[i, 0]; fm[pm._slice_y[i]] = W[i, 1]; fm[pm._slice_psi[i]] = W[i, 2]
+            fm[pm._slice_phi[i]] = W[i, 3]; fm[pm._slice_v[i]] = W[i, 4]
+        feas[tag + '_W'] = W; feas[tag + '_time'] = np.array(df['time'])
+        feas[tag + '_cost'] = cc.cost(fm, pm); feas[tag + '_grad_norm'] = np.linalg.norm(cc.cost_grad(fm, pm))
+    np.savez_compressed(os.path.join(OUT, 'planner_feasibility_goldens.npz'), **feas)
 
 
 def fx_tracking_trace():

@@ -248,3 +248,129 @@ def test_catalogue_scenarios_on_the_collocation_backend():
     finally:
         for k, v in keep.items():
             setattr(sc.exp_0, k, v)
+
+
+def _trap4_like_the_golden(gold, tag='st_line'):
+    """multi_opt_planner.trap_4 with the end poses and horizon of a committed four-aircraft plan (tests/golden/
+    planner_feasibility_goldens.npz, from the reference's src/*.csv): the scenario src/11_full_sim_case1.py:444-447 builds."""
+    import multi_opt_planner as mop
+    g = gold('planner_feasibility_goldens')
+    W = g[tag + '_W']                                    # (4, 5, N)
+    t = g[tag + '_time']
+    scen = mop.trap_4
+    keep = (scen.t1, scen.p0s, scen.p1s)
+    scen.t1 = float(t[-1])
+    scen.p0s = tuple((W[a, 0, 0], W[a, 1, 0], W[a, 2, 0], 0., 12.) for a in range(4))
+    scen.p1s = tuple((W[a, 0, -1], W[a, 1, -1], W[a, 2, -1], 0., 12.) for a in range(4))
+    return scen, keep, W, g
+
+
+def test_joint_multi_aircraft_problem_reproduces_the_committed_plan(gold):
+    """The reference's multi-aircraft Problem (src/multi_opt_planner.py:69-78,86: all aircraft in ONE NLP, CostCollision between
+    aircraft 0 and 1) on the device in one launch (d2d_nlp_solve_groups), started from the reference's committed IPOPT output
+    src/opt_states_st_line.csv (4 aircraft, 71 nodes): the solve stays at that plan -- the reference's cost of our solution is
+    its cost of the committed one, 0.2024378405, within 1e-5 and not above it (IPOPT stopped at tol 1e-5), every aircraft collocation-
+    feasible to 1e-8 with its hard bounds held, the pair settled."""
+    import multi_opt_planner as mop
+    scen, keep, Wg, g = _trap4_like_the_golden(gold)
+    try:
+        _p = mop.Planner(scen, initialize=True, backend='nlp')
+        assert _p.num_nodes == 71 and _p.prob.num_free == 5 * 4 * 71
+        x0 = np.zeros(_p.prob.num_free)
+        for a in range(4):
+            for c, s in enumerate((_p._slice_x, _p._slice_y, _p._slice_psi, _p._slice_phi, _p._slice_v)):
+                x0[s[a]] = Wg[a, c]
+        c_gold = scen.cost.cost(x0, _p)
+        assert abs(c_gold - 0.2024378405) <= 1e-9                    # the mirrored cost plug-in on the committed plan (the known answer)
+        _p.run(initial_guess=x0, tol=scen.tol, max_iter=scen.max_iter)
+        _p.interpret_solution()
+        assert all(s == 1 for s in _p.info['status']), _p.info
+        assert _p.info['sweeps'] <= 12 and _p.info['moved'] <= 1e-7
+        c = scen.cost.cost(_p.solution, _p)
+        # (measured: 0.20243398 -- 3.9e-6 BELOW the committed run's 0.20243784: IPOPT stopped on its tol = 1e-5, this solve goes on to 1e-7)
+        assert abs(c - 0.2024378405) <= 1e-5 and c <= 0.2024378405, c
+        for i in range(4):
+            assert _feas(_p.sol_x[i], _p.sol_y[i], _p.sol_psi[i], _p.sol_phi[i], _p.sol_v[i], _p.time_step) <= 1e-8
+            assert np.abs(_p.sol_phi[i]).max() <= scen.phi_constraint[1] and _p.sol_v[i].min() >= scen.v_constraint[0] and _p.sol_v[i].max() <= scen.v_constraint[1]
+            # the plan itself: node positions within centimetres of the committed ones (the cost sees v and phi only: flat directions)
+            assert np.abs(_p.sol_x[i] - Wg[i, 0]).max() <= 0.05 and np.abs(_p.sol_y[i] - Wg[i, 1]).max() <= 0.05
+        # from the reference's own 'tri' guess instead: the same cost level (a minimum at least as good)
+        _q = mop.Planner(scen, initialize=True, backend='nlp')
+        _q.run(initial_guess=_q.get_initial_guess('tri'), tol=scen.tol, max_iter=scen.max_iter)
+        assert all(s == 1 for s in _q.info['status']), _q.info
+        assert scen.cost.cost(_q.solution, _q) <= c * (1 + 1e-3)
+    finally:
+        scen.t1, scen.p0s, scen.p1s = keep
+
+
+def test_joint_problems_in_batches_equal_the_single_launches(gold):
+    """d2d_nlp_solve_groups over R scenarios = R separate launches (the scenarios are independent), coupled pair and uncoupled aircraft
+    alike; a scenario whose first row carries KCOL = 0 is uncoupled; full_sim.plan_batch(backend='nlp') is the batched entry point."""
+    import d2dhip
+    import full_sim
+    import multi_opt_planner as mop
+    scen, keep, Wg, g = _trap4_like_the_golden(gold)
+    try:
+        _p = mop.Planner(scen, initialize=True, backend='nlp')
+        rows, coupled = _p.prob._rows()
+        assert coupled and rows.shape == (4, d2dhip.SCEN_STRIDE)
+        x0 = _p.get_initial_guess('tri')
+        W0 = np.stack([np.stack([x0[s[a]] for s in (_p._slice_x, _p._slice_y, _p._slice_psi, _p._slice_phi, _p._slice_v)]) for a in range(4)])
+        R = 6
+        rng = np.random.default_rng(5)
+        allrows = np.tile(rows, (R, 1)); allW = np.tile(W0, (R, 1, 1))
+        for r in range(R):                       # move aircraft 1 towards aircraft 0 so that the collision term matters more or less
+            allrows[4 * r + 1, [d2dhip.SC_Y0, d2dhip.SC_Y1]] -= rng.uniform(0.0, 25.0)
+            allW[4 * r + 1, 1] = np.linspace(allrows[4 * r + 1, d2dhip.SC_Y0], allrows[4 * r + 1, d2dhip.SC_Y1], W0.shape[2])
+        allrows[4 * (R - 1):, d2dhip.SC_KCOL] = 0.0                       # the last scenario: no coupling
+        ctx = d2dhip.default_context()
+        out = full_sim.plan_batch(allrows, W0.shape[2], None, None, backend='nlp', W0=allW, h=_p.time_step, n_ac=4)
+        Wb = out['W'].cpu().numpy()
+        st = out['status'].cpu().numpy(); sw = out['sweeps'].cpu().numpy()
+        assert (st == 1).all(), st
+        assert sw[-1] == 0 and (sw[:-1] >= 1).all() and (out['moved'].cpu().numpy() <= 1e-7).all()
+        for r in (0, 3, R - 1):
+            d1 = ctx.dev(allrows[4 * r:4 * r + 4].copy()); W1 = ctx.dev(allW[4 * r:4 * r + 4].copy())
+            o1 = ctx.nlp_solve_groups(d1, W1, _p.time_step, 4)
+            ctx.sync()
+            assert np.array_equal(W1.cpu().numpy(), Wb[4 * r:4 * r + 4])             # same kernel, same inputs: same bits
+            assert np.array_equal(o1['cost'].cpu().numpy(), out['cost'].cpu().numpy()[4 * r:4 * r + 4])
+        # the coupling acts: with aircraft 1 flown close to aircraft 0 the pair keeps more distance than the uncoupled plans would
+        from oracle import nlp as ON
+        for r in range(R - 1):
+            dmin = np.hypot(Wb[4 * r, 0] - Wb[4 * r + 1, 0], Wb[4 * r, 1] - Wb[4 * r + 1, 1]).min()
+            assert dmin > 1.0
+            # each aircraft of the pair is a KKT point of ITS sub-problem against the partner's final positions (= joint KKT):
+            # the oracle's solver started at the kernel's answer with the partner frozen stays there
+            for a, o in ((0, 1), (1, 0)):
+                pb = ON.problem_from_row(allrows[4 * r + a], W0.shape[2], _p.time_step)
+                pb.partner = Wb[4 * r + o, :2].T.copy()
+                Wo, info = ON.solve(pb, Wb[4 * r + a].T.copy())
+                assert info['status'] == 1 and abs(info['cost'] - out['cost'].cpu().numpy()[4 * r + a]) <= 1e-7 * max(1.0, info['cost'])
+                assert np.abs(Wo[:, :2] - Wb[4 * r + a, :2].T).max() <= 1e-4
+            if r >= 1:
+                break
+    finally:
+        scen.t1, scen.p0s, scen.p1s = keep
+
+
+def test_unusable_rows_are_refused_at_once():
+    """PHIMAX = 0 (an unset row), VMIN >= VMAX or VMIN <= 0 gave a zero-width box and NaN pivots for outer_max x 30
+    assemblies; such a problem now reports D2D_ST_NONFINITE with NaN cost immediately, its neighbours in the batch are unaffected."""
+    import d2dhip
+    ctx = d2dhip.default_context()
+    N, h = 31, 0.1
+    row = np.zeros(d2dhip.SCEN_STRIDE)
+    row[d2dhip.SC_X1] = 35.0; row[d2dhip.SC_VSP], row[d2dhip.SC_KV], row[d2dhip.SC_S] = 12., 1., 1. / N
+    row[d2dhip.SC_PHIMAX], row[d2dhip.SC_VMIN], row[d2dhip.SC_VMAX] = np.deg2rad(30.), 9., 15.
+    rows = np.tile(row, (4, 1))
+    rows[1, d2dhip.SC_PHIMAX] = 0.0
+    rows[2, d2dhip.SC_VMIN] = 16.0
+    rows[3, d2dhip.SC_VMIN] = 0.0
+    W0 = np.stack([np.linspace(0, 35, N), np.zeros(N), np.zeros(N), np.zeros(N), np.full(N, 12.)])
+    W = ctx.dev(np.tile(W0, (4, 1, 1)))
+    out = ctx.nlp_solve(ctx.dev(rows), W, h)
+    ctx.sync()
+    st = out['status'].cpu().numpy(); it = out['iters'].cpu().numpy(); c = out['cost'].cpu().numpy()
+    assert st[0] == 1 and np.isfinite(c[0])
+    assert (st[1:] == d2dhip.ST_NONFINITE).all() and (it[1:] == 0).all() and np.isnan(c[1:]).all()
