@@ -180,6 +180,36 @@ def cpu_baseline_nlp(n=3):
             'sample': f'oracle/nlp.py solve() on the first {n} problems of the batch', 'cost': costs, 'newton_steps': steps}
 
 
+def _nlp_oracle_one(args):
+    from oracle import nlp as ON
+    row, W0, h = args
+    pb = ON.problem_from_row(row, W0.shape[1], h)
+    _, info = ON.solve(pb, W0.T.copy())
+    return info['status'], info['cost'], info['feas'], info['inner']
+
+
+def nlp_verify(rows, W0, h, st, cost, feas, n_each=32):
+    """The GPU's verdicts against the oracle's solver (oracle/nlp.py, the CPU statement of the same algorithm) on a sample that
+    holds n_each problems the GPU reported D2D_ST_STALLED (no feasible point: the perturbed end poses cannot be joined in 12 s at
+    v <= 15) and n_each it reported converged: status, residual and cost of both.  (Spawned pool: the GPU context exists.)"""
+    import multiprocessing as mp
+    stalled = np.nonzero(st == 4)[0][:n_each]; conv = np.nonzero(st == 1)[0][:n_each]
+    idx = np.concatenate([stalled, conv])
+    with mp.get_context('spawn').Pool(min(_host_cores(), 16)) as pool:
+        res = pool.map(_nlp_oracle_one, [(rows[i], W0[i], h) for i in idx], chunksize=1)
+    o_st = np.array([r[0] for r in res]); o_cost = np.array([r[1] for r in res]); o_feas = np.array([r[2] for r in res])
+    ns = len(stalled)
+    rec = {'n': int(len(idx)), 'stalled_sampled': int(ns), 'converged_sampled': int(len(conv)),
+           'what': 'oracle/nlp.py solve() on the sampled problems (spawned pool): same verdict, and for the stalled ones the same residual',
+           'status_agree_frac': float(np.mean(o_st == st[idx])),
+           'stalled_both': int(np.sum(o_st[:ns] == 4)),
+           'stalled_residual_gpu_min_max': [float(feas[stalled].min()), float(feas[stalled].max())] if ns else None,
+           'stalled_residual_oracle_min_max': [float(o_feas[:ns].min()), float(o_feas[:ns].max())] if ns else None,
+           'stalled_max_rel_residual_diff': float(np.max(np.abs(o_feas[:ns] - feas[stalled]) / np.maximum(feas[stalled], 1e-300))) if ns else None,
+           'converged_max_rel_cost_diff': float(np.max(np.abs(o_cost[ns:] - cost[conv]) / np.abs(cost[conv]))) if len(conv) else None}
+    return rec
+
+
 def nlp_record(ctx, torch, cpu, B=4096):
     """the collocation-NLP backend (d2d_nlp_solve, what opty.direct_collocation.Problem(...).solve runs) on B perturbed
     copies of the reference's exp_14, one launch, one wavefront per problem."""
@@ -192,7 +222,7 @@ def nlp_record(ctx, torch, cpu, B=4096):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         out = ctx.nlp_solve(dsc, W, h)
         torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
-    st, it, cost = out['status'].cpu().numpy(), out['iters'].cpu().numpy(), out['cost'].cpu().numpy()
+    st, it, cost, feas = out['status'].cpu().numpy(), out['iters'].cpu().numpy(), out['cost'].cpu().numpy(), out['feas'].cpu().numpy()
     rec = {'metric': 'collocation problems/sec (121 nodes x 5 node variables, hard bounds)', 'value': B / best, 'unit': 'problems/s',
            'workload': f'{B} perturbed copies of optyplan_scenarios.exp_14 (end poses moved by N(0, [3 m, 3 m, 0.1 rad])), tri initial guess',
            'seconds': best, 'dtype': 'f64', 'converged_frac': float((st == 1).mean()),
@@ -206,6 +236,7 @@ def nlp_record(ctx, torch, cpu, B=4096):
                        'frac': alg / best / 1e9 / HBM_PEAK_GBS, 'traffic': rec['hbm_traffic_per_launch'], 'alg_bytes_per_launch': alg,
                        'note': 'latency-bound on the twisted 3x3 block recursion (one wavefront per problem, two waves per SIMD); traffic = FETCH_SIZE + WRITE_SIZE of the committed PMC passes'}
     if cpu is not None:
+        rec['verdicts_vs_oracle'] = nlp_verify(rows, W0, h, st, cost, feas)
         n = len(cpu['cost'])
         rec['parity'] = {'n': n, 'max_rel_cost_diff_vs_oracle': float(np.max(np.abs(cost[:n] - np.array(cpu['cost'])) / np.array(cpu['cost']))),
                          'newton_steps_gpu': it[:n].tolist(), 'newton_steps_oracle': cpu['newton_steps']}

@@ -139,6 +139,8 @@ class Planner:
         self.solution, self.info = self.prob.solve(initial_guess)
         if self.backend == 'nlp':
             self.fit_q = self.fit_plan = self.fit_scen = self.fit_coefs = None
+        else:
+            sop.Planner._harden(self)      # backend='auto': a plan that overshoots a bound is re-planned by the collocation backend
 
     def interpret_solution(self):
         self.sol_time = np.linspace(0.0, self.duration, num=self.num_nodes)

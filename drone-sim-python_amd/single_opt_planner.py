@@ -18,7 +18,11 @@ seed = None
 #   'fit' -- the batched polynomial fit (flat outputs, soft bounds; the north-star path)
 #   'nlp' -- opty.direct_collocation.Problem on the GPU: the reference's own parameterisation (node values, backward-Euler
 #            equalities, HARD bounds), built by the very call the reference makes (src/single_opt_planner.py:62-71)
-BACKEND = 'fit'
+#   'auto' (default) -- the fit first; if its plan overshoots a bound of the scenario (phi, v or the x / y box: the fit's bounds are
+#            soft rows) by more than AUTO_TOL, the collocation problem is solved from that plan, so that what a script gets from
+#            Planner(scen).run() never violates a bound IPOPT would have enforced; info['backend_used'] says which one answered
+BACKEND = 'auto'
+AUTO_TOL = 1e-6        # rad, m/s, m
 N_SEG = 6
 W_WAYPOINT = 0.02      # weight of the 'tri' waypoint rows (regulariser)
 W_BOUND = 1.0          # weight of the soft phi / v bound rows
@@ -179,6 +183,29 @@ class Planner:
         elif initialize:
             self.prob = _FitProblem(self, 1)
 
+    def _harden(self):
+        """backend='auto': the fit's plan overshoots a bound -> the collocation problem (hard bounds), started from that plan."""
+        viol = max(self.info.get('box_violation', 0.), self.info.get('phi_violation', 0.), self.info.get('v_violation', 0.))
+        self.info['backend_used'] = 'fit'
+        if self.backend != 'auto' or not (viol > AUTO_TOL):
+            return
+        try:
+            hard = type(self)(getattr(self, 'exp', None) or self.scen, initialize=True, backend='nlp')
+            for k, v in self.prob.options.items():
+                if k in ('tol',):
+                    hard.prob.addOption(k, v)
+            sol, info = hard.prob.solve(self.solution)
+        except NotImplementedError as e:     # a cost / bound variant without a collocation kernel: the soft-bound plan stands, and says so
+            self.info['nlp_status'] = f'unsupported: {e}'
+            return
+        st = np.atleast_1d(info['status'])
+        info['fit_info'] = self.info
+        if (st == 1).all():
+            info['backend_used'] = 'nlp'
+            self.solution, self.info = sol, info
+        else:                              # (e.g. a scenario whose bounds cannot all hold: the soft-bound compromise is what there is)
+            self.info['nlp_status'] = info['status']
+
     def configure(self, tol=1e-8, max_iter=3000):
         self.prob.addOption('tol', tol)
         self.prob.addOption('max_iter', max_iter)
@@ -230,6 +257,8 @@ class Planner:
         if initial_guess is None:
             initial_guess = self.get_initial_guess('tri')
         self.solution, self.info = self.prob.solve(initial_guess)
+        if self.backend != 'nlp':
+            self._harden()
         self.interpret_solution()
 
     def interpret_solution(self):

@@ -257,8 +257,10 @@ def _trap4_like_the_golden(gold, tag='st_line'):
     g = gold('planner_feasibility_goldens')
     W = g[tag + '_W']                                    # (4, 5, N)
     t = g[tag + '_time']
+    import d2d.multiopty_utils as d2mou
     scen = mop.trap_4
-    keep = (scen.t1, scen.p0s, scen.p1s)
+    keep = (scen.t1, scen.p0s, scen.p1s, scen.cost)
+    scen.cost = d2mou.CostComposit(kvel=70., kbank=1., kobs=float('NaN'), kcol=10., vsp=12., obss=[], obs_kind=0, rcol=10)
     scen.t1 = float(t[-1])
     scen.p0s = tuple((W[a, 0, 0], W[a, 1, 0], W[a, 2, 0], 0., 12.) for a in range(4))
     scen.p1s = tuple((W[a, 0, -1], W[a, 1, -1], W[a, 2, -1], 0., 12.) for a in range(4))
@@ -300,7 +302,7 @@ def test_joint_multi_aircraft_problem_reproduces_the_committed_plan(gold):
         assert all(s == 1 for s in _q.info['status']), _q.info
         assert scen.cost.cost(_q.solution, _q) <= c * (1 + 1e-3)
     finally:
-        scen.t1, scen.p0s, scen.p1s = keep
+        scen.t1, scen.p0s, scen.p1s, scen.cost = keep
 
 
 def test_joint_problems_in_batches_equal_the_single_launches(gold):
@@ -351,7 +353,7 @@ def test_joint_problems_in_batches_equal_the_single_launches(gold):
             if r >= 1:
                 break
     finally:
-        scen.t1, scen.p0s, scen.p1s = keep
+        scen.t1, scen.p0s, scen.p1s, scen.cost = keep
 
 
 def test_unusable_rows_are_refused_at_once():
