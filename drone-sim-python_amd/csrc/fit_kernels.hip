@@ -1151,7 +1151,9 @@ fit_lm_long_kernel(int B, FitGeom g, LongLds L, d2d_fit_opts opts, int iter_budg
                    const float *__restrict__ gG32, const float *__restrict__ gWt, const double *__restrict__ prep,
                    double *__restrict__ q_io, double *__restrict__ cost_io, double *__restrict__ g_io,
                    double *__restrict__ lm, int32_t *__restrict__ flags, int32_t *__restrict__ queue,
-                   const int32_t *__restrict__ order) {
+                   const int32_t *__restrict__ order, GroupArgs ga) {
+  // ga (coupled groups): trajectory of hand-out position i = ga.off + i * ga.stride (one aircraft index of every scenario per
+  // launch), collision rows against the positions table ga.pos; uncoupled: {nullptr, 0, 0, 1, 0}
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   constexpr int N = 16 * NB, NT = NB * (NB + 1) / 2;
   stage(lds + L.Wt, gWt, NT * 256 * 4);
@@ -1183,8 +1185,9 @@ fit_lm_long_kernel(int B, FitGeom g, LongLds L, d2d_fit_opts opts, int iter_budg
     return __builtin_amdgcn_readfirstlane(t);
   };
   for (int bi = blockIdx.x + gridDim.x * wave; (unsigned)bi < (unsigned)B; bi = next_index(bi)) {
-    const int b = order ? __builtin_amdgcn_readfirstlane(order[bi]) : bi;
+    const int b = ga.off + (order ? __builtin_amdgcn_readfirstlane(order[bi]) : bi) * ga.stride;
     if (flags[4 * b + FL_STATUS] != D2D_ST_RUNNING) continue;
+    const GroupCtx gc{ga.pos, ga.n_ac, ga.n_ac > 0 ? b % ga.n_ac : 0, ga.n_ac > 0 ? (b / ga.n_ac) * ga.n_ac : 0, ga.pos ? ga.nds : 0};
     const double *pkb = pk + (size_t)b * FIT_PK * g.K;
     double qi = act ? q_io[(size_t)b * n + lane] : 0.0;
     double lam = lm[LM_STRIDE * b + 0], nu = lm[LM_STRIDE * b + 1];
@@ -1217,7 +1220,7 @@ fit_lm_long_kernel(int B, FitGeom g, LongLds L, d2d_fit_opts opts, int iter_budg
       wave_lds_sync();
       const int kbank = long_bank_argmax<NQ, TL>(g, GT, pkb, qs, load_scenp(sp), lane);
       double ca = 0.0;
-      for (int k0 = 0; k0 < g.K; k0 += 64) ca += long_phase1<NQ, false, TL>(g, GT, pkb, sp, qs, us, cf, cfp, false, kbank, k0, lane);
+      for (int k0 = 0; k0 < g.K; k0 += 64) ca += long_phase1<NQ, false, TL>(g, GT, pkb, sp, qs, us, cf, cfp, false, kbank, k0, lane, gc);
       return uniform_d(ca);
     };
     // full evaluation at qi: c, gi, and (want_H) hrow = this lane's row of J^T J (+ the waypoint block) with -g as row N
@@ -1231,7 +1234,7 @@ fit_lm_long_kernel(int B, FitGeom g, LongLds L, d2d_fit_opts opts, int iter_budg
       double ca = 0.0, ga = 0.0;
       for (int k0 = 0; k0 < g.K; k0 += 64) {
         const int kn = g.K - k0 < 64 ? g.K - k0 : 64;
-        ca += long_phase1<NQ, true, TL>(g, GT, pkb, sp, qs, us, cf, cfp, so, kbank, k0, lane);
+        ca += long_phase1<NQ, true, TL>(g, GT, pkb, sp, qs, us, cf, cfp, so, kbank, k0, lane, gc);
         ga += long_phase2<NQ>(g, G64g, us, k0, kn, lane);
         if (want_H) {
           const int toff = L.G32 + 4 * k0 * nq;                            // this chunk's first row of the fp32 planes (LDS copy)
@@ -1709,7 +1712,7 @@ static int launch_lm(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, double *q, con
   return D2D_OK;
 }
 
-static int launch_lm_long(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, double *q, const d2d_fit_opts &o, int budget) {
+static int launch_lm_long(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, double *q, const d2d_fit_opts &o, int budget, GroupArgs ga = no_groups()) {
   const FitGeom gm = geom_of(pl);
   const int NB = (2 * pl->nq + 15) / 16;
   // D2D_FIT_LONG_TABLES (A/B switch): 0 = both tables from global memory, 1 = fp64 block in the LDS and the fp32 planes from global
@@ -1725,10 +1728,10 @@ static int launch_lm_long(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, double *q
   const int blocks = B < pl->n_cu ? B : pl->n_cu;
   static const bool no_queue = getenv("D2D_LM_STATIC") != nullptr;
   int32_t *queue = no_queue ? nullptr : ctx->counter_dev + 8;
-  const int32_t *order = (pl->order_B == B) ? pl->d_order : nullptr;
+  const int32_t *order = (pl->order_B == B && ga.pos == nullptr) ? pl->d_order : nullptr;
 #define LAUNCH_LONG__(NBV, NQV, TLV, TL32V, MODEV)                                                                     \
   hipLaunchKernelGGL((fit_lm_long_kernel<NBV, NQV, TLV, TL32V, MODEV>), dim3(blocks), dim3(64 * wpb), L.total, ctx->stream, B, gm, L, o, budget, \
-                     pl->d_GT, pl->d_G, pl->d_pk, pl->d_G32, pl->d_W32, pl->d_prep, q, pl->d_cost, pl->d_g, pl->d_lm, pl->d_flags, queue, order)
+                     pl->d_GT, pl->d_G, pl->d_pk, pl->d_G32, pl->d_W32, pl->d_prep, q, pl->d_cost, pl->d_g, pl->d_lm, pl->d_flags, queue, order, ga)
 #define LAUNCH_LONG_(NBV, NQV, TLV, TL32V) do { if (o.mode == D2D_LM_MODE_FAST) LAUNCH_LONG__(NBV, NQV, TLV, TL32V, D2D_LM_MODE_FAST); else LAUNCH_LONG__(NBV, NQV, TLV, TL32V, D2D_LM_MODE_MINPACK); } while (0)
 #define LAUNCH_LONG(NBV, NQV) do { if (mode == 2) LAUNCH_LONG_(NBV, NQV, true, true); else if (mode == 1) LAUNCH_LONG_(NBV, NQV, true, false); else LAUNCH_LONG_(NBV, NQV, false, false); } while (0)
   if (pl->nq == 24) LAUNCH_LONG(3, 24);
@@ -2158,8 +2161,12 @@ int d2d_fit_plan_set_groups(d2d_fit_plan *pl, int n_ac) {
     if (pl->split_ok && pick_eval_layout(pl->K, pl->nq, &g32, &we, 0)) { pl->g32_lds = g32; pl->wpb_eval = we; }
     return D2D_OK;
   }
-  D2D_REQUIRE(pl->split_ok, "d2d_fit_plan_set_groups: K=%d does not fit the LDS image of the coupled-group kernels", pl->K);
   const int nds = n_ac > 1 ? 4 * ((n_ac - 1 + 3) / 4) : 0;
+  if (!pl->split_ok) {                  // long horizons: the visits of d2d_fit_solve_groups run on the chunked persistent kernel (any K)
+    D2D_REQUIRE(pl->use_long, "d2d_fit_plan_set_groups: K=%d fits neither the coupled-group kernels nor the long-horizon kernel", pl->K);
+    pl->n_group = n_ac; pl->nds = nds;
+    return D2D_OK;
+  }
   bool g32;
   int we, ws;
   const int N = 16 * ((2 * pl->nq + 15) / 16);
@@ -2235,6 +2242,10 @@ int d2d_fit_solve_groups(d2d_ctx *ctx, d2d_fit_plan *pl, int R, const double *sc
     return D2D_OK;
   }
   // ---- launch-pair path (other plan shapes): every scenario sweeps until the slowest one has settled
+  // (D2D_GROUPS_LONG=1: tests force the chunked kernel on a horizon the launch-pair kernels also hold)
+  const bool long_path = !pl->split_ok || (pl->use_long && getenv("D2D_GROUPS_LONG") != nullptr);
+  d2d_fit_opts o_long = o;
+  o_long.mode = D2D_LM_MODE_FAST; o_long.so_lambda = 0.0; o_long.max_iter = inner_iters; o_long.slice = 0;
   const FitGeom gm = geom_of(pl);
   const dim3 gB((B + 255) / 256), b1(256), gR((R + 255) / 256);
   hipLaunchKernelGGL(fit_state_init_kernel, gB, b1, 0, ctx->stream, B, 0, 1, pl->d_lm, pl->d_flags, (int32_t *)nullptr);
@@ -2248,6 +2259,13 @@ int d2d_fit_solve_groups(d2d_ctx *ctx, d2d_fit_plan *pl, int R, const double *sc
       hipLaunchKernelGGL(fit_state_init_kernel, gR, b1, 0, ctx->stream, R, i, n_ac, pl->d_lm, pl->d_flags, (int32_t *)nullptr);
       D2D_LAUNCH_CHECK();
       const GroupArgs ga{pl->d_pos, n_ac, i, n_ac, pl->nds};
+      if (long_path) {
+        // long horizons (the basis does not fit the launch-pair kernels' LDS image, e.g. 07_multioptyplan's 276- and 401-node
+        // scenarios): the visit is ONE launch of the chunked persistent kernel on aircraft i of every scenario, Gauss-Newton rows
+        D2D_CHECK_HIP(hipMemsetAsync(ctx->counter_dev + 8, 0, 2 * sizeof(int32_t), ctx->stream));
+        if (int rc = launch_lm_long(ctx, pl, R, q, o_long, inner_iters, ga)) return rc;
+        continue;
+      }
       for (int it = 0; it < inner_iters; ++it) {
         if (int rc = launch_eval(ctx, pl, R, q, pl->d_flags, pl->d_cost, pl->d_g, pl->d_H, ga)) return rc;
         if (int rc = launch_step(ctx, pl, R, q, o, ga)) return rc;
@@ -2265,7 +2283,11 @@ int d2d_fit_solve_groups(d2d_ctx *ctx, d2d_fit_plan *pl, int R, const double *sc
   hipLaunchKernelGGL(fit_pos_kernel, dim3(((long)B * pl->K + 255) / 256), b1, 0, ctx->stream, B, gm, pl->d_G, pl->d_Gp, pl->d_prep, q, pl->d_pos);
   D2D_LAUNCH_CHECK();
   const GroupArgs gall{pl->d_pos, n_ac, 0, 1, pl->nds};
-  if (int rc = launch_eval(ctx, pl, B, q, nullptr, pl->d_cost, pl->d_g, nullptr, gall)) return rc;
+  if (long_path) {       // an evaluation-only pass of the chunked kernel: every trajectory RUNNING with no iterations left
+    hipLaunchKernelGGL(fit_state_init_kernel, gB, b1, 0, ctx->stream, B, 0, 1, pl->d_lm, pl->d_flags, ctx->counter_dev + 8);
+    D2D_LAUNCH_CHECK();
+    if (int rc = launch_lm_long(ctx, pl, B, q, o_long, 0, gall)) return rc;
+  } else if (int rc = launch_eval(ctx, pl, B, q, nullptr, pl->d_cost, pl->d_g, nullptr, gall)) return rc;
   if (cost) D2D_CHECK_HIP(hipMemcpyAsync(cost, pl->d_cost, (size_t)B * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
   if (stats) {
     D2D_CHECK_HIP(hipMemsetAsync(ctx->stats_dev, 0, 4 * sizeof(double), ctx->stream));

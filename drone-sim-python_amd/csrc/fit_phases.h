@@ -218,10 +218,12 @@ __device__ __forceinline__ int long_bank_argmax(const FitGeom &g, const double *
 // second-order mode), chunk-local indices; a lane beyond the horizon writes zero records (the MFMA passes read the
 // whole chunk up to its last sample and one padded sample).  Returns the chunk's sum r^2 (wave-uniform).
 // WANT_JAC = false: the cost alone (trial points).
+// gc (coupled groups, the long-horizon path of d2d_fit_solve_groups): the collision rows against the partners' frozen positions
+// join the two contracted position rows through partner_sums -> sample_terms' xin, as in eval_phase1_grp (Gauss-Newton rows only).
 template <int NQ, bool WANT_JAC, bool TL = false>
 __device__ __forceinline__ double long_phase1(const FitGeom &g, const double *GT, const double *__restrict__ pkb,
                                               const double *sp, const double *qs, double *us, f32x4 *cf, float2 *cfp,
-                                              bool so, int kbank, int k0, int lane) {
+                                              bool so, int kbank, int k0, int lane, const GroupCtx &gc = GroupCtx{nullptr, 1, 0, 0, 0}) {
   LAUNDER(lane);
   const int k = k0 + lane;
   double cacc = 0.0;
@@ -232,15 +234,18 @@ __device__ __forceinline__ double long_phase1(const FitGeom &g, const double *GT
     for (int c = 0; c < FIT_PK; ++c) pk[c] = pkb[(size_t)c * g.K + k];
     if (TL) flat_outputs_pk<NQ>(g, GT, qs, pk, k, Y); else flat_outputs_gt<NQ>(g, GT, qs, pk, k, Y);
     const ScenP s = load_scenp(sp);
+    double xin[6];
+    const bool grp = gc.pos != nullptr;
+    if (grp) partner_sums(s, gc, g.K, k, Y[0], Y[1], xin);
     if (!WANT_JAC) {
-      cacc = sample_terms<false>(s, Y, pk[6], pk[7], nullptr, nullptr, k == kbank);
+      cacc = sample_terms<false>(s, Y, pk[6], pk[7], nullptr, nullptr, k == kbank, nullptr, grp ? xin : nullptr);
     } else {
       if (so) {
         float2 pos[2];
         cacc = sample_terms<true>(s, Y, pk[6], pk[7], u, coef, k == kbank, pos);
         cfp[lane * 2] = pos[0]; cfp[lane * 2 + 1] = pos[1];
       } else {
-        cacc = sample_terms<true>(s, Y, pk[6], pk[7], u, coef, k == kbank);
+        cacc = sample_terms<true>(s, Y, pk[6], pk[7], u, coef, k == kbank, nullptr, grp ? xin : nullptr);
       }
 #pragma unroll
       for (int c = 0; c < 6; ++c) us[lane * 6 + c] = u[c];

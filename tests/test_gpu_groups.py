@@ -98,3 +98,55 @@ def test_groups_config2_batch_properties(env):
     with pytest.raises(d2dhip.D2DError):
         plan.group_order_from_last(R + 1)          # no sweep counts of a solve over R + 1 scenarios
     plan.set_groups(1)
+
+
+def test_long_horizon_groups_on_the_chunked_kernel(monkeypatch):
+    """Coupled groups beyond the LDS image of the group kernels (07_multioptyplan's 50 Hz scenarios: exp_2 276 nodes, exp_5 401):
+    every visit of the block Gauss-Seidel is one launch of the chunked persistent kernel with the collision rows in its phase 1.
+    At K = 71 both paths exist: the same fixed points as the launch-pair kernels and as the oracle's bgs_solve; at K = 301 (only
+    the chunked path) against the oracle and the joint scipy arbiter."""
+    import d2dhip
+    from d2dhip import synth
+    from scipy.optimize import least_squares
+    ctx = d2dhip.Context(0)
+    try:
+        for K2, hz, both in ((71, 10.0, True), (301, 50.0, False)):
+            dur = F.planner_timing(0, (K2 - 1) / hz, hz)[2]
+            n_ac, R = 4, 3
+            s = 1.0 / K2
+            plan = d2dhip.FitPlan(ctx, S_, K2, dur, (0.02 ** 2, s * 5.0 / n_ac, s / n_ac / F.G_ACC ** 2))
+            ob = F.FitBasis.from_arrays(S_, K2, dur, *plan.basis())
+            sc = synth.circle_group_scenarios(n_ac, R, dur, K2, seed=3, obj_scale=1.0)
+            dsc = ctx.dev(sc.reshape(R * n_ac, -1))
+            try:
+                assert plan.kernel == 'long'
+                monkeypatch.setenv('D2D_GROUPS_LONG', '1')
+                qa = plan.init(dsc)
+                ca, swa, sta = plan.solve_groups(dsc, qa, n_ac, max_sweeps=80, inner_iters=8, tol=1e-12)
+                monkeypatch.delenv('D2D_GROUPS_LONG')
+                assert swa < 80 and sta[2] <= 1e-12, (swa, sta)
+                qh = qa.cpu().numpy().reshape(R, n_ac, -1)
+                if both:
+                    qb = plan.init(dsc)
+                    cb, swb, stb = plan.solve_groups(dsc, qb, n_ac, max_sweeps=80, inner_iters=8, tol=1e-12)
+                    assert np.abs(qa.cpu().numpy() - qb.cpu().numpy()).max() <= 1e-6 * np.abs(qb.cpu().numpy()).max()
+                    np.testing.assert_allclose(ca.cpu().numpy(), cb.cpu().numpy(), rtol=1e-8)
+                r = 0
+                qo, co, swo = F.bgs_solve(ob, sc[r], sweeps=80, inner_iters=8, tol=1e-12)
+                zg = np.array([F.coefficients(ob, sc[r, i], qh[r, i]) for i in range(n_ac)])
+                zo = np.array([F.coefficients(ob, sc[r, i], qo[i]) for i in range(n_ac)])
+                assert np.abs(zg - zo).max() <= 1e-6 * np.abs(zo).max()
+                cj = F.group_cost(ob, sc[r], qh[r])
+                assert abs(co - cj) <= 1e-6 * cj
+                pol = least_squares(lambda x: F.group_residuals(ob, sc[r], x), qh[r].reshape(-1), method='lm', xtol=1e-14, ftol=1e-14, gtol=1e-14)
+                assert abs(2 * pol.cost - cj) <= 1e-6 * cj
+                pos = F.group_positions(ob, sc[r], qh[r])
+                chh = ca.cpu().numpy().reshape(R, n_ac)
+                for i in range(n_ac):
+                    oth = [pos[j] for j in F.partners(sc[r, i], i, n_ac)]
+                    assert abs(chh[r, i] - F.cost(ob, sc[r, i], qh[r, i], others=oth)) <= 1e-9 * max(chh[r, i], 1e-3)
+            finally:
+                plan.set_groups(1)
+                plan.close()
+    finally:
+        ctx.close()
