@@ -61,10 +61,31 @@ def pmc_traffic(kernel):
     tools/condense_profile.py -> profiles/r02/06_bench_final_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate passes,
     corrected as MI355X_MICROARCH.md prescribes).  bench.py cannot read hardware counters itself; None when the file is absent."""
     try:
-        t = json.load(open(os.path.join(ROOT, 'profiles', 'r02', '06_bench_final_traffic.json')))[kernel][0]
+        import glob
+        files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r03', '*_traffic.json'))) or [os.path.join(ROOT, 'profiles', 'r02', '06_bench_final_traffic.json')]
+        t = json.load(open(files[-1]))[kernel][0]
+        t['file'] = os.path.relpath(files[-1], ROOT)
     except (OSError, KeyError, IndexError, ValueError):
         return None, None
     return t['fetch_bytes_per_launch'] + t['write_bytes_per_launch'], t
+
+
+def pmc_valu(kernel, launch_s):
+    """roofline against the fp64 vector pipe for the kernels it bounds (the simulation loops): executed fp64 flop per launch from the
+    committed rocprofv3 pass of THIS command (profiles/r03/*_valu.json, tools/condense_profile.py) over the launch time measured
+    here.  None when the file is absent."""
+    for rnd in ('r03',):
+        try:
+            import glob
+            f = sorted(glob.glob(os.path.join(ROOT, 'profiles', rnd, '*_valu.json')))[-1]
+            v = json.load(open(f))[kernel]
+        except (OSError, KeyError, IndexError, ValueError):
+            continue
+        tf = v['fp64_flop_per_launch'] / launch_s / 1e12
+        return {'bound': 'valu_fp64', 'kernel': kernel, 'achieved': tf, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': tf / FP64_PEAK_TFLOPS,
+                'executed_fp64_flop_per_launch': v['fp64_flop_per_launch'], 'valu_wave_insts_per_launch': v['valu_insts'], 'source': os.path.basename(f),
+                'note': 'executed flop = (2 FMA + MUL + ADD) x 64 from SQ_INSTS_VALU_*_F64 of the committed PMC pass; one wave per SIMD at 65 536 drones'}
+    return None
 
 
 def _plan_consts():
@@ -346,7 +367,7 @@ def sim_records(ctx, torch, cpu_g, cpu_t, drones=65536, steps=10000, track_steps
                                 'unit': 'GB/s', 'frac': n_steps * 56 / dte / 1e9 / HBM_PEAK_GBS, 'traffic': pmc_traffic('gvf_run_kernel')[0], 'alg_bytes_per_unit': 56,
                                 'note': 'integration-bound (fp64 VALU); HBM GB/s reported as BASELINE configs[4] asks; PMC WRITE_SIZE = '
                                         'algorithmic to 0.03 % (profiles/)'},
-                   'cpu_baseline': cpu_g}
+                   'roofline_valu': pmc_valu('gvf_run_kernel', dte), 'cpu_baseline': cpu_g}
     del out
     torch.cuda.empty_cache()
     T = track_steps + 1
@@ -363,7 +384,7 @@ def sim_records(ctx, torch, cpu_g, cpu_t, drones=65536, steps=10000, track_steps
                      'roofline': {'bound': 'hbm', 'kernel': 'gradient_kernel x4 + track_run_kernel', 'achieved': n_steps * 104 / dte / 1e9,
                                   'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': n_steps * 104 / dte / 1e9 / HBM_PEAK_GBS, 'traffic': pmc_traffic('track_run_kernel')[0],
                                   'alg_bytes_per_unit': 104, 'note': 'CARE-bound (fp64 VALU); HBM GB/s as configs[4] asks'},
-                     'cpu_baseline': cpu_t}
+                     'roofline_valu': pmc_valu('track_run_kernel', dte), 'cpu_baseline': cpu_t}
     del o
     torch.cuda.empty_cache()
     return recs

@@ -135,7 +135,14 @@ struct NlpProb {
   double *ws;                // WS_TOTAL * N doubles (see above)
   double *mu;                // [3][N]
   const double *partner;     // [2][N] or null
+  double *lds;               // this wavefront's NLP_LDS_DOUBLES doubles of LDS (nlp_assemble: neighbour hand-over, record transposition)
 };
+// LDS of one wavefront: up [65][9] (what a node hands to the node before it; row 64 = the first node of the chunk processed before),
+// then rec [64][19] (the reduced-node records of a chunk, odd stride: conflict-free both ways)
+#define NLP_LDS_UP 0
+#define NLP_LDS_REC (65 * 9)
+#define NLP_REC_STRIDE 19
+#define NLP_LDS_DOUBLES (65 * 9 + 64 * NLP_REC_STRIDE)
 #define NLP_W(c, i) pb.W[(c) * pb.N + (i)]
 #define NLP_P(plane, i) pb.ws[(plane) * pb.N + (i)]
 #define NLP_MU(k, i) pb.mu[(k) * pb.N + (i)]
@@ -237,9 +244,14 @@ __device__ double nlp_assemble(const NlpProb &pb, const NlpScen &s, const double
   const double h = pb.h, ih = 1.0 / h;
   double err = 0.0;
   int bad = 0;
-  for (int i0 = 0; i0 < N; i0 += 64) {
+  // The chunks of 64 nodes are visited from the LAST to the first: node i needs what node i+1 hands to it (the hand-over of the
+  // elimination, below), and for the last lane of a chunk that is the first node of the chunk visited before.
+  double *lds_up = pb.lds + NLP_LDS_UP, *lds_rec = pb.lds + NLP_LDS_REC;
+  for (int i0 = ((N - 1) / 64) * 64; i0 >= 0; i0 -= 64) {
     const int i = i0 + lane;
-    if (i >= N) continue;
+    const bool live = i < N;
+    double sinv[SIN_N], upv[9];
+    if (live) {
     const bool has_next = i + 1 < N;
     double rhsv[NLP_NV];
     double wp[3] = {0, 0, 0}, wc[NLP_NV], wn[NLP_NV] = {0, 0, 0, 0, 1};
@@ -364,19 +376,53 @@ __device__ double nlp_assemble(const NlpProb &pb, const NlpScen &s, const double
       for (int k = 0; k < 3; ++k) { NLP_EL(EL_Q + j * 3 + k, i) = Qt[j][k]; NLP_EL(EL_R + j * 3 + k, i) = Rt[j][k]; }
       NLP_EL(EL_T + j, i) = tt[j];
     }
-    // what node i-1 gets from this node's elimination, and this node's own part of the reduced node (node-major)
+    // what node i-1 gets from this node's elimination, and this node's own part of the reduced node
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
 #pragma unroll
       for (int c = 0; c <= a; ++c) {
-        NLP_UP(UP_RR + a * (a + 1) / 2 + c, i) = Rt[0][a] * Rt[0][c] + Rt[1][a] * Rt[1][c];
-        NLP_SIN(SIN_D + a * (a + 1) / 2 + c, i) = D[a][c] - (Qt[0][a] * Qt[0][c] + Qt[1][a] * Qt[1][c]);
+        upv[UP_RR + a * (a + 1) / 2 + c] = Rt[0][a] * Rt[0][c] + Rt[1][a] * Rt[1][c];
+        sinv[SIN_D + a * (a + 1) / 2 + c] = D[a][c] - (Qt[0][a] * Qt[0][c] + Qt[1][a] * Qt[1][c]);
       }
-      NLP_UP(UP_RT + a, i) = Rt[0][a] * tt[0] + Rt[1][a] * tt[1];
+      upv[UP_RT + a] = Rt[0][a] * tt[0] + Rt[1][a] * tt[1];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) NLP_SIN(SIN_E + a * 3 + k, i) = E[a][k] - (Qt[0][a] * Rt[0][k] + Qt[1][a] * Rt[1][k]);
-      NLP_SIN(SIN_T + a, i) = 0.5 * rhsv[a] - (Qt[0][a] * tt[0] + Qt[1][a] * tt[1]);
+      for (int k = 0; k < 3; ++k) sinv[SIN_E + a * 3 + k] = E[a][k] - (Qt[0][a] * Rt[0][k] + Qt[1][a] * Rt[1][k]);
+      sinv[SIN_T + a] = 0.5 * rhsv[a] - (Qt[0][a] * tt[0] + Qt[1][a] * tt[1]);
     }
+    }
+    // ---- hand-over between neighbours, D'_i -= (Rt^T Rt)_{i+1}, t'_i -= (Rt^T tt)_{i+1}, through the LDS (the records used to make
+    // a round trip through HBM for it), then the node-major records of the chunk transposed through the LDS so that they leave as
+    // full 512-byte rows: 8-byte stores at a stride of 144 bytes reached the memory as partial sectors (WRITE_SIZE 1.6 x algorithmic)
+    if (live) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) lds_up[lane * 9 + k] = upv[k];
+    }
+    nlp_phase_sync();
+    if (live && i + 1 < N) {
+      const double *nb = lds_up + (lane + 1) * 9;           // lane 63: row 64 = node i0 + 64, left there by the chunk visited before
+#pragma unroll
+      for (int k = 0; k < 6; ++k) sinv[SIN_D + k] -= nb[UP_RR + k];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) sinv[SIN_T + a] -= nb[UP_RT + a];
+    }
+    if (live) {
+#pragma unroll
+      for (int k = 0; k < SIN_N; ++k) lds_rec[lane * NLP_REC_STRIDE + k] = sinv[k];
+    }
+    nlp_phase_sync();
+    if (lane == 0) {                                        // this chunk's first node for the chunk below
+#pragma unroll
+      for (int k = 0; k < 9; ++k) lds_up[64 * 9 + k] = upv[k];
+    }
+    {
+      const int cnt = (N - i0 < 64 ? N - i0 : 64) * SIN_N;
+      double *dst = pb.ws + (size_t)WS_SIN * N + (size_t)i0 * SIN_N;
+      for (int e = lane; e < cnt; e += 64) {
+        const int node = e / SIN_N;
+        dst[e] = lds_rec[node * NLP_REC_STRIDE + (e - node * SIN_N)];
+      }
+    }
+    nlp_phase_sync();
   }
   *pd_out = __builtin_amdgcn_ballot_w64(bad != 0) == 0ull;
   return wave_max(err);
@@ -389,17 +435,6 @@ __device__ double nlp_assemble(const NlpProb &pb, const NlpScen &s, const double
 // the serial chain.
 // The elimination itself is the tail of nlp_assemble (the blocks are in registers there); what remains is the hand-over between
 // neighbours (lane = node):  D'_i -= (Rt^T Rt)_{i+1},  t'_i -= (Rt^T tt)_{i+1}.
-__device__ void nlp_eliminate_b(const NlpProb &pb, int lane) {
-  const int N = pb.N;
-  for (int i0 = 0; i0 < N; i0 += 64) {
-    const int i = i0 + lane;
-    if (i + 1 >= N) continue;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) NLP_SIN(SIN_D + k, i) -= NLP_UP(UP_RR + k, i + 1);
-#pragma unroll
-    for (int a = 0; a < 3; ++a) NLP_SIN(SIN_T + a, i) -= NLP_UP(UP_RT + a, i + 1);
-  }
-}
 
 // The two serial recursions, TWISTED: the block Cholesky runs from both ends of the horizon towards the middle node m = N/2 at
 // the same time -- lanes 0..31 eliminate nodes 0, 1, .. m-1, lanes 32..63 nodes N-1, N-2, .. m+1, one instruction stream (inside a
@@ -732,7 +767,7 @@ struct NlpOut { double cost, feas; int iters, status; };
 // The solve of ONE problem by one wavefront (lane = threadIdx.x & 63): sc its scenario row, Wb [5][N] in/out, wsb its workspace,
 // multb [3][N] or null, partner [2][N] frozen positions of the CostCollision partner or null.  Wave-uniform control flow.
 __device__ __forceinline__ void nlp_solve_one(int N, double h, const d2d_nlp_opts &o, const double *__restrict__ sc, const double *partner,
-                                              double *Wb, double *wsb, double *multb, int lane, NlpOut &out, unsigned long long *stamps) {
+                                              double *Wb, double *wsb, double *multb, int lane, NlpOut &out, unsigned long long *stamps, double *ldsw) {
   // diagnostics (D2D_NLP_STAMPS): cycles per phase -- merit, assembly, factorisation, back substitution, ratio tests, update
   unsigned long long st_t = 0, st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define NLP_STAMP(k) if (st_on) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[k] += t_ - st_t; st_t = t_; }
@@ -745,6 +780,7 @@ __device__ __forceinline__ void nlp_solve_one(int N, double h, const d2d_nlp_opt
   pb.ws = wsb;
   pb.mu = multb ? multb : pb.ws + (size_t)WS_MU * N;
   pb.partner = partner;
+  pb.lds = ldsw;
   // (a row whose bounds are unset or inverted would give a zero-width box, infinite duals and NaN pivots for
   // outer_max x 30 assemblies -- refuse it at once)
   {
@@ -806,9 +842,6 @@ __device__ __forceinline__ void nlp_solve_one(int N, double h, const d2d_nlp_opt
         NLP_STAMP(1)
         if (tr == 0 && err <= tol_in) { converged = true; break; }
         if (pd) {
-          nlp_eliminate_b(pb, lane);
-          nlp_phase_sync();
-          NLP_STAMP(6)
           pd = nlp_factor(pb.ws + (size_t)WS_SIN * N, pb.ws + (size_t)WS_SF * N, pb.ws + (size_t)WS_UP * N, N);   // (UP is free by now)
         }
         NLP_STAMP(2)
@@ -897,9 +930,10 @@ nlp_solve_kernel(int B, int N, double h, d2d_nlp_opts o, const double *__restric
                  int32_t *__restrict__ iters_out, int32_t *__restrict__ status_out, unsigned long long *stamps) {
   const int b = blockIdx.x, lane = threadIdx.x;
   if (b >= B) return;
+  extern __shared__ __attribute__((aligned(16))) double nlp_lds[];
   NlpOut out;
   nlp_solve_one(N, h, o, scen + (size_t)b * D2D_SCEN_STRIDE, partner ? partner + (size_t)b * 2 * N : nullptr, W + (size_t)b * NLP_NV * N,
-                work + (size_t)b * WS_TOTAL * N, mult ? mult + (size_t)b * 3 * N : nullptr, lane, out, b == 0 ? stamps : nullptr);
+                work + (size_t)b * WS_TOTAL * N, mult ? mult + (size_t)b * 3 * N : nullptr, lane, out, b == 0 ? stamps : nullptr, nlp_lds);
   if (lane == 0) {
     cost_out[b] = out.cost;
     feas_out[b] = out.feas;
@@ -921,6 +955,7 @@ nlp_groups_kernel(int R, int n_ac, int N, double h, d2d_nlp_opts o, int max_swee
                   int32_t *__restrict__ iters_out, int32_t *__restrict__ status_out, int32_t *__restrict__ sweeps_out,
                   double *__restrict__ moved_out) {
   __shared__ double moved_s[2];
+  extern __shared__ __attribute__((aligned(16))) double nlp_lds[];
   const int r = blockIdx.x, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int b = r * n_ac + wave;
   const double *sc = scen + (size_t)b * D2D_SCEN_STRIDE;
@@ -930,7 +965,8 @@ nlp_groups_kernel(int R, int n_ac, int N, double h, d2d_nlp_opts o, int max_swee
   const bool coupled = n_ac >= 2 && scen[(size_t)(r * n_ac) * D2D_SCEN_STRIDE + D2D_SC_KCOL] > 0.0;       // wave-uniform for the whole group
   NlpOut out;
   int iters_total = 0;
-  nlp_solve_one(N, h, o, sc, nullptr, Wb, wsb, mb, lane, out, nullptr);
+  double *ldsw = nlp_lds + (size_t)wave * NLP_LDS_DOUBLES;
+  nlp_solve_one(N, h, o, sc, nullptr, Wb, wsb, mb, lane, out, nullptr, ldsw);
   iters_total += out.iters;
   if (threadIdx.x < 2) moved_s[threadIdx.x] = 0.0;
   __threadfence_block();
@@ -944,7 +980,7 @@ nlp_groups_kernel(int R, int n_ac, int N, double h, d2d_nlp_opts o, int max_swee
         if (wave == turn) {
           const double *pw = W + (size_t)(r * n_ac + (1 - turn)) * NLP_NV * N;      // the partner's x and y planes
           for (int i = lane; i < 2 * N; i += 64) pv[i] = Wb[i];
-          nlp_solve_one(N, h, o, sc, pw, Wb, wsb, mb, lane, out, nullptr);
+          nlp_solve_one(N, h, o, sc, pw, Wb, wsb, mb, lane, out, nullptr, ldsw);
           iters_total += out.iters;
           double m = 0.0;
           for (int i = lane; i < 2 * N; i += 64) m = fmax(m, fabs(Wb[i] - pv[i]));
@@ -987,7 +1023,7 @@ int d2d_nlp_solve(d2d_ctx *ctx, int B, int N, double h, const double *scen, cons
   D2D_REQUIRE(o.inner_max >= 1 && o.outer_max >= 1 && o.rho0 > 0 && o.mub0 > 0 && o.mub_min > 0, "d2d_nlp_solve: bad options");
   unsigned long long *stamps = nullptr;
   if (getenv("D2D_NLP_STAMPS")) D2D_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&stamps), 16 * sizeof(unsigned long long)));
-  hipLaunchKernelGGL(nlp_solve_kernel, dim3(B), dim3(64), 0, ctx->stream, B, N, h, o, scen, partner, W, work, mult, cost, feas, iters,
+  hipLaunchKernelGGL(nlp_solve_kernel, dim3(B), dim3(64), NLP_LDS_DOUBLES * sizeof(double), ctx->stream, B, N, h, o, scen, partner, W, work, mult, cost, feas, iters,
                      status, stamps);
   D2D_LAUNCH_CHECK();
   if (stamps) {                                            // diagnostics: synchronous
@@ -1014,7 +1050,8 @@ int d2d_nlp_solve_groups(d2d_ctx *ctx, int R, int n_ac, int N, double h, const d
   D2D_REQUIRE(o.inner_max >= 1 && o.outer_max >= 1 && o.rho0 > 0 && o.mub0 > 0 && o.mub_min > 0, "d2d_nlp_solve_groups: bad options");
   // scratch for the positions before a turn: the tail of aircraft 0's workspace is not free, so it lives behind the workspaces
   double *prev = work + (size_t)R * n_ac * WS_TOTAL * N;
-  hipLaunchKernelGGL(nlp_groups_kernel, dim3(R), dim3(64 * n_ac), 0, ctx->stream, R, n_ac, N, h, o, max_sweeps, tol, scen, W, work, mult, prev,
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(nlp_groups_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * NLP_LDS_DOUBLES * (int)sizeof(double));
+  hipLaunchKernelGGL(nlp_groups_kernel, dim3(R), dim3(64 * n_ac), (size_t)n_ac * NLP_LDS_DOUBLES * sizeof(double), ctx->stream, R, n_ac, N, h, o, max_sweeps, tol, scen, W, work, mult, prev,
                      cost, feas, iters, status, sweeps, moved);
   D2D_LAUNCH_CHECK();
   return D2D_OK;

@@ -46,5 +46,20 @@ for k, cs in acc.items():
             'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (KiB), separate passes, mean over the launches of the pass'
                     + ('' if wide else '; 8-B-per-lane loads: FETCH_SIZE uncalibrated for this width (MI355X_MICROARCH.md)')})
 json.dump(traffic, open(prefix + '_traffic.json', 'w'), indent=1)
+# executed fp64 flop of the simulation kernels (they are bound by the fp64 vector pipe, not by HBM): one pass of
+# SQ_INSTS_VALU_{FMA,MUL,ADD,TRANS}_F64 (wave-instructions): flop = (2 FMA + MUL + ADD) x 64 lanes, per launch
+valu = {}
+for k, cs in acc.items():
+    name = next((n for n in ('gvf_run_kernel', 'track_run_kernel', 'nlp_solve_kernel', 'nlp_groups_kernel') if n in k), None)
+    if name is None or 'SQ_INSTS_VALU_FMA_F64' not in cs:
+        continue
+    m = lambda c: sum(cs[c]) / len(cs[c]) if c in cs else 0.0        # noqa: E731
+    valu[name] = {'kernel': k[:80], 'launches': len(cs['SQ_INSTS_VALU_FMA_F64']),
+                  'fma_f64': m('SQ_INSTS_VALU_FMA_F64'), 'mul_f64': m('SQ_INSTS_VALU_MUL_F64'), 'add_f64': m('SQ_INSTS_VALU_ADD_F64'),
+                  'trans_f64': m('SQ_INSTS_VALU_TRANS_F64'), 'valu_insts': m('SQ_INSTS_VALU'),
+                  'fp64_flop_per_launch': (2 * m('SQ_INSTS_VALU_FMA_F64') + m('SQ_INSTS_VALU_MUL_F64') + m('SQ_INSTS_VALU_ADD_F64')) * 64,
+                  'note': 'rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 '
+                          '(wave-instructions, mean over the launches of the pass); executed flop = (2 FMA + MUL + ADD) x 64'}
+json.dump(valu, open(prefix + '_valu.json', 'w'), indent=1)
 print(open(prefix + '_pmc_summary.txt').read()[:3000])
 print(json.dumps(traffic, indent=1)[:2000])
