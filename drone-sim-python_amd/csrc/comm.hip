@@ -1,0 +1,116 @@
+// The convergence exchange of the sharded fit as a C-ABI entry point (d2d_allreduce_stats), for hosts without
+// torch.distributed: RCCL (the ROCm collective library over xGMI) is loaded at run time -- dlopen, so that libd2dhip.so itself
+// carries no link-time dependency on it and single-GPU users never touch it.
+#include <dlfcn.h>
+
+#include <cstring>
+
+#include "common.h"
+
+namespace {
+// the handful of RCCL declarations used (rccl.h: ncclUniqueId is 128 opaque bytes; ncclFloat64 = 8; ncclSum = 0, ncclMax = 2)
+struct UniqueId { char internal[128]; };
+typedef void *Comm;
+typedef int (*GetUniqueIdFn)(UniqueId *);
+typedef int (*CommInitRankFn)(Comm *, int, UniqueId, int);
+typedef int (*CommDestroyFn)(Comm);
+typedef int (*AllReduceFn)(const void *, void *, size_t, int, int, Comm, hipStream_t);
+typedef int (*GroupFn)(void);
+typedef const char *(*ErrStrFn)(int);
+struct Rccl {
+  void *h = nullptr;
+  GetUniqueIdFn get_id = nullptr;
+  CommInitRankFn init_rank = nullptr;
+  CommDestroyFn destroy = nullptr;
+  AllReduceFn all_reduce = nullptr;
+  GroupFn group_start = nullptr, group_end = nullptr;
+  ErrStrFn err = nullptr;
+};
+Rccl g_rccl;
+
+int load_rccl() {
+  if (g_rccl.h) return D2D_OK;
+  void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) { d2d_set_error("RCCL not found (dlopen librccl.so.1): %s", dlerror()); return D2D_ESTATE; }
+  Rccl r;
+  r.h = h;
+  r.get_id = reinterpret_cast<GetUniqueIdFn>(dlsym(h, "ncclGetUniqueId"));
+  r.init_rank = reinterpret_cast<CommInitRankFn>(dlsym(h, "ncclCommInitRank"));
+  r.destroy = reinterpret_cast<CommDestroyFn>(dlsym(h, "ncclCommDestroy"));
+  r.all_reduce = reinterpret_cast<AllReduceFn>(dlsym(h, "ncclAllReduce"));
+  r.group_start = reinterpret_cast<GroupFn>(dlsym(h, "ncclGroupStart"));
+  r.group_end = reinterpret_cast<GroupFn>(dlsym(h, "ncclGroupEnd"));
+  r.err = reinterpret_cast<ErrStrFn>(dlsym(h, "ncclGetErrorString"));
+  if (!r.get_id || !r.init_rank || !r.destroy || !r.all_reduce || !r.group_start || !r.group_end) {
+    d2d_set_error("librccl is missing an expected symbol");
+    return D2D_ESTATE;
+  }
+  g_rccl = r;
+  return D2D_OK;
+}
+#define D2D_CHECK_NCCL(expr)                                                                                  \
+  do {                                                                                                        \
+    const int e_ = (expr);                                                                                    \
+    if (e_ != 0) {                                                                                            \
+      d2d_set_error("%s failed: %s", #expr, g_rccl.err ? g_rccl.err(e_) : "RCCL error");                      \
+      return D2D_EHIP;                                                                                        \
+    }                                                                                                         \
+  } while (0)
+}  // namespace
+
+struct d2d_comm {
+  Comm comm = nullptr;
+  int rank = 0, world = 1;
+};
+
+extern "C" {
+
+int d2d_comm_unique_id(void *id_out) {
+  D2D_REQUIRE(id_out != nullptr, "d2d_comm_unique_id: id_out is NULL");
+  if (int rc = load_rccl()) return rc;
+  UniqueId id;
+  D2D_CHECK_NCCL(g_rccl.get_id(&id));
+  std::memcpy(id_out, id.internal, D2D_COMM_ID_BYTES);
+  return D2D_OK;
+}
+
+int d2d_comm_create(d2d_ctx *ctx, const void *id, int rank, int world, d2d_comm **out) {
+  D2D_REQUIRE(ctx && id && out, "d2d_comm_create: null argument");
+  D2D_REQUIRE(world >= 1 && rank >= 0 && rank < world, "d2d_comm_create: rank %d not in [0, %d)", rank, world);
+  if (int rc = load_rccl()) return rc;
+  D2D_CHECK_HIP(hipSetDevice(ctx->device));
+  UniqueId uid;
+  std::memcpy(uid.internal, id, D2D_COMM_ID_BYTES);
+  d2d_comm *c = new d2d_comm();
+  c->rank = rank; c->world = world;
+  const int e = g_rccl.init_rank(&c->comm, world, uid, rank);
+  if (e != 0) {
+    d2d_set_error("ncclCommInitRank failed: %s", g_rccl.err ? g_rccl.err(e) : "RCCL error");
+    delete c;
+    return D2D_EHIP;
+  }
+  *out = c;
+  return D2D_OK;
+}
+
+int d2d_comm_destroy(d2d_comm *comm) {
+  if (!comm) return D2D_OK;
+  if (comm->comm && g_rccl.destroy) g_rccl.destroy(comm->comm);
+  delete comm;
+  return D2D_OK;
+}
+
+int d2d_allreduce_stats(d2d_ctx *ctx, d2d_comm *comm, double *stats) {
+  D2D_REQUIRE(ctx && comm && stats, "d2d_allreduce_stats: null argument");
+  // one grouped exchange: sum of the costs and of the running counts, max of the gradient norms
+  D2D_CHECK_NCCL(g_rccl.group_start());
+  D2D_CHECK_NCCL(g_rccl.all_reduce(stats, stats, 1, 8 /* ncclFloat64 */, 0 /* ncclSum */, comm->comm, ctx->stream));
+  D2D_CHECK_NCCL(g_rccl.all_reduce(stats + 1, stats + 1, 1, 8, 2 /* ncclMax */, comm->comm, ctx->stream));
+  D2D_CHECK_NCCL(g_rccl.all_reduce(stats + 2, stats + 2, 1, 8, 0, comm->comm, ctx->stream));
+  D2D_CHECK_NCCL(g_rccl.group_end());
+  return D2D_OK;
+}
+
+}  // extern "C"

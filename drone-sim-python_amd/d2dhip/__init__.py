@@ -81,6 +81,10 @@ _SIGS = {
     'd2d_ctx_create': (C.c_int, [C.c_int, _P, C.POINTER(_P)]),
     'd2d_ctx_destroy': (C.c_int, [_P]),
     'd2d_ctx_sync': (C.c_int, [_P]),
+    'd2d_comm_unique_id': (C.c_int, [_P]),
+    'd2d_comm_create': (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(_P)]),
+    'd2d_comm_destroy': (C.c_int, [_P]),
+    'd2d_allreduce_stats': (C.c_int, [_P, _P, _P]),
     'd2d_step': (C.c_int, [_P, C.c_int, _P, _P, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _P]),
     'd2d_sim_gvf_run': (C.c_int, [_P, C.POINTER(GvfParams)] + [_P] * 13),
     'd2d_ctrl_gain': (C.c_int, [_P, C.POINTER(TrackParams)] + [_P] * 6),

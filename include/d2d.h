@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define D2D_VERSION 104
+#define D2D_VERSION 105
 
 /* error codes */
 #define D2D_OK 0
@@ -47,6 +47,23 @@ const char *d2d_last_error(void);
 int d2d_ctx_create(int device, void *stream, d2d_ctx **out);
 int d2d_ctx_destroy(d2d_ctx *ctx);
 int d2d_ctx_sync(d2d_ctx *ctx);   /* hipStreamSynchronize on the context's stream */
+
+/* Multi-GPU convergence exchange (one process per GPU; BASELINE configs[3]: trajectories shard by rank, the only collective is this
+ * one).  The reference has no counterpart (it is single-process Python); SURVEY.md 8b asks for the entry point so that a host
+ * without torch.distributed can drive the sharded solve.  RCCL is loaded at run time (dlopen of librccl.so.1): the library has
+ * no link-time dependency on it.
+ *   d2d_comm_unique_id  rank 0 creates the 128-byte id (ncclGetUniqueId) and hands it to the other ranks by whatever channel the
+ *                       host has (a file, MPI, a TCP store);
+ *   d2d_comm_create     every rank, same id: ncclCommInitRank on the context's device;
+ *   d2d_allreduce_stats stats dev double[3] in place, enqueued on the context's stream as ONE grouped exchange:
+ *                       [0] sum (cost), [1] max (|J^T r|_inf), [2] sum (trajectories still running) -- the three scalars
+ *                       d2d_fit_finish reports in stats[0..2].  The caller synchronises the stream before reading them. */
+typedef struct d2d_comm d2d_comm;
+#define D2D_COMM_ID_BYTES 128
+int d2d_comm_unique_id(void *id_out);
+int d2d_comm_create(d2d_ctx *ctx, const void *id, int rank, int world, d2d_comm **out);
+int d2d_comm_destroy(d2d_comm *comm);
+int d2d_allreduce_stats(d2d_ctx *ctx, d2d_comm *comm, double *stats);
 
 /* ------------------------------------------------------------------------------------
  * Plant and guidance (fp64).  State components: x, y, psi, phi, v; inputs: phi_c, v_c.

@@ -40,3 +40,28 @@ def test_two_rank_bench_equals_two_single_rank_solves(rehearsal):
         assert line['value'] > 0 and line['ms_per_step'] > 0
     finally:
         plan.close(); ctx.close()
+
+
+def test_rccl_entry_point_single_rank():
+    """d2d_allreduce_stats: the convergence exchange as a C-ABI entry point, RCCL loaded at run time.  One GPU per box:
+    a communicator of one rank -- unique id, init, the grouped sum / max / sum exchange on the context's stream, destroy."""
+    import ctypes as C
+    import torch
+    import d2dhip
+    ctx = d2dhip.Context(0)
+    lib = ctx.lib
+    try:
+        uid = (C.c_char * 128)()
+        assert lib.d2d_comm_unique_id(uid) == 0, lib.d2d_last_error()
+        assert any(b != b'\x00' for b in uid)
+        comm = C.c_void_p()
+        assert lib.d2d_comm_create(ctx.h, uid, 0, 1, C.byref(comm)) == 0, lib.d2d_last_error()
+        stats = torch.tensor([1.5, 2.5, 3.0], dtype=torch.float64, device=ctx.device)
+        assert lib.d2d_allreduce_stats(ctx.h, comm, C.c_void_p(stats.data_ptr())) == 0, lib.d2d_last_error()
+        ctx.sync()
+        assert stats.cpu().tolist() == [1.5, 2.5, 3.0]
+        assert lib.d2d_comm_destroy(comm) == 0
+        assert lib.d2d_comm_create(ctx.h, uid, 2, 2, C.byref(comm)) != 0            # rank out of range: refused with a message
+        assert b'rank' in lib.d2d_last_error()
+    finally:
+        ctx.close()
