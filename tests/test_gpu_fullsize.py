@@ -229,3 +229,33 @@ def test_collocation_batch_16384_properties(ctx):
         pb = ON.problem_from_row(rows[b], N, h)
         Wo, info = ON.solve(pb, W0[b].T.copy())
         assert info['status'] == 1 and abs(info['cost'] - cost[b]) <= 1e-7 * cost[b], (b, info['cost'], cost[b])
+
+
+@pytest.mark.parametrize('mode', ['minpack', 'fast'])
+def test_time_sliced_handout_is_bit_identical(ctx, plan, mode):
+    """d2d_fit_opts.slice > 0: fits that have run `slice` iterations while others wait go to the back of the device-wide ring and are
+    resumed by whichever wavefront pops them (state through device-scope atomics, fetch-add tickets).  Scheduling only: every result
+    bit for bit what the run-to-completion hand-out gives, every fit handled exactly once, on a batch that makes the ring work
+    (more fits than wave slots) and on ragged / small ones."""
+    import torch
+    import d2dhip
+    from d2dhip import synth
+    kw = {} if mode == 'minpack' else {'mode': d2dhip.MODE_FAST}
+    for B, sl in ((4500, 8), (2049, 4), (300, 4), (1, 4)):
+        dsc = ctx.dev(synth.synth_scenarios(B, seed=31, obj_scale=0.1, K=K))
+        q0 = plan.init(dsc)
+        qa, qb = q0.clone(), q0.clone()
+        ca, ia, sa, sta = plan.solve(dsc, qa, max_iter=300, **kw)
+        cb, ib, sb, stb = plan.solve(dsc, qb, max_iter=300, slice=sl, **kw)
+        assert torch.equal(qa, qb) and torch.equal(ia, ib) and torch.equal(ca, cb) and torch.equal(sa, sb), (B, sl)
+        assert (sa.cpu().numpy() != 0).all() and stb[3] >= sta[3]        # (a resumed fit re-evaluates its rows: more evaluations, same answers)
+    # ... and across launches: the host's convergence poll (check_every) stops and restarts fits with the same answers
+    dsc = ctx.dev(synth.synth_scenarios(3000, seed=32, obj_scale=0.1, K=K))
+    q0 = plan.init(dsc)
+    qa, qb = q0.clone(), q0.clone()
+    ca, ia, sa, _ = plan.solve(dsc, qa, max_iter=300, **kw)
+    plan.begin(3000)
+    while plan.iterate(dsc, qb, 7, max_iter=300, slice=5, **kw) > 0:
+        pass
+    cb, ib, sb, _ = plan.finish(dsc, qb)
+    assert torch.equal(qa, qb) and torch.equal(ia, ib) and torch.equal(ca, cb) and torch.equal(sa, sb)
