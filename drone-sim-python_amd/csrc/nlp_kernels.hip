@@ -142,7 +142,9 @@ struct NlpProb {
 #define NLP_LDS_UP 0
 #define NLP_LDS_REC (65 * 9)
 #define NLP_REC_STRIDE 19
-#define NLP_LDS_DOUBLES (65 * 9 + 64 * NLP_REC_STRIDE)
+#define NLP_BCR_STRIDE 19                 // odd: a lane per node reads its record without 8-way bank conflicts
+#define NLP_BCR_LDS_NODES 121
+#define NLP_LDS_DOUBLES 2304              // >= 65 * 9 + 64 * NLP_REC_STRIDE (assembly) and >= NLP_BCR_LDS_NODES * NLP_BCR_STRIDE (cyclic reduction)
 #define NLP_W(c, i) pb.W[(c) * pb.N + (i)]
 #define NLP_P(plane, i) pb.ws[(plane) * pb.N + (i)]
 #define NLP_MU(k, i) pb.mu[(k) * pb.N + (i)]
@@ -501,6 +503,153 @@ __device__ __forceinline__ bool nlp_block_chol(const double (&S)[6], const doubl
   return ok;
 }
 
+
+// ---- the reduced system by BLOCK CYCLIC REDUCTION (round 3) ----------------------------------------------------------------
+// The block-tridiagonal system of the reduced nodes (3x3 blocks D'_i, E'_i = block (i, i-1), right-hand sides t'_i) is symmetric
+// positive definite when the step is usable, so any elimination order is a Cholesky factorisation of it.  Odd-even order: at the
+// level of stride s the nodes j = s (2m + 1) are eliminated ALL AT ONCE, one lane per node, against their neighbours a = j - s and
+// b = j + s, which survive with
+//     D_a -= E_j^T P_j,  t_a -= E_j^T r_j;      D_b -= E_b Q_j,  t_b -= E_b r_j,  E_b <- -E_b P_j  (now block (b, a))
+//     P_j = D_j^-1 E_j,  Q_j = D_j^-1 E_b^T,  r_j = D_j^-1 t_j
+// and after ceil(log2 N) levels node 0 is alone; the unknowns come back level by level, x_j = r_j - P_j x_a - Q_j x_b.  The
+// twisted recursion it replaces is a dependent chain of N/2 block pivots (88 k + 27 k of the 200 k cycles of a Newton step at
+// N = 121); this is 7 levels of independent 3x3 work.  A node has one left and one right producer per level: the producers apply
+// their update to the left neighbour first, then (after a wave-level sync) to the right one, so no two lanes touch a record at once.
+// Up to NLP_BCR_LDS_NODES nodes the records live in the wave's LDS (stride 19), P_j and Q_j take the place of the eliminated
+// node's record and x_j that of P_j; longer horizons run the same code on the records in global memory.
+__device__ __forceinline__ void nlp_solve3(const double (&L)[6], const double b0, const double b1, const double b2, double &x0, double &x1, double &x2) {
+  // L L^T x = b with the factor of nlp_block_chol (reciprocal diagonal)
+  const double y0 = b0 * L[0];
+  const double y1 = (b1 - L[1] * y0) * L[2];
+  const double y2 = (b2 - L[3] * y0 - L[4] * y1) * L[5];
+  x2 = y2 * L[5];
+  x1 = (y1 - L[4] * x2) * L[2];
+  x0 = (y0 - L[1] * x1 - L[3] * x2) * L[0];
+}
+
+__device__ __attribute__((noinline)) bool nlp_bcr(double *sin_g, double *sf_g, double *ds_g, double *lds, int N) {
+  const int lane = threadIdx.x & 63;
+  const bool in_lds = N <= NLP_BCR_LDS_NODES;
+  double *rec = in_lds ? lds : sin_g;                 // records [node][rs]: D' (6), E' (9), t' (3)
+  const int rs = in_lds ? NLP_BCR_STRIDE : SIN_N;
+  double *pq = in_lds ? lds : sf_g;                   // P (9), Q (9) of an eliminated node [node][ps]
+  const int ps = in_lds ? NLP_BCR_STRIDE : SF_N;
+  if (in_lds) {
+    for (int e = lane; e < N * SIN_N; e += 64) {
+      const int node = e / SIN_N;
+      lds[node * NLP_BCR_STRIDE + (e - node * SIN_N)] = sin_g[e];
+    }
+    nlp_phase_sync();
+  }
+  int bad = 0;
+  int s = 1;
+  for (; s < N; s <<= 1) {
+    const int n_el = (N - 1 - s) / (2 * s) + 1;       // eliminated nodes of this level: j = s (2m + 1) < N
+    for (int m0 = 0; m0 < n_el; m0 += 64) {
+      const int m = m0 + lane;
+      const bool act = m < n_el;
+      const int j = act ? s * (2 * m + 1) : s, a = j - s, b = j + s;
+      const bool has_b = act && b < N;
+      double D[6], E[3][3], t[3], Eb[3][3], L[6], y[3], P[3][3], Q[3][3], r[3];
+      const double *pj = rec + (size_t)j * rs, *pb = rec + (size_t)(has_b ? b : j) * rs;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) D[q] = pj[SIN_D + q];
+#pragma unroll
+      for (int q = 0; q < 9; ++q) { E[q / 3][q % 3] = pj[SIN_E + q]; Eb[q / 3][q % 3] = has_b ? pb[SIN_E + q] : 0.0; }
+#pragma unroll
+      for (int q = 0; q < 3; ++q) t[q] = pj[SIN_T + q];
+      const bool ok = nlp_block_chol(D, t, L, y);
+      if (act && !ok) bad = 1;
+      nlp_solve3(L, t[0], t[1], t[2], r[0], r[1], r[2]);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        nlp_solve3(L, E[0][k], E[1][k], E[2][k], P[0][k], P[1][k], P[2][k]);           // column k of E_j
+        nlp_solve3(L, Eb[k][0], Eb[k][1], Eb[k][2], Q[0][k], Q[1][k], Q[2][k]);        // column k of E_b^T = row k of E_b
+      }
+      // the left neighbour: D_a -= E_j^T P_j, t_a -= E_j^T r_j
+      if (act) {
+        double *pa = rec + (size_t)a * rs;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+#pragma unroll
+          for (int v = 0; v <= u; ++v)
+            pa[SIN_D + u * (u + 1) / 2 + v] -= E[0][u] * P[0][v] + E[1][u] * P[1][v] + E[2][u] * P[2][v];
+          pa[SIN_T + u] -= E[0][u] * r[0] + E[1][u] * r[1] + E[2][u] * r[2];
+        }
+      }
+      nlp_phase_sync();
+      // the right neighbour: D_b -= E_b Q_j, t_b -= E_b r_j, E_b <- -E_b P_j
+      if (has_b) {
+        double *pbw = rec + (size_t)b * rs;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+#pragma unroll
+          for (int v = 0; v <= u; ++v)
+            pbw[SIN_D + u * (u + 1) / 2 + v] -= Eb[u][0] * Q[0][v] + Eb[u][1] * Q[1][v] + Eb[u][2] * Q[2][v];
+          pbw[SIN_T + u] -= Eb[u][0] * r[0] + Eb[u][1] * r[1] + Eb[u][2] * r[2];
+#pragma unroll
+          for (int v = 0; v < 3; ++v) pbw[SIN_E + u * 3 + v] = -(Eb[u][0] * P[0][v] + Eb[u][1] * P[1][v] + Eb[u][2] * P[2][v]);
+        }
+      }
+      // what the way back needs of node j: P_j, Q_j (in place of its record / in the factor's workspace), r_j (in the step's slot)
+      if (act) {
+        double *o = pq + (size_t)j * ps;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) { o[q] = P[q / 3][q % 3]; o[9 + q] = Q[q / 3][q % 3]; }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) ds_g[(size_t)j * 3 + q] = r[q];
+      }
+      nlp_phase_sync();
+    }
+  }
+  if (__builtin_amdgcn_ballot_w64(bad != 0) != 0ull) return false;
+  // node 0 alone
+  {
+    double D[6], t[3], L[6], y[3], x[3];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) D[q] = rec[SIN_D + q];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) t[q] = rec[SIN_T + q];
+    if (!nlp_block_chol(D, t, L, y)) return false;
+    nlp_solve3(L, t[0], t[1], t[2], x[0], x[1], x[2]);
+    nlp_phase_sync();
+    // (every lane stores the same values: no branch between the loads above and these stores)
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { ds_g[q] = x[q]; if (in_lds) lds[q] = x[q]; }
+    nlp_phase_sync();
+  }
+  // the way back: the unknowns of a level from those of the coarser ones (in the LDS path x_j takes the place of P_j)
+  const double *xs = in_lds ? lds : ds_g;
+  const int xst = in_lds ? NLP_BCR_STRIDE : 3;
+  for (s >>= 1; s >= 1; s >>= 1) {
+    const int n_el = (N - 1 - s) / (2 * s) + 1;
+    for (int m0 = 0; m0 < n_el; m0 += 64) {
+      const int m = m0 + lane;
+      const bool act = m < n_el;
+      const int j = act ? s * (2 * m + 1) : s, a = j - s, b = j + s;
+      const bool has_b = act && b < N;
+      double x[3];
+      if (act) {
+        const double *o = pq + (size_t)j * ps;
+        const double *xa = xs + (size_t)a * xst, *xb = xs + (size_t)(has_b ? b : a) * xst;
+        const double a0 = xa[0], a1 = xa[1], a2 = xa[2];
+        const double b0 = has_b ? xb[0] : 0.0, b1 = has_b ? xb[1] : 0.0, b2 = has_b ? xb[2] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+          x[u] = ds_g[(size_t)j * 3 + u] - (o[u * 3] * a0 + o[u * 3 + 1] * a1 + o[u * 3 + 2] * a2)
+                 - (o[9 + u * 3] * b0 + o[9 + u * 3 + 1] * b1 + o[9 + u * 3 + 2] * b2);
+      }
+      nlp_phase_sync();                       // (every P_j of the chunk has been read before an x_j overwrites one)
+      if (act) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) { ds_g[(size_t)j * 3 + u] = x[u]; if (in_lds) lds[(size_t)j * NLP_BCR_STRIDE + u] = x[u]; }
+      }
+      nlp_phase_sync();
+    }
+  }
+  return true;
+}
+
 // mid: 9 doubles of scratch for the second coupling block of the middle node (its coupling to node m+1)
 __device__ __attribute__((noinline)) bool nlp_factor(double *sin_generic, double *sf_generic, double *mid_generic, int N) {
   const gdouble *sin = (const gdouble *)sin_generic;
@@ -842,12 +991,13 @@ __device__ __forceinline__ void nlp_solve_one(int N, double h, const d2d_nlp_opt
         NLP_STAMP(1)
         if (tr == 0 && err <= tol_in) { converged = true; break; }
         if (pd) {
-          pd = nlp_factor(pb.ws + (size_t)WS_SIN * N, pb.ws + (size_t)WS_SF * N, pb.ws + (size_t)WS_UP * N, N);   // (UP is free by now)
+          if (o.serial) pd = nlp_factor(pb.ws + (size_t)WS_SIN * N, pb.ws + (size_t)WS_SF * N, pb.ws + (size_t)WS_UP * N, N);   // (UP is free by now)
+          else pd = nlp_bcr(pb.ws + (size_t)WS_SIN * N, pb.ws + (size_t)WS_SF * N, pb.ws + (size_t)WS_DS * N, pb.lds, N);
         }
         NLP_STAMP(2)
         if (!pd) { lam = fmin(lam * 8.0, D2D_LM_LAMBDA_MAX); continue; }
         nlp_phase_sync();
-        nlp_backsolve(pb.ws + (size_t)WS_SF * N, pb.ws + (size_t)WS_UP * N, pb.ws + (size_t)WS_DS * N, N);
+        if (o.serial) nlp_backsolve(pb.ws + (size_t)WS_SF * N, pb.ws + (size_t)WS_UP * N, pb.ws + (size_t)WS_DS * N, N);
         nlp_phase_sync();
         NLP_STAMP(3)
         const double tau = fmax(0.99, 1.0 - mub);
@@ -1018,8 +1168,9 @@ int d2d_nlp_solve(d2d_ctx *ctx, int B, int N, double h, const double *scen, cons
                   const double *partner, double *work, double *mult, double *cost, double *feas, int32_t *iters, int32_t *status) {
   D2D_REQUIRE(ctx && scen && W && work && cost && feas, "d2d_nlp_solve: null argument");
   D2D_REQUIRE(B >= 1 && N >= 3 && h > 0, "d2d_nlp_solve: B >= 1, N >= 3, h > 0 required (B=%d N=%d h=%g)", B, N, h);
-  d2d_nlp_opts o = {D2D_NLP_RHO0, D2D_NLP_MUB0, D2D_NLP_MUB_MIN, 1e-9, 1e-7, 60, 40};
+  d2d_nlp_opts o = {D2D_NLP_RHO0, D2D_NLP_MUB0, D2D_NLP_MUB_MIN, 1e-9, 1e-7, 60, 40, 0, 0};
   if (opts) o = *opts;
+  if (getenv("D2D_NLP_SERIAL")) o.serial = atoi(getenv("D2D_NLP_SERIAL"));      // A/B switch
   D2D_REQUIRE(o.inner_max >= 1 && o.outer_max >= 1 && o.rho0 > 0 && o.mub0 > 0 && o.mub_min > 0, "d2d_nlp_solve: bad options");
   unsigned long long *stamps = nullptr;
   if (getenv("D2D_NLP_STAMPS")) D2D_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&stamps), 16 * sizeof(unsigned long long)));
@@ -1045,8 +1196,9 @@ int d2d_nlp_solve_groups(d2d_ctx *ctx, int R, int n_ac, int N, double h, const d
   D2D_REQUIRE(ctx && scen && W && work && cost && feas, "d2d_nlp_solve_groups: null argument");
   D2D_REQUIRE(R >= 1 && n_ac >= 1 && n_ac <= 8 && N >= 3 && h > 0, "d2d_nlp_solve_groups: R >= 1, 1 <= n_ac <= 8, N >= 3, h > 0 required (R=%d n_ac=%d N=%d h=%g)", R, n_ac, N, h);
   D2D_REQUIRE(max_sweeps >= 1 && tol >= 0, "d2d_nlp_solve_groups: max_sweeps >= 1 and tol >= 0 required");
-  d2d_nlp_opts o = {D2D_NLP_RHO0, D2D_NLP_MUB0, D2D_NLP_MUB_MIN, 1e-9, 1e-7, 60, 40};
+  d2d_nlp_opts o = {D2D_NLP_RHO0, D2D_NLP_MUB0, D2D_NLP_MUB_MIN, 1e-9, 1e-7, 60, 40, 0, 0};
   if (opts) o = *opts;
+  if (getenv("D2D_NLP_SERIAL")) o.serial = atoi(getenv("D2D_NLP_SERIAL"));
   D2D_REQUIRE(o.inner_max >= 1 && o.outer_max >= 1 && o.rho0 > 0 && o.mub0 > 0 && o.mub_min > 0, "d2d_nlp_solve_groups: bad options");
   // scratch for the positions before a turn: the tail of aircraft 0's workspace is not free, so it lives behind the workspaces
   double *prev = work + (size_t)R * n_ac * WS_TOTAL * N;

@@ -473,6 +473,10 @@ typedef struct {
   double opt_tol;    /* barrier KKT error of the last inner problem (default 1e-7)                            */
   int32_t inner_max; /* Newton steps per outer iteration (default 60)                                         */
   int32_t outer_max; /* outer iterations: multiplier / barrier updates (default 40)                           */
+  int32_t serial;    /* solver of the reduced block-tridiagonal system of a Newton step: 0 (default) block cyclic reduction -- log2 N
+                        levels of independent 3x3 eliminations, one lane per node; 1 the twisted serial block recursion of round 2
+                        (N/2 dependent block pivots).  Same step to rounding.                                   */
+  int32_t reserved;
 } d2d_nlp_opts;
 int d2d_nlp_workspace_doubles(int N);
 /* A problem whose row is unusable -- PHIMAX <= 0, VMIN <= 0 or VMIN >= VMAX (the model divides by v and the barrier needs an
