@@ -456,7 +456,6 @@ __device__ double nlp_assemble(const NlpProb &pb, const NlpScen &s, const double
 struct NlpNodeIn {
   double v[SIN_N];
 };
-typedef __attribute__((address_space(1))) double gdouble;
 
 __device__ __forceinline__ double nlp_other_half(double v) {              // the value the lane 32 places away holds
   return __hiloint2double(__builtin_amdgcn_ds_bpermute(((threadIdx.x ^ 32) & 63) << 2, __double2hiint(v)),
@@ -504,6 +503,7 @@ __device__ __forceinline__ bool nlp_block_chol(const double (&S)[6], const doubl
 }
 
 
+typedef __attribute__((address_space(1))) double gdouble;
 // ---- the reduced system by BLOCK CYCLIC REDUCTION (round 3) ----------------------------------------------------------------
 // The block-tridiagonal system of the reduced nodes (3x3 blocks D'_i, E'_i = block (i, i-1), right-hand sides t'_i) is symmetric
 // positive definite when the step is usable, so any elimination order is a Cholesky factorisation of it.  Odd-even order: at the
@@ -527,13 +527,19 @@ __device__ __forceinline__ void nlp_solve3(const double (&L)[6], const double b0
   x0 = (y0 - L[1] * x1 - L[3] * x2) * L[0];
 }
 
-__device__ __attribute__((noinline)) bool nlp_bcr(double *sin_g, double *sf_g, double *ds_g, double *lds, int N) {
+// RT: pointer type of the records -- LDS (address space 3) or global (1): stated, so that the accesses are ds_ / global_ instructions
+// (through generic pointers they were flat_ ones: 51 k cycles per Newton step instead of the 30 k of this version)
+typedef __attribute__((address_space(3))) double ldouble;
+template <typename RT, bool in_lds>
+__device__ __attribute__((noinline)) bool nlp_bcr_t(double *sin_generic, double *sf_generic, double *ds_generic, double *lds_generic, int N) {
   const int lane = threadIdx.x & 63;
-  const bool in_lds = N <= NLP_BCR_LDS_NODES;
-  double *rec = in_lds ? lds : sin_g;                 // records [node][rs]: D' (6), E' (9), t' (3)
-  const int rs = in_lds ? NLP_BCR_STRIDE : SIN_N;
-  double *pq = in_lds ? lds : sf_g;                   // P (9), Q (9) of an eliminated node [node][ps]
-  const int ps = in_lds ? NLP_BCR_STRIDE : SF_N;
+  gdouble *sin_g = (gdouble *)sin_generic;
+  gdouble *ds_g = (gdouble *)ds_generic;
+  RT *lds = (RT *)lds_generic;
+  RT *rec = in_lds ? (RT *)lds_generic : (RT *)sin_generic;      // records [node][rs]: D' (6), E' (9), t' (3)
+  constexpr int rs = in_lds ? NLP_BCR_STRIDE : SIN_N;
+  RT *pq = in_lds ? (RT *)lds_generic : (RT *)sf_generic;        // P (9), Q (9) of an eliminated node [node][ps]
+  constexpr int ps = in_lds ? NLP_BCR_STRIDE : SF_N;
   if (in_lds) {
     for (int e = lane; e < N * SIN_N; e += 64) {
       const int node = e / SIN_N;
@@ -551,7 +557,7 @@ __device__ __attribute__((noinline)) bool nlp_bcr(double *sin_g, double *sf_g, d
       const int j = act ? s * (2 * m + 1) : s, a = j - s, b = j + s;
       const bool has_b = act && b < N;
       double D[6], E[3][3], t[3], Eb[3][3], L[6], y[3], P[3][3], Q[3][3], r[3];
-      const double *pj = rec + (size_t)j * rs, *pb = rec + (size_t)(has_b ? b : j) * rs;
+      const RT *pj = rec + (size_t)j * rs, *pb = rec + (size_t)(has_b ? b : j) * rs;
 #pragma unroll
       for (int q = 0; q < 6; ++q) D[q] = pj[SIN_D + q];
 #pragma unroll
@@ -568,7 +574,7 @@ __device__ __attribute__((noinline)) bool nlp_bcr(double *sin_g, double *sf_g, d
       }
       // the left neighbour: D_a -= E_j^T P_j, t_a -= E_j^T r_j
       if (act) {
-        double *pa = rec + (size_t)a * rs;
+        RT *pa = rec + (size_t)a * rs;
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
 #pragma unroll
@@ -580,7 +586,7 @@ __device__ __attribute__((noinline)) bool nlp_bcr(double *sin_g, double *sf_g, d
       nlp_phase_sync();
       // the right neighbour: D_b -= E_b Q_j, t_b -= E_b r_j, E_b <- -E_b P_j
       if (has_b) {
-        double *pbw = rec + (size_t)b * rs;
+        RT *pbw = rec + (size_t)b * rs;
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
 #pragma unroll
@@ -593,7 +599,7 @@ __device__ __attribute__((noinline)) bool nlp_bcr(double *sin_g, double *sf_g, d
       }
       // what the way back needs of node j: P_j, Q_j (in place of its record / in the factor's workspace), r_j (in the step's slot)
       if (act) {
-        double *o = pq + (size_t)j * ps;
+        RT *o = pq + (size_t)j * ps;
 #pragma unroll
         for (int q = 0; q < 9; ++q) { o[q] = P[q / 3][q % 3]; o[9 + q] = Q[q / 3][q % 3]; }
 #pragma unroll
@@ -619,8 +625,8 @@ __device__ __attribute__((noinline)) bool nlp_bcr(double *sin_g, double *sf_g, d
     nlp_phase_sync();
   }
   // the way back: the unknowns of a level from those of the coarser ones (in the LDS path x_j takes the place of P_j)
-  const double *xs = in_lds ? lds : ds_g;
-  const int xst = in_lds ? NLP_BCR_STRIDE : 3;
+  const RT *xs = in_lds ? (const RT *)lds_generic : (const RT *)ds_generic;
+  constexpr int xst = in_lds ? NLP_BCR_STRIDE : 3;
   for (s >>= 1; s >= 1; s >>= 1) {
     const int n_el = (N - 1 - s) / (2 * s) + 1;
     for (int m0 = 0; m0 < n_el; m0 += 64) {
@@ -630,8 +636,8 @@ __device__ __attribute__((noinline)) bool nlp_bcr(double *sin_g, double *sf_g, d
       const bool has_b = act && b < N;
       double x[3];
       if (act) {
-        const double *o = pq + (size_t)j * ps;
-        const double *xa = xs + (size_t)a * xst, *xb = xs + (size_t)(has_b ? b : a) * xst;
+        const RT *o = pq + (size_t)j * ps;
+        const RT *xa = xs + (size_t)a * xst, *xb = xs + (size_t)(has_b ? b : a) * xst;
         const double a0 = xa[0], a1 = xa[1], a2 = xa[2];
         const double b0 = has_b ? xb[0] : 0.0, b1 = has_b ? xb[1] : 0.0, b2 = has_b ? xb[2] : 0.0;
 #pragma unroll
@@ -648,6 +654,10 @@ __device__ __attribute__((noinline)) bool nlp_bcr(double *sin_g, double *sf_g, d
     }
   }
   return true;
+}
+__device__ __forceinline__ bool nlp_bcr(double *sin_g, double *sf_g, double *ds_g, double *lds, int N) {
+  if (N <= NLP_BCR_LDS_NODES) return nlp_bcr_t<ldouble, true>(sin_g, sf_g, ds_g, lds, N);
+  return nlp_bcr_t<gdouble, false>(sin_g, sf_g, ds_g, lds, N);
 }
 
 // mid: 9 doubles of scratch for the second coupling block of the middle node (its coupling to node m+1)
