@@ -250,12 +250,14 @@ def nlp_record(ctx, torch, cpu, B=4096):
            'infeasible_frac': float((st == 4).mean()),     # D2D_ST_STALLED: perturbed end poses that no v <= 15 path joins in 12 s (the oracle agrees)
            'mean_newton_steps': float(it.mean()),
            'max_newton_steps': int(it.max()), 'hbm_traffic_per_launch': pmc_traffic('nlp_solve_kernel')[0], 'cpu_baseline': cpu}
-    # algorithmic HBM bytes: per problem and Newton step the 88 N doubles of workspace are read and written about once per phase
-    # (~100 kB read + ~96 kB written at N = 121); the kernel is bound by its serial block recursion, not by HBM
-    alg = float(it.sum()) * (100e3 + 96e3) * (W0.shape[2] / 121.0)
+    # algorithmic HBM bytes per node and Newton step of the round-3 algorithm (every value a phase needs read once, every
+    # value it produces written once, neighbours from the cache): merit 13 doubles read x ~1.3 calls, assembly 18 read + 40 written
+    # (x ~1.1 with the retries), cyclic reduction 21 read + 6 written (the reduced records live in the LDS), recovery 40 read + 5
+    # written, update 20 read + 15 written = 118 doubles read + 70 written = 114 kB + 68 kB per step at N = 121
+    alg = float(it.sum()) * (114e3 + 68e3) * (W0.shape[2] / 121.0)
     rec['roofline'] = {'bound': 'hbm', 'kernel': 'nlp_solve_kernel', 'achieved': alg / best / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                        'frac': alg / best / 1e9 / HBM_PEAK_GBS, 'traffic': rec['hbm_traffic_per_launch'], 'alg_bytes_per_launch': alg,
-                       'note': 'latency-bound on the twisted 3x3 block recursion (one wavefront per problem, two waves per SIMD); traffic = FETCH_SIZE + WRITE_SIZE of the committed PMC passes'}
+                       'note': 'latency-bound (dependent fp64 chains of the assembly and of the seven cyclic-reduction levels, one wavefront per problem, two waves per SIMD); traffic = FETCH_SIZE + WRITE_SIZE of the committed PMC passes (FETCH_SIZE uncalibrated for 8-B-per-lane loads)'}
     if cpu is not None:
         rec['verdicts_vs_oracle'] = nlp_verify(rows, W0, h, st, cost, feas)
         n = len(cpu['cost'])
