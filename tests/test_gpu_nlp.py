@@ -376,3 +376,39 @@ def test_unusable_rows_are_refused_at_once():
     st = out['status'].cpu().numpy(); it = out['iters'].cpu().numpy(); c = out['cost'].cpu().numpy()
     assert st[0] == 1 and np.isfinite(c[0])
     assert (st[1:] == d2dhip.ST_NONFINITE).all() and (it[1:] == 0).all() and np.isnan(c[1:]).all()
+
+
+def test_cyclic_reduction_equals_the_serial_recursion():
+    """d2d_nlp_opts.serial: the reduced block-tridiagonal system of a Newton step by block cyclic reduction (default; records in the LDS up
+    to 121 nodes, in global memory beyond) and by round 2's twisted serial recursion are the same Cholesky solve in another elimination
+    order: same verdicts, costs and node values to rounding on a batch with converged and infeasible problems, at horizons on both sides of
+    the LDS limit and at the smallest ones (3 .. 6 nodes: levels with a single eliminated node, a missing right neighbour)."""
+    import d2dhip
+    from d2dhip import synth
+    ctx = d2dhip.default_context()
+    for N in (121, 150, 64, 65, 6, 5, 4, 3):
+        rows, W0, h = synth.nlp_problems(48, N=max(N, 8))
+        if N < 8:                                   # a short, gently curved leg of N nodes at h = 0.1 s
+            W0 = np.ascontiguousarray(W0[:, :, :N]); h = 0.1
+            leg = 11.0 * h * (N - 1)
+            rows[:, d2dhip.SC_X1] = rows[:, d2dhip.SC_X0] + leg * np.cos(rows[:, d2dhip.SC_PSI0] + 0.02)
+            rows[:, d2dhip.SC_Y1] = rows[:, d2dhip.SC_Y0] + leg * np.sin(rows[:, d2dhip.SC_PSI0] + 0.02)
+            rows[:, d2dhip.SC_PSI1] = rows[:, d2dhip.SC_PSI0] + 0.04
+            rows[:, d2dhip.SC_S] = 1.0 / N
+            for b in range(len(rows)):
+                W0[b, 0] = np.linspace(rows[b, d2dhip.SC_X0], rows[b, d2dhip.SC_X1], N); W0[b, 1] = np.linspace(rows[b, d2dhip.SC_Y0], rows[b, d2dhip.SC_Y1], N)
+                W0[b, 2] = np.linspace(rows[b, d2dhip.SC_PSI0], rows[b, d2dhip.SC_PSI1], N); W0[b, 3] = 0.0; W0[b, 4] = 11.0
+        dsc = ctx.dev(rows)
+        Wa, Wb = ctx.dev(np.ascontiguousarray(W0)), ctx.dev(np.ascontiguousarray(W0))
+        oa = ctx.nlp_solve(dsc, Wa, h, serial=0)
+        ob = ctx.nlp_solve(dsc, Wb, h, serial=1)
+        ctx.sync()
+        sa, sb = oa['status'].cpu().numpy(), ob['status'].cpu().numpy()
+        assert (sa == sb).all(), (N, sa, sb)
+        ca, cb = oa['cost'].cpu().numpy(), ob['cost'].cpu().numpy()
+        conv = sa == 1
+        assert conv.sum() >= len(sa) // 2, (N, sa)
+        np.testing.assert_allclose(ca[conv], cb[conv], rtol=1e-9, atol=1e-12)
+        # (node values along the objective's flat directions -- the cost sees v only -- differ at the 1e-5 level between two rounding paths)
+        assert np.abs(Wa.cpu().numpy()[conv] - Wb.cpu().numpy()[conv]).max() <= 1e-3
+        assert float(oa['feas'].cpu().numpy()[conv].max()) <= 1e-8
