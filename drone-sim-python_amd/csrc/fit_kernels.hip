@@ -514,7 +514,7 @@ fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_cap,
   // fit: every fit of the batch advances at the same rate (processor sharing), so the launch ends when the work is done or
   // when its longest fit is, whichever is later, without knowing the lengths in advance.  A wave leaves when nothing waits;
   // a wave only pushes when something waits and pops right after, so no entry is left behind.  queue[1] counts the waves that
-  // have left: the last one zeroes the counters for the next launch.  queue == NULL: static striding, no yields.
+  // have left: the last one zeroes the counters for the next launch.
   const int stride = gridDim.x * (blockDim.x >> 6);
   auto take = [&](bool first) -> int {          // trajectory index, or -1: nothing waits
     if (first) {
@@ -522,7 +522,6 @@ fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_cap,
       if (bi >= B) return -1;
       return order ? __builtin_amdgcn_readfirstlane(order[bi]) : bi;
     }
-    if (queue == nullptr) return -1;
     int t = -1;
     if (lane == 0) {
       if (stride + __hip_atomic_load(queue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < B) {
@@ -1677,8 +1676,7 @@ static int launch_lm(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, double *q, con
   unsigned long long *stamps = want_stamps ? reinterpret_cast<unsigned long long *>(ctx->stats_dev + 8) : nullptr;
   if (want_stamps) D2D_CHECK_HIP(hipMemsetAsync(stamps, 0, 13 * sizeof(unsigned long long), ctx->stream));
   const int blocks = B < pl->n_cu ? B : pl->n_cu;     // persistent: one workgroup per CU
-  static const bool no_queue = getenv("D2D_LM_STATIC") != nullptr;      // A/B switch: static striding instead of the work queue
-  int32_t *queue = no_queue ? nullptr : ctx->counter_dev + 8;
+  int32_t *queue = ctx->counter_dev + 8;
   static const int prio_only = getenv("D2D_LM_PRIO_AT") ? atoi(getenv("D2D_LM_PRIO_AT")) : 48;     // (A/B switch; large = never)
   static const int slice_env = getenv("D2D_LM_SLICE") ? atoi(getenv("D2D_LM_SLICE")) : -1;         // (A/B switch: overrides opts.slice)
   d2d_fit_opts oo = o;
