@@ -109,6 +109,8 @@ int fit_basis_build(d2d_fit_plan *pl) {
       tau[k] = t - s * T;
     }
   }
+  pl->seg = seg;
+  pl->tau = tau;
   // --- Phi_d (K x 8S), d = 0..2
   std::vector<Dense> Phi;
   for (int d = 0; d < 3; ++d) {
@@ -203,5 +205,74 @@ int fit_basis_build(d2d_fit_plan *pl) {
       pl->Pinit[(size_t)i * K + k] = s / L(i, i);
     }
   }
+  return D2D_OK;
+}
+
+// The segment formulation of the long-horizon kernel (fit_seg.h): on segment s the polynomial of one axis is
+//   sum_p z_p tau^p = sum_i l_i P_i(x),  x = 2 tau / T - 1,  l = Zl_s q_axis + Zlp_s d_axis,
+// P_i the Legendre polynomials.  With sigma = tau / T and P_i(2 sigma - 1) = sum_p C[i][p] sigma^p (C lower triangular, by the
+// three-term recurrence), sigma^p = sum_i Cinv[p][i] P_i and Zl_s[i][j] = sum_p Cinv[p][i] T^p Z[8 s + p][j].
+// Lanes of a wavefront are dealt to the segments in proportion to their sample counts (SegMap).
+int fit_basis_segments(d2d_fit_plan *pl) {
+  const int S = pl->S, K = pl->K, nq = pl->nq;
+  const double T = pl->T;
+  long double C[8][8] = {{0}}, Ci[8][8] = {{0}};
+  C[0][0] = 1.0L; C[1][0] = -1.0L; C[1][1] = 2.0L;
+  for (int n = 1; n < 7; ++n)                       // (n+1) P_{n+1} = (2n+1) (2 sigma - 1) P_n - n P_{n-1}
+    for (int p = 0; p < 8; ++p) {
+      long double v = -(2.0L * n + 1.0L) * C[n][p] - (long double)n * C[n - 1][p];
+      if (p > 0) v += (2.0L * n + 1.0L) * 2.0L * C[n][p - 1];
+      C[n + 1][p] = v / (n + 1.0L);
+    }
+  // sigma^p = sum_i Ci[p][i] P_i: row p of Ci solves Ci[p][.] C = e_p (C lower triangular: back substitution from i = p)
+  for (int p = 0; p < 8; ++p)
+    for (int i = p; i >= 0; --i) {
+      long double v = (i == p) ? 1.0L : 0.0L;
+      for (int m = i + 1; m <= p; ++m) v -= Ci[p][m] * C[m][i];
+      Ci[p][i] = v / C[i][i];
+    }
+  pl->Zl.assign((size_t)8 * S * nq, 0.0);
+  pl->Zlp.assign((size_t)8 * S * 4, 0.0);
+  for (int s = 0; s < S; ++s)
+    for (int i = 0; i < 8; ++i) {
+      for (int j = 0; j < nq; ++j) {
+        long double v = 0;
+        for (int p = i; p < 8; ++p) v += Ci[p][i] * powl((long double)T, p) * (long double)pl->Z[(size_t)(8 * s + p) * nq + j];
+        pl->Zl[(size_t)(8 * s + i) * nq + j] = (double)v;
+      }
+      for (int j = 0; j < 4; ++j) {
+        long double v = 0;
+        for (int p = i; p < 8; ++p) v += Ci[p][i] * powl((long double)T, p) * (long double)pl->Zp[(size_t)(8 * s + p) * 4 + j];
+        pl->Zlp[(size_t)(8 * s + i) * 4 + j] = (double)v;
+      }
+    }
+  pl->sx.resize(K);
+  for (int k = 0; k < K; ++k) pl->sx[k] = 2.0 * pl->tau[k] / T - 1.0;
+  // samples of a segment are consecutive
+  pl->seg_S = S;
+  for (int s = 0; s < S; ++s) { pl->seg_Ks[s] = 0; pl->seg_k0[s] = 0; }
+  for (int k = K - 1; k >= 0; --k) { pl->seg_Ks[pl->seg[k]]++; pl->seg_k0[pl->seg[k]] = k; }
+  for (int k = 1; k < K; ++k)
+    if (pl->seg[k] < pl->seg[k - 1]) { d2d_set_error("fit_basis_segments: samples not in segment order"); return D2D_EINVAL; }
+  int L[D2D_FIT_MAX_S];
+  int used = 0;
+  for (int s = 0; s < S; ++s) { L[s] = pl->seg_Ks[s] > 0 ? 1 : 0; used += L[s]; }
+  auto chunks = [&](int s) { return L[s] ? (pl->seg_Ks[s] + L[s] - 1) / L[s] : 0; };
+  for (; used < 64; ++used) {                       // the next lane goes to the segment that needs the most chunks
+    int best = -1;
+    for (int s = 0; s < S; ++s)
+      if (L[s] && L[s] < pl->seg_Ks[s] &&
+          (best < 0 || chunks(s) > chunks(best) || (chunks(s) == chunks(best) && pl->seg_Ks[s] * L[best] > pl->seg_Ks[best] * L[s])))
+        best = s;
+    if (best < 0) break;
+    L[best]++;
+  }
+  pl->seg_nchunk = 0;
+  pl->seg_l0[0] = 0;
+  for (int s = 0; s < S; ++s) {
+    pl->seg_l0[s + 1] = pl->seg_l0[s] + L[s];
+    if (chunks(s) > pl->seg_nchunk) pl->seg_nchunk = chunks(s);
+  }
+  for (int s = S; s < D2D_FIT_MAX_S; ++s) pl->seg_l0[s + 1] = pl->seg_l0[S];
   return D2D_OK;
 }

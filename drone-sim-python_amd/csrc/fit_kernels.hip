@@ -17,6 +17,7 @@
 
 #include "fit_device.h"
 #include "fit_phases.h"
+#include "fit_seg.h"
 #include "fit_plan.h"
 
 // wavefronts (= trajectories) per workgroup, fewer when K is large.  The launch bounds set the VGPR cap:
@@ -1139,41 +1140,86 @@ static int long_tables_waves(int K, int nq, int N, bool g32) {
   return 0;
 }
 
+// LDS of the segment formulation (fit_seg.h): plan constants + per-wave blocks, none of which depends on K
+static SegLds seg_lds_layout(int N, int nq, int S, int wpb) {
+  SegLds L;
+  int o = 0;
+  L.Wt = o; o = align16(o + (N / 16) * (N / 16 + 1) / 2 * 256 * 4);
+  L.Zl64 = o; o = align16(o + 8 * S * (nq + 1) * 8);
+  L.Zl32 = o; o = align16(o + 8 * S * nq * 4);
+  L.wave0 = o;
+  int w = 0;
+  L.qs = w; w = align16(w + N * 8);
+  L.sp = w; w = align16(w + FIT_PREP_STRIDE * 8);
+  L.zc = w; w = align16(w + 8 * D2D_FIT_MAX_S * 2 * 8);
+  L.big = w;
+  L.cf = w;
+  L.cfp = L.cf + SEG_ROWS * 4 * 16;
+  L.psi = align16(L.cfp + SEG_ROWS * 2 * 8);
+  int big = L.psi + 3 * SEG_ROWS * 8 * 4 - L.big;
+  if ((N + 3) * (N + 4) * 4 > big) big = (N + 3) * (N + 4) * 4;             // image of J^T J / its Cholesky factor
+  if (64 * SEG_RED_STRIDE * 8 > big) big = 64 * SEG_RED_STRIDE * 8;         // moment reduction scratch
+  w = align16(w + big);
+  L.wave_stride = w;
+  L.total = o + wpb * w;
+  return L;
+}
+struct SegArgs {
+  SegMap m;
+  SegLds L;
+  const double *Zl64, *Zlp, *sx;
+  const float *Zl32;
+  double c1;              // 2 / T
+};
+
 // TL: the basis tables are staged into the LDS once per workgroup (they fit beside >= 3 per-wave blocks: K <= 121 at nq = 24) and
 // the phases read them there like the K <= 64 kernel does -- from global memory every phase of every chunk is a chain of L2
 // round trips (measured at K = 121: 287 us per LM iteration and wave with 8 waves per CU against 40 us with 3).
+// SEG (round 3, the default): the segment formulation of fit_seg.h -- no K-sized table at all, one MFMA per sample.
 // MODE: as fit_lm_kernel (D2D_LM_MODE_MINPACK: lmder's trials through mp_trial, then the second-order loop)
-template <int NB, int NQ, bool TL, bool TL32, int MODE>
+template <int NB, int NQ, bool TL, bool TL32, int MODE, bool SEG = false>
 __global__ void __launch_bounds__(64 * FIT_LM_WPB_MAX)
 fit_lm_long_kernel(int B, FitGeom g, LongLds L, d2d_fit_opts opts, int iter_budget,
                    const double *__restrict__ GTg, const double *__restrict__ G64gl, const double *__restrict__ pk,
                    const float *__restrict__ gG32, const float *__restrict__ gWt, const double *__restrict__ prep,
                    double *__restrict__ q_io, double *__restrict__ cost_io, double *__restrict__ g_io,
                    double *__restrict__ lm, int32_t *__restrict__ flags, int32_t *__restrict__ queue,
-                   const int32_t *__restrict__ order, GroupArgs ga) {
+                   const int32_t *__restrict__ order, GroupArgs ga, SegArgs sa) {
   // ga (coupled groups): trajectory of hand-out position i = ga.off + i * ga.stride (one aircraft index of every scenario per
   // launch), collision rows against the positions table ga.pos; uncoupled: {nullptr, 0, 0, 1, 0}
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   constexpr int N = 16 * NB, NT = NB * (NB + 1) / 2;
-  stage(lds + L.Wt, gWt, NT * 256 * 4);
-  if (TL) {
-    stage(lds + L.G64, G64gl, 3 * g.K * g.gstr * 8);
-    if (TL32) stage(lds + L.G32, gG32, (3 * g.K + 1) * g.nq * 4);
+  if (SEG) {
+    stage(lds + sa.L.Wt, gWt, NT * 256 * 4);
+    stage(lds + sa.L.Zl64, sa.Zl64, 8 * sa.m.S * (g.nq + 1) * 8);
+    stage(lds + sa.L.Zl32, sa.Zl32, 8 * sa.m.S * g.nq * 4);
+  } else {
+    stage(lds + L.Wt, gWt, NT * 256 * 4);
+    if (TL) {
+      stage(lds + L.G64, G64gl, 3 * g.K * g.gstr * 8);
+      if (TL32) stage(lds + L.G32, gG32, (3 * g.K + 1) * g.nq * 4);
+    }
   }
   __syncthreads();
-  const float *Wt = reinterpret_cast<const float *>(lds + L.Wt);
+  const float *Wt = reinterpret_cast<const float *>(lds + (SEG ? sa.L.Wt : L.Wt));
   // phase 1 table / phase 2 table: the LDS copy of the row-major block, or the transposed / row-major global tables
   const double *GT = TL ? reinterpret_cast<const double *>(lds + L.G64) : GTg;
   const double *G64g = TL ? reinterpret_cast<const double *>(lds + L.G64) : G64gl;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int woff = L.wave0 + wave * L.wave_stride;
+  const int woff = SEG ? sa.L.wave0 + wave * sa.L.wave_stride : L.wave0 + wave * L.wave_stride;
   unsigned char *wl = lds + woff;
-  double *qs = reinterpret_cast<double *>(wl + L.qs);
-  double *sp = reinterpret_cast<double *>(wl + L.sp);
+  double *qs = reinterpret_cast<double *>(wl + (SEG ? sa.L.qs : L.qs));
+  double *sp = reinterpret_cast<double *>(wl + (SEG ? sa.L.sp : L.sp));
   double *us = reinterpret_cast<double *>(wl + L.big);
-  f32x4 *cf = reinterpret_cast<f32x4 *>(wl + L.cf);
-  float2 *cfp = reinterpret_cast<float2 *>(wl + L.cfp);
-  float *big = reinterpret_cast<float *>(wl + L.big);          // image of J^T J, then of its Cholesky factor (aliases us / cf / cfp)
+  f32x4 *cf = reinterpret_cast<f32x4 *>(wl + (SEG ? sa.L.cf : L.cf));
+  float2 *cfp = reinterpret_cast<float2 *>(wl + (SEG ? sa.L.cfp : L.cfp));
+  float *big = reinterpret_cast<float *>(wl + (SEG ? sa.L.big : L.big));          // image of J^T J, then of its Cholesky factor (aliases us / cf / cfp)
+  // segment formulation: Legendre coefficients of the trial point, operand planes, plan constants, this lane's segment
+  double *zc = reinterpret_cast<double *>(wl + sa.L.zc);
+  float *psi = reinterpret_cast<float *>(wl + sa.L.psi);
+  const double *Zl64 = reinterpret_cast<const double *>(lds + sa.L.Zl64);
+  const float *Zl32 = reinterpret_cast<const float *>(lds + sa.L.Zl32);
+  const LaneSeg ls = lane_segment(sa.m, lane);
   const int nq = NQ ? NQ : g.nq, n = 2 * nq;
   const bool act = lane < n;
   const int stride = gridDim.x * (blockDim.x >> 6);
@@ -1213,34 +1259,91 @@ fit_lm_long_kernel(int B, FitGeom g, LongLds L, d2d_fit_opts opts, int iter_budg
     for (int i = lane; i < FIT_PREP_STRIDE; i += 64) sp[i] = prep[(size_t)b * FIT_PREP_STRIDE + i];
     wave_lds_sync();
 
+    // segment formulation: the end-condition part of this lane's Legendre coefficient pair (lane = (segment, degree))
+    double zpx = 0.0, zpy = 0.0;
+    if (SEG && lane < 8 * sa.m.S) {
+#pragma unroll
+      for (int mm_ = 0; mm_ < 4; ++mm_) {
+        const double zv = sa.Zlp[lane * 4 + mm_];
+        zpx = fma(zv, sp[PR_DX + mm_], zpx); zpy = fma(zv, sp[PR_DY + mm_], zpy);
+      }
+    }
+    double mom_none[16];
+
     // cost at qi + alpha * delta (cost-only pass over the chunks)
     auto cost_at = [&](double alpha, double delta) -> double {
       if (act) qs[q_slot(lane, nq)] = qi + alpha * delta;
       wave_lds_sync();
-      const int kbank = long_bank_argmax<NQ, TL>(g, GT, pkb, qs, load_scenp(sp), lane);
       double ca = 0.0;
-      for (int k0 = 0; k0 < g.K; k0 += 64) ca += long_phase1<NQ, false, TL>(g, GT, pkb, sp, qs, us, cf, cfp, false, kbank, k0, lane, gc);
+      if (SEG) {
+        segment_coefs<NQ>(nq, sa.m.S, Zl64, qs, zpx, zpy, zc, lane);
+        const int kbank = segment_bank_argmax(sa.m, ls, sa.sx, sa.c1, zc, load_scenp(sp));
+        for (int c = 0; c < sa.m.nchunk; ++c)
+          ca += segment_phase1<false>(ls, g.K, sa.sx, sa.c1, pkb, sp, zc, cf, cfp, psi, mom_none, false, kbank, c, lane, gc);
+      } else {
+        const int kbank = long_bank_argmax<NQ, TL>(g, GT, pkb, qs, load_scenp(sp), lane);
+        for (int k0 = 0; k0 < g.K; k0 += 64) ca += long_phase1<NQ, false, TL>(g, GT, pkb, sp, qs, us, cf, cfp, false, kbank, k0, lane, gc);
+      }
       return uniform_d(ca);
     };
     // full evaluation at qi: c, gi, and (want_H) hrow = this lane's row of J^T J (+ the waypoint block) with -g as row N
     auto eval_full = [&](bool so, bool want_H) {
       if (act) qs[q_slot(lane, nq)] = qi;
       wave_lds_sync();
-      const int kbank = long_bank_argmax<NQ, TL>(g, GT, pkb, qs, load_scenp(sp), lane);
       f32x4 acc[NT];
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
       double ca = 0.0, ga = 0.0;
-      for (int k0 = 0; k0 < g.K; k0 += 64) {
-        const int kn = g.K - k0 < 64 ? g.K - k0 : 64;
-        ca += long_phase1<NQ, true, TL>(g, GT, pkb, sp, qs, us, cf, cfp, so, kbank, k0, lane, gc);
-        ga += long_phase2<NQ>(g, G64g, us, k0, kn, lane);
-        if (want_H) {
-          const int toff = L.G32 + 4 * k0 * nq;                            // this chunk's first row of the fp32 planes (LDS copy)
-          if (so) jtj_mfma_so<NB, NQ, TL32>(g, lds, toff, woff + L.cf, woff + L.cfp, lane, acc, gG32 + (size_t)k0 * nq, kn, true);
-          else jtj_mfma<NB, NQ, TL32>(g, lds, toff, gG32 + (size_t)k0 * nq, woff + L.cf, lane, kn, acc, 0, 0, true);
+      if (SEG) {
+        segment_coefs<NQ>(nq, sa.m.S, Zl64, qs, zpx, zpy, zc, lane);
+        const int kbank = segment_bank_argmax(sa.m, ls, sa.sx, sa.c1, zc, load_scenp(sp));
+        const FitGeom g8{SEG_ROWS, 8, 9};                 // the chunk's operand planes: SEG_ROWS rows of eight Legendre values per derivative order
+        f32x4 bs[D2D_FIT_MAX_S][1];
+        double mom[16];
+#pragma unroll
+        for (int s = 0; s < D2D_FIT_MAX_S; ++s) bs[s][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mom[i] = 0.0;
+        for (int c = 0; c < sa.m.nchunk; ++c) {
+          ca += segment_phase1<true>(ls, g.K, sa.sx, sa.c1, pkb, sp, zc, cf, cfp, psi, mom, so, kbank, c, lane, gc);
+          if (want_H) {
+            // (unrolled over the segments: every offset of a pass is an immediate.  A runtime loop with one copy of the pass and
+            // of the projection -- 45 instead of 270 MFMA instructions of code -- was 8 % slower.)
+#pragma unroll
+            for (int s = 0; s < D2D_FIT_MAX_S; ++s) {
+              if (s < sa.m.S) {
+                const int Ls = sa.m.l0[s + 1] - sa.m.l0[s];
+                const int left = sa.m.Ks[s] - c * Ls;
+                const int kn = left < Ls ? left : Ls;
+                if (kn > 0) {
+                  const int poff = sa.L.psi + sa.m.l0[s] * 32, coff = sa.L.cf + sa.m.l0[s] * 64, cpoff = sa.L.cfp + sa.m.l0[s] * 16;
+                  if (so) jtj_mfma_so<1, 8, true>(g8, lds, woff + poff, woff + coff, woff + cpoff, lane, bs[s], nullptr, kn, true, true);
+                  else jtj_mfma<1, 8, true>(g8, lds, woff + poff, nullptr, woff + coff, lane, kn, bs[s], 0, 0, true);
+                }
+              }
+            }
+          }
+          wave_lds_sync();                              // every lane is done with this chunk's records
         }
-        wave_lds_sync();                              // every lane is done with this chunk's records
+        ga = segment_gradient<NQ>(sa.m, nq, Zl64, mom, reinterpret_cast<double *>(big), zc, lane);
+        if (want_H) {
+#pragma unroll
+          for (int s = 0; s < D2D_FIT_MAX_S; ++s)
+            if (s < sa.m.S) segment_project<NB, NQ>(nq, Zl32, s, bs[s][0], lane, acc);
+        }
+      } else {
+        const int kbank = long_bank_argmax<NQ, TL>(g, GT, pkb, qs, load_scenp(sp), lane);
+        for (int k0 = 0; k0 < g.K; k0 += 64) {
+          const int kn = g.K - k0 < 64 ? g.K - k0 : 64;
+          ca += long_phase1<NQ, true, TL>(g, GT, pkb, sp, qs, us, cf, cfp, so, kbank, k0, lane, gc);
+          ga += long_phase2<NQ>(g, G64g, us, k0, kn, lane);
+          if (want_H) {
+            const int toff = L.G32 + 4 * k0 * nq;                            // this chunk's first row of the fp32 planes (LDS copy)
+            if (so) jtj_mfma_so<NB, NQ, TL32>(g, lds, toff, woff + L.cf, woff + L.cfp, lane, acc, gG32 + (size_t)k0 * nq, kn, true);
+            else jtj_mfma<NB, NQ, TL32>(g, lds, toff, gG32 + (size_t)k0 * nq, woff + L.cf, lane, kn, acc, 0, 0, true);
+          }
+          wave_lds_sync();                              // every lane is done with this chunk's records
+        }
       }
       c = uniform_d(ca); gi = ga;
       if (want_H) {
@@ -1727,11 +1830,25 @@ static int launch_lm_long(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, double *q
   static const bool no_queue = getenv("D2D_LM_STATIC") != nullptr;
   int32_t *queue = no_queue ? nullptr : ctx->counter_dev + 8;
   const int32_t *order = (pl->order_B == B && ga.pos == nullptr) ? pl->d_order : nullptr;
-#define LAUNCH_LONG__(NBV, NQV, TLV, TL32V, MODEV)                                                                     \
-  hipLaunchKernelGGL((fit_lm_long_kernel<NBV, NQV, TLV, TL32V, MODEV>), dim3(blocks), dim3(64 * wpb), L.total, ctx->stream, B, gm, L, o, budget, \
-                     pl->d_GT, pl->d_G, pl->d_pk, pl->d_G32, pl->d_W32, pl->d_prep, q, pl->d_cost, pl->d_g, pl->d_lm, pl->d_flags, queue, order, ga)
-#define LAUNCH_LONG_(NBV, NQV, TLV, TL32V) do { if (o.mode == D2D_LM_MODE_FAST) LAUNCH_LONG__(NBV, NQV, TLV, TL32V, D2D_LM_MODE_FAST); else LAUNCH_LONG__(NBV, NQV, TLV, TL32V, D2D_LM_MODE_MINPACK); } while (0)
-#define LAUNCH_LONG(NBV, NQV) do { if (mode == 2) LAUNCH_LONG_(NBV, NQV, true, true); else if (mode == 1) LAUNCH_LONG_(NBV, NQV, true, false); else LAUNCH_LONG_(NBV, NQV, false, false); } while (0)
+  // the segment formulation (fit_seg.h) is the default; D2D_FIT_LONG_SEG=0 or a forced table placement selects the table kernels (A/B)
+  static const bool seg_off = getenv("D2D_FIT_LONG_SEG") && atoi(getenv("D2D_FIT_LONG_SEG")) == 0;
+  const bool seg = !seg_off && force < 0;
+  SegArgs sa{};
+  if (seg) {
+    sa.m.S = pl->seg_S; sa.m.nchunk = pl->seg_nchunk;
+    for (int i = 0; i <= D2D_FIT_MAX_S; ++i) sa.m.l0[i] = pl->seg_l0[i];
+    for (int i = 0; i < D2D_FIT_MAX_S; ++i) { sa.m.k0[i] = pl->seg_k0[i]; sa.m.Ks[i] = pl->seg_Ks[i]; }
+    sa.L = seg_lds_layout(16 * NB, pl->nq, pl->S, FIT_LM_WPB_MAX);
+    sa.Zl64 = pl->d_Zl64; sa.Zl32 = pl->d_Zl32; sa.Zlp = pl->d_Zlp; sa.sx = pl->d_sx;
+    sa.c1 = 2.0 / pl->T;
+  }
+  const int wpb_l = seg ? FIT_LM_WPB_MAX : wpb;
+  const int lds_l = seg ? sa.L.total : L.total;
+#define LAUNCH_LONG__(NBV, NQV, TLV, TL32V, MODEV, SEGV)                                                               \
+  hipLaunchKernelGGL((fit_lm_long_kernel<NBV, NQV, TLV, TL32V, MODEV, SEGV>), dim3(blocks), dim3(64 * wpb_l), lds_l, ctx->stream, B, gm, L, o, budget, \
+                     pl->d_GT, pl->d_G, pl->d_pk, pl->d_G32, pl->d_W32, pl->d_prep, q, pl->d_cost, pl->d_g, pl->d_lm, pl->d_flags, queue, order, ga, sa)
+#define LAUNCH_LONG_(NBV, NQV, TLV, TL32V, SEGV) do { if (o.mode == D2D_LM_MODE_FAST) LAUNCH_LONG__(NBV, NQV, TLV, TL32V, D2D_LM_MODE_FAST, SEGV); else LAUNCH_LONG__(NBV, NQV, TLV, TL32V, D2D_LM_MODE_MINPACK, SEGV); } while (0)
+#define LAUNCH_LONG(NBV, NQV) do { if (seg) LAUNCH_LONG_(NBV, NQV, false, false, true); else if (mode == 2) LAUNCH_LONG_(NBV, NQV, true, true, false); else if (mode == 1) LAUNCH_LONG_(NBV, NQV, true, false, false); else LAUNCH_LONG_(NBV, NQV, false, false, false); } while (0)
   if (pl->nq == 24) LAUNCH_LONG(3, 24);
   else if (NB == 1) LAUNCH_LONG(1, 0);
   else if (NB == 2) LAUNCH_LONG(2, 0);
@@ -1761,6 +1878,7 @@ int d2d_fit_plan_create(d2d_ctx *ctx, int S, int K, double duration, const doubl
   pl->S = S; pl->K = K; pl->duration = duration;
   for (int i = 0; i < 3; ++i) pl->wref[i] = wref[i];
   if (int rc = fit_basis_build(pl)) { delete pl; return rc; }
+  if (int rc = fit_basis_segments(pl)) { delete pl; return rc; }
   const int nq = pl->nq, gstr = nq + 1;
   // the split-path kernels (public d2d_fit_eval, coupled groups) stage the whole basis block in LDS: K <~ 229 at S = 6
   pl->split_ok = pick_eval_layout(K, nq, &pl->g32_lds, &pl->wpb_eval, 0) &&
@@ -1815,6 +1933,16 @@ int d2d_fit_plan_create(d2d_ctx *ctx, int S, int K, double duration, const doubl
   if (!rc) rc = upload(&pl->d_Z, pl->Z);
   if (!rc) rc = upload(&pl->d_Zp, pl->Zp);
   if (!rc) rc = upload(&pl->d_Pinit, pl->Pinit);
+  {
+    std::vector<double> zl64((size_t)8 * S * gstr, 0.0);
+    std::vector<float> zl32((size_t)8 * S * nq);
+    for (int i = 0; i < 8 * S; ++i)
+      for (int j = 0; j < nq; ++j) { zl64[(size_t)i * gstr + j] = pl->Zl[(size_t)i * nq + j]; zl32[(size_t)i * nq + j] = (float)pl->Zl[(size_t)i * nq + j]; }
+    if (!rc) rc = upload(&pl->d_Zl64, zl64);
+    if (!rc) rc = upload(&pl->d_Zl32, zl32);
+    if (!rc) rc = upload(&pl->d_Zlp, pl->Zlp);
+    if (!rc) rc = upload(&pl->d_sx, pl->sx);
+  }
   if (rc) { d2d_fit_plan_destroy(pl); return rc; }
   // opt in to large dynamic LDS
   allow_big_lds(&fit_eval_kernel<1, 0, true>); allow_big_lds(&fit_eval_kernel<2, 0, true>); allow_big_lds(&fit_eval_kernel<3, 0, true>);
@@ -1827,6 +1955,8 @@ int d2d_fit_plan_create(d2d_ctx *ctx, int S, int K, double duration, const doubl
   allow_big_lds(&fit_lm_long_kernel<3, 24, true, true, D2D_LM_MODE_FAST>); allow_big_lds(&fit_lm_long_kernel<3, 0, true, true, D2D_LM_MODE_FAST>); allow_big_lds(&fit_lm_long_kernel<2, 0, true, true, D2D_LM_MODE_FAST>); allow_big_lds(&fit_lm_long_kernel<1, 0, true, true, D2D_LM_MODE_FAST>);
   allow_big_lds(&fit_lm_long_kernel<3, 24, true, false, D2D_LM_MODE_MINPACK>); allow_big_lds(&fit_lm_long_kernel<3, 0, true, false, D2D_LM_MODE_MINPACK>); allow_big_lds(&fit_lm_long_kernel<2, 0, true, false, D2D_LM_MODE_MINPACK>); allow_big_lds(&fit_lm_long_kernel<1, 0, true, false, D2D_LM_MODE_MINPACK>);
   allow_big_lds(&fit_lm_long_kernel<3, 24, true, false, D2D_LM_MODE_FAST>); allow_big_lds(&fit_lm_long_kernel<3, 0, true, false, D2D_LM_MODE_FAST>); allow_big_lds(&fit_lm_long_kernel<2, 0, true, false, D2D_LM_MODE_FAST>); allow_big_lds(&fit_lm_long_kernel<1, 0, true, false, D2D_LM_MODE_FAST>);
+  allow_big_lds(&fit_lm_long_kernel<3, 24, false, false, D2D_LM_MODE_MINPACK, true>); allow_big_lds(&fit_lm_long_kernel<3, 0, false, false, D2D_LM_MODE_MINPACK, true>); allow_big_lds(&fit_lm_long_kernel<2, 0, false, false, D2D_LM_MODE_MINPACK, true>); allow_big_lds(&fit_lm_long_kernel<1, 0, false, false, D2D_LM_MODE_MINPACK, true>);
+  allow_big_lds(&fit_lm_long_kernel<3, 24, false, false, D2D_LM_MODE_FAST, true>); allow_big_lds(&fit_lm_long_kernel<3, 0, false, false, D2D_LM_MODE_FAST, true>); allow_big_lds(&fit_lm_long_kernel<2, 0, false, false, D2D_LM_MODE_FAST, true>); allow_big_lds(&fit_lm_long_kernel<1, 0, false, false, D2D_LM_MODE_FAST, true>);
   allow_big_lds(&fit_groups_kernel<3, 24>);
   allow_big_lds(&fit_lm_kernel<3, 24, false, D2D_LM_MODE_MINPACK>);
   allow_big_lds(&fit_lm_kernel<3, 24, true, D2D_LM_MODE_MINPACK>);
@@ -1842,7 +1972,7 @@ int d2d_fit_plan_destroy(d2d_fit_plan *pl) {
   if (!pl) return D2D_OK;
   hipSetDevice(pl->device);
   for (hipEvent_t e : pl->prof_ev) (void)hipEventDestroy(e);
-  void *ptrs[] = {pl->d_G, pl->d_GT, pl->d_Gp, pl->d_G32, pl->d_W32, pl->d_Z, pl->d_Zp, pl->d_Pinit};
+  void *ptrs[] = {pl->d_G, pl->d_GT, pl->d_Gp, pl->d_G32, pl->d_W32, pl->d_Z, pl->d_Zp, pl->d_Pinit, pl->d_Zl64, pl->d_Zl32, pl->d_Zlp, pl->d_sx};
   for (void *p : ptrs)
     if (p) hipFree(p);
   free_scratch(pl);

@@ -426,9 +426,12 @@ __device__ __forceinline__ void jtj_mfma(const FitGeom &g, const unsigned char *
 template <int NB, int NQ, bool T_LDS = true>
 __device__ __forceinline__ void jtj_mfma_so(const FitGeom &g, const unsigned char *lds_base, int t32_off, int cf_off,
                                             int cfp_off, int lane, f32x4 (&acc)[NB * (NB + 1) / 2],
-                                            const float *T32g = nullptr, int Kmf = -1, bool accumulate = false) {
+                                            const float *T32g = nullptr, int Kmf = -1, bool accumulate = false,
+                                            bool tail_mask = false) {
   // T_LDS = false / Kmf / accumulate: one chunk of a long horizon (see jtj_mfma); Kmf samples, records at cf_off / cfp_off,
   // T32g = the fp32 planes in global memory advanced by the chunk's first sample
+  // tail_mask (segment formulation, fit_seg.h): the record behind the last sample is not a zero record but the next segment's
+  // first sample -- an odd Kmf leaves the second half of its last pair out instead
   if (Kmf < 0) Kmf = g.K;
   LAUNDER(lane);
   const int rho = lane >> 4, ci = lane & 15;
@@ -460,6 +463,7 @@ __device__ __forceinline__ void jtj_mfma_so(const FitGeom &g, const unsigned cha
 #pragma unroll
     for (int half = 0; half < 2; ++half) {                  // velocity k-steps of samples k and k+1
       const int ks = k + half;
+      if (tail_mask && ks >= Kmf) break;
       const f32x4 rec = lds_get<f32x4>(lds_base + cf_off + (ks * 4 + rho) * 16);
       float va_[NB], vb_[NB];
 #pragma unroll
@@ -477,7 +481,7 @@ __device__ __forceinline__ void jtj_mfma_so(const FitGeom &g, const unsigned cha
 #pragma unroll
         for (int c = 0; c < NB; ++c) {
           const float g0 = SO_T(0, kp, jj[c]);
-          const bool live = 16 * c + ci < 2 * nq;
+          const bool live = 16 * c + ci < 2 * nq && !(tail_mask && kp >= Kmf);
           vb_[c] = live ? (ayc[c] ? rp.y : rp.x) * g0 : 0.f;
           va_[c] = (live && row_y == ayc[c]) ? g0 : 0.f;
         }

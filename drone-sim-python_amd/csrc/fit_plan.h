@@ -11,6 +11,11 @@ struct d2d_fit_plan {
   double wref[3];
   // host copies (fp64)
   std::vector<double> G, Gp, Z, Zp, Pinit, G0tG0;
+  // segment formulation of the long-horizon kernel (fit_seg.h; fit_basis.cpp fit_basis_segments)
+  std::vector<int> seg;             // [K]  segment of every sample
+  std::vector<double> tau;          // [K]  its local time
+  std::vector<double> Zl, Zlp, sx;  // [8S][nq] / [8S][4] maps to the Legendre coefficients of the segments; [K] x_k = 2 tau_k / T - 1
+  int seg_S = 0, seg_nchunk = 0, seg_l0[7] = {0}, seg_k0[6] = {0}, seg_Ks[6] = {0};
   // device copies
   double *d_G = nullptr;     // [3][K][GSTR]   GSTR = nq+1 (odd stride: conflict-free LDS image)
   double *d_GT = nullptr;    // [3][nq][K]    transposed copy for the long-horizon kernel (lane = sample reads are contiguous)
@@ -20,6 +25,10 @@ struct d2d_fit_plan {
   double *d_Z = nullptr;     // [8S][nq]
   double *d_Zp = nullptr;    // [8S][4]
   double *d_Pinit = nullptr; // [nq][K]
+  double *d_Zl64 = nullptr;  // [8S][nq+1]  (odd stride: conflict-free rows and columns in the LDS)
+  float *d_Zl32 = nullptr;   // [8S][nq]
+  double *d_Zlp = nullptr;   // [8S][4]
+  double *d_sx = nullptr;    // [K]
   // solver scratch, grown on demand (d2d_fit_solve)
   int cap_B = 0;
   double *d_g = nullptr;     // [B][2nq]
@@ -55,3 +64,4 @@ struct d2d_fit_plan {
 };
 
 int fit_basis_build(d2d_fit_plan *pl);   // fills the host vectors
+int fit_basis_segments(d2d_fit_plan *pl);   // ... of the segment formulation (after fit_basis_build)
