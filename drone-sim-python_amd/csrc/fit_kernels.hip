@@ -1170,6 +1170,7 @@ struct SegArgs {
   const double *Zl64, *Zlp, *sx;
   const float *Zl32;
   double c1;              // 2 / T
+  unsigned long long *stamps;   // D2D_LM_STAMPS=1 (diagnostics): wave-cycle totals per phase, NULL otherwise
 };
 
 // TL: the basis tables are staged into the LDS once per workgroup (they fit beside >= 3 per-wave blocks: K <= 121 at nq = 24) and
@@ -1220,6 +1221,12 @@ fit_lm_long_kernel(int B, FitGeom g, LongLds L, d2d_fit_opts opts, int iter_budg
   const double *Zl64 = reinterpret_cast<const double *>(lds + sa.L.Zl64);
   const float *Zl32 = reinterpret_cast<const float *>(lds + sa.L.Zl32);
   const LaneSeg ls = lane_segment(sa.m, lane);
+  // diagnostics (SEG, sa.stamps != NULL): 0 coefficients, 1 rows of trial points, 2 rows of evaluations, 3 MFMA passes, 4 J^T r, 5 projection,
+  // 6 image, 7 everything else (solves, bookkeeping)
+  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = 0;
+  const bool st_on = SEG && sa.stamps != nullptr;
+#define SEG_STAMP(i) if (st_on) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_last; st_last = t_; }
+  if (st_on) st_last = __builtin_amdgcn_s_memtime();
   const int nq = NQ ? NQ : g.nq, n = 2 * nq;
   const bool act = lane < n;
   const int stride = gridDim.x * (blockDim.x >> 6);
@@ -1276,10 +1283,17 @@ fit_lm_long_kernel(int B, FitGeom g, LongLds L, d2d_fit_opts opts, int iter_budg
       wave_lds_sync();
       double ca = 0.0;
       if (SEG) {
+        SEG_STAMP(7)
         segment_coefs<NQ>(nq, sa.m.S, Zl64, qs, zpx, zpy, zc, lane);
+        SEG_STAMP(0)
         const int kbank = segment_bank_argmax(sa.m, ls, sa.sx, sa.c1, zc, load_scenp(sp));
-        for (int c = 0; c < sa.m.nchunk; ++c)
-          ca += segment_phase1<false>(ls, g.K, sa.sx, sa.c1, pkb, sp, zc, cf, cfp, psi, mom_none, false, kbank, c, lane, gc);
+        SegIn nin = segment_inputs(ls, g.K, sa.sx, pkb, 0);
+        for (int c = 0; c < sa.m.nchunk; ++c) {
+          const SegIn in = nin;
+          if (c + 1 < sa.m.nchunk) nin = segment_inputs(ls, g.K, sa.sx, pkb, c + 1);
+          ca += segment_phase1<false>(ls, g.K, in, sa.c1, sp, zc, cf, cfp, psi, mom_none, false, kbank, c, lane, gc);
+        }
+        SEG_STAMP(1)
       } else {
         const int kbank = long_bank_argmax<NQ, TL>(g, GT, pkb, qs, load_scenp(sp), lane);
         for (int k0 = 0; k0 < g.K; k0 += 64) ca += long_phase1<NQ, false, TL>(g, GT, pkb, sp, qs, us, cf, cfp, false, kbank, k0, lane, gc);
@@ -1295,7 +1309,9 @@ fit_lm_long_kernel(int B, FitGeom g, LongLds L, d2d_fit_opts opts, int iter_budg
       for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
       double ca = 0.0, ga = 0.0;
       if (SEG) {
+        SEG_STAMP(7)
         segment_coefs<NQ>(nq, sa.m.S, Zl64, qs, zpx, zpy, zc, lane);
+        SEG_STAMP(0)
         const int kbank = segment_bank_argmax(sa.m, ls, sa.sx, sa.c1, zc, load_scenp(sp));
         const FitGeom g8{SEG_ROWS, 8, 9};                 // the chunk's operand planes: SEG_ROWS rows of eight Legendre values per derivative order
         f32x4 bs[D2D_FIT_MAX_S][1];
@@ -1304,8 +1320,12 @@ fit_lm_long_kernel(int B, FitGeom g, LongLds L, d2d_fit_opts opts, int iter_budg
         for (int s = 0; s < D2D_FIT_MAX_S; ++s) bs[s][0] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 16; ++i) mom[i] = 0.0;
+        SegIn nin = segment_inputs(ls, g.K, sa.sx, pkb, 0);
         for (int c = 0; c < sa.m.nchunk; ++c) {
-          ca += segment_phase1<true>(ls, g.K, sa.sx, sa.c1, pkb, sp, zc, cf, cfp, psi, mom, so, kbank, c, lane, gc);
+          const SegIn in = nin;
+          if (c + 1 < sa.m.nchunk) nin = segment_inputs(ls, g.K, sa.sx, pkb, c + 1);
+          ca += segment_phase1<true>(ls, g.K, in, sa.c1, sp, zc, cf, cfp, psi, mom, so, kbank, c, lane, gc);
+          SEG_STAMP(2)
           if (want_H) {
             // (unrolled over the segments: every offset of a pass is an immediate.  A runtime loop with one copy of the pass and
             // of the projection -- 45 instead of 270 MFMA instructions of code -- was 8 % slower.)
@@ -1324,13 +1344,16 @@ fit_lm_long_kernel(int B, FitGeom g, LongLds L, d2d_fit_opts opts, int iter_budg
             }
           }
           wave_lds_sync();                              // every lane is done with this chunk's records
+          SEG_STAMP(3)
         }
         ga = segment_gradient<NQ>(sa.m, nq, Zl64, mom, reinterpret_cast<double *>(big), zc, lane);
+        SEG_STAMP(4)
         if (want_H) {
 #pragma unroll
           for (int s = 0; s < D2D_FIT_MAX_S; ++s)
             if (s < sa.m.S) segment_project<NB, NQ>(nq, Zl32, s, bs[s][0], lane, acc);
         }
+        SEG_STAMP(5)
       } else {
         const int kbank = long_bank_argmax<NQ, TL>(g, GT, pkb, qs, load_scenp(sp), lane);
         for (int k0 = 0; k0 < g.K; k0 += 64) {
@@ -1359,6 +1382,7 @@ fit_lm_long_kernel(int B, FitGeom g, LongLds L, d2d_fit_opts opts, int iter_budg
         if (MODE == D2D_LM_MODE_MINPACK) hdiag = big[(lane < N ? lane : 0) * CHOL_LS + (lane < N ? lane : 0)];
         wave_lds_sync();
         nev += (so ? 3 : 2) * ((g.K + 49) / 50);      // contracted rows in units of 100 (FL_NEVAL; one unit = 200 rows)
+        SEG_STAMP(6)
       }
     };
 
@@ -1439,6 +1463,12 @@ fit_lm_long_kernel(int B, FitGeom g, LongLds L, d2d_fit_opts opts, int iter_budg
       flags[4 * b + FL_NEVAL] += nev;
     }
   }
+  if (st_on) {
+    SEG_STAMP(7)
+    if (lane == 0)
+      for (int i = 0; i < 8; ++i) atomicAdd(&sa.stamps[i], st_acc[i]);
+  }
+#undef SEG_STAMP
   if (queue != nullptr && lane == 0) {
     if (atomicAdd(queue + 1, 1) == stride - 1) { queue[0] = 0; queue[1] = 0; }
   }
@@ -1841,6 +1871,11 @@ static int launch_lm_long(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, double *q
     sa.L = seg_lds_layout(16 * NB, pl->nq, pl->S, FIT_LM_WPB_MAX);
     sa.Zl64 = pl->d_Zl64; sa.Zl32 = pl->d_Zl32; sa.Zlp = pl->d_Zlp; sa.sx = pl->d_sx;
     sa.c1 = 2.0 / pl->T;
+    static const bool want_stamps = getenv("D2D_LM_STAMPS") != nullptr;
+    if (want_stamps) {
+      sa.stamps = reinterpret_cast<unsigned long long *>(ctx->stats_dev + 8);
+      D2D_CHECK_HIP(hipMemsetAsync(sa.stamps, 0, 8 * sizeof(unsigned long long), ctx->stream));
+    }
   }
   const int wpb_l = seg ? FIT_LM_WPB_MAX : wpb;
   const int lds_l = seg ? sa.L.total : L.total;
@@ -1857,6 +1892,17 @@ static int launch_lm_long(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, double *q
 #undef LAUNCH_LONG_
 #undef LAUNCH_LONG
   D2D_LAUNCH_CHECK();
+  if (seg && sa.stamps) {
+    unsigned long long h[8];
+    D2D_CHECK_HIP(hipMemcpyAsync(h, sa.stamps, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    D2D_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    static const char *nm[8] = {"coefs", "rows(trial)", "rows(eval)", "mfma", "JTr", "project", "image", "solve+rest"};
+    double tot = 0;
+    for (int i = 0; i < 8; ++i) tot += (double)h[i];
+    fprintf(stderr, "[fit_lm_long seg stamps] K=%d B=%d:", pl->K, B);
+    for (int i = 0; i < 8; ++i) fprintf(stderr, " %s=%.1f%%", nm[i], 100.0 * (double)h[i] / tot);
+    fprintf(stderr, " total=%.3e\n", tot);
+  }
   return D2D_OK;
 }
 

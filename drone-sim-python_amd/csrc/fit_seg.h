@@ -137,9 +137,21 @@ __device__ __forceinline__ int segment_bank_argmax(const SegMap &m, const LaneSe
 // the fp32 operand planes psi [3][SEG_ROWS][8] (plane d = d-th derivative of the eight Legendre rows), and the lane's share of
 // the segment moments added to mom[16] (mom[2 i + axis] += Psi_i . u over the three derivative orders).  Returns the chunk's
 // sum r^2 (wave-uniform).
+// The per-sample inputs of a chunk (abscissa, 'tri' waypoint) are requested one chunk ahead (SegIn): three loads per lane whose
+// latency would otherwise open every chunk.
+struct SegIn {
+  double x, wpx, wpy;
+};
+__device__ __forceinline__ SegIn segment_inputs(const LaneSeg &t, int K, const double *__restrict__ sx,
+                                                const double *__restrict__ pkb, int c) {
+  const int k = segment_sample(t, c);
+  SegIn in{0.0, 0.0, 0.0};
+  if (k >= 0) { in.x = sx[k]; in.wpx = pkb[(size_t)6 * K + k]; in.wpy = pkb[(size_t)7 * K + k]; }
+  return in;
+}
 template <bool WANT_JAC>
-__device__ __forceinline__ double segment_phase1(const LaneSeg &t, int K, const double *__restrict__ sx, double c1,
-                                                 const double *__restrict__ pkb, const double *sp, const double *zc,
+__device__ __forceinline__ double segment_phase1(const LaneSeg &t, int K, const SegIn &in, double c1,
+                                                 const double *sp, const double *zc,
                                                  f32x4 *cf, float2 *cfp, float *psi, double (&mom)[16], bool so, int kbank, int c,
                                                  int lane, const GroupCtx &gc) {
   LAUNDER(lane);
@@ -149,8 +161,8 @@ __device__ __forceinline__ double segment_phase1(const LaneSeg &t, int K, const 
   if (k >= 0) {
     double P[8], dP[8], ddP[8], Y[6], u[6] = {0, 0, 0, 0, 0, 0};
     f32x4 coef[4];
-    legendre_rows(sx[k], c1, P, dP, ddP);
-    const double wpx = pkb[(size_t)6 * K + k], wpy = pkb[(size_t)7 * K + k];
+    legendre_rows(in.x, c1, P, dP, ddP);
+    const double wpx = in.wpx, wpy = in.wpy;
     segment_flat(zc, sg, P, dP, ddP, Y);
     const ScenP s = load_scenp(sp);
     double xin[6];
