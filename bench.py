@@ -266,13 +266,14 @@ def nlp_record(ctx, torch, cpu, B=4096):
     return rec
 
 
-def long_horizon_record(ctx, torch, d2dhip, B=4096, K=121, t1=12.0):
-    """The reference's own planner horizons (101 .. 151 nodes at 10 Hz: exp_14 = 121) on the chunked persistent kernel
-    (fit_lm_long_kernel, K > 64): B independent fits of K nodes, same solver as the headline."""
+def long_horizon_record(ctx, torch, d2dhip, B=4096, K=121, t1=12.0, more=((301, 30.0),)):
+    """The reference's own planner horizons (101 .. 151 nodes at 10 Hz: exp_14 = 121; its 50 Hz scenarios: 211 .. 601) on the chunked
+    persistent kernel (fit_lm_long_kernel, K > 64; the segment formulation of csrc/fit_seg.h): B independent fits of K nodes, same
+    solver as the headline.  `more`: further (nodes, seconds) horizons reported under 'horizons'."""
     from d2dhip import synth
     dur = synth.planner_timing(0, t1, 10)[2]
     plan = d2dhip.FitPlan(ctx, S_, K, dur, synth.default_wref(OBJ_SCALE, K))
-    dsc = ctx.dev(synth.synth_scenarios(B, seed=SEED, obj_scale=OBJ_SCALE, K=K, dist_range=(100., 150.)))
+    dsc = ctx.dev(synth.synth_scenarios(B, seed=SEED, obj_scale=OBJ_SCALE, K=K, dist_range=(100. * t1 / 12.0, 150. * t1 / 12.0)))
     q0 = plan.init(dsc)
     cost, iters, status, stats = plan.solve(dsc, q0.clone(), max_iter=300)
 
@@ -290,11 +291,17 @@ def long_horizon_record(ctx, torch, d2dhip, B=4096, K=121, t1=12.0):
     plan.clear_order()
     st = status.cpu().numpy()
     rec = {'metric': f'trajectory-optimisations/sec (6-seg poly, {K} nodes)', 'value': B / best, 'unit': 'trajectory-optimisations/s',
-           'workload': f'{B} independent fits, {K} nodes over {t1:g} s, end poses 100-150 m apart (the horizon of optyplan_scenarios.exp_14)',
+           'workload': f'{B} independent fits, {K} nodes over {t1:g} s, end poses {100. * t1 / 12.0:g}-{150. * t1 / 12.0:g} m apart' + (' (the horizon of optyplan_scenarios.exp_14)' if K == 121 else ''),
            'kernel': plan.kernel, 'solver': 'library default (MINPACK lmder path + second-order finish)', 'handout': 'index order',
            'ms_per_step': 1e3 * best, 'value_with_order_hint': B / hinted, 'converged_frac': float((st == 1).mean()),
-           'mean_iters': float(iters.float().mean().item()), 'evals_per_fit': float(stats[3]) / B}
+           'mean_iters': float(iters.float().mean().item()), 'max_iters': int(iters.max().item()), 'evals_per_fit': float(stats[3]) / B}
     plan.close()
+    if more:
+        rec['horizons'] = []
+        for (K2, t2) in more:
+            r2 = long_horizon_record(ctx, torch, d2dhip, B=B, K=K2, t1=t2, more=())
+            rec['horizons'].append({k: r2[k] for k in ('metric', 'value', 'workload', 'ms_per_step', 'value_with_order_hint', 'converged_frac',
+                                                      'mean_iters', 'max_iters')})
     return rec
 
 
