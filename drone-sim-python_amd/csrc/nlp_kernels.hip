@@ -29,7 +29,7 @@ struct NlpScen {
   int n_obs, okind;
 };
 
-__device__ __forceinline__ NlpScen nlp_load_scen(const double *__restrict__ sc, const d2d_nlp_opts &o) {
+__device__ __forceinline__ NlpScen nlp_load_scen(const double *__restrict__ sc, const d2d_nlp_opts &o, const double *__restrict__ bnd) {
   NlpScen s;
   s.p0[0] = sc[D2D_SC_X0]; s.p0[1] = sc[D2D_SC_Y0]; s.p0[2] = sc[D2D_SC_PSI0];
   s.p1[0] = sc[D2D_SC_X1]; s.p1[1] = sc[D2D_SC_Y1]; s.p1[2] = sc[D2D_SC_PSI1];
@@ -41,6 +41,10 @@ __device__ __forceinline__ NlpScen nlp_load_scen(const double *__restrict__ sc, 
   if (sc[D2D_SC_YMIN] < sc[D2D_SC_YMAX]) { s.lo[1] = sc[D2D_SC_YMIN]; s.hi[1] = sc[D2D_SC_YMAX]; }
   s.lo[3] = -sc[D2D_SC_PHIMAX]; s.hi[3] = sc[D2D_SC_PHIMAX];
   s.lo[4] = sc[D2D_SC_VMIN]; s.hi[4] = sc[D2D_SC_VMAX];
+  if (bnd) {                                           // d2d_nlp_opts.bounds: an asymmetric phi interval, a box on psi
+    if (bnd[0] < bnd[1]) { s.lo[3] = bnd[0]; s.hi[3] = bnd[1]; }
+    if (bnd[2] < bnd[3]) { s.lo[2] = bnd[2]; s.hi[2] = bnd[3]; }
+  }
   s.wobs = ss * sc[D2D_SC_KOBS];
   const double kcol = sc[D2D_SC_KCOL], rcol = sc[D2D_SC_RCOL];
   s.wcol = (kcol > 0.0 && rcol > 0.0) ? sc[D2D_SC_SCOL] * kcol : 0.0;
@@ -926,13 +930,14 @@ struct NlpOut { double cost, feas; int iters, status; };
 // The solve of ONE problem by one wavefront (lane = threadIdx.x & 63): sc its scenario row, Wb [5][N] in/out, wsb its workspace,
 // multb [3][N] or null, partner [2][N] frozen positions of the CostCollision partner or null.  Wave-uniform control flow.
 __device__ __forceinline__ void nlp_solve_one(int N, double h, const d2d_nlp_opts &o, const double *__restrict__ sc, const double *partner,
-                                              double *Wb, double *wsb, double *multb, int lane, NlpOut &out, unsigned long long *stamps, double *ldsw) {
+                                              double *Wb, double *wsb, double *multb, int lane, NlpOut &out, unsigned long long *stamps, double *ldsw,
+                                              const double *__restrict__ bnd) {
   // diagnostics (D2D_NLP_STAMPS): cycles per phase -- merit, assembly, factorisation, back substitution, ratio tests, update
   unsigned long long st_t = 0, st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define NLP_STAMP(k) if (st_on) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[k] += t_ - st_t; st_t = t_; }
   const bool st_on = stamps != nullptr;
   if (st_on) st_t = __builtin_amdgcn_s_memtime();
-  const NlpScen s = nlp_load_scen(sc, o);
+  const NlpScen s = nlp_load_scen(sc, o, bnd);
   NlpProb pb;
   pb.N = N; pb.h = h;
   pb.W = Wb;
@@ -943,7 +948,7 @@ __device__ __forceinline__ void nlp_solve_one(int N, double h, const d2d_nlp_opt
   // (a row whose bounds are unset or inverted would give a zero-width box, infinite duals and NaN pivots for
   // outer_max x 30 assemblies -- refuse it at once)
   {
-    bool bad = !(s.hi[3] > s.lo[3]) || !(s.hi[4] > s.lo[4]) || !(s.lo[4] > 0.0) || !(s.hi[0] > s.lo[0]) || !(s.hi[1] > s.lo[1]);
+    bool bad = !(s.hi[3] > s.lo[3]) || !(s.hi[4] > s.lo[4]) || !(s.lo[4] > 0.0) || !(s.hi[0] > s.lo[0]) || !(s.hi[1] > s.lo[1]) || !(s.hi[2] > s.lo[2]);
     for (int c = 0; c < 3; ++c) bad = bad || !(fabs(s.p0[c]) <= 1.79e308) || !(fabs(s.p1[c]) <= 1.79e308);
     if (bad) {
       out.cost = out.feas = __builtin_nan(""); out.iters = 0; out.status = D2D_ST_NONFINITE;
@@ -1093,7 +1098,8 @@ nlp_solve_kernel(int B, int N, double h, d2d_nlp_opts o, const double *__restric
   extern __shared__ __attribute__((aligned(16))) double nlp_lds[];
   NlpOut out;
   nlp_solve_one(N, h, o, scen + (size_t)b * D2D_SCEN_STRIDE, partner ? partner + (size_t)b * 2 * N : nullptr, W + (size_t)b * NLP_NV * N,
-                work + (size_t)b * WS_TOTAL * N, mult ? mult + (size_t)b * 3 * N : nullptr, lane, out, b == 0 ? stamps : nullptr, nlp_lds);
+                work + (size_t)b * WS_TOTAL * N, mult ? mult + (size_t)b * 3 * N : nullptr, lane, out, b == 0 ? stamps : nullptr, nlp_lds,
+                o.bounds ? o.bounds + (size_t)b * 4 : nullptr);
   if (lane == 0) {
     cost_out[b] = out.cost;
     feas_out[b] = out.feas;
@@ -1126,7 +1132,8 @@ nlp_groups_kernel(int R, int n_ac, int N, double h, d2d_nlp_opts o, int max_swee
   NlpOut out;
   int iters_total = 0;
   double *ldsw = nlp_lds + (size_t)wave * NLP_LDS_DOUBLES;
-  nlp_solve_one(N, h, o, sc, nullptr, Wb, wsb, mb, lane, out, nullptr, ldsw);
+  const double *bnd = o.bounds ? o.bounds + (size_t)b * 4 : nullptr;
+  nlp_solve_one(N, h, o, sc, nullptr, Wb, wsb, mb, lane, out, nullptr, ldsw, bnd);
   iters_total += out.iters;
   if (threadIdx.x < 2) moved_s[threadIdx.x] = 0.0;
   __threadfence_block();
@@ -1140,7 +1147,7 @@ nlp_groups_kernel(int R, int n_ac, int N, double h, d2d_nlp_opts o, int max_swee
         if (wave == turn) {
           const double *pw = W + (size_t)(r * n_ac + (1 - turn)) * NLP_NV * N;      // the partner's x and y planes
           for (int i = lane; i < 2 * N; i += 64) pv[i] = Wb[i];
-          nlp_solve_one(N, h, o, sc, pw, Wb, wsb, mb, lane, out, nullptr, ldsw);
+          nlp_solve_one(N, h, o, sc, pw, Wb, wsb, mb, lane, out, nullptr, ldsw, bnd);
           iters_total += out.iters;
           double m = 0.0;
           for (int i = lane; i < 2 * N; i += 64) m = fmax(m, fabs(Wb[i] - pv[i]));
@@ -1178,7 +1185,7 @@ int d2d_nlp_solve(d2d_ctx *ctx, int B, int N, double h, const double *scen, cons
                   const double *partner, double *work, double *mult, double *cost, double *feas, int32_t *iters, int32_t *status) {
   D2D_REQUIRE(ctx && scen && W && work && cost && feas, "d2d_nlp_solve: null argument");
   D2D_REQUIRE(B >= 1 && N >= 3 && h > 0, "d2d_nlp_solve: B >= 1, N >= 3, h > 0 required (B=%d N=%d h=%g)", B, N, h);
-  d2d_nlp_opts o = {D2D_NLP_RHO0, D2D_NLP_MUB0, D2D_NLP_MUB_MIN, 1e-9, 1e-7, 60, 40, 0, 0};
+  d2d_nlp_opts o = {D2D_NLP_RHO0, D2D_NLP_MUB0, D2D_NLP_MUB_MIN, 1e-9, 1e-7, 60, 40, 0, 0, nullptr};
   if (opts) o = *opts;
   if (getenv("D2D_NLP_SERIAL")) o.serial = atoi(getenv("D2D_NLP_SERIAL"));      // A/B switch
   D2D_REQUIRE(o.inner_max >= 1 && o.outer_max >= 1 && o.rho0 > 0 && o.mub0 > 0 && o.mub_min > 0, "d2d_nlp_solve: bad options");
@@ -1206,7 +1213,7 @@ int d2d_nlp_solve_groups(d2d_ctx *ctx, int R, int n_ac, int N, double h, const d
   D2D_REQUIRE(ctx && scen && W && work && cost && feas, "d2d_nlp_solve_groups: null argument");
   D2D_REQUIRE(R >= 1 && n_ac >= 1 && n_ac <= 8 && N >= 3 && h > 0, "d2d_nlp_solve_groups: R >= 1, 1 <= n_ac <= 8, N >= 3, h > 0 required (R=%d n_ac=%d N=%d h=%g)", R, n_ac, N, h);
   D2D_REQUIRE(max_sweeps >= 1 && tol >= 0, "d2d_nlp_solve_groups: max_sweeps >= 1 and tol >= 0 required");
-  d2d_nlp_opts o = {D2D_NLP_RHO0, D2D_NLP_MUB0, D2D_NLP_MUB_MIN, 1e-9, 1e-7, 60, 40, 0, 0};
+  d2d_nlp_opts o = {D2D_NLP_RHO0, D2D_NLP_MUB0, D2D_NLP_MUB_MIN, 1e-9, 1e-7, 60, 40, 0, 0, nullptr};
   if (opts) o = *opts;
   if (getenv("D2D_NLP_SERIAL")) o.serial = atoi(getenv("D2D_NLP_SERIAL"));
   D2D_REQUIRE(o.inner_max >= 1 && o.outer_max >= 1 && o.rho0 > 0 && o.mub0 > 0 && o.mub_min > 0, "d2d_nlp_solve_groups: bad options");

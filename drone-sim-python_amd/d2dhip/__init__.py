@@ -52,7 +52,8 @@ class TrackParams(C.Structure):
 
 class NlpOpts(C.Structure):
     _fields_ = [('rho0', C.c_double), ('mub0', C.c_double), ('mub_min', C.c_double), ('feas_tol', C.c_double),
-                ('opt_tol', C.c_double), ('inner_max', C.c_int32), ('outer_max', C.c_int32), ('serial', C.c_int32), ('reserved', C.c_int32)]
+                ('opt_tol', C.c_double), ('inner_max', C.c_int32), ('outer_max', C.c_int32), ('serial', C.c_int32), ('reserved', C.c_int32),
+                ('bounds', C.c_void_p)]
 
 
 class FitOpts(C.Structure):
@@ -341,9 +342,10 @@ class Context:
         return out
 
     def nlp_solve(self, scen, W, h, partner=None, rho0=10.0, mub0=0.1, mub_min=1e-9, feas_tol=1e-9, opt_tol=1e-7, inner_max=60,
-                  outer_max=40, want_mult=False, serial=0):
+                  outer_max=40, want_mult=False, serial=0, bounds=None):
         """Direct-collocation NLP in node variables (d2d_nlp_solve): scen dev [B][SCEN_STRIDE], W dev [B][5][N] in/out (initial
-        guess -> solution), partner dev [B][2][N] or None.  Returns dict(cost, feas, iters, status[, mult [B][3][N]]) of device tensors."""
+        guess -> solution), partner dev [B][2][N] or None, bounds dev [B][4] = (phi_lo, phi_hi, psi_lo, psi_hi) or None (d2d_nlp_opts.bounds).
+        Returns dict(cost, feas, iters, status[, mult [B][3][N]]) of device tensors."""
         torch = _torch()
         B, _, N = W.shape
         assert W.is_contiguous() and scen.shape[0] == B and (partner is None or (partner.is_contiguous() and partner.shape == (B, 2, N)))
@@ -351,7 +353,8 @@ class Context:
         cost, feas = self.empty(B), self.empty(B)
         iters = torch.empty(B, dtype=torch.int32, device=self.device); status = torch.empty(B, dtype=torch.int32, device=self.device)
         mult = self.zeros(B, 3, N) if want_mult else None
-        o = NlpOpts(rho0, mub0, mub_min, feas_tol, opt_tol, inner_max, outer_max, serial, 0)
+        assert bounds is None or (bounds.is_contiguous() and tuple(bounds.shape) == (B, 4))
+        o = NlpOpts(rho0, mub0, mub_min, feas_tol, opt_tol, inner_max, outer_max, serial, 0, None if bounds is None else bounds.data_ptr())
         _check(self.lib.d2d_nlp_solve(self.h, B, N, float(h), _ptr(scen), C.byref(o), _ptr(W), _ptr(partner), _ptr(work), _ptr(mult),
                                       _ptr(cost), _ptr(feas), _ptr(iters), _ptr(status)))
         out = dict(cost=cost, feas=feas, iters=iters, status=status, work=work)
@@ -360,7 +363,7 @@ class Context:
         return out
 
     def nlp_solve_groups(self, scen, W, h, n_ac, max_sweeps=12, tol=1e-7, rho0=10.0, mub0=0.1, mub_min=1e-9, feas_tol=1e-9, opt_tol=1e-7,
-                         inner_max=60, outer_max=40, serial=0):
+                         inner_max=60, outer_max=40, serial=0, bounds=None):
         """The reference's multi-aircraft Problem for R scenarios in one launch (d2d_nlp_solve_groups): scen dev [R*n_ac][SCEN_STRIDE],
         W dev [R*n_ac][5][N] in/out, the aircraft of a scenario consecutive; CostCollision couples aircraft 0 and 1 (rows' KCOL > 0).
         Returns dict(cost, feas, iters, status per aircraft; sweeps, moved per scenario) of device tensors."""
@@ -372,7 +375,8 @@ class Context:
         cost, feas, moved = self.empty(B), self.empty(B), self.empty(R)
         iters = torch.empty(B, dtype=torch.int32, device=self.device); status = torch.empty(B, dtype=torch.int32, device=self.device)
         sweeps = torch.empty(R, dtype=torch.int32, device=self.device)
-        o = NlpOpts(rho0, mub0, mub_min, feas_tol, opt_tol, inner_max, outer_max, serial, 0)
+        assert bounds is None or (bounds.is_contiguous() and tuple(bounds.shape) == (B, 4))
+        o = NlpOpts(rho0, mub0, mub_min, feas_tol, opt_tol, inner_max, outer_max, serial, 0, None if bounds is None else bounds.data_ptr())
         _check(self.lib.d2d_nlp_solve_groups(self.h, R, n_ac, N, float(h), _ptr(scen), C.byref(o), int(max_sweeps), float(tol), _ptr(W), _ptr(work),
                                              None, _ptr(cost), _ptr(feas), _ptr(iters), _ptr(status), _ptr(sweeps), _ptr(moved)))
         return dict(cost=cost, feas=feas, iters=iters, status=status, sweeps=sweeps, moved=moved, work=work)

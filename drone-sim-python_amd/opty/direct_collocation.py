@@ -9,7 +9,8 @@
 What is interpreted instead of compiled:
   * eom / state_symbols  -- the fixed kinematic model of d2d.opty_utils.Aircraft.get_eom (an `Eom`: wind, g, aircraft count);
   * instance_constraints -- `x(t) - value` objects: the end conditions of every aircraft;
-  * bounds               -- {phi(t): (lo, hi), v(t): ..., x(t): ..., y(t): ...}: HARD boxes (primal-dual barrier);
+  * bounds               -- {phi(t): (lo, hi), v(t): ..., x(t): ..., y(t): ..., psi(t): ...}: HARD boxes (primal-dual barrier); the phi
+                            interval need not be symmetric (d2d_nlp_opts.bounds carries it and the psi box to the kernel);
   * obj / obj_grad       -- the reference passes closures over a cost plug-in and the planner
                             (`lambda _free: obj.cost(_free, self)`); the plug-in is taken from the closure (or from the explicit
                             `cost=` / `planner=` keywords) and lowered structurally (single_opt_planner.lower_cost): the known
@@ -82,8 +83,6 @@ class Problem:
         for bd in self.bounds:
             if 'phi' not in bd or 'v' not in bd:
                 raise NotImplementedError('phi and v bounds are required (the model divides by v)')
-            if 'psi' in bd:
-                raise NotImplementedError('bounds on psi have no kernel')
 
     def addOption(self, k, v):
         self.options[k] = v
@@ -106,8 +105,6 @@ class Problem:
         for a in range(n):
             la = low if (a == 0 or not multi) else low[:4] + ((),) + low[5:]     # static obstacles act on aircraft 0 only (multi, :74)
             bd = self.bounds[a]
-            if abs(bd['phi'][0] + bd['phi'][1]) > 1e-12:
-                raise NotImplementedError('asymmetric phi bounds')
             r = sop.scen_row(tuple(self.p0s[a]) + (0., 0.), tuple(self.p1s[a]) + (0., 0.), 0., la, s, self.wind, bd['phi'], bd['v'],
                              x_c=bd.get('x'), y_c=bd.get('y'))
             if multi and la[4]:
@@ -140,12 +137,16 @@ class Problem:
         kw.update(opt_tol=min(tol, 1e-7), feas_tol=min(1e-2 * tol, 1e-9))
         dsc = ctx.dev(rows)
         dW = ctx.dev(np.ascontiguousarray(W))
+        # an asymmetric phi interval / a box on psi travel beside the rows (d2d_nlp_opts.bounds; lo >= hi: not set)
+        bnd = None
+        if any('psi' in bd or abs(bd['phi'][0] + bd['phi'][1]) > 1e-12 for bd in self.bounds):
+            bnd = ctx.dev(np.array([[bd['phi'][0], bd['phi'][1]] + list(bd.get('psi', (0.0, 0.0))) for bd in self.bounds]))
         # one launch for the whole Problem: wavefront a of a workgroup solves aircraft a; the pair coupled by CostCollision
         # alternates on the device (block Gauss-Seidel, d2d_nlp_solve_groups) until neither aircraft moves
         if not coupled:
             dsc[:, d2dhip.SC_KCOL] = 0.0
         out = ctx.nlp_solve_groups(dsc, dW, self.time_step, n, max_sweeps=int(self.options.get('max_sweeps', 12)),
-                                   tol=float(self.options.get('sweep_tol', 1e-7)), **kw)
+                                   tol=float(self.options.get('sweep_tol', 1e-7)), bounds=bnd, **kw)
         sweeps = int(out['sweeps'][0].item())
         moved = float(out['moved'][0].item())
         ctx.sync()

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define D2D_VERSION 105
+#define D2D_VERSION 106
 
 /* error codes */
 #define D2D_OK 0
@@ -477,6 +477,10 @@ typedef struct {
                         levels of independent 3x3 eliminations, one lane per node; 1 the twisted serial block recursion of round 2
                         (N/2 dependent block pivots).  Same step to rounding.                                   */
   int32_t reserved;
+  const double *bounds; /* dev [B][4] = (phi_lo, phi_hi, psi_lo, psi_hi) per problem, or NULL.  phi_lo < phi_hi replaces the symmetric
+                           |phi| <= D2D_SC_PHIMAX of the scenario row (opty's bounds dict may hold any interval,
+                           src/single_opt_planner.py:53); psi_lo < psi_hi adds a box on the heading of the free nodes (none
+                           otherwise; the end headings are equalities).                                             */
 } d2d_nlp_opts;
 int d2d_nlp_workspace_doubles(int N);
 /* A problem whose row is unusable -- PHIMAX <= 0, VMIN <= 0 or VMIN >= VMAX (the model divides by v and the barrier needs an

@@ -412,3 +412,44 @@ def test_cyclic_reduction_equals_the_serial_recursion():
         # (node values along the objective's flat directions -- the cost sees v only -- differ at the 1e-5 level between two rounding paths)
         assert np.abs(Wa.cpu().numpy()[conv] - Wb.cpu().numpy()[conv]).max() <= 1e-3
         assert float(oa['feas'].cpu().numpy()[conv].max()) <= 1e-8
+
+
+def test_asymmetric_phi_interval_and_psi_box_vs_oracle(ctx):
+    """opty's bounds dict may hold any interval (src/single_opt_planner.py:53): an asymmetric bank interval and a box on the heading
+    travel beside the scenario rows (d2d_nlp_opts.bounds).  A left turn-around with phi in [-5, +35] deg (the right bank nearly
+    forbidden) and psi in [-0.2, pi + 0.2]: same cost and nodes as the oracle with the same lo / hi, both bounds held, the upper
+    bank bound binding; problem 1 of the batch has no override and stays on its row's symmetric interval."""
+    N, h = 71, 0.1
+    p0 = (0., 0., 0., 0., 12.); p1 = (0., 40., np.pi, 0., 12.)
+    pb = nlp.Problem(N, h, p0, p1, vsp=12., kv=1., kphi=0.5, obj_scale=1., phi_max=np.deg2rad(35.), v_min=9., v_max=15.)
+    pa = nlp.Problem(N, h, p0, p1, vsp=12., kv=1., kphi=0.5, obj_scale=1., phi_max=np.deg2rad(35.), v_min=9., v_max=15.)
+    philo, phihi, psilo, psihi = -np.deg2rad(5.), np.deg2rad(35.), -0.2, np.pi + 0.2
+    pa.lo[:, 3], pa.hi[:, 3] = philo, phihi
+    pa.lo[1:-1, 2], pa.hi[1:-1, 2] = psilo, psihi
+    W0 = nlp.from_free(C.single_guess('tri', p0, p1, 12., (N - 1) * h, N), N)
+    bnd = ctx.dev(np.array([[philo, phihi, psilo, psihi], [0., 0., 0., 0.]]))
+    W, out = _solve(ctx, [pa, pb], [W0, W0], [_row(pb), _row(pb)], bounds=bnd)
+    assert (out['status'] == 1).all(), out['status']
+    Wa, Wb = W[:, :, 0], W[:, :, 1]
+    assert Wa[:, 3].min() >= philo and Wa[:, 3].max() <= phihi and Wa[1:-1, 2].min() >= psilo and Wa[1:-1, 2].max() <= psihi
+    assert (Wa[:, 3] > phihi - 1e-4).sum() >= 3                         # the bank limit binds in the turn
+    for p_, W_, k in ((pa, Wa, 0), (pb, Wb, 1)):
+        Wo, info = nlp.solve(p_, W0)
+        assert info['status'] == 1
+        assert abs(info['cost'] - out['cost'][k]) <= 1e-7 * info['cost'], (k, info['cost'], out['cost'][k])
+        assert np.abs(W_ - Wo).max() <= 1e-4
+        assert np.abs(nlp.constraints(p_, W_)).max() <= 1e-8
+    assert Wb[:, 3].min() < philo - 1e-3 or abs(out['cost'][0] - out['cost'][1]) < 1e-9       # the override changed problem 0 only
+    # ... and through the reference's plug-point: Problem(bounds={phi: (lo, hi), psi: (lo, hi)})
+    import contextlib, io
+    import d2d.optyplan_scenarios as sc
+    import single_opt_planner as sop
+
+    class turn(sc.exp_0):
+        t1, p1 = 7.0, (0., 40., np.pi, 0., 12.)
+        p0 = (0., 0., 0., 0., 12.)
+        phi_constraint = (philo, phihi)
+    with contextlib.redirect_stdout(io.StringIO()):
+        p = sop.Planner(turn, initialize=True, backend='nlp')
+        p.run(p.get_initial_guess('tri'))
+    assert p.sol_phi.min() >= philo - 1e-12 and p.sol_phi.max() <= phihi + 1e-12 and (p.sol_phi > phihi - 1e-4).sum() >= 3
