@@ -156,3 +156,36 @@ def test_501_nodes_plan_and_eval_limits(ctx):
             plan.eval(dsc, q)
     finally:
         plan.close()
+
+
+@pytest.mark.parametrize('S,K', [(2, 81), (3, 65), (5, 131), (1, 70)])
+def test_other_segment_counts_on_the_long_kernel(ctx, S, K):
+    """The segment formulation deals the 64 lanes of a wave to S segments (SegMap) and projects S blocks: every instantiation
+    (one, two and three column tiles; 1 .. 5 segments) against the oracle's evaluation and its LM solve."""
+    import d2dhip
+    dur = (K - 1) / 10.0
+    s = 1.0 / K
+    p = d2dhip.FitPlan(ctx, S, K, dur, (0.02 ** 2, s * 5.0, s / F.G_ACC ** 2))
+    try:
+        assert p.kernel == 'long'
+        ob = F.FitBasis.from_arrays(S, K, dur, *p.basis())
+        sc = F.set_scale(F.synth_scenarios(6, seed=100 + S), 1.0, K)
+        scale = 12.0 * dur / 49.0 * 0.8
+        sc[:, F.SC_X1] = sc[:, F.SC_X0] + (sc[:, F.SC_X1] - sc[:, F.SC_X0]) * scale
+        sc[:, F.SC_Y1] = sc[:, F.SC_Y0] + (sc[:, F.SC_Y1] - sc[:, F.SC_Y0]) * scale
+        sc[:, [F.SC_O0R, F.SC_O1R]] = 0.0
+        dsc = ctx.dev(sc)
+        q = p.init(dsc)
+        q0 = q.cpu().numpy().copy()
+        cost, iters, status, _ = p.solve(dsc, q, mode=d2dhip.MODE_FAST)
+        ch, qh = cost.cpu().numpy(), q.cpu().numpy()
+        same = 0
+        for i in range(6):
+            assert abs(F.cost(ob, sc[i], qh[i]) - ch[i]) <= 1e-10 * ch[i]
+            assert ch[i] <= F.cost(ob, sc[i], q0[i]) * (1 + 1e-12)
+            qo, co, ito, sto = F.lm_solve(ob, sc[i], q0=q0[i], hess_dtype=np.float32, chol_dtype=np.float32)
+            same += int(abs(co - ch[i]) <= 1e-6 * co)
+        assert same >= 5, same
+        assert np.isin(status.cpu().numpy(), (d2dhip.ST_CONVERGED, d2dhip.ST_STALLED)).all()
+    finally:
+        p.close()
