@@ -1475,6 +1475,90 @@ fit_lm_long_kernel(int B, FitGeom g, LongLds L, d2d_fit_opts opts, int iter_budg
 }
 
 // ------------------------------------------------------------------------------------
+// cost, J^T r, J^T J at given points for horizons the LDS image of fit_eval_kernel cannot hold (the public d2d_fit_eval beyond
+// ~229 nodes): one evaluation in the segment formulation (fit_seg.h), Gauss-Newton rows; H in fit_eval_kernel's tile layout,
+// without the waypoint block (untile_kernel adds it).
+template <int NB, int NQ>
+__global__ void __launch_bounds__(64 * FIT_LM_WPB_MAX)
+fit_eval_seg_kernel(int B, FitGeom g, SegArgs sa, const double *__restrict__ pk, const double *__restrict__ prep,
+                    const double *__restrict__ q_in, double *__restrict__ cost_out, double *__restrict__ g_out, float *__restrict__ H_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  constexpr int NT = NB * (NB + 1) / 2;
+  stage(lds + sa.L.Zl64, sa.Zl64, 8 * sa.m.S * (g.nq + 1) * 8);
+  stage(lds + sa.L.Zl32, sa.Zl32, 8 * sa.m.S * g.nq * 4);
+  __syncthreads();
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int woff = sa.L.wave0 + wave * sa.L.wave_stride;
+  unsigned char *wl = lds + woff;
+  double *qs = reinterpret_cast<double *>(wl + sa.L.qs), *sp = reinterpret_cast<double *>(wl + sa.L.sp), *zc = reinterpret_cast<double *>(wl + sa.L.zc);
+  f32x4 *cf = reinterpret_cast<f32x4 *>(wl + sa.L.cf);
+  float2 *cfp = reinterpret_cast<float2 *>(wl + sa.L.cfp);
+  float *psi = reinterpret_cast<float *>(wl + sa.L.psi);
+  double *red = reinterpret_cast<double *>(wl + sa.L.big);
+  const double *Zl64 = reinterpret_cast<const double *>(lds + sa.L.Zl64);
+  const float *Zl32 = reinterpret_cast<const float *>(lds + sa.L.Zl32);
+  const LaneSeg ls = lane_segment(sa.m, lane);
+  const int nq = NQ ? NQ : g.nq, n = 2 * nq;
+  const GroupCtx gc{nullptr, 1, 0, 0, 0};
+  for (int b = blockIdx.x * (blockDim.x >> 6) + wave; b < B; b += gridDim.x * (blockDim.x >> 6)) {
+    const double *pkb = pk + (size_t)b * FIT_PK * g.K;
+    if (lane < n) qs[q_slot(lane, nq)] = q_in[(size_t)b * n + lane];
+    for (int i = lane; i < FIT_PREP_STRIDE; i += 64) sp[i] = prep[(size_t)b * FIT_PREP_STRIDE + i];
+    wave_lds_sync();
+    double zpx = 0.0, zpy = 0.0;
+    if (lane < 8 * sa.m.S) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const double zv = sa.Zlp[lane * 4 + m];
+        zpx = fma(zv, sp[PR_DX + m], zpx); zpy = fma(zv, sp[PR_DY + m], zpy);
+      }
+    }
+    segment_coefs<NQ>(nq, sa.m.S, Zl64, qs, zpx, zpy, zc, lane);
+    const int kbank = segment_bank_argmax(sa.m, ls, sa.sx, sa.c1, zc, load_scenp(sp));
+    const FitGeom g8{SEG_ROWS, 8, 9};
+    f32x4 bs[D2D_FIT_MAX_S][1];
+    double mom[16], ca = 0.0;
+#pragma unroll
+    for (int s = 0; s < D2D_FIT_MAX_S; ++s) bs[s][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 16; ++i) mom[i] = 0.0;
+    for (int c = 0; c < sa.m.nchunk; ++c) {
+      const SegIn in = segment_inputs(ls, g.K, sa.sx, pkb, c);
+      ca += segment_phase1<true>(ls, g.K, in, sa.c1, sp, zc, cf, cfp, psi, mom, false, kbank, c, lane, gc);
+      if (H_out) {
+#pragma unroll
+        for (int s = 0; s < D2D_FIT_MAX_S; ++s) {
+          if (s < sa.m.S) {
+            const int Ls = sa.m.l0[s + 1] - sa.m.l0[s];
+            const int left = sa.m.Ks[s] - c * Ls;
+            const int kn = left < Ls ? left : Ls;
+            if (kn > 0) jtj_mfma<1, 8, true>(g8, lds, woff + sa.L.psi + sa.m.l0[s] * 32, nullptr, woff + sa.L.cf + sa.m.l0[s] * 64, lane, kn, bs[s], 0, 0, true);
+          }
+        }
+      }
+      wave_lds_sync();
+    }
+    const double gl = segment_gradient<NQ>(sa.m, nq, Zl64, mom, red, zc, lane);
+    if (lane < n && g_out) g_out[(size_t)b * n + lane] = gl;
+    if (lane == 0 && cost_out) cost_out[b] = uniform_d(ca);
+    if (H_out) {
+      f32x4 acc[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < D2D_FIT_MAX_S; ++s)
+        if (s < sa.m.S) segment_project<NB, NQ>(nq, Zl32, s, bs[s][0], lane, acc);
+      float *Hb = H_out + (size_t)b * NT * 256;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Hb[(t * 4 + r) * 64 + lane] = acc[t][r];
+    }
+    wave_lds_sync();
+  }
+}
+
+// ------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 fit_state_init_kernel(int B, int off, int stride, double *__restrict__ lm, int32_t *__restrict__ flags,
                       int32_t *__restrict__ queue) {
@@ -1843,6 +1927,17 @@ static int launch_lm(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, double *q, con
   return D2D_OK;
 }
 
+static SegArgs seg_args_of(const d2d_fit_plan *pl, int NB) {
+  SegArgs sa{};
+  sa.m.S = pl->seg_S; sa.m.nchunk = pl->seg_nchunk;
+  for (int i = 0; i <= D2D_FIT_MAX_S; ++i) sa.m.l0[i] = pl->seg_l0[i];
+  for (int i = 0; i < D2D_FIT_MAX_S; ++i) { sa.m.k0[i] = pl->seg_k0[i]; sa.m.Ks[i] = pl->seg_Ks[i]; }
+  sa.L = seg_lds_layout(16 * NB, pl->nq, pl->S, FIT_LM_WPB_MAX);
+  sa.Zl64 = pl->d_Zl64; sa.Zl32 = pl->d_Zl32; sa.Zlp = pl->d_Zlp; sa.sx = pl->d_sx;
+  sa.c1 = 2.0 / pl->T;
+  return sa;
+}
+
 static int launch_lm_long(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, double *q, const d2d_fit_opts &o, int budget, GroupArgs ga = no_groups()) {
   const FitGeom gm = geom_of(pl);
   const int NB = (2 * pl->nq + 15) / 16;
@@ -1865,12 +1960,7 @@ static int launch_lm_long(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, double *q
   const bool seg = !seg_off && force < 0;
   SegArgs sa{};
   if (seg) {
-    sa.m.S = pl->seg_S; sa.m.nchunk = pl->seg_nchunk;
-    for (int i = 0; i <= D2D_FIT_MAX_S; ++i) sa.m.l0[i] = pl->seg_l0[i];
-    for (int i = 0; i < D2D_FIT_MAX_S; ++i) { sa.m.k0[i] = pl->seg_k0[i]; sa.m.Ks[i] = pl->seg_Ks[i]; }
-    sa.L = seg_lds_layout(16 * NB, pl->nq, pl->S, FIT_LM_WPB_MAX);
-    sa.Zl64 = pl->d_Zl64; sa.Zl32 = pl->d_Zl32; sa.Zlp = pl->d_Zlp; sa.sx = pl->d_sx;
-    sa.c1 = 2.0 / pl->T;
+    sa = seg_args_of(pl, NB);
     static const bool want_stamps = getenv("D2D_LM_STAMPS") != nullptr;
     if (want_stamps) {
       sa.stamps = reinterpret_cast<unsigned long long *>(ctx->stats_dev + 8);
@@ -2003,6 +2093,7 @@ int d2d_fit_plan_create(d2d_ctx *ctx, int S, int K, double duration, const doubl
   allow_big_lds(&fit_lm_long_kernel<3, 24, true, false, D2D_LM_MODE_FAST>); allow_big_lds(&fit_lm_long_kernel<3, 0, true, false, D2D_LM_MODE_FAST>); allow_big_lds(&fit_lm_long_kernel<2, 0, true, false, D2D_LM_MODE_FAST>); allow_big_lds(&fit_lm_long_kernel<1, 0, true, false, D2D_LM_MODE_FAST>);
   allow_big_lds(&fit_lm_long_kernel<3, 24, false, false, D2D_LM_MODE_MINPACK, true>); allow_big_lds(&fit_lm_long_kernel<3, 0, false, false, D2D_LM_MODE_MINPACK, true>); allow_big_lds(&fit_lm_long_kernel<2, 0, false, false, D2D_LM_MODE_MINPACK, true>); allow_big_lds(&fit_lm_long_kernel<1, 0, false, false, D2D_LM_MODE_MINPACK, true>);
   allow_big_lds(&fit_lm_long_kernel<3, 24, false, false, D2D_LM_MODE_FAST, true>); allow_big_lds(&fit_lm_long_kernel<3, 0, false, false, D2D_LM_MODE_FAST, true>); allow_big_lds(&fit_lm_long_kernel<2, 0, false, false, D2D_LM_MODE_FAST, true>); allow_big_lds(&fit_lm_long_kernel<1, 0, false, false, D2D_LM_MODE_FAST, true>);
+  allow_big_lds(&fit_eval_seg_kernel<3, 24>); allow_big_lds(&fit_eval_seg_kernel<3, 0>); allow_big_lds(&fit_eval_seg_kernel<2, 0>); allow_big_lds(&fit_eval_seg_kernel<1, 0>);
   allow_big_lds(&fit_groups_kernel<3, 24>);
   allow_big_lds(&fit_lm_kernel<3, 24, false, D2D_LM_MODE_MINPACK>);
   allow_big_lds(&fit_lm_kernel<3, 24, true, D2D_LM_MODE_MINPACK>);
@@ -2066,13 +2157,31 @@ int d2d_fit_eval(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, const double *scen
                  double *cost, double *g, float *H) {
   D2D_REQUIRE(ctx && pl && scen && q, "d2d_fit_eval: null argument");
   D2D_REQUIRE(B >= 1, "d2d_fit_eval: B must be >= 1");
-  D2D_REQUIRE(pl->split_ok, "d2d_fit_eval: K=%d does not fit the LDS image of the evaluation kernel (d2d_fit_solve handles any K)", pl->K);
+  D2D_REQUIRE(pl->split_ok || pl->n_group <= 1, "d2d_fit_eval: K=%d with coupled groups does not fit the LDS image of the evaluation kernel", pl->K);
   d2d_fit_plan *plm = const_cast<d2d_fit_plan *>(pl);
   if (plm->active_B != 0 && B > plm->cap_B) { d2d_set_error("d2d_fit_eval: a solve of a smaller batch is in progress on this plan"); return D2D_ESTATE; }
   if (int rc = ensure_scratch(plm, B)) return rc;
   if (int rc = launch_prep(ctx, pl, B, scen)) return rc;
   if (int rc = prof_begin(ctx, plm, 0)) return rc;       // (d2d_fit_profile: the J^T J kernel alone, every trajectory active)
-  if (int rc = launch_eval(ctx, pl, B, q, nullptr, cost, g, H ? plm->d_H : nullptr)) return rc;
+  if (pl->split_ok) {
+    if (int rc = launch_eval(ctx, pl, B, q, nullptr, cost, g, H ? plm->d_H : nullptr)) return rc;
+  } else {
+    // a horizon the LDS image of fit_eval_kernel cannot hold: the same evaluation in the segment formulation (no K-sized table)
+    const int NB = (2 * pl->nq + 15) / 16;
+    const SegArgs sa = seg_args_of(pl, NB);
+    const FitGeom gm = geom_of(pl);
+    const int wpb = FIT_LM_WPB_MAX;
+    int blocks = (B + wpb - 1) / wpb;
+    if (blocks > pl->n_cu) blocks = pl->n_cu;
+#define LAUNCH_EVAL_SEG(NBV, NQV) hipLaunchKernelGGL((fit_eval_seg_kernel<NBV, NQV>), dim3(blocks), dim3(64 * wpb), sa.L.total, ctx->stream, B, gm, sa, \
+                                                     pl->d_pk, pl->d_prep, q, cost, g, H ? plm->d_H : nullptr)
+    if (pl->nq == 24) LAUNCH_EVAL_SEG(3, 24);
+    else if (NB == 1) LAUNCH_EVAL_SEG(1, 0);
+    else if (NB == 2) LAUNCH_EVAL_SEG(2, 0);
+    else LAUNCH_EVAL_SEG(3, 0);
+#undef LAUNCH_EVAL_SEG
+    D2D_LAUNCH_CHECK();
+  }
   if (int rc = prof_end(ctx, plm)) return rc;
   plm->prep_valid_for = nullptr;
   if (H) {

@@ -132,9 +132,10 @@ def test_long_kernel_equals_fused_kernel_at_K50(ctx):
         pf.close(); pl.close()
 
 
-def test_501_nodes_plan_and_eval_limits(ctx):
+def test_501_nodes_plan_solve_and_eval(ctx):
     """K = 501 (multi_opt_planner.exp_0: 10 s at 50 Hz, src/multi_opt_planner.py:170-185): the plan exists, d2d_fit_solve runs the
-    long kernel, the basis-in-LDS entry points refuse it with a clear error instead of a launch failure."""
+    long kernel, and the public d2d_fit_eval (cost, J^T r, J^T J at given points) has no horizon limit either: beyond the LDS image
+    of fit_eval_kernel it evaluates in the segment formulation (fit_eval_seg_kernel) -- against the oracle's eval_normal."""
     import d2dhip
     plan, dur = _plan(ctx, 501, hz=50.0)
     try:
@@ -152,8 +153,13 @@ def test_501_nodes_plan_and_eval_limits(ctx):
             assert abs(ch[i] - co) <= 1e-10 * co and co < c0[i]
             _, go, _ = F.eval_normal(ob, sc[i], qh[i])
             assert np.abs(go).max() <= 1e-6
-        with pytest.raises(d2dhip.D2DError, match='LDS'):
-            plan.eval(dsc, q)
+        q1 = plan.init(dsc)
+        c, g, H = plan.eval(dsc, q1)
+        for i in range(3):
+            co, go, Ho = F.eval_normal(ob, sc[i], q1.cpu().numpy()[i])
+            assert abs(c.cpu().numpy()[i] - co) <= 1e-11 * co
+            assert np.abs(g.cpu().numpy()[i] - go).max() <= 1e-10 * max(1.0, np.abs(go).max())
+            assert np.abs(H.cpu().numpy()[i] - Ho).max() <= 2e-5 * np.abs(Ho).max()
     finally:
         plan.close()
 
