@@ -171,6 +171,33 @@ def cpu_baseline(batch, n_sample=1024, n_oracle=1024):
     return rec, keep
 
 
+LONG_HORIZONS = ((121, 12.0), (301, 30.0))       # (nodes, seconds) of the long_horizon record
+
+
+def _long_scenarios(B, K2, t2):
+    from d2dhip import synth
+    return synth.synth_scenarios(B, seed=SEED, obj_scale=OBJ_SCALE, K=K2, dist_range=(100. * t2 / 12.0, 150. * t2 / 12.0))
+
+
+def cpu_long_horizon(n=96, B=4096):
+    """cpu leg of the long_horizon record: scipy least_squares('lm') on the first n scenarios of each horizon (oracle residuals),
+    for the record's parity_vs_scipy.  Returns {nodes: (costs, q, fits per second)}."""
+    import multiprocessing as mp
+    from oracle import fit as F
+    from d2dhip import synth
+    out = {}
+    cores = _host_cores()
+    with mp.get_context('fork').Pool(cores) as pool:
+        for (K2, t2) in LONG_HORIZONS:
+            dur = synth.planner_timing(0, t2, 10)[2]
+            basis = F.FitBasis(S_, K2, dur, synth.default_wref(OBJ_SCALE, K2))
+            sc = _long_scenarios(B, K2, t2)[:n]             # (the first n rows of the batch the GPU solves)
+            t0 = time.perf_counter()
+            res = pool.map(_cpu_fit_one, [(basis, sc[i], None) for i in range(n)], chunksize=1)
+            out[K2] = (np.array([r[0] for r in res]), np.array([r[1] for r in res]), n / (time.perf_counter() - t0), cores)
+    return out
+
+
 def cpu_polish(keep, q_gpu, n_polish=256):
     """scipy LM started FROM the GPU's solutions (CPU pool; the GPU context exists by now, so the pool is spawned, not forked):
     how far does the CPU arbiter move them?  Returns the largest relative moves of cost and unknowns."""
@@ -266,16 +293,17 @@ def nlp_record(ctx, torch, cpu, B=4096):
     return rec
 
 
-def long_horizon_record(ctx, torch, d2dhip, B=4096, K=121, t1=12.0, more=((301, 30.0),)):
+def long_horizon_record(ctx, torch, d2dhip, B=4096, K=121, t1=12.0, more=LONG_HORIZONS[1:], cpu_long=None):
     """The reference's own planner horizons (101 .. 151 nodes at 10 Hz: exp_14 = 121; its 50 Hz scenarios: 211 .. 601) on the chunked
     persistent kernel (fit_lm_long_kernel, K > 64; the segment formulation of csrc/fit_seg.h): B independent fits of K nodes, same
     solver as the headline.  `more`: further (nodes, seconds) horizons reported under 'horizons'."""
     from d2dhip import synth
     dur = synth.planner_timing(0, t1, 10)[2]
     plan = d2dhip.FitPlan(ctx, S_, K, dur, synth.default_wref(OBJ_SCALE, K))
-    dsc = ctx.dev(synth.synth_scenarios(B, seed=SEED, obj_scale=OBJ_SCALE, K=K, dist_range=(100. * t1 / 12.0, 150. * t1 / 12.0)))
+    dsc = ctx.dev(_long_scenarios(B, K, t1))
     q0 = plan.init(dsc)
-    cost, iters, status, stats = plan.solve(dsc, q0.clone(), max_iter=300)
+    q_first = q0.clone()
+    cost, iters, status, stats = plan.solve(dsc, q_first, max_iter=300)
 
     def best_of(n):
         best = 1e30
@@ -296,12 +324,22 @@ def long_horizon_record(ctx, torch, d2dhip, B=4096, K=121, t1=12.0, more=((301, 
            'ms_per_step': 1e3 * best, 'value_with_order_hint': B / hinted, 'converged_frac': float((st == 1).mean()),
            'mean_iters': float(iters.float().mean().item()), 'max_iters': int(iters.max().item()), 'evals_per_fit': float(stats[3]) / B}
     plan.close()
+    if cpu_long and K in cpu_long:                  # the same scenarios through the CPU arbiter (scipy on the oracle's residuals), same start
+        cs, qs, rate, cores = cpu_long[K]
+        n = len(cs)
+        cg, qg = cost.cpu().numpy()[:n], q_first.cpu().numpy()[:n]
+        rel_c = np.abs(cg - cs) / np.abs(cs); rel_q = np.abs(qg - qs).max(1) / np.abs(qs).max(1)
+        rec['parity_vs_scipy'] = {'n': n, 'same_minimum_frac': float(((rel_c <= 1e-6) & (rel_q <= 1e-6)).mean()),
+                                  'cost_rel_le_1e-6_frac': float((rel_c <= 1e-6).mean()), 'gpu_cost_lower_frac': float((cg < cs * (1 - 1e-6)).mean()),
+                                  'cpu_fits_per_s': rate, 'cores': cores,
+                                  'what': 'd2d_fit_solve (default solver, long-horizon kernel) vs scipy.optimize.least_squares(lm, tol 1e-15) on oracle/fit.py '
+                                          'residuals from the same start; same minimum = cost and unknowns within 1e-6 relative'}
     if more:
         rec['horizons'] = []
         for (K2, t2) in more:
-            r2 = long_horizon_record(ctx, torch, d2dhip, B=B, K=K2, t1=t2, more=())
+            r2 = long_horizon_record(ctx, torch, d2dhip, B=B, K=K2, t1=t2, more=(), cpu_long=cpu_long)
             rec['horizons'].append({k: r2[k] for k in ('metric', 'value', 'workload', 'ms_per_step', 'value_with_order_hint', 'converged_frac',
-                                                      'mean_iters', 'max_iters')})
+                                                      'mean_iters', 'max_iters', 'parity_vs_scipy') if k in r2})
     return rec
 
 
@@ -438,13 +476,14 @@ def main():
         print(json.dumps({'rank': rank, 'world': world, 'local_rank': local_rank, 'gpus': a.gpus}), flush=True)
         return
     B = a.batch
-    cpu = keep = cpu_g = cpu_t = cpu_n = None
+    cpu = keep = cpu_g = cpu_t = cpu_n = cpu_l = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu, keep = cpu_baseline(B, a.cpu_sample)
         if not a.no_sim:
             cpu_g, cpu_t = cpu_baseline_sim_gvf(), cpu_baseline_sim_track()
         if not a.no_nlp:
             cpu_n = cpu_baseline_nlp()
+            cpu_l = cpu_long_horizon()
 
     import torch
     import d2dhip
@@ -729,7 +768,7 @@ def main():
     if rank == 0 and world == 1 and not a.no_nlp:
         torch.cuda.empty_cache()
         nlp = nlp_record(ctx, torch, cpu_n)
-        longh = long_horizon_record(ctx, torch, d2dhip)
+        longh = long_horizon_record(ctx, torch, d2dhip, cpu_long=cpu_l)
 
     if rank == 0:
         line = {
