@@ -2020,9 +2020,10 @@ int d2d_fit_plan_create(d2d_ctx *ctx, int S, int K, double duration, const doubl
   pl->split_ok = pick_eval_layout(K, nq, &pl->g32_lds, &pl->wpb_eval, 0) &&
                  pick_step_layout(K, nq, 16 * ((2 * nq + 15) / 16), &pl->wpb_step);
   pl->use_lm = (nq == 24) && pick_fused_layout(K, nq, 48, &pl->wpb_lm) && !getenv("D2D_FIT_SPLIT");
-  // long horizons: the chunked persistent kernel reads the basis through L2, any K (also chosen when the split path cannot
-  // hold K; D2D_FIT_LONG=1 forces it for K <= 64, tests do)
-  pl->use_long = !pl->use_lm && (K > 64 || getenv("D2D_FIT_LONG")) && (!getenv("D2D_FIT_SPLIT") || !pl->split_ok);
+  // everything else -- long horizons, segment counts other than six -- runs on the chunked persistent kernel (the segment
+  // formulation needs no K-sized table and deals its lanes to any number of segments); D2D_FIT_LONG=1 forces it for S = 6,
+  // K <= 64 (tests do), D2D_FIT_SPLIT=1 selects the launch-pair path where its LDS image holds K
+  pl->use_long = !pl->use_lm && (!getenv("D2D_FIT_SPLIT") || !pl->split_ok);
   if (getenv("D2D_FIT_LONG") && !getenv("D2D_FIT_SPLIT")) { pl->use_lm = false; pl->use_long = true; }
   if (pl->use_long) pl->wpb_lm = FIT_LM_WPB_MAX;
   if (!pl->split_ok && !pl->use_long) {

@@ -334,7 +334,8 @@ int d2d_fit_plan_destroy(d2d_fit_plan *plan);
 /* Which kernel d2d_fit_solve runs for this plan (uncoupled): the fused persistent LM kernel (S = 6, K <= 64, everything in
  * LDS), the long-horizon persistent kernel (K > 64: the segment formulation of csrc/fit_seg.h -- Legendre coefficients per segment
  * instead of basis tables, LDS footprint independent of K: any K, e.g. the reference's 101 .. 151-node scenarios and its 50 Hz
- * horizons of 351 .. 1501 nodes), or the launch-pair path (S != 6, K <= 64).  d2d_fit_eval uses the launch-pair evaluation kernel
+ * horizons of 351 .. 1501 nodes; since round 3 also every plan with S != 6: the kernel deals its lanes to any number of segments), or
+ * the launch-pair path (D2D_FIT_SPLIT=1 in the environment).  d2d_fit_eval uses the launch-pair evaluation kernel
  * while the basis block fits the LDS (K <~ 229 at S = 6) and the segment formulation beyond; coupled groups run on the group
  * kernels up to that K and on the long-horizon kernel beyond; d2d_fit_rows / d2d_fit_jtj (the contraction-only pair of the
  * bench) keep the LDS limit (D2D_EINVAL beyond). */

@@ -14,6 +14,7 @@ Ks = [int(x) for x in sys.argv[2:]] or [65, 101, 121, 151, 201, 301, 501]
 ctx = d2dhip.Context(0)
 res = {}
 B = 4096
+MAXIT = int(os.environ.get('MAXIT', '300'))
 for K in Ks:
     t1 = (K - 1) / 10.0
     dur = synth.planner_timing(0, t1, 10)[2]
@@ -24,11 +25,11 @@ for K in Ks:
         best = 1e9
         for rep in range(3):
             q = q0.clone(); torch.cuda.synchronize(); t0 = time.perf_counter()
-            cost, iters, status, stats = plan.solve(dsc, q, max_iter=300, **kw)
+            cost, iters, status, stats = plan.solve(dsc, q, max_iter=MAXIT, **kw)
             torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
         plan.order_from_iters(iters)
         q = q0.clone(); torch.cuda.synchronize(); t0 = time.perf_counter()
-        plan.solve(dsc, q, max_iter=300, **kw)
+        plan.solve(dsc, q, max_iter=MAXIT, **kw)
         torch.cuda.synchronize(); hinted = time.perf_counter() - t0
         plan.clear_order()
         st = status.cpu().numpy()
