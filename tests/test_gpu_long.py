@@ -195,3 +195,34 @@ def test_other_segment_counts_on_the_long_kernel(ctx, S, K):
         assert np.isin(status.cpu().numpy(), (d2dhip.ST_CONVERGED, d2dhip.ST_STALLED)).all()
     finally:
         p.close()
+
+
+@pytest.mark.parametrize('S,K,mode', [(6, 121, 'minpack'), (6, 121, 'fast'), (4, 50, 'minpack')])
+def test_budgeted_launches_equal_one_solve_on_the_long_kernel(ctx, S, K, mode):
+    """d2d_fit_begin / iterate / finish on the long-horizon kernel: a solve cut into launches of 7 trials (the solver state -- damping,
+    trust region, lmder phase -- travels through lm[b][8] between them) ends exactly where the single launch does."""
+    import d2dhip
+    kw = {} if mode == 'minpack' else {'mode': d2dhip.MODE_FAST}
+    dur = (K - 1) / 10.0
+    s = 0.1 / K
+    p = d2dhip.FitPlan(ctx, S, K, dur, (0.02 ** 2, s * 5.0, s / F.G_ACC ** 2))
+    try:
+        assert p.kernel == 'long'
+        sc = _scen(40, K, dur, seed=7) if K > 64 else F.set_scale(F.synth_scenarios(40, seed=7), 0.1, K)
+        dsc = ctx.dev(sc)
+        q0 = p.init(dsc)
+        qa, qb = q0.clone(), q0.clone()
+        ca, ia, sa, _ = p.solve(dsc, qa, max_iter=150, **kw)
+        p.begin(40)
+        n = 0
+        while p.iterate(dsc, qb, 7, max_iter=150, **kw) > 0:
+            n += 1
+            assert n < 100
+        cb, ib, sb, _ = p.finish(dsc, qb)
+        assert n >= 2
+        np.testing.assert_array_equal(sa.cpu().numpy(), sb.cpu().numpy())
+        np.testing.assert_array_equal(ia.cpu().numpy(), ib.cpu().numpy())
+        np.testing.assert_allclose(cb.cpu().numpy(), ca.cpu().numpy(), rtol=1e-12)
+        np.testing.assert_allclose(qb.cpu().numpy(), qa.cpu().numpy(), rtol=0, atol=1e-9 * np.abs(qa.cpu().numpy()).max())
+    finally:
+        p.close()
