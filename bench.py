@@ -179,7 +179,7 @@ def _long_scenarios(B, K2, t2):
     return synth.synth_scenarios(B, seed=SEED, obj_scale=OBJ_SCALE, K=K2, dist_range=(100. * t2 / 12.0, 150. * t2 / 12.0))
 
 
-def cpu_long_horizon(n=96, B=4096):
+def cpu_long_horizon(n=512, B=4096):
     """cpu leg of the long_horizon record: scipy least_squares('lm') on the first n scenarios of each horizon (oracle residuals),
     for the record's parity_vs_scipy.  Returns {nodes: (costs, q, fits per second)}."""
     import multiprocessing as mp
