@@ -2526,8 +2526,10 @@ int d2d_fit_solve_groups(d2d_ctx *ctx, d2d_fit_plan *pl, int R, const double *sc
     return D2D_OK;
   }
   // ---- launch-pair path (other plan shapes): every scenario sweeps until the slowest one has settled
-  // (D2D_GROUPS_LONG=1: tests force the chunked kernel on a horizon the launch-pair kernels also hold)
-  const bool long_path = !pl->split_ok || (pl->use_long && getenv("D2D_GROUPS_LONG") != nullptr);
+  // (plans of the long-horizon kernel -- more than 64 nodes -- run every visit as ONE launch of it: 1.6 .. 3 x faster than the
+  // launch pairs at 71 .. 201 nodes, tools/dev_groups_long.py; D2D_GROUPS_PAIRS=1 keeps the launch pairs where their LDS image
+  // holds K, tests compare the two)
+  const bool long_path = !pl->split_ok || (pl->use_long && getenv("D2D_GROUPS_PAIRS") == nullptr);
   d2d_fit_opts o_long = o;
   o_long.mode = D2D_LM_MODE_FAST; o_long.so_lambda = 0.0; o_long.max_iter = inner_iters; o_long.slice = 0;
   const FitGeom gm = geom_of(pl);

@@ -120,15 +120,15 @@ def test_long_horizon_groups_on_the_chunked_kernel(monkeypatch):
             dsc = ctx.dev(sc.reshape(R * n_ac, -1))
             try:
                 assert plan.kernel == 'long'
-                monkeypatch.setenv('D2D_GROUPS_LONG', '1')
                 qa = plan.init(dsc)
-                ca, swa, sta = plan.solve_groups(dsc, qa, n_ac, max_sweeps=80, inner_iters=8, tol=1e-12)
-                monkeypatch.delenv('D2D_GROUPS_LONG')
+                ca, swa, sta = plan.solve_groups(dsc, qa, n_ac, max_sweeps=80, inner_iters=8, tol=1e-12)      # (the default beyond 64 nodes)
                 assert swa < 80 and sta[2] <= 1e-12, (swa, sta)
                 qh = qa.cpu().numpy().reshape(R, n_ac, -1)
                 if both:
+                    monkeypatch.setenv('D2D_GROUPS_PAIRS', '1')       # the launch pairs of round 1, where their LDS image holds K
                     qb = plan.init(dsc)
                     cb, swb, stb = plan.solve_groups(dsc, qb, n_ac, max_sweeps=80, inner_iters=8, tol=1e-12)
+                    monkeypatch.delenv('D2D_GROUPS_PAIRS')
                     assert np.abs(qa.cpu().numpy() - qb.cpu().numpy()).max() <= 1e-6 * np.abs(qb.cpu().numpy()).max()
                     np.testing.assert_allclose(ca.cpu().numpy(), cb.cpu().numpy(), rtol=1e-8)
                 r = 0
