@@ -1277,6 +1277,10 @@ fit_lm_long_kernel(int B, FitGeom g, LongLds L, d2d_fit_opts opts, int iter_budg
     }
     double mom_none[16];
 
+    // (segment formulation) zc holds the Legendre coefficients and kbank_t the bank-max sample of the LAST trial point: the evaluation
+    // of an accepted step -- the same point -- starts from them instead of projecting q through Zl again
+    bool zc_trial = false;
+    int kbank_t = -1;
     // cost at qi + alpha * delta (cost-only pass over the chunks)
     auto cost_at = [&](double alpha, double delta) -> double {
       if (act) qs[q_slot(lane, nq)] = qi + alpha * delta;
@@ -1293,6 +1297,7 @@ fit_lm_long_kernel(int B, FitGeom g, LongLds L, d2d_fit_opts opts, int iter_budg
           if (c + 1 < sa.m.nchunk) nin = segment_inputs(ls, g.K, sa.sx, pkb, c + 1);
           ca += segment_phase1<false>(ls, g.K, in, sa.c1, sp, zc, cf, cfp, psi, mom_none, false, kbank, c, lane, gc);
         }
+        zc_trial = true; kbank_t = kbank;
         SEG_STAMP(1)
       } else {
         const int kbank = long_bank_argmax<NQ, TL>(g, GT, pkb, qs, load_scenp(sp), lane);
@@ -1310,9 +1315,13 @@ fit_lm_long_kernel(int B, FitGeom g, LongLds L, d2d_fit_opts opts, int iter_budg
       double ca = 0.0, ga = 0.0;
       if (SEG) {
         SEG_STAMP(7)
-        segment_coefs<NQ>(nq, sa.m.S, Zl64, qs, zpx, zpy, zc, lane);
+        int kbank = kbank_t;
+        if (!zc_trial) {                                 // (not the point of the last trial: the first evaluation of a fit, a resumed one)
+          segment_coefs<NQ>(nq, sa.m.S, Zl64, qs, zpx, zpy, zc, lane);
+          kbank = segment_bank_argmax(sa.m, ls, sa.sx, sa.c1, zc, load_scenp(sp));
+        }
+        zc_trial = false;                                // (segment_gradient below uses zc as scratch)
         SEG_STAMP(0)
-        const int kbank = segment_bank_argmax(sa.m, ls, sa.sx, sa.c1, zc, load_scenp(sp));
         const FitGeom g8{SEG_ROWS, 8, 9};                 // the chunk's operand planes: SEG_ROWS rows of eight Legendre values per derivative order
         f32x4 bs[D2D_FIT_MAX_S][1];
         double mom[16];
