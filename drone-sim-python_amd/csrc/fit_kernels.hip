@@ -1281,6 +1281,7 @@ fit_lm_long_kernel(int B, FitGeom g, LongLds L, d2d_fit_opts opts, int iter_budg
     // of an accepted step -- the same point -- starts from them instead of projecting q through Zl again
     bool zc_trial = false;
     int kbank_t = -1;
+    const SegIn in0 = SEG ? segment_inputs(ls, g.K, sa.sx, pkb, 0) : SegIn{0.0, 0.0, 0.0};   // chunk 0's inputs: loaded once per fit
     // cost at qi + alpha * delta (cost-only pass over the chunks)
     auto cost_at = [&](double alpha, double delta) -> double {
       if (act) qs[q_slot(lane, nq)] = qi + alpha * delta;
@@ -1291,7 +1292,7 @@ fit_lm_long_kernel(int B, FitGeom g, LongLds L, d2d_fit_opts opts, int iter_budg
         segment_coefs<NQ>(nq, sa.m.S, Zl64, qs, zpx, zpy, zc, lane);
         SEG_STAMP(0)
         const int kbank = segment_bank_argmax(sa.m, ls, sa.sx, sa.c1, zc, load_scenp(sp));
-        SegIn nin = segment_inputs(ls, g.K, sa.sx, pkb, 0);
+        SegIn nin = in0;
         for (int c = 0; c < sa.m.nchunk; ++c) {
           const SegIn in = nin;
           if (c + 1 < sa.m.nchunk) nin = segment_inputs(ls, g.K, sa.sx, pkb, c + 1);
@@ -1329,7 +1330,7 @@ fit_lm_long_kernel(int B, FitGeom g, LongLds L, d2d_fit_opts opts, int iter_budg
         for (int s = 0; s < D2D_FIT_MAX_S; ++s) bs[s][0] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 16; ++i) mom[i] = 0.0;
-        SegIn nin = segment_inputs(ls, g.K, sa.sx, pkb, 0);
+        SegIn nin = in0;
         for (int c = 0; c < sa.m.nchunk; ++c) {
           const SegIn in = nin;
           if (c + 1 < sa.m.nchunk) nin = segment_inputs(ls, g.K, sa.sx, pkb, c + 1);
