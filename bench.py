@@ -293,7 +293,7 @@ def nlp_record(ctx, torch, cpu, B=4096):
     return rec
 
 
-def long_horizon_record(ctx, torch, d2dhip, B=4096, K=121, t1=12.0, more=LONG_HORIZONS[1:], cpu_long=None):
+def long_horizon_record(ctx, torch, d2dhip, B=4096, K=121, t1=12.0, more=LONG_HORIZONS[1:], cpu_long=None, large_B=32768):
     """The reference's own planner horizons (101 .. 151 nodes at 10 Hz: exp_14 = 121; its 50 Hz scenarios: 211 .. 601) on the chunked
     persistent kernel (fit_lm_long_kernel, K > 64; the segment formulation of csrc/fit_seg.h): B independent fits of K nodes, same
     solver as the headline.  `more`: further (nodes, seconds) horizons reported under 'horizons'."""
@@ -337,9 +337,19 @@ def long_horizon_record(ctx, torch, d2dhip, B=4096, K=121, t1=12.0, more=LONG_HO
     if more:
         rec['horizons'] = []
         for (K2, t2) in more:
-            r2 = long_horizon_record(ctx, torch, d2dhip, B=B, K=K2, t1=t2, more=(), cpu_long=cpu_long)
-            rec['horizons'].append({k: r2[k] for k in ('metric', 'value', 'workload', 'ms_per_step', 'value_with_order_hint', 'converged_frac',
-                                                      'mean_iters', 'max_iters', 'parity_vs_scipy') if k in r2})
+            r2 = long_horizon_record(ctx, torch, d2dhip, B=B, K=K2, t1=t2, more=(), cpu_long=cpu_long, large_B=0)
+            h = {k: r2[k] for k in ('metric', 'value', 'workload', 'ms_per_step', 'value_with_order_hint', 'converged_frac',
+                                    'mean_iters', 'max_iters', 'parity_vs_scipy') if k in r2}
+            if large_B:
+                # the throughput regime: 4096 fits of 23 trials on average and 84 at most keep the machine a quarter full
+                # (profiles/r03/06_*); 32 768 fill it.  dense_count: J^T J flops by the SURVEY's count for the rows contracted
+                # (rows x P x (P + 1); the segment formulation EXECUTES one 16x16x4 MFMA per sample + 216 per evaluation instead)
+                r3 = long_horizon_record(ctx, torch, d2dhip, B=large_B, K=K2, t1=t2, more=(), cpu_long=None, large_B=0)
+                tf = r3['evals_per_fit'] * 470400.0 * large_B / (r3['ms_per_step'] * 1e-3) / 1e12
+                h['large_batch'] = {'batch': large_B, 'value': r3['value'], 'ms_per_step': r3['ms_per_step'], 'value_with_order_hint': r3['value_with_order_hint'],
+                                    'converged_frac': r3['converged_frac'], 'mean_iters': r3['mean_iters'], 'evals_per_fit': r3['evals_per_fit'],
+                                    'jtj_dense_count_tflops': tf, 'jtj_dense_count_frac': tf / FP32_PEAK_TFLOPS}
+            rec['horizons'].append(h)
     return rec
 
 

@@ -13,7 +13,7 @@ out = sys.argv[1]
 Ks = [int(x) for x in sys.argv[2:]] or [65, 101, 121, 151, 201, 301, 501]
 ctx = d2dhip.Context(0)
 res = {}
-B = 4096
+B = int(os.environ.get('BATCH', '4096'))
 MAXIT = int(os.environ.get('MAXIT', '300'))
 for K in Ks:
     t1 = (K - 1) / 10.0
