@@ -208,24 +208,21 @@ def cpu_polish(keep, q_gpu, n_polish=256):
     return np.array([r[0] for r in res]), np.array([r[1] for r in res])
 
 
-def cpu_baseline_nlp(n=3):
+def cpu_baseline_nlp(n=32):
     """cpu_baseline leg of the collocation record: the oracle's solver (numpy + banded LAPACK, the same algorithm as the kernel)
-    on the first n problems of the batch, one core."""
-    from oracle import nlp as ON               # the oracle is the thing timed in this leg only
-    import d2dhip
+    on the first n problems of the batch, one problem per host core at a time (forked pool: runs before the GPU is touched)."""
+    import multiprocessing as mp
     from d2dhip import synth
     rows, W0, h = synth.nlp_problems(n)
-    t0 = time.perf_counter()
-    costs, steps = [], []
-    for b in range(n):
-        r = rows[b]
-        pb = ON.Problem(W0.shape[2], h, r[d2dhip.SC_X0:d2dhip.SC_X0 + 3], r[d2dhip.SC_X1:d2dhip.SC_X1 + 3], vsp=12., kv=1., kphi=0., obj_scale=1.,
-                        phi_max=np.deg2rad(40.), v_min=9., v_max=15., x_box=(-150, 150), y_box=(-150, 150))
-        _, info = ON.solve(pb, W0[b].T.copy())
-        costs.append(info['cost']); steps.append(info['inner'])
-    dt = time.perf_counter() - t0
-    return {'value': n / dt, 'unit': 'problems/s', 'cores': 1, 'kind': 'port', 'seconds': dt,
-            'sample': f'oracle/nlp.py solve() on the first {n} problems of the batch', 'cost': costs, 'newton_steps': steps}
+    cores = min(_host_cores(), n)
+    with mp.get_context('fork').Pool(cores) as pool:
+        pool.map(_nlp_oracle_one, [(rows[b], W0[b], h) for b in range(min(cores, n))], chunksize=1)      # warm the workers
+        t0 = time.perf_counter()
+        res = pool.map(_nlp_oracle_one, [(rows[b], W0[b], h) for b in range(n)], chunksize=1)
+        dt = time.perf_counter() - t0
+    return {'value': n / dt, 'unit': 'problems/s', 'cores': cores, 'kind': 'port', 'seconds': dt,
+            'sample': f'oracle/nlp.py solve() on the first {n} problems of the batch, multiprocessing.Pool({cores})',
+            'status': [int(r[0]) for r in res], 'cost': [float(r[1]) for r in res], 'newton_steps': [int(r[3]) for r in res]}
 
 
 def _nlp_oracle_one(args):
@@ -288,7 +285,9 @@ def nlp_record(ctx, torch, cpu, B=4096):
     if cpu is not None:
         rec['verdicts_vs_oracle'] = nlp_verify(rows, W0, h, st, cost, feas)
         n = len(cpu['cost'])
-        rec['parity'] = {'n': n, 'max_rel_cost_diff_vs_oracle': float(np.max(np.abs(cost[:n] - np.array(cpu['cost'])) / np.array(cpu['cost']))),
+        both = (st[:n] == 1) & (np.array(cpu['status']) == 1)
+        rec['parity'] = {'n': n, 'status_agree_frac': float(np.mean(st[:n] == np.array(cpu['status']))), 'both_converged': int(both.sum()),
+                         'max_rel_cost_diff_vs_oracle': float(np.max(np.abs(cost[:n] - np.array(cpu['cost']))[both] / np.array(cpu['cost'])[both])) if both.any() else None,
                          'newton_steps_gpu': it[:n].tolist(), 'newton_steps_oracle': cpu['newton_steps']}
     return rec
 
