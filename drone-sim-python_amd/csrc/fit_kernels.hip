@@ -293,7 +293,7 @@ static StepLds step_lds_layout(int K, int nq, int N, int wpb) {
   L.wave0 = o;
   int w = 0;
   {
-    L.Lm = w; w = align16(w + (N + 3) * (N + 4) * 4);     // image of J^T J, then of its Cholesky factor
+    L.Lm = w; w = align16(w + CHOL_IMAGE_BYTES(N));     // image of J^T J, then of its Cholesky factor
   }
   L.vec = w; w = align16(w + N * 4);
   L.qt = w; w = align16(w + N * 8);
@@ -360,9 +360,10 @@ fit_step_kernel(int B, FitGeom g, StepLds L, d2d_fit_opts opts, GroupArgs ga,
   }
   wave_lds_sync();
   image_row<N>(Lm, lane, hrow);
+  const float hdiag = image_diag<N>(Lm, lane);
   wave_lds_sync();
   float dgi, dl;
-  const bool ok = damped_solve<N>(hrow, lam, act, lane, Lm, dgi, dl);
+  const bool ok = damped_solve<N>(hrow, lam, act, lane, Lm, dgi, dl, nullptr, false, 0, 0.0, nullptr, nullptr, hdiag, true);
   const double delta = (double)dl;
   // ---- trial points (the full step, then up to two shortened ones), predicted and actual reduction ------
   const ScenP s = load_scenp(prep + (size_t)b * FIT_PREP_STRIDE);
@@ -438,7 +439,7 @@ static FusedLds fused_lds_layout(int K, int nq, int N, int wpb, int nds = 0) {
   L.cfp = L.cf + cf_bytes;                      // second-order mode: position-block records [K+1][2] float2
   // (coupled groups, fit_groups_kernel: the collision-row records [K+1][nds] float2 take the place of the second-order records)
   int big = us_bytes + cf_bytes + align16((K + 1) * (nds > 2 ? nds : 2) * 8);
-  if ((N + 3) * (N + 4) * 4 > big) big = (N + 3) * (N + 4) * 4;
+  if (CHOL_IMAGE_BYTES(N) > big) big = CHOL_IMAGE_BYTES(N);
   w = align16(w + big);
   L.wave_stride = w;
   L.total = o + wpb * w;
@@ -565,7 +566,12 @@ fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_cap,
     const double *prow = prep + (size_t)b * FIT_PREP_STRIDE;
     const double *pkb = pk + (size_t)b * FIT_PK * g.K;
     double *lmb = lm + (size_t)b * LM_STRIDE;
-    double qi = act ? ld_dev(q_io + (size_t)b * n + lane) : 0.0;
+    double qi = 0.0;
+    {
+      int lane_ld = lane;      // (laundered like the output addresses below: not worth a VGPR pair -- or a spill -- across the whole launch)
+      LAUNDER(lane_ld);
+      if (act) qi = ld_dev(q_io + (size_t)b * n + lane_ld);
+    }
     // Wave-uniform state lives in scalar registers, of which there are ~100: values that are never live together share one.
     //   s0, s1       phase 1: V_lam, V_nu (damping, Nielsen's growth factor); phase 0: V_par, the trust-region radius
     //   u0 .. u7     scratch of one iteration: phase 0 (lmpar + lmder) V_parl, V_paru, V_fp, V_pn, V_gnrm, V_gnorm, V_par;
@@ -657,7 +663,7 @@ fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_cap,
             image_put_rhs<N>(big, lane, gi);
             wave_lds_sync();
             image_row<N>(big, lane, hrow);
-            if (MODE == D2D_LM_MODE_MINPACK) hdiag = big[(lane < N ? lane : 0) * CHOL_LS + (lane < N ? lane : 0)];
+            hdiag = image_diag<N>(big, lane);
             wave_lds_sync();
             LM_STAMP(4)
           }
@@ -693,8 +699,8 @@ fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_cap,
           double dxn = 0.0, t2 = 0.0;
           float dls;
           const bool unit = MODE == D2D_LM_MODE_MINPACK && phase == 0;
-          ok = uniform_i(damped_solve<N, MODE == D2D_LM_MODE_MINPACK>(hrow, solve_lam, act, lane, big, dgi, dls, STAMPS ? st_solve : nullptr,
-                                                                    unit, isq_mode, V_mp_delta, &dxn, &t2) ? 1 : 0) != 0;
+          ok = uniform_i(damped_solve<N, MODE == D2D_LM_MODE_MINPACK, (NQ > 0 && 2 * NQ == N)>(hrow, solve_lam, act, lane, big, dgi, dls, STAMPS ? st_solve : nullptr,
+                                                                    unit, isq_mode, V_mp_delta, &dxn, &t2, hdiag, true) ? 1 : 0) != 0;
           LM_STAMP(5)
           if (MODE == D2D_LM_MODE_MINPACK && phase == 0) {
             ++mp.nfac;
@@ -978,6 +984,7 @@ fit_groups_kernel(int R, int n_ac, int nds, FitGeom g, FusedLds L, d2d_fit_opts 
         int iters = 0, status = D2D_ST_RUNNING;
         double c = 0.0, gi = 0.0;
         f32x2 hrow[N / 2];
+        float hdiag = 0.f;
 #pragma unroll
         for (int m = 0; m < N / 2; ++m) hrow[m] = f32x2{0.f, 0.f};
         if (act) qs[q_slot(lane, g.nq)] = qi;
@@ -1010,13 +1017,14 @@ fit_groups_kernel(int R, int n_ac, int nds, FitGeom g, FusedLds L, d2d_fit_opts 
             image_put_rhs<N>(big, lane, gi);
             wave_lds_sync();
             image_row<N>(big, lane, hrow);
+            hdiag = image_diag<N>(big, lane);
             wave_lds_sync();
           }
           if (iters >= inner_iters) break;
           const double gmax = uniform_d(wave_max(fabs(gi)));
           if (gmax <= opts.gtol) { status = D2D_ST_CONVERGED; break; }
           float dgi, dl;
-          const int ok = uniform_i(damped_solve<N>(hrow, lam, act, lane, big, dgi, dl) ? 1 : 0);
+          const int ok = uniform_i(damped_solve<N, false, (NQ > 0 && 2 * NQ == N)>(hrow, lam, act, lane, big, dgi, dl, nullptr, false, 0, 0.0, nullptr, nullptr, hdiag, true) ? 1 : 0);
           const double delta = (double)dl;
           const double pred = uniform_d(wave_sum(delta * (lam * (double)dgi * delta - gi)));
           const double dmax = uniform_d(wave_max(fabs(delta))), qmax = uniform_d(wave_max(fabs(qi)));
@@ -1125,7 +1133,7 @@ static LongLds long_lds_layout(int N, int wpb, int K = 0, int nq = 0, bool g32 =
   L.cf = w + us_bytes;
   L.cfp = L.cf + cf_bytes;
   int big = us_bytes + cf_bytes + cfp_bytes;
-  if ((N + 3) * (N + 4) * 4 > big) big = (N + 3) * (N + 4) * 4;
+  if (CHOL_IMAGE_BYTES(N) > big) big = CHOL_IMAGE_BYTES(N);
   w = align16(w + big);
   L.wave_stride = w;
   L.total = o + wpb * w;
@@ -1157,7 +1165,7 @@ static SegLds seg_lds_layout(int N, int nq, int S, int wpb) {
   L.cfp = L.cf + SEG_ROWS * 4 * 16;
   L.psi = align16(L.cfp + SEG_ROWS * 2 * 8);
   int big = L.psi + 3 * SEG_ROWS * 8 * 4 - L.big;
-  if ((N + 3) * (N + 4) * 4 > big) big = (N + 3) * (N + 4) * 4;             // image of J^T J / its Cholesky factor
+  if (CHOL_IMAGE_BYTES(N) > big) big = CHOL_IMAGE_BYTES(N);             // image of J^T J / its Cholesky factor
   if (64 * SEG_RED_STRIDE * 8 > big) big = 64 * SEG_RED_STRIDE * 8;         // moment reduction scratch
   w = align16(w + big);
   L.wave_stride = w;
@@ -1389,7 +1397,7 @@ fit_lm_long_kernel(int B, FitGeom g, LongLds L, d2d_fit_opts opts, int iter_budg
         image_put_rhs<N>(big, lane, gi);
         wave_lds_sync();
         image_row<N>(big, lane, hrow);
-        if (MODE == D2D_LM_MODE_MINPACK) hdiag = big[(lane < N ? lane : 0) * CHOL_LS + (lane < N ? lane : 0)];
+        hdiag = image_diag<N>(big, lane);
         wave_lds_sync();
         nev += (so ? 3 : 2) * ((g.K + 49) / 50);      // contracted rows in units of 100 (FL_NEVAL; one unit = 200 rows)
         SEG_STAMP(6)
@@ -1410,7 +1418,7 @@ fit_lm_long_kernel(int B, FitGeom g, LongLds L, d2d_fit_opts opts, int iter_budg
         status = mp_trial(mp, opts, c, qi, gi, hdiag, act, iters,
                           [&](double lamv, int isq_mode, double trd, float &dls, double &dxn, double &t2) -> bool {
                             float dgi_;
-                            return uniform_i(damped_solve<N, true>(hrow, lamv, act, lane, big, dgi_, dls, nullptr, true, isq_mode, trd, &dxn, &t2) ? 1 : 0) != 0;
+                            return uniform_i(damped_solve<N, true, (NQ > 0 && 2 * NQ == N)>(hrow, lamv, act, lane, big, dgi_, dls, nullptr, true, isq_mode, trd, &dxn, &t2, hdiag, true) ? 1 : 0) != 0;
                           },
                           [&](float dls) -> double { return cost_at(1.0, (double)dls); }, taken);
         ++iters; ++local;
@@ -1423,7 +1431,7 @@ fit_lm_long_kernel(int B, FitGeom g, LongLds L, d2d_fit_opts opts, int iter_budg
       const double gmax = uniform_d(wave_max(fabs(gi)));
       if (gmax <= opts.gtol) { status = D2D_ST_CONVERGED; break; }
       float dgi, dl;
-      const int ok = uniform_i(damped_solve<N>(hrow, lam, act, lane, big, dgi, dl) ? 1 : 0);
+      const int ok = uniform_i(damped_solve<N, false, (NQ > 0 && 2 * NQ == N)>(hrow, lam, act, lane, big, dgi, dl, nullptr, false, 0, 0.0, nullptr, nullptr, hdiag, true) ? 1 : 0);
       const double delta = (double)dl;
       const bool so_next = MODE == D2D_LM_MODE_MINPACK ? true : (opts.so_lambda > 0.0 && lam <= opts.so_lambda);
       const double pred = uniform_d(wave_sum(delta * (lam * (double)dgi * delta - gi)));

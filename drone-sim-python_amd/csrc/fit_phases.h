@@ -539,110 +539,167 @@ __device__ __forceinline__ void image_row(const float *Hs, int lane, f32x2 (&hro
   }
 }
 
+// diagonal entry of row `lane` of the image (1 for the lanes that own no row of it)
+template <int N>
+__device__ __forceinline__ float image_diag(const float *Hs, int lane) {
+  LAUNDER(lane);
+  const int li = lane < N ? lane : 0;
+  return Hs[li * CHOL_LS + li];
+}
+
 __device__ __forceinline__ float lane_value(float v, int l) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
 }
 
 // ---- damped normal-equation solve -----------------------------------------------------------
 // hrow = row `lane` of J^T J (pairs of columns); lane N holds the right-hand side b = -g (image_put_rhs).
-// Solves (J^T J + lam*diag(max(J^T J_ii, floor))) delta = b in fp32.  Left-looking Cholesky, lane i owns
-// row i in registers.  Step j needs row j of the factor in every lane: entries k <= j-2 come from the LDS
-// image Lm [N+3][N+4] (each lane mirrors its finished entries there; one address for the whole wave = a
-// broadcast read, requested a whole step ahead), the newest entry L[j][j-1] comes straight from lane j's
-// register by v_readlane, so the LDS write -> read round trip is off the critical path.  Dot products
-// run as two packed (v_pk_fma_f32) chains.  Lane N rides along as row N of the augmented matrix, which
-// makes its entries the forward substitution L y = b; the back substitution reads the columns of Lm.
-// A non-positive pivot is not clamped: it turns the step into NaN, which the gain-ratio test rejects
-// like any failed step.  Returns false if a pivot is not positive.
+// Solves (J^T J + lam*diag(max(J^T J_ii, floor))) delta = b in fp32.  Left-looking Cholesky in PANELS of four columns, lane i
+// owns row i of the factor in registers (row[], strictly lower triangular: zeros on and above the diagonal, the reciprocal
+// diagonal in a side row of the image -- no per-lane selects in the substitutions).  Panel p = columns j0 = 4p .. 4p+3:
+//   * the four dot products s_c = a[lane][j0+c] - sum_{k<j0} L[lane][k] L[j0+c][k] run as eight packed (v_pk_fma_f32) chains
+//     over "chunks" of four k: rows j0 .. j0+3 of the factor come from the LDS image Lm (one address for the whole wave = a
+//     broadcast read; software-pipelined two chunks ahead, and the first two chunks of the NEXT panel -- final since the
+//     panel before -- are requested before this panel's diagonal block so that their latency lands under its dependent chain);
+//   * the 4x4 diagonal block is factorised across lanes j0 .. j0+3 with v_readlane (10 per panel) and v_rsq_f32;
+//   * the four new entries of every row are published with ONE 16-byte store and one wave-level sync per panel
+//     (round 3: one 4-byte store, one sync, two v_readlane and a packed-chain reduction per COLUMN).
+// The damping is added to the pivot itself (pivot_j = (a_jj - sum_k L_jk^2) + damp_j, the damp row travels through the image
+// as one broadcast quad per panel), so the rows need no copy with a modified diagonal.  Lane N rides along as row N of the
+// augmented matrix, which makes its entries the forward substitution L y = b; the back substitution reads the columns of Lm.
+// A non-positive pivot is not clamped: it turns the step into NaN, which the gain-ratio test rejects like any failed step.
+// Returns false if a pivot is not positive.
+// hd / have_hd: the caller already holds the diagonal entry of its row (read from the image after tiles_to_image).
+// FULL: every lane < N is a row of the system (2 nq == N): the rows need no masking.
 // MP (the MINPACK mode, mp_trial below): `unit` (wave-uniform) damps with lam * I instead of lam * diag; dxnorm = ||delta||_2;
 // isq_mode 1 (always) / 2 (only when | ||delta|| - tr_delta | > 0.1 tr_delta): isq = || L^-1 (delta / ||delta||) ||^2 -- the
 // quantity lmpar's Newton correction of the damping needs -- by a forward substitution through the rows of the factor,
 // which every lane still holds in registers (right-looking: z_j = w_j / L_jj, w_i -= L_ij z_j).
-template <int N, bool MP = false>
+#define CHOL_ROWS (N + 4)          // rows of the image: N of the factor, the right-hand side / y, a dummy row, 1 / diagonal, damping
+#define CHOL_IMAGE_BYTES(n) (((n) + 4) * ((n) + 4) * 4)
+
+// v on the lanes above lane j (a compile-time number once the panel loops are unrolled), zero on the others: the lane mask is
+// ones << (j + 1) in a scalar register pair (one s_lshl_b64), no per-lane compare.  `ones` = ~0 made opaque to the compiler:
+// as a literal the 64-bit mask reaches s_mov_b64 as a 32-bit literal, which the hardware zero-extends (lanes 32 .. 63 lost).
+__device__ __forceinline__ float lanes_above(float v, int j, unsigned long long ones) {
+  const unsigned long long m = j >= 63 ? 0ull : (ones << (j + 1));
+  float r;
+  asm("v_cndmask_b32 %0, 0, %1, %2" : "=v"(r) : "v"(v), "s"(m));
+  return r;
+}
+
+template <int N, bool MP = false, bool FULL = false>
 __device__ __forceinline__ bool damped_solve(const f32x2 (&hrow)[N / 2], double lam, bool act, int lane,
                                              float *Lm, float &dgi, float &delta, unsigned long long *tt = nullptr,
                                              bool unit = false, int isq_mode = 0, double tr_delta = 0.0,
-                                             double *dxnorm = nullptr, double *isq = nullptr) {
-  constexpr int LS = CHOL_LS;
-  // tt (diagnostics, fused kernel with D2D_LM_STAMPS): cycles of setup, steps [0,N/3), [N/3,2N/3), [2N/3,N), substitution
+                                             double *dxnorm = nullptr, double *isq = nullptr, float hd = 0.f, bool have_hd = false) {
+  constexpr int LS = CHOL_LS, NP = N / 4;
+  // tt (diagnostics, fused kernel with D2D_LM_STAMPS): cycles of setup, panels of columns [0,N/3), [N/3,2N/3), [2N/3,N), substitution
   unsigned long long tl = 0;
 #define DS_STAMP(i) if (tt) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tt[i] += t_ - tl; tl = t_; }
   if (tt) tl = __builtin_amdgcn_s_memtime();
-  // (every `lane > j` mask below is loop-invariant in the caller's iteration loop: hoisted, they would
-  // need 2N scalar registers the wave does not have)
   LAUNDER(lane);
   const bool live = act || lane == N;           // rows of the system + the right-hand side row
-  f32x2 row[N / 2];
-  float d = 1.f;
+  float d = hd;
+  if (!have_hd) {
+    d = 1.f;
 #pragma unroll
-  for (int m = 0; m < N / 2; ++m) {
-    row[m] = live ? hrow[m] : f32x2{0.f, 0.f};
-    if (2 * m == lane) d = hrow[m].x;
-    if (2 * m + 1 == lane) d = hrow[m].y;
+    for (int m = 0; m < N / 2; ++m) {
+      if (2 * m == lane) d = hrow[m].x;
+      if (2 * m + 1 == lane) d = hrow[m].y;
+    }
   }
   if (!act) d = 1.f;
   dgi = fmaxf(fabsf(d), (float)D2D_LM_DIAG_FLOOR);      // (|.|: the second-order Hessian may have a negative diagonal)
-  const float dd = act ? d + ((MP && unit) ? (float)lam : (float)(lam * (double)dgi)) : 1.f;
-#pragma unroll
-  for (int m = 0; m < N / 2; ++m) {
-    if (2 * m == lane) row[m].x = dd;
-    if (2 * m + 1 == lane) row[m].y = dd;
-  }
-#define ROW_EL(k) (((k) & 1) ? row[(k) >> 1].y : row[(k) >> 1].x)
-  // The factor is kept STRICTLY lower triangular, in registers and in the image (every lane stores
-  // its entry of column j at every step, zeros on and above the diagonal), and the reciprocal
-  // diagonal goes to a side row of the image: no per-lane selects in the substitutions.
-  int pivmin = 0x7f800000;           // min over the pivots' bit patterns: > 0 <=> every pivot positive (scalar unit)
-  float *wrow = Lm + (lane <= N ? lane : N + 1) * LS;  // lanes > N (all zeros) write a dummy row
+  // what is added to the pivot of this lane's column; a row that is not part of the system is masked to zero below and gets pivot 1
+  const float dadd = act ? ((MP && unit) ? (float)lam : (float)(lam * (double)dgi)) : 1.f;
+  float *wrow = Lm + (lane <= N ? lane : N + 1) * LS;  // lanes > N write a dummy row
   float *dinv = Lm + (N + 2) * LS;                     // [N] reciprocal diagonal
-  // lq[j&1]: the quads of row j of the factor, requested a whole step ahead (double-buffered: row j+1 is
-  // requested at the top of step j, before step j's own FMAs, so the LDS latency never sits on the
-  // chain); ljp = L[j][j-1] for the step to come.
-  f32x4 lq[2][N / 4];
-  float ljp = 0.f;
+  float *damp = Lm + (N + 3) * LS;                     // [N] damping of the pivots
+  damp[lane < N ? lane : N] = dadd;
+  wave_lds_sync();
+#define HEL(k) (((k) & 1) ? hrow[(k) >> 1].y : hrow[(k) >> 1].x)
+#define CHUNK_READ(PP, T)                                                                                     \
+  {                                                                                                           \
+    _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_)                                                          \
+      ring[(T) % 3][c_] = lds_get<f32x4>(Lm + (4 * (PP) + c_) * LS + 4 * (T));                               \
+  }
+  f32x2 row[N / 2];
+  f32x4 ring[3][4];          // chunk t of the current panel lives in ring[t % 3]
+  unsigned long long ones = ~0ull;
+  asm volatile("" : "+s"(ones));
   DS_STAMP(0)
 #pragma unroll
-  for (int j = 0; j < N; ++j) {
-    if (j == N / 3) { DS_STAMP(1) }
-    if (j == 2 * (N / 3)) { DS_STAMP(2) }
-    __builtin_amdgcn_sched_barrier(0);                   // (the next step's FMAs must not drift into this step's tail: they wait on LDS)
-    const int nk = j - 1;            // entries 0 .. j-2 of row j come from the image
-    if (j >= 1) wave_lds_sync();                         // column j-1 is in the image
-    if (j + 1 < N) {                                     // row j+1: its entries <= j-1 are final
+  for (int p = 0; p < NP; ++p) {
+    if (4 * p == N / 3) { DS_STAMP(1) }
+    if (4 * p == 2 * (N / 3)) { DS_STAMP(2) }
+    const int j0 = 4 * p;
+    __builtin_amdgcn_sched_barrier(0);
+    // chunks 0 .. pre-1 were requested during the panel before (entries of columns < j0 - 4: final by then)
+    const int pre = p >= 1 ? (p - 1 < 2 ? p - 1 : 2) : 0;
+    const f32x4 dq = lds_get<f32x4>(damp + j0);
 #pragma unroll
-      for (int k4 = 0; 4 * k4 < j; ++k4) lq[(j + 1) & 1][k4] = lds_get<f32x4>(Lm + (j + 1) * LS + 4 * k4);
+    for (int t = pre; t < p && t < 2; ++t) CHUNK_READ(p, t)
+    // one packed chain per column (four independent chains in flight)
+    f32x2 acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] = f32x2{0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < p; ++t) {
+      if (t + 2 < p) CHUNK_READ(p, t + 2)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const f32x4 l = ring[t % 3][c];
+        acc[c] = __builtin_elementwise_fma(row[2 * t], f32x2{l.x, l.y}, acc[c]);
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const f32x4 l = ring[t % 3][c];
+        acc[c] = __builtin_elementwise_fma(row[2 * t + 1], f32x2{l.z, l.w}, acc[c]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // the first chunks of the next panel (rows j0+4 .., columns < j0): under the diagonal block's dependent chain
+    if (p + 1 < NP) {
+#pragma unroll
+      for (int t = 0; t < 2 && t < p; ++t) CHUNK_READ(p + 1, t)
     }
     __builtin_amdgcn_sched_barrier(0);
-    // dot = sum_k L[lane][k] L[j][k]
-    f32x2 d01 = {0.f, 0.f}, d23 = {0.f, 0.f};
+    float s[4];
 #pragma unroll
-    for (int k4 = 0; 4 * k4 < nk; ++k4) {
-      const f32x4 l = lq[j & 1][k4];
-      if (4 * k4 + 1 < nk) d01 = __builtin_elementwise_fma(row[2 * k4], f32x2{l.x, l.y}, d01);
-      else d01.x = fmaf(row[2 * k4].x, l.x, d01.x);
-      if (4 * k4 + 3 < nk) d23 = __builtin_elementwise_fma(row[2 * k4 + 1], f32x2{l.z, l.w}, d23);
-      else if (4 * k4 + 2 < nk) d23.x = fmaf(row[2 * k4 + 1].x, l.z, d23.x);
+    for (int c = 0; c < 4; ++c) {
+      float a = HEL(j0 + c);
+      if (!FULL) a = live ? a : 0.f;
+      s[c] = p > 0 ? a - (acc[c].x + acc[c].y) : a;
     }
-    float sres = ROW_EL(j);
-    if (j >= 2) { const f32x2 dd2 = d01 + d23; sres -= dd2.x + dd2.y; }
-    if (j >= 1) sres = fmaf(-ROW_EL(j - 1), ljp, sres);
-    const float djj = lane_value(sres, j);
-    const float snext = (j + 1 < N) ? lane_value(sres, j + 1) : 0.f;
-    pivmin = min(pivmin, __builtin_bit_cast(int, djj));
-    const float inv = __builtin_amdgcn_rsqf(djj);
-    const float lij = (lane > j) ? sres * inv : 0.f;    // L[lane][j], strictly lower
-    ljp = snext * inv;                                   // L[j+1][j], uniform
-    if (j & 1) row[j >> 1].y = lij; else row[j >> 1].x = lij;
-    wrow[j] = lij;
-    dinv[j] = inv;                                      // uniform value, one address
+    // 4x4 diagonal block across lanes j0 .. j0+3; l[c] = L[lane][j0+c] (valid on the lanes below the pivot)
+    float l[4], inv[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float piv = lane_value(s[c], j0 + c) + dq[c];
+      inv[c] = __builtin_amdgcn_rsqf(piv);
+      l[c] = s[c] * inv[c];
+#pragma unroll
+      for (int c2 = c + 1; c2 < 4; ++c2) s[c2] = fmaf(-l[c], lane_value(l[c], j0 + c2), s[c2]);
+    }
+    float lm[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) lm[c] = lanes_above(l[c], j0 + c, ones);      // strictly lower
+    row[2 * p] = f32x2{lm[0], lm[1]};
+    row[2 * p + 1] = f32x2{lm[2], lm[3]};
+    lds_put<f32x4>(wrow + j0, f32x4{lm[0], lm[1], lm[2], lm[3]});
+    lds_put<f32x4>(dinv + j0, f32x4{inv[0], inv[1], inv[2], inv[3]});   // uniform values, one address
+    wave_lds_sync();                                                     // columns j0 .. j0+3 are in the image
   }
-#undef ROW_EL
+#undef HEL
+#undef CHUNK_READ
   DS_STAMP(3)
   // back substitution L^T delta = y through the columns of the image; y = row N of the factor
-  wave_lds_sync();
   LAUNDER(lane);
   const int li = lane < N ? lane : 0;
   const float myinv = dinv[li];                          // 1 / L[lane][lane]
+  // every pivot positive <=> every reciprocal root finite and positive (a non-positive pivot leaves NaN or inf in all that follow)
+  const bool pos = __all(!(lane < N) || (myinv > 0.f && myinv < 3.0e38f));
   const float *col = Lm + li;
   float dl = col[N * LS] * myinv;                        // running (y_i - sum_{k>i} L[k][i] delta_k) / L[i][i]
 #pragma unroll
@@ -654,7 +711,7 @@ __device__ __forceinline__ bool damped_solve(const f32x2 (&hrow)[N / 2], double 
     *dxnorm = dn;
     *isq = 0.0;
     const bool want = isq_mode == 1 || (isq_mode == 2 && fabs(dn - tr_delta) > 0.1 * tr_delta);
-    if (want && dn > 0.0 && pivmin > 0) {
+    if (want && dn > 0.0 && pos) {
       float wcur = delta * (float)(1.0 / dn);
 #pragma unroll
       for (int j = 0; j < N - 1; ++j) {
@@ -668,7 +725,7 @@ __device__ __forceinline__ bool damped_solve(const f32x2 (&hrow)[N / 2], double 
   }
   DS_STAMP(4)
 #undef DS_STAMP
-  return pivmin > 0;
+  return pos;
 }
 
 // Outcome of one damped step (oracle/fit.py lm_solve): Nielsen's gain-ratio rule for a full step, the parabola
