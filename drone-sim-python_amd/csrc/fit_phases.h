@@ -553,16 +553,21 @@ __device__ __forceinline__ float lane_value(float v, int l) {
 
 // ---- damped normal-equation solve -----------------------------------------------------------
 // hrow = row `lane` of J^T J (pairs of columns); lane N holds the right-hand side b = -g (image_put_rhs).
-// Solves (J^T J + lam*diag(max(J^T J_ii, floor))) delta = b in fp32.  Left-looking Cholesky in PANELS of four columns, lane i
-// owns row i of the factor in registers (row[], strictly lower triangular: zeros on and above the diagonal, the reciprocal
-// diagonal in a side row of the image -- no per-lane selects in the substitutions).  Panel p = columns j0 = 4p .. 4p+3:
-//   * the four dot products s_c = a[lane][j0+c] - sum_{k<j0} L[lane][k] L[j0+c][k] run as eight packed (v_pk_fma_f32) chains
-//     over "chunks" of four k: rows j0 .. j0+3 of the factor come from the LDS image Lm (one address for the whole wave = a
-//     broadcast read; software-pipelined two chunks ahead, and the first two chunks of the NEXT panel -- final since the
-//     panel before -- are requested before this panel's diagonal block so that their latency lands under its dependent chain);
-//   * the 4x4 diagonal block is factorised across lanes j0 .. j0+3 with v_readlane (10 per panel) and v_rsq_f32;
-//   * the four new entries of every row are published with ONE 16-byte store and one wave-level sync per panel
-//     (round 3: one 4-byte store, one sync, two v_readlane and a packed-chain reduction per COLUMN).
+// Solves (J^T J + lam*diag(max(J^T J_ii, floor))) delta = b in fp32 by a Cholesky factorisation in two levels:
+//   * BLOCK COLUMNS of 16 (right-looking, on the matrix cores).  Once the 16 columns c0 .. c0+15 of the factor are in the LDS
+//     image Lm, their contribution L[R][c0..] . L[C][c0..]^T to every later block column is accumulated by
+//     v_mfma_f32_16x16x4_f32 into 16x16 tiles T[I'][J] (rows of block J, columns of block I').  The operand of a tile is ONE
+//     16-byte read per lane of the image -- lane (m, g) takes L[16 J + m][c0 + 4 g .. + 3], the k-index of MFMA q is 4 g + q, the
+//     same fragment serves as A and as B operand -- and the matrix core distributes it; in rounds 1-3 (and in the first version
+//     of this round) every lane formed these dot products itself from rows of the factor that reached it as BROADCAST reads of
+//     the image, 276 x 1 KiB per factorisation, and the launch was bound by exactly that LDS traffic (tools/dev/chol_unit.hip:
+//     7.7 us per solve with them, 3.6 us without).  The rows of the right-hand side ride along as a fourth row block (row N).
+//   * inside a block column, lane i owns row i (prow[], strictly lower triangular: zeros on and above the diagonal, the
+//     reciprocal diagonal in a side row of the image -- no per-lane selects in the substitutions) and the 16 columns are
+//     factorised left-looking in PANELS of four: the finished tiles come back through the image (the block column's own, not
+//     yet written, entries) as the lane's 16 values D[lane][.], the panel-internal dot products run as packed FMA chains on
+//     broadcast reads (24 per block column), the 4x4 diagonal block is factorised across lanes j0 .. j0+3 with v_readlane and
+//     v_rsq_f32, and the four new entries of every row are published with ONE 16-byte store and one wave-level sync per panel.
 // The damping is added to the pivot itself (pivot_j = (a_jj - sum_k L_jk^2) + damp_j, the damp row travels through the image
 // as one broadcast quad per panel), so the rows need no copy with a modified diagonal.  Lane N rides along as row N of the
 // augmented matrix, which makes its entries the forward substitution L y = b; the back substitution reads the columns of Lm.
@@ -572,8 +577,8 @@ __device__ __forceinline__ float lane_value(float v, int l) {
 // FULL: every lane < N is a row of the system (2 nq == N): the rows need no masking.
 // MP (the MINPACK mode, mp_trial below): `unit` (wave-uniform) damps with lam * I instead of lam * diag; dxnorm = ||delta||_2;
 // isq_mode 1 (always) / 2 (only when | ||delta|| - tr_delta | > 0.1 tr_delta): isq = || L^-1 (delta / ||delta||) ||^2 -- the
-// quantity lmpar's Newton correction of the damping needs -- by a forward substitution through the rows of the factor,
-// which every lane still holds in registers (right-looking: z_j = w_j / L_jj, w_i -= L_ij z_j).
+// quantity lmpar's Newton correction of the damping needs -- by a forward substitution through the rows of the factor
+// (right-looking: z_j = w_j / L_jj, w_i -= L_ij z_j; the lane reads its row back from the image).
 #define CHOL_ROWS (N + 4)          // rows of the image: N of the factor, the right-hand side / y, a dummy row, 1 / diagonal, damping
 #define CHOL_IMAGE_BYTES(n) (((n) + 4) * ((n) + 4) * 4)
 
@@ -592,8 +597,8 @@ __device__ __forceinline__ bool damped_solve(const f32x2 (&hrow)[N / 2], double 
                                              float *Lm, float &dgi, float &delta, unsigned long long *tt = nullptr,
                                              bool unit = false, int isq_mode = 0, double tr_delta = 0.0,
                                              double *dxnorm = nullptr, double *isq = nullptr, float hd = 0.f, bool have_hd = false) {
-  constexpr int LS = CHOL_LS, NP = N / 4;
-  // tt (diagnostics, fused kernel with D2D_LM_STAMPS): cycles of setup, panels of columns [0,N/3), [N/3,2N/3), [2N/3,N), substitution
+  constexpr int LS = CHOL_LS, NBK = N / 16;
+  // tt (diagnostics, fused kernel with D2D_LM_STAMPS): cycles of setup, block columns [0,N/3), [N/3,2N/3), [2N/3,N), substitution
   unsigned long long tl = 0;
 #define DS_STAMP(i) if (tt) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tt[i] += t_ - tl; tl = t_; }
   if (tt) tl = __builtin_amdgcn_s_memtime();
@@ -617,82 +622,119 @@ __device__ __forceinline__ bool damped_solve(const f32x2 (&hrow)[N / 2], double 
   float *damp = Lm + (N + 3) * LS;                     // [N] damping of the pivots
   damp[lane < N ? lane : N] = dadd;
   wave_lds_sync();
+  const int m16 = lane & 15, g4 = lane >> 4;           // tile coordinates of this lane (MFMA operand and accumulator layouts)
+  // the tiles of the block columns to come: T[I'][J] = rows of block J (J == NBK: the block of the right-hand side, row N),
+  // columns of block I'; lane (m, g) holds rows 4 g + r, column m
+  f32x4 T[NBK][NBK + 1];
+#pragma unroll
+  for (int ip = 0; ip < NBK; ++ip)
+#pragma unroll
+    for (int j = 0; j <= NBK; ++j) T[ip][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #define HEL(k) (((k) & 1) ? hrow[(k) >> 1].y : hrow[(k) >> 1].x)
-#define CHUNK_READ(PP, T)                                                                                     \
-  {                                                                                                           \
-    _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_)                                                          \
-      ring[(T) % 3][c_] = lds_get<f32x4>(Lm + (4 * (PP) + c_) * LS + 4 * (T));                               \
-  }
-  f32x2 row[N / 2];
-  f32x4 ring[3][4];          // chunk t of the current panel lives in ring[t % 3]
   unsigned long long ones = ~0ull;
   asm volatile("" : "+s"(ones));
   DS_STAMP(0)
 #pragma unroll
-  for (int p = 0; p < NP; ++p) {
-    if (4 * p == N / 3) { DS_STAMP(1) }
-    if (4 * p == 2 * (N / 3)) { DS_STAMP(2) }
-    const int j0 = 4 * p;
-    __builtin_amdgcn_sched_barrier(0);
-    // chunks 0 .. pre-1 were requested during the panel before (entries of columns < j0 - 4: final by then)
-    const int pre = p >= 1 ? (p - 1 < 2 ? p - 1 : 2) : 0;
-    const f32x4 dq = lds_get<f32x4>(damp + j0);
+  for (int I = 0; I < NBK; ++I) {
+    if (NBK == 3 && I == 1) { DS_STAMP(1) }
+    if (NBK == 3 && I == 2) { DS_STAMP(2) }
+    const int c0 = 16 * I;
+    f32x2 prow[8];                     // this lane's entries of the block column (pairs of columns)
+    f32x4 dv[4];                       // D[lane][c0 .. c0+15]: what the block columns before contribute to this lane's dot products
 #pragma unroll
-    for (int t = pre; t < p && t < 2; ++t) CHUNK_READ(p, t)
-    // one packed chain per column (four independent chains in flight)
-    f32x2 acc[4];
+    for (int sp = 0; sp < 4; ++sp) dv[sp] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (I > 0) {
+      // the finished tiles of this block column -> the image (its own entries of rows >= c0, not written yet) -> lane = row
 #pragma unroll
-    for (int c = 0; c < 4; ++c) acc[c] = f32x2{0.f, 0.f};
+      for (int J = I; J < NBK; ++J)
 #pragma unroll
-    for (int t = 0; t < p; ++t) {
-      if (t + 2 < p) CHUNK_READ(p, t + 2)
+        for (int r = 0; r < 4; ++r) Lm[(16 * J + 4 * g4 + r) * LS + c0 + m16] = T[I][J][r];
+      Lm[(g4 == 0 ? N : N + 1) * LS + c0 + m16] = T[I][NBK][0];        // row N of the right-hand side's block (the rest: dummy row)
+      wave_lds_sync();
+      const float *own = Lm + (lane <= N ? lane : N) * LS + c0;
+#pragma unroll
+      for (int sp = 0; sp < 4; ++sp) dv[sp] = lds_get<f32x4>(own + 4 * sp);
+    }
+    f32x4 ring[3][4];                  // chunk kq (columns c0 + 4 kq .. + 3) of rows j0 .. j0+3
+#pragma unroll
+    for (int sp = 0; sp < 4; ++sp) {
+      const int j0 = c0 + 4 * sp;
       __builtin_amdgcn_sched_barrier(0);
+      const f32x4 dq = lds_get<f32x4>(damp + j0);
+      // the newest chunk (published by the panel before); the older ones were requested before that panel's diagonal block
+      if (sp > 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) ring[sp - 1][c] = lds_get<f32x4>(Lm + (j0 + c) * LS + c0 + 4 * (sp - 1));
+      }
+      f32x2 acc[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[c] = f32x2{0.f, 0.f};
+#pragma unroll
+      for (int kq = 0; kq < sp; ++kq) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const f32x4 l = ring[kq][c];
+          acc[c] = __builtin_elementwise_fma(prow[2 * kq], f32x2{l.x, l.y}, acc[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const f32x4 l = ring[kq][c];
+          acc[c] = __builtin_elementwise_fma(prow[2 * kq + 1], f32x2{l.z, l.w}, acc[c]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // the older chunks of the next panel (rows j0+4 .., columns c0 .. j0-1): under the diagonal block's dependent chain
+      if (sp < 3) {
+#pragma unroll
+        for (int kq = 0; kq < sp; ++kq)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) ring[kq][c] = lds_get<f32x4>(Lm + (j0 + 4 + c) * LS + c0 + 4 * kq);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      float s[4];
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        const f32x4 l = ring[t % 3][c];
-        acc[c] = __builtin_elementwise_fma(row[2 * t], f32x2{l.x, l.y}, acc[c]);
+        float a = HEL(j0 + c);
+        if (!FULL) a = live ? a : 0.f;
+        if (I > 0) a -= dv[sp][c];
+        s[c] = sp > 0 ? a - (acc[c].x + acc[c].y) : a;
       }
+      // 4x4 diagonal block across lanes j0 .. j0+3; l[c] = L[lane][j0+c] (valid on the lanes below the pivot)
+      float l[4], inv[4];
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        const f32x4 l = ring[t % 3][c];
-        acc[c] = __builtin_elementwise_fma(row[2 * t + 1], f32x2{l.z, l.w}, acc[c]);
+        const float piv = lane_value(s[c], j0 + c) + dq[c];
+        inv[c] = __builtin_amdgcn_rsqf(piv);
+        l[c] = s[c] * inv[c];
+#pragma unroll
+        for (int c2 = c + 1; c2 < 4; ++c2) s[c2] = fmaf(-l[c], lane_value(l[c], j0 + c2), s[c2]);
       }
-      __builtin_amdgcn_sched_barrier(0);
+      float lm[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) lm[c] = lanes_above(l[c], j0 + c, ones);      // strictly lower
+      prow[2 * sp] = f32x2{lm[0], lm[1]};
+      prow[2 * sp + 1] = f32x2{lm[2], lm[3]};
+      lds_put<f32x4>(wrow + j0, f32x4{lm[0], lm[1], lm[2], lm[3]});
+      lds_put<f32x4>(dinv + j0, f32x4{inv[0], inv[1], inv[2], inv[3]});   // uniform values, one address
+      wave_lds_sync();                                                     // columns j0 .. j0+3 are in the image
     }
-    // the first chunks of the next panel (rows j0+4 .., columns < j0): under the diagonal block's dependent chain
-    if (p + 1 < NP) {
+    // block column I is complete: its contribution to the tiles of the block columns behind it
+    if (I + 1 < NBK) {
+      f32x4 op[NBK + 1];               // op[J]: L[16 J + m][c0 + 4 g .. + 3]; the rows behind N (block NBK) are not used
 #pragma unroll
-      for (int t = 0; t < 2 && t < p; ++t) CHUNK_READ(p + 1, t)
+      for (int J = I + 1; J <= NBK; ++J) {
+        const int rowi = (J < NBK) ? 16 * J + m16 : (N + (m16 & 3));
+        op[J] = lds_get<f32x4>(Lm + rowi * LS + c0 + 4 * g4);
+      }
+#pragma unroll
+      for (int ip = I + 1; ip < NBK; ++ip)
+#pragma unroll
+        for (int J = ip; J <= NBK; ++J)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) T[ip][J] = __builtin_amdgcn_mfma_f32_16x16x4f32(op[J][q], op[ip][q], T[ip][J], 0, 0, 0);
     }
-    __builtin_amdgcn_sched_barrier(0);
-    float s[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      float a = HEL(j0 + c);
-      if (!FULL) a = live ? a : 0.f;
-      s[c] = p > 0 ? a - (acc[c].x + acc[c].y) : a;
-    }
-    // 4x4 diagonal block across lanes j0 .. j0+3; l[c] = L[lane][j0+c] (valid on the lanes below the pivot)
-    float l[4], inv[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const float piv = lane_value(s[c], j0 + c) + dq[c];
-      inv[c] = __builtin_amdgcn_rsqf(piv);
-      l[c] = s[c] * inv[c];
-#pragma unroll
-      for (int c2 = c + 1; c2 < 4; ++c2) s[c2] = fmaf(-l[c], lane_value(l[c], j0 + c2), s[c2]);
-    }
-    float lm[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) lm[c] = lanes_above(l[c], j0 + c, ones);      // strictly lower
-    row[2 * p] = f32x2{lm[0], lm[1]};
-    row[2 * p + 1] = f32x2{lm[2], lm[3]};
-    lds_put<f32x4>(wrow + j0, f32x4{lm[0], lm[1], lm[2], lm[3]});
-    lds_put<f32x4>(dinv + j0, f32x4{inv[0], inv[1], inv[2], inv[3]});   // uniform values, one address
-    wave_lds_sync();                                                     // columns j0 .. j0+3 are in the image
   }
 #undef HEL
-#undef CHUNK_READ
   DS_STAMP(3)
   // back substitution L^T delta = y through the columns of the image; y = row N of the factor
   LAUNDER(lane);
@@ -712,12 +754,14 @@ __device__ __forceinline__ bool damped_solve(const f32x2 (&hrow)[N / 2], double 
     *isq = 0.0;
     const bool want = isq_mode == 1 || (isq_mode == 2 && fabs(dn - tr_delta) > 0.1 * tr_delta);
     if (want && dn > 0.0 && pos) {
+      f32x4 lrow[N / 4];                                 // this lane's row of the factor, zero on and above the diagonal
+#pragma unroll
+      for (int t = 0; t < N / 4; ++t) lrow[t] = lds_get<f32x4>(Lm + li * LS + 4 * t);
       float wcur = delta * (float)(1.0 / dn);
 #pragma unroll
       for (int j = 0; j < N - 1; ++j) {
         const float zj = lane_value(wcur * myinv, j);
-        const float lj = (j & 1) ? row[j >> 1].y : row[j >> 1].x;      // L[lane][j], zero on and above the diagonal
-        wcur = fmaf(-lj, zj, wcur);
+        wcur = fmaf(-lrow[j >> 2][j & 3], zj, wcur);
       }
       const float z = act ? wcur * myinv : 0.f;
       *isq = uniform_d(wave_sum((double)z * (double)z));
