@@ -341,7 +341,7 @@ template <bool WANT_JAC>
 // two contracted position rows like obstacles 2.. do.
 __device__ __forceinline__ double sample_terms(const ScenP &s, const double Y[6], double wpx,
                                                double wpy, double u[6], f32x4 coef[4], bool bank_sel = false,
-                                               float2 *so = nullptr, const double *xin = nullptr) {
+                                               float2 *so = nullptr, const double *xin = nullptr, bool xin_on = true) {
   const double cphi = s.cphimax > 0.0 ? (bank_sel ? s.cphimax : 0.0) : s.cphi;
   const double cphi2 = s.cphimax > 0.0 ? cphi * cphi : s.cphi2;
   const double x = Y[0], y = Y[1];
@@ -371,8 +371,11 @@ __device__ __forceinline__ double sample_terms(const ScenP &s, const double Y[6]
   // obstacles 2.. and the position box (rare): their rows only enter through sums -- cost, D^T r and the 2x2
   // position block
   double xh2 = 0.0, xux = 0.0, xuy = 0.0, xpxx = 0.0, xpxy = 0.0, xpyy = 0.0;
-  if (xin) { xh2 = xin[0]; xux = xin[1]; xuy = xin[2]; xpxx = xin[3]; xpxy = xin[4]; xpyy = xin[5]; }
-  const int xcode = (int)s.ext[PR_NEXT - PR_EXT] | (xin ? FIT_XIN : 0);
+  // (xin_on: a runtime switch beside the pointer -- a caller that SELECTS between an array and nullptr forces the array into
+  // scratch memory and its reads through a dynamic address)
+  const bool have_xin = xin != nullptr && xin_on;
+  if (have_xin) { xh2 = xin[0]; xux = xin[1]; xuy = xin[2]; xpxx = xin[3]; xpxy = xin[4]; xpyy = xin[5]; }
+  const int xcode = (int)s.ext[PR_NEXT - PR_EXT] | (have_xin ? FIT_XIN : 0);
   const int next = xcode & (FIT_XBOX - 1);
   if (xcode & FIT_XBOX) {                             // rows w_b*dist(x, [xmin, xmax]), w_b*dist(y, [ymin, ymax])
     const double *bx = s.ext + (PR_BOX - PR_EXT);

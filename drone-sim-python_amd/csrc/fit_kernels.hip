@@ -1160,6 +1160,7 @@ static SegLds seg_lds_layout(int N, int nq, int S, int wpb) {
   L.qs = w; w = align16(w + N * 8);
   L.sp = w; w = align16(w + FIT_PREP_STRIDE * 8);
   L.zc = w; w = align16(w + 8 * D2D_FIT_MAX_S * 2 * 8);
+  L.park = w; w = align16(w + 5 * 64 * 8);          // per-lane constants of the running fit (fit_lm_long_kernel), [5][64]
   L.big = w;
   L.cf = w;
   L.cfp = L.cf + SEG_ROWS * 4 * 16;
@@ -1274,14 +1275,22 @@ fit_lm_long_kernel(int B, FitGeom g, LongLds L, d2d_fit_opts opts, int iter_budg
     for (int i = lane; i < FIT_PREP_STRIDE; i += 64) sp[i] = prep[(size_t)b * FIT_PREP_STRIDE + i];
     wave_lds_sync();
 
-    // segment formulation: the end-condition part of this lane's Legendre coefficient pair (lane = (segment, degree))
-    double zpx = 0.0, zpy = 0.0;
-    if (SEG && lane < 8 * sa.m.S) {
+    // segment formulation: the end-condition part of this lane's Legendre coefficient pair (lane = (segment, degree)) and chunk 0's
+    // inputs, constant for the whole fit.  They are parked in the wave's LDS block ([5][64], one 8-byte read each where a pass
+    // needs them): held in registers across the solves and the MFMA passes they were ten VGPRs the kernel does not have and
+    // went to scratch memory with a dozen other values.
+    double *park = reinterpret_cast<double *>(wl + sa.L.park);
+    if (SEG) {
+      double zpx = 0.0, zpy = 0.0;
+      if (lane < 8 * sa.m.S) {
 #pragma unroll
-      for (int mm_ = 0; mm_ < 4; ++mm_) {
-        const double zv = sa.Zlp[lane * 4 + mm_];
-        zpx = fma(zv, sp[PR_DX + mm_], zpx); zpy = fma(zv, sp[PR_DY + mm_], zpy);
+        for (int mm_ = 0; mm_ < 4; ++mm_) {
+          const double zv = sa.Zlp[lane * 4 + mm_];
+          zpx = fma(zv, sp[PR_DX + mm_], zpx); zpy = fma(zv, sp[PR_DY + mm_], zpy);
+        }
       }
+      const SegIn i0 = segment_inputs(ls, g.K, sa.sx, pkb, 0);
+      park[lane] = zpx; park[64 + lane] = zpy; park[128 + lane] = i0.x; park[192 + lane] = i0.wpx; park[256 + lane] = i0.wpy;
     }
     double mom_none[16];
 
@@ -1289,7 +1298,7 @@ fit_lm_long_kernel(int B, FitGeom g, LongLds L, d2d_fit_opts opts, int iter_budg
     // of an accepted step -- the same point -- starts from them instead of projecting q through Zl again
     bool zc_trial = false;
     int kbank_t = -1;
-    const SegIn in0 = SEG ? segment_inputs(ls, g.K, sa.sx, pkb, 0) : SegIn{0.0, 0.0, 0.0};   // chunk 0's inputs: loaded once per fit
+    auto parked_inputs = [&]() -> SegIn { int l_ = lane; LAUNDER(l_); return SegIn{park[128 + l_], park[192 + l_], park[256 + l_]}; };   // chunk 0's inputs
     // cost at qi + alpha * delta (cost-only pass over the chunks)
     auto cost_at = [&](double alpha, double delta) -> double {
       if (act) qs[q_slot(lane, nq)] = qi + alpha * delta;
@@ -1297,10 +1306,10 @@ fit_lm_long_kernel(int B, FitGeom g, LongLds L, d2d_fit_opts opts, int iter_budg
       double ca = 0.0;
       if (SEG) {
         SEG_STAMP(7)
-        segment_coefs<NQ>(nq, sa.m.S, Zl64, qs, zpx, zpy, zc, lane);
+        segment_coefs<NQ>(nq, sa.m.S, Zl64, qs, park, zc, lane);
         SEG_STAMP(0)
         const int kbank = segment_bank_argmax(sa.m, ls, sa.sx, sa.c1, zc, load_scenp(sp));
-        SegIn nin = in0;
+        SegIn nin = parked_inputs();
         for (int c = 0; c < sa.m.nchunk; ++c) {
           const SegIn in = nin;
           if (c + 1 < sa.m.nchunk) nin = segment_inputs(ls, g.K, sa.sx, pkb, c + 1);
@@ -1326,7 +1335,7 @@ fit_lm_long_kernel(int B, FitGeom g, LongLds L, d2d_fit_opts opts, int iter_budg
         SEG_STAMP(7)
         int kbank = kbank_t;
         if (!zc_trial) {                                 // (not the point of the last trial: the first evaluation of a fit, a resumed one)
-          segment_coefs<NQ>(nq, sa.m.S, Zl64, qs, zpx, zpy, zc, lane);
+          segment_coefs<NQ>(nq, sa.m.S, Zl64, qs, park, zc, lane);
           kbank = segment_bank_argmax(sa.m, ls, sa.sx, sa.c1, zc, load_scenp(sp));
         }
         zc_trial = false;                                // (segment_gradient below uses zc as scratch)
@@ -1338,7 +1347,7 @@ fit_lm_long_kernel(int B, FitGeom g, LongLds L, d2d_fit_opts opts, int iter_budg
         for (int s = 0; s < D2D_FIT_MAX_S; ++s) bs[s][0] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 16; ++i) mom[i] = 0.0;
-        SegIn nin = in0;
+        SegIn nin = parked_inputs();
         for (int c = 0; c < sa.m.nchunk; ++c) {
           const SegIn in = nin;
           if (c + 1 < sa.m.nchunk) nin = segment_inputs(ls, g.K, sa.sx, pkb, c + 1);
@@ -1401,6 +1410,12 @@ fit_lm_long_kernel(int B, FitGeom g, LongLds L, d2d_fit_opts opts, int iter_budg
         wave_lds_sync();
         nev += (so ? 3 : 2) * ((g.K + 49) / 50);      // contracted rows in units of 100 (FL_NEVAL; one unit = 200 rows)
         SEG_STAMP(6)
+      } else {
+        // (an evaluation ALWAYS defines the row: the old one is then dead on entry and need not survive the passes above in
+        // scratch -- 48 registers the compiler otherwise spills around every evaluation)
+#pragma unroll
+        for (int m = 0; m < N / 2; ++m) hrow[m] = f32x2{0.f, 0.f};
+        hdiag = 0.f;
       }
     };
 
@@ -1531,7 +1546,9 @@ fit_eval_seg_kernel(int B, FitGeom g, SegArgs sa, const double *__restrict__ pk,
         zpx = fma(zv, sp[PR_DX + m], zpx); zpy = fma(zv, sp[PR_DY + m], zpy);
       }
     }
-    segment_coefs<NQ>(nq, sa.m.S, Zl64, qs, zpx, zpy, zc, lane);
+    double *park = reinterpret_cast<double *>(wl + sa.L.park);
+    park[lane] = zpx; park[64 + lane] = zpy;
+    segment_coefs<NQ>(nq, sa.m.S, Zl64, qs, park, zc, lane);
     const int kbank = segment_bank_argmax(sa.m, ls, sa.sx, sa.c1, zc, load_scenp(sp));
     const FitGeom g8{SEG_ROWS, 8, 9};
     f32x4 bs[D2D_FIT_MAX_S][1];

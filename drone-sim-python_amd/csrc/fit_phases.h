@@ -234,18 +234,18 @@ __device__ __forceinline__ double long_phase1(const FitGeom &g, const double *GT
     for (int c = 0; c < FIT_PK; ++c) pk[c] = pkb[(size_t)c * g.K + k];
     if (TL) flat_outputs_pk<NQ>(g, GT, qs, pk, k, Y); else flat_outputs_gt<NQ>(g, GT, qs, pk, k, Y);
     const ScenP s = load_scenp(sp);
-    double xin[6];
+    double xin[6] = {0, 0, 0, 0, 0, 0};
     const bool grp = gc.pos != nullptr;
     if (grp) partner_sums(s, gc, g.K, k, Y[0], Y[1], xin);
     if (!WANT_JAC) {
-      cacc = sample_terms<false>(s, Y, pk[6], pk[7], nullptr, nullptr, k == kbank, nullptr, grp ? xin : nullptr);
+      cacc = sample_terms<false>(s, Y, pk[6], pk[7], nullptr, nullptr, k == kbank, nullptr, xin, grp);
     } else {
       if (so) {
         float2 pos[2];
         cacc = sample_terms<true>(s, Y, pk[6], pk[7], u, coef, k == kbank, pos);
         cfp[lane * 2] = pos[0]; cfp[lane * 2 + 1] = pos[1];
       } else {
-        cacc = sample_terms<true>(s, Y, pk[6], pk[7], u, coef, k == kbank, nullptr, grp ? xin : nullptr);
+        cacc = sample_terms<true>(s, Y, pk[6], pk[7], u, coef, k == kbank, nullptr, xin, grp);
       }
 #pragma unroll
       for (int c = 0; c < 6; ++c) us[lane * 6 + c] = u[c];
@@ -703,11 +703,15 @@ __device__ __forceinline__ bool damped_solve(const f32x2 (&hrow)[N / 2], double 
       float l[4], inv[4];
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
+#ifndef ABL_NODIAG
         const float piv = lane_value(s[c], j0 + c) + dq[c];
         inv[c] = __builtin_amdgcn_rsqf(piv);
         l[c] = s[c] * inv[c];
 #pragma unroll
         for (int c2 = c + 1; c2 < 4; ++c2) s[c2] = fmaf(-l[c], lane_value(l[c], j0 + c2), s[c2]);
+#else
+        inv[c] = dq[c] + 1.f; l[c] = s[c] * inv[c];
+#endif
       }
       float lm[4];
 #pragma unroll
@@ -731,7 +735,11 @@ __device__ __forceinline__ bool damped_solve(const f32x2 (&hrow)[N / 2], double 
 #pragma unroll
         for (int J = ip; J <= NBK; ++J)
 #pragma unroll
+#ifndef ABL_NOMFMA
           for (int q = 0; q < 4; ++q) T[ip][J] = __builtin_amdgcn_mfma_f32_16x16x4f32(op[J][q], op[ip][q], T[ip][J], 0, 0, 0);
+#else
+          for (int q = 0; q < 1; ++q) T[ip][J] += op[J] * op[ip];
+#endif
     }
   }
 #undef HEL
@@ -744,8 +752,10 @@ __device__ __forceinline__ bool damped_solve(const f32x2 (&hrow)[N / 2], double 
   const bool pos = __all(!(lane < N) || (myinv > 0.f && myinv < 3.0e38f));
   const float *col = Lm + li;
   float dl = col[N * LS] * myinv;                        // running (y_i - sum_{k>i} L[k][i] delta_k) / L[i][i]
+#ifndef ABL_NOSUB
 #pragma unroll
   for (int i = N - 1; i >= 1; --i) dl = fmaf(-col[i * LS] * myinv, lane_value(dl, i), dl);   // L[i][lane] = 0 for i <= lane
+#endif
   delta = act ? dl : 0.f;
   if (MP) {
     const double dn2 = uniform_d(wave_sum((double)delta * (double)delta));

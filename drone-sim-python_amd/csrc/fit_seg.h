@@ -29,7 +29,7 @@ struct SegMap {
 };
 
 struct SegLds {   // byte offsets
-  int Wt, Zl64, Zl32, wave0, wave_stride, qs, sp, zc, big, cf, cfp, psi, total;
+  int Wt, Zl64, Zl32, wave0, wave_stride, qs, sp, zc, park, big, cf, cfp, psi, total;
 };
 #define SEG_ROWS 65          // records per chunk: one per lane + one padded row (the MFMA passes fetch one record ahead)
 #define SEG_RED_STRIDE 17    // doubles per lane of the moment reduction scratch (odd: conflict-free column reads)
@@ -53,14 +53,15 @@ __device__ __forceinline__ void legendre_rows(double x, double c1, double P[8], 
 // Legendre coefficients of the trial point: lane = (segment, degree) computes zc[lane] = (x-axis, y-axis) coefficient
 // = the end-condition part zp (constant per fit, this lane's registers) + Zl64[lane] . q.  qs: interleaved LDS copy of q.
 template <int NQ>
-__device__ __forceinline__ void segment_coefs(int nq_rt, int S, const double *Zl64, const double *qs, double zpx, double zpy,
+__device__ __forceinline__ void segment_coefs(int nq_rt, int S, const double *Zl64, const double *qs, const double *park,
                                               double *zc, int lane) {
+  // park: [0][lane] / [1][lane] = the end-condition parts zpx, zpy of this lane's coefficient pair (the wave's LDS block)
   typedef double __attribute__((ext_vector_type(2), may_alias)) f64x2a;
   const int nq = NQ ? NQ : nq_rt;
   LAUNDER(lane);
   if (lane < 8 * S) {
     const double *zr = Zl64 + (size_t)lane * (nq + 1);
-    double ax = zpx, ay = zpy;
+    double ax = park[lane], ay = park[64 + lane];
 #pragma unroll 8
     for (int j = 0; j < nq; ++j) {
       const f64x2a qq = *reinterpret_cast<const f64x2a *>(qs + 2 * j);
@@ -165,18 +166,18 @@ __device__ __forceinline__ double segment_phase1(const LaneSeg &t, int K, const 
     const double wpx = in.wpx, wpy = in.wpy;
     segment_flat(zc, sg, P, dP, ddP, Y);
     const ScenP s = load_scenp(sp);
-    double xin[6];
+    double xin[6] = {0, 0, 0, 0, 0, 0};
     const bool grp = gc.pos != nullptr;
     if (grp) partner_sums(s, gc, K, k, Y[0], Y[1], xin);
     if (!WANT_JAC) {
-      cacc = sample_terms<false>(s, Y, wpx, wpy, nullptr, nullptr, k == kbank, nullptr, grp ? xin : nullptr);
+      cacc = sample_terms<false>(s, Y, wpx, wpy, nullptr, nullptr, k == kbank, nullptr, xin, grp);
     } else {
       if (so) {
         float2 pos[2];
         cacc = sample_terms<true>(s, Y, wpx, wpy, u, coef, k == kbank, pos);
         cfp[lane * 2] = pos[0]; cfp[lane * 2 + 1] = pos[1];
       } else {
-        cacc = sample_terms<true>(s, Y, wpx, wpy, u, coef, k == kbank, nullptr, grp ? xin : nullptr);
+        cacc = sample_terms<true>(s, Y, wpx, wpy, u, coef, k == kbank, nullptr, xin, grp);
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) cf[lane * 4 + q] = coef[q];

@@ -89,10 +89,13 @@ static int run(int n_act, double lam, int unit, unsigned seed) {
 // Throughput of the solve under the fused kernel's occupancy: 256 workgroups x 8 wavefronts, every wave its own image in the LDS
 // (11 kB per wave + a 49.5 kB block that is only allocated), REPS solves in a row.  Prints microseconds per solve and wave.
 template <int N, bool MP, bool FULL>
-__global__ void __launch_bounds__(512) k_bench(const float *H, const float *b, double lam, int reps, float *out) {
+#ifndef BENCH_THREADS
+#define BENCH_THREADS 512
+#endif
+__global__ void __launch_bounds__(BENCH_THREADS) k_bench(const float *H, const float *b, double lam, int reps, float *out) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  float *img = lds + 12672 + wave * (CHOL_IMAGE_BYTES(N) / 4 + 288);
+  float *img = lds + (BENCH_THREADS > 512 ? 2048 : 12672) + wave * (CHOL_IMAGE_BYTES(N) / 4 + 288);
   for (int i = lane; i < N * N; i += 64) img[(i / N) * CHOL_LS + (i % N)] = H[i];
   if (lane < N) img[N * CHOL_LS + lane] = b[lane];
   wave_lds_sync();
@@ -106,8 +109,11 @@ __global__ void __launch_bounds__(512) k_bench(const float *H, const float *b, d
     double dxn = 0.0, isq = 0.0;
     SOLVE(N, MP, FULL, hrow, lam * (1 + r), lane < N, lane, img, dgi, delta, nullptr, true, MP ? 2 : 0, 1e30, &dxn, &isq);
     acc += delta;
+#ifdef USE_ISQ
+    acc += (float)isq;
+#endif
   }
-  out[blockIdx.x * 512 + threadIdx.x] = acc;
+  out[blockIdx.x * BENCH_THREADS + threadIdx.x] = acc;
 }
 
 template <int N, bool MP, bool FULL>
@@ -115,9 +121,9 @@ static void bench(int waves) {
   std::vector<float> Hf(N * N, 0.f), bf(N, 1.f);
   for (int i = 0; i < N; ++i) for (int j = 0; j < N; ++j) Hf[i * N + j] = (i == j ? 2.f : 0.f) + 1.f / (1 + i + j);
   float *dH, *db, *dout;
-  hipMalloc(&dH, N * N * 4); hipMalloc(&db, N * 4); hipMalloc(&dout, 256 * 512 * 4);
+  hipMalloc(&dH, N * N * 4); hipMalloc(&db, N * 4); hipMalloc(&dout, 256 * 1024 * 4);
   hipMemcpy(dH, Hf.data(), N * N * 4, hipMemcpyHostToDevice); hipMemcpy(db, bf.data(), N * 4, hipMemcpyHostToDevice);
-  const int lds = 12672 * 4 + 8 * (CHOL_IMAGE_BYTES(N) + 288 * 4);
+  const int lds = 12672 * 4 + waves * (CHOL_IMAGE_BYTES(N) + 288 * 4) > 160 * 1024 ? 160 * 1024 : 12672 * 4 + waves * (CHOL_IMAGE_BYTES(N) + 288 * 4);
   hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bench<N, MP, FULL>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const int reps = 400;
@@ -141,8 +147,13 @@ int main() {
   bad += run<32, false, false>(32, 1e-2, 0, 6);
   bad += run<16, false, false>(12, 1e-2, 0, 7);
   printf(bad ? "FAILED %d\n" : "all ok\n", bad);
+#if BENCH_THREADS > 512
+  bench<48, true, true>(12);
+  bench<48, true, true>(8);
+#else
   bench<48, true, true>(8);
   bench<48, true, true>(4);
   bench<48, false, true>(8);
+#endif
   return bad;
 }
