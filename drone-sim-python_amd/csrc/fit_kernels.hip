@@ -601,10 +601,10 @@ fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_cap,
     bool so_rows = uniform_i(ld_dev(lmb + 3) != 0.0 ? 1 : 0) != 0;      // mode of the rows in us / cf (and of hrow after the MFMA pass)
     int phase = 1;
     MpState mp;
-    mp.dx_gn = 0.0; mp.t2_gn = 0.0; mp.p_gn = 0.f; mp.gn_valid = 0; mp.gn_ok = 0; mp.first = 0; mp.calm = 0; mp.nfac = 0;
+    mp.dx_gn = 0.0; mp.t2_gn = 0.0; mp.p_gn = 0.f; mp.gn_valid = 0; mp.gn_ok = 0; mp.first = 0; mp.calm = 0; mp.slow = 0; mp.nfac = 0;
     if (MODE == D2D_LM_MODE_MINPACK) {
-      const int pw = uniform_i((int)ld_dev(lmb + 6));                   // phase | first << 1 | calm << 2
-      phase = pw & 1; mp.first = (pw >> 1) & 1; mp.calm = pw >> 2;
+      const int pw = uniform_i((int)ld_dev(lmb + 6));                   // phase | first << 1 | calm << 2 | slow << 16
+      phase = pw & 1; mp.first = (pw >> 1) & 1; mp.calm = (pw >> 2) & 0x3fff; mp.slow = pw >> 16;
     }
     if (phase == 0) { V_mp_par = uniform_d(ld_dev(lmb + 4)); V_mp_delta = uniform_d(ld_dev(lmb + 5)); }
     else { V_lam = uniform_d(ld_dev(lmb + 0)); V_nu = uniform_d(ld_dev(lmb + 1)); }
@@ -793,6 +793,7 @@ fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_cap,
             mp.calm = (V_par == 0.0 && ratio >= 0.75) ? mp.calm + 1 : 0;
             fresh = true;
           }
+          mp.slow = fabs(actred) <= D2D_LM_MP_SLOW_TOL ? mp.slow + 1 : 0;
           ++iters; ++local;
           sub = 0;
           const double xnorm = sqrt(uniform_d(wave_sum(qi * qi)));
@@ -805,8 +806,9 @@ fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_cap,
             else if (V_gnorm <= MP_EPSMCH) info = 8;
           }
           if (info != 0) status = D2D_ST_CONVERGED;
-          if (taken && status == D2D_ST_RUNNING && opts.mp_finish > 0 && mp.calm >= opts.mp_finish) {
-            // the trust region has been inactive for mp_finish steps: second-order finish from here (rows of this point in that mode)
+          if (taken && status == D2D_ST_RUNNING && opts.mp_finish > 0 && (mp.calm >= opts.mp_finish || (opts.mp_slow > 0 && mp.slow >= opts.mp_slow))) {
+            // the trust region has been inactive for mp_finish steps, or lmder has stagnated for mp_slow trials (include/d2d.h):
+            // second-order finish from here (rows of this point in that mode)
             phase = 1; V_lam = D2D_LM_LAMBDA0; V_nu = 2.0; so_rows = true;
             reenter = true;
             break;
@@ -861,7 +863,7 @@ fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_cap,
       if (!yield) cost_io[b] = c;
       st_dev(lmb + 2, gmax); st_dev(lmb + 3, so_rows ? 1.0 : 0.0);
       if (phase == 0) { st_dev(lmb + 4, V_mp_par); st_dev(lmb + 5, V_mp_delta); } else { st_dev(lmb + 0, V_lam); st_dev(lmb + 1, V_nu); }
-      if (MODE == D2D_LM_MODE_MINPACK) { st_dev(lmb + 6, (double)(phase | (mp.first << 1) | (mp.calm << 2))); st_dev(lmb + 7, ld_dev(lmb + 7) + (double)mp.nfac); }
+      if (MODE == D2D_LM_MODE_MINPACK) { st_dev(lmb + 6, (double)(phase | (mp.first << 1) | ((mp.calm & 0x3fff) << 2) | (mp.slow << 16))); st_dev(lmb + 7, ld_dev(lmb + 7) + (double)mp.nfac); }
       st_dev(flags + 4 * b + FL_STATUS, status); st_dev(flags + 4 * b + FL_ITERS, iters); st_dev(flags + 4 * b + FL_NEED, 1);
       st_dev(flags + 4 * b + FL_NEVAL, ld_dev(flags + 4 * b + FL_NEVAL) + nev);
     }
@@ -1257,10 +1259,10 @@ fit_lm_long_kernel(int B, FitGeom g, LongLds L, d2d_fit_opts opts, int iter_budg
     bool so_rows = uniform_i(lm[LM_STRIDE * b + 3] != 0.0 ? 1 : 0) != 0;
     int phase = 1;
     MpState mp;
-    mp.par = 0.0; mp.delta = 0.0; mp.dx_gn = 0.0; mp.t2_gn = 0.0; mp.p_gn = 0.f; mp.gn_valid = 0; mp.gn_ok = 0; mp.first = 0; mp.calm = 0; mp.nfac = 0;
+    mp.par = 0.0; mp.delta = 0.0; mp.dx_gn = 0.0; mp.t2_gn = 0.0; mp.p_gn = 0.f; mp.gn_valid = 0; mp.gn_ok = 0; mp.first = 0; mp.calm = 0; mp.slow = 0; mp.nfac = 0;
     if (MODE == D2D_LM_MODE_MINPACK) {
-      const int pw = uniform_i((int)lm[LM_STRIDE * b + 6]);            // phase | first << 1 | calm << 2
-      phase = pw & 1; mp.first = (pw >> 1) & 1; mp.calm = pw >> 2;
+      const int pw = uniform_i((int)lm[LM_STRIDE * b + 6]);            // phase | first << 1 | calm << 2 | slow << 16
+      phase = pw & 1; mp.first = (pw >> 1) & 1; mp.calm = (pw >> 2) & 0x3fff; mp.slow = pw >> 16;
       mp.par = uniform_d(lm[LM_STRIDE * b + 4]); mp.delta = uniform_d(lm[LM_STRIDE * b + 5]);
       if (phase == 0 && mp.first && mp.delta <= 0.0) {                   // lmder's first radius: factor * ||x||
         const double xn = sqrt(uniform_d(wave_sum(qi * qi)));
@@ -1439,7 +1441,7 @@ fit_lm_long_kernel(int B, FitGeom g, LongLds L, d2d_fit_opts opts, int iter_budg
         ++iters; ++local;
         if (taken) {
           need_eval = true;                                // (also when converged: cost and J^T r at the final point)
-          if (status == D2D_ST_RUNNING && opts.mp_finish > 0 && mp.calm >= opts.mp_finish) { phase = 1; lam = D2D_LM_LAMBDA0; nu = 2.0; so_rows = true; }
+          if (status == D2D_ST_RUNNING && opts.mp_finish > 0 && (mp.calm >= opts.mp_finish || (opts.mp_slow > 0 && mp.slow >= opts.mp_slow))) { phase = 1; lam = D2D_LM_LAMBDA0; nu = 2.0; so_rows = true; }
         }
         continue;
       }
@@ -1490,7 +1492,7 @@ fit_lm_long_kernel(int B, FitGeom g, LongLds L, d2d_fit_opts opts, int iter_budg
       lm[LM_STRIDE * b + 0] = lam; lm[LM_STRIDE * b + 1] = nu; lm[LM_STRIDE * b + 2] = gmax; lm[LM_STRIDE * b + 3] = so_rows ? 1.0 : 0.0;
       if (MODE == D2D_LM_MODE_MINPACK) {
         lm[LM_STRIDE * b + 4] = mp.par; lm[LM_STRIDE * b + 5] = mp.delta;
-        lm[LM_STRIDE * b + 6] = (double)(phase | (mp.first << 1) | (mp.calm << 2)); lm[LM_STRIDE * b + 7] += (double)mp.nfac;
+        lm[LM_STRIDE * b + 6] = (double)(phase | (mp.first << 1) | ((mp.calm & 0x3fff) << 2) | (mp.slow << 16)); lm[LM_STRIDE * b + 7] += (double)mp.nfac;
       }
       flags[4 * b + FL_STATUS] = status; flags[4 * b + FL_ITERS] = iters; flags[4 * b + FL_NEED] = 1;
       flags[4 * b + FL_NEVAL] += nev;
@@ -2331,7 +2333,7 @@ int d2d_fit_profile_read(d2d_fit_plan *pl, double *out) {
 }
 
 static d2d_fit_opts opts_or_default(const d2d_fit_opts *opts) {
-  d2d_fit_opts o = {200, 8, 1e-14, 1e-9, 1e-11, D2D_LM_SO_LAMBDA, D2D_LM_MODE_MINPACK, D2D_LM_MP_FINISH, 1e-15, 1e-15, 1e-15, D2D_LM_SLICE, 0};
+  d2d_fit_opts o = {200, 8, 1e-14, 1e-9, 1e-11, D2D_LM_SO_LAMBDA, D2D_LM_MODE_MINPACK, D2D_LM_MP_FINISH, 1e-15, 1e-15, 1e-15, D2D_LM_SLICE, D2D_LM_MP_SLOW};
   if (opts) o = *opts;
   return o;
 }

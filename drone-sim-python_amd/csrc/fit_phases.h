@@ -844,6 +844,7 @@ struct MpState {
   float p_gn;               // ... and the step itself (this lane's entry)
   int gn_valid, gn_ok;      // the cache holds the step of the current J^T J / it could be factorised
   int first, calm, nfac;    // first trial of the fit (Delta = min(Delta, ||p||)); accepted steps in a row with par = 0 and ratio >= 0.75
+  int slow;                 // trials in a row (accepted or not) that changed the cost by no more than D2D_LM_MP_SLOW_TOL of itself
 };
 #define MP_DWARF 2.2250738585072014e-308
 #define MP_EPSMCH 2.220446049250313e-16
@@ -933,6 +934,7 @@ __device__ __forceinline__ int mp_trial(MpState &s, const d2d_fit_opts &o, doubl
     s.gn_valid = 0;
     s.calm = (par == 0.0 && ratio >= 0.75) ? s.calm + 1 : 0;
   }
+  s.slow = fabs(actred) <= D2D_LM_MP_SLOW_TOL ? s.slow + 1 : 0;
   const double xnorm = sqrt(uniform_d(wave_sum(qi * qi)));
   int info = 0;
   if (fabs(actred) <= o.mp_ftol && prered <= o.mp_ftol && 0.5 * ratio <= 1.0) info = 1;

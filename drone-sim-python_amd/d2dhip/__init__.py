@@ -60,19 +60,20 @@ class FitOpts(C.Structure):
     _fields_ = [('max_iter', C.c_int32), ('check_every', C.c_int32), ('ftol', C.c_double),
                 ('gtol', C.c_double), ('xtol', C.c_double), ('so_lambda', C.c_double),
                 ('mode', C.c_int32), ('mp_finish', C.c_int32), ('mp_ftol', C.c_double), ('mp_xtol', C.c_double),
-                ('mp_gtol', C.c_double), ('slice', C.c_int32), ('reserved', C.c_int32)]
+                ('mp_gtol', C.c_double), ('slice', C.c_int32), ('mp_slow', C.c_int32)]
 
 
 SO_LAMBDA = 1e-4          # D2D_LM_SO_LAMBDA: damping below which the evaluations carry the second-order term (FAST mode)
 MODE_MINPACK, MODE_FAST = 0, 1     # D2D_LM_MODE_*: MINPACK's lmder path (what scipy least_squares('lm') follows) / rounds 1-2's loop
 MP_FINISH = 3             # D2D_LM_MP_FINISH: calm lmder steps before the second-order finish (0 = pure lmder)
+MP_SLOW = 8               # D2D_LM_MP_SLOW: stagnating lmder trials (cost change <= 1e-4 of itself) in a row before the finish (0 = never)
 SLICE = 0                 # D2D_LM_SLICE: iterations a fit runs before it yields its wavefront to waiting fits (0 = never)
 
 
 def fit_opts(max_iter=200, check_every=8, ftol=1e-14, gtol=1e-9, xtol=1e-11, so_lambda=SO_LAMBDA, mode=MODE_MINPACK,
-             mp_finish=MP_FINISH, mp_tol=1e-15, slice=SLICE):
+             mp_finish=MP_FINISH, mp_tol=1e-15, slice=SLICE, mp_slow=MP_SLOW):
     """d2d_fit_opts with the library's defaults (include/d2d.h)."""
-    return FitOpts(max_iter, check_every, ftol, gtol, xtol, so_lambda, mode, mp_finish, mp_tol, mp_tol, mp_tol, slice, 0)
+    return FitOpts(max_iter, check_every, ftol, gtol, xtol, so_lambda, mode, mp_finish, mp_tol, mp_tol, mp_tol, slice, mp_slow)
 
 
 _P = C.c_void_p

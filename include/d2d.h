@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define D2D_VERSION 106
+#define D2D_VERSION 107
 
 /* error codes */
 #define D2D_OK 0
@@ -297,12 +297,18 @@ enum { D2D_ST_RUNNING = 0, D2D_ST_CONVERGED = 1, D2D_ST_MAXITER = 2, D2D_ST_NONF
  *      factor of J^T J + par I instead of the QR factors of J.  Once the trust region has been inactive for mp_finish accepted
  *      steps in a row (par = 0 and ratio >= 0.75: the basin is decided and Gauss-Newton crawls at its linear rate) the fit is
  *      handed to the second-order loop below, started at lambda0, for the quadratic finish; mp_finish = 0 never hands over
- *      (pure lmder, stopping on mp_ftol / mp_xtol / mp_gtol exactly as MINPACK does).
+ *      (pure lmder, stopping on mp_ftol / mp_xtol / mp_gtol exactly as MINPACK does).  The same hand-over happens when lmder has
+ *      STAGNATED: mp_slow trials in a row, accepted or not, each changed the cost by no more than D2D_LM_MP_SLOW_TOL of itself
+ *      without meeting lmder's own stopping tests -- the zig-zag of Gauss-Newton on a large-residual fit (the full step
+ *      overshoots, the radius shrinks, a damped step gains 1e-7 ...), which scipy follows for hundreds of evaluations (736 on one
+ *      121-node bench scenario) and which is never "calm"; the exact Hessian ends it in a handful of iterations at the same minimum.
  *  D2D_LM_MODE_FAST  Nielsen's gain-ratio damping on (H + lam diag|H|) with shortened steps along a rejected direction and
  *      the second-order term once lam <= so_lambda (rounds 1-2): fewer factorisations per fit, but it reaches another local
  *      minimum than scipy on ~13 % of the synthetic bench scenarios. */
 enum { D2D_LM_MODE_MINPACK = 0, D2D_LM_MODE_FAST = 1 };
 #define D2D_LM_MP_FINISH 3       /* default of d2d_fit_opts.mp_finish */
+#define D2D_LM_MP_SLOW 8         /* default of d2d_fit_opts.mp_slow */
+#define D2D_LM_MP_SLOW_TOL 1e-4  /* a trial is "slow" when it changes the cost by no more than this fraction (|actred| of lmder) */
 #define D2D_LM_SLICE 0           /* default of d2d_fit_opts.slice */
 typedef struct {
   int32_t max_iter;     /* trial points (damped solves in FAST mode) per trajectory (default 200)      */
@@ -323,7 +329,8 @@ typedef struct {
                            they were handed out in.  Results are bit-identical.  Measured: equal shares end
                            a 4096-fit launch at (longest fit) + (the excess of the first rounds) -- 1.5 % sooner than running
                            every fit to its end in index order, 4 % later at 32 768 fits -- so the default is 0 = off     */
-  int32_t reserved;
+  int32_t mp_slow;      /* MINPACK mode: stagnating trials in a row before the second-order finish (default D2D_LM_MP_SLOW; 0 = never;
+                           only with mp_finish > 0).  (Was `reserved`, always 0, up to version 106.)                          */
 } d2d_fit_opts;
 
 /* Build the shared basis block on the host (fp64) and upload it.  wref[3] = weights of the

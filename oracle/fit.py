@@ -730,6 +730,7 @@ MP_FACTOR = 100.0
 MP_P1, MP_P5, MP_P25, MP_P75, MP_P0001 = 0.1, 0.5, 0.25, 0.75, 1e-4
 MP_DWARF = 2.2250738585072014e-308
 MP_EPS = 2.220446049250313e-16
+MP_SLOW_TOL = 1e-4     # include/d2d.h D2D_LM_MP_SLOW_TOL
 
 
 def _chol_solve(A, b, dtype):
@@ -795,11 +796,15 @@ def lmpar_normal(H, g, delta, par, chol_dtype=np.float64):
 
 
 def lmder_solve(basis, sc, q0=None, ftol=1e-15, xtol=1e-15, gtol=1e-15, max_nfev=None, hess_dtype=np.float64,
-                chol_dtype=np.float64, finish=None, trace=None):
+                chol_dtype=np.float64, finish=None, trace=None, slow=None):
     """MINPACK's lmder (the solver behind scipy least_squares(method='lm')) on the normal equations, unit scaling (mode 2).
     f = the residual vector (cost c = ||f||^2), J its Jacobian.  One "iteration" here = one trial point (one nfev).
     finish = (n_ok, ...) see lm_finish_rule: hand over to the second-order loop once the trust region has been inactive
-    (par = 0, ratio >= 0.75) for n_ok consecutive steps -- None: pure lmder.
+    (par = 0, ratio >= 0.75) for n_ok consecutive steps -- None: pure lmder.  slow (only with finish): hand over as well once
+    `slow` trials in a row, accepted or not, each changed the cost by no more than MP_SLOW_TOL of itself (lmder stagnates in the
+    zig-zag of Gauss-Newton on a large-residual fit: the full step overshoots, the radius shrinks, a damped step gains 1e-7, ...;
+    scipy follows it for hundreds of evaluations and it is never calm) -- the hand-over is taken after an accepted step, like
+    the calm one.
     Returns q, cost, nfev, status (ST_*), info dict."""
     wp = waypoints(sc, basis.K, basis.duration)
     x = initial_guess(basis, sc, wp) if q0 is None else np.array(q0, float)
@@ -818,6 +823,7 @@ def lmder_solve(basis, sc, q0=None, ftol=1e-15, xtol=1e-15, gtol=1e-15, max_nfev
     first = True
     info = 0
     calm = 0
+    nslow = 0
     while True:
         acn = np.sqrt(np.maximum(np.diag(H), 0.0))
         gnorm = 0.0
@@ -880,11 +886,12 @@ def lmder_solve(basis, sc, q0=None, ftol=1e-15, xtol=1e-15, gtol=1e-15, max_nfev
                     info = 8
             if accepted:
                 calm = calm + 1 if (par == 0.0 and ratio >= MP_P75) else 0
+            nslow = nslow + 1 if abs(actred) <= MP_SLOW_TOL else 0
             if info != 0 or accepted:
                 break
         if info != 0:
             break
-        if finish is not None and calm >= finish:
+        if finish is not None and (calm >= finish or (slow and nslow >= slow)):
             break
         c, g, H = eval_normal(basis, sc, x, wp)
         H = H.astype(hess_dtype).astype(np.float64)
@@ -893,16 +900,18 @@ def lmder_solve(basis, sc, q0=None, ftol=1e-15, xtol=1e-15, gtol=1e-15, max_nfev
 
 
 MP_FINISH = 3          # include/d2d.h D2D_LM_MP_FINISH
+MP_SLOW = 8            # include/d2d.h D2D_LM_MP_SLOW
 
 
 def solve_minpack(basis, sc, q0=None, finish=MP_FINISH, max_iter=200, mp_tol=1e-15, ftol=1e-14, gtol=1e-9, xtol=1e-11,
-                  hess_dtype=np.float64, chol_dtype=np.float64):
+                  hess_dtype=np.float64, chol_dtype=np.float64, slow=MP_SLOW):
     """The default solver of the HIP path (d2d_fit_opts.mode = D2D_LM_MODE_MINPACK): lmder until the trust region has been
-    inactive for `finish` accepted steps in a row, then the second-order loop of lm_solve (every evaluation with the exact
+    inactive for `finish` accepted steps in a row (or has stagnated for `slow` trials in a row, lmder_solve), then the second-order loop of lm_solve (every evaluation with the exact
     Hessian, damping restarted at LM_LAMBDA0) to the end; finish = 0: lmder alone.  max_iter bounds the trial points of both
     phases together.  Returns q, cost, iterations (trial points), status, info (factorisations of the lmder phase, its trials)."""
     q, c, nfev, st, info = lmder_solve(basis, sc, q0, ftol=mp_tol, xtol=mp_tol, gtol=mp_tol, max_nfev=max_iter + 1,
-                                       hess_dtype=hess_dtype, chol_dtype=chol_dtype, finish=finish if finish > 0 else None)
+                                       hess_dtype=hess_dtype, chol_dtype=chol_dtype, finish=finish if finish > 0 else None,
+                                       slow=slow if finish > 0 else None)
     it = nfev - 1
     out = {'nfac': info['nfac'], 'mp_trials': it, 'handover': info['handover']}
     if info['handover'] and it < max_iter:

@@ -36,7 +36,7 @@ def test_struct_layouts_match_header():
     import d2dhip
     assert ctypes.sizeof(d2dhip.GvfParams) == 4 * 4 + 9 * 8 + 2 * 4 + 3 * 8
     assert ctypes.sizeof(d2dhip.TrackParams) == 2 * 4 + 5 * 8 + 5 * 8 + 3 * 8 + 7 * 8
-    assert ctypes.sizeof(d2dhip.FitOpts) == 2 * 4 + 4 * 8 + 2 * 4 + 3 * 8 + 2 * 4     # + mode, mp_finish, mp_ftol/xtol/gtol, slice, reserved
+    assert ctypes.sizeof(d2dhip.FitOpts) == 2 * 4 + 4 * 8 + 2 * 4 + 3 * 8 + 2 * 4     # + mode, mp_finish, mp_ftol/xtol/gtol, slice, mp_slow
     assert d2dhip.SCEN_STRIDE == 80 and d2dhip.MAX_OBS == 16
 
 
