@@ -102,14 +102,34 @@ int d2d_comm_destroy(d2d_comm *comm) {
   return D2D_OK;
 }
 
+int d2d_comm_info(const d2d_comm *comm, int32_t *rank, int32_t *world) {
+  D2D_REQUIRE(comm != nullptr, "d2d_comm_info: comm is NULL");
+  if (rank) *rank = comm->rank;
+  if (world) *world = comm->world;
+  return D2D_OK;
+}
+
 int d2d_allreduce_stats(d2d_ctx *ctx, d2d_comm *comm, double *stats) {
   D2D_REQUIRE(ctx && comm && stats, "d2d_allreduce_stats: null argument");
-  // one grouped exchange: sum of the costs and of the running counts, max of the gradient norms
+  // (a host pointer would fail asynchronously inside the collective: refuse it here)
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, stats) != hipSuccess || attr.type != hipMemoryTypeDevice) {
+    (void)hipGetLastError();
+    d2d_set_error("d2d_allreduce_stats: stats must point to device memory (three doubles)");
+    return D2D_EINVAL;
+  }
+  // one grouped exchange: sum of the costs and of the running counts, max of the gradient norms.  A failure between
+  // group_start and group_end still closes the group: left open, it would swallow every later collective of this thread.
   D2D_CHECK_NCCL(g_rccl.group_start());
-  D2D_CHECK_NCCL(g_rccl.all_reduce(stats, stats, 1, 8 /* ncclFloat64 */, 0 /* ncclSum */, comm->comm, ctx->stream));
-  D2D_CHECK_NCCL(g_rccl.all_reduce(stats + 1, stats + 1, 1, 8, 2 /* ncclMax */, comm->comm, ctx->stream));
-  D2D_CHECK_NCCL(g_rccl.all_reduce(stats + 2, stats + 2, 1, 8, 0, comm->comm, ctx->stream));
-  D2D_CHECK_NCCL(g_rccl.group_end());
+  int e = g_rccl.all_reduce(stats, stats, 1, 8 /* ncclFloat64 */, 0 /* ncclSum */, comm->comm, ctx->stream);
+  if (e == 0) e = g_rccl.all_reduce(stats + 1, stats + 1, 1, 8, 2 /* ncclMax */, comm->comm, ctx->stream);
+  if (e == 0) e = g_rccl.all_reduce(stats + 2, stats + 2, 1, 8, 0, comm->comm, ctx->stream);
+  const int e_end = g_rccl.group_end();
+  if (e == 0) e = e_end;
+  if (e != 0) {
+    d2d_set_error("d2d_allreduce_stats: ncclAllReduce failed: %s", g_rccl.err ? g_rccl.err(e) : "RCCL error");
+    return D2D_EHIP;
+  }
   return D2D_OK;
 }
 

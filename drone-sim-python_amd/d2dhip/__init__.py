@@ -86,6 +86,7 @@ _SIGS = {
     'd2d_comm_unique_id': (C.c_int, [_P]),
     'd2d_comm_create': (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(_P)]),
     'd2d_comm_destroy': (C.c_int, [_P]),
+    'd2d_comm_info': (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     'd2d_allreduce_stats': (C.c_int, [_P, _P, _P]),
     'd2d_step': (C.c_int, [_P, C.c_int, _P, _P, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _P]),
     'd2d_sim_gvf_run': (C.c_int, [_P, C.POINTER(GvfParams)] + [_P] * 13),
@@ -117,6 +118,7 @@ _SIGS = {
     'd2d_fit_finish': (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P, _P, _P]),
     'd2d_fit_plan_set_order': (C.c_int, [_P, _P, C.c_int, _P]),
     'd2d_fit_plan_set_group_order': (C.c_int, [_P, _P, C.c_int, C.c_int]),
+    'd2d_fit_group_report': (C.c_int, [_P, _P, C.c_int, _P, _P]),
     'd2d_fit_plan_set_groups': (C.c_int, [_P, C.c_int]),
     'd2d_fit_solve_groups': (C.c_int, [_P, _P, C.c_int, _P, _P, C.POINTER(FitOpts), C.c_int, C.c_int, C.c_double, _P,
                                        C.POINTER(C.c_int32), _P]),
@@ -166,6 +168,34 @@ def _hptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+class Comm:
+    """d2d_comm: the RCCL communicator of the sharded solve's convergence exchange (d2d_allreduce_stats)."""
+
+    def __init__(self, ctx, uid, rank, world):
+        assert len(uid) == 128
+        self.ctx = ctx
+        h = _P()
+        _check(ctx.lib.d2d_comm_create(ctx.h, C.c_char_p(uid), int(rank), int(world), C.byref(h)))
+        self.h = h
+
+    def info(self):
+        r, w = C.c_int32(-1), C.c_int32(-1)
+        _check(self.ctx.lib.d2d_comm_info(self.h, C.byref(r), C.byref(w)))
+        return r.value, w.value
+
+    def allreduce_stats(self, stats_dev):
+        """stats_dev: device tensor of three doubles, in place: [0] sum, [1] max, [2] sum over the ranks; enqueued on the context's stream."""
+        assert stats_dev.is_cuda and stats_dev.dtype == _torch().float64 and stats_dev.numel() == 3 and stats_dev.is_contiguous()
+        _check(self.ctx.lib.d2d_allreduce_stats(self.ctx.h, self.h, _ptr(stats_dev)))
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.ctx.lib.d2d_comm_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+
 class Context:
     """d2d_ctx bound to the current torch stream of `device`."""
 
@@ -188,6 +218,17 @@ class Context:
 
     def sync(self):
         _check(self.lib.d2d_ctx_sync(self.h))
+
+    # -- multi-GPU convergence exchange through the C-ABI (RCCL, include/d2d.h d2d_comm_*) ------------
+    def comm_unique_id(self):
+        """128 opaque bytes (ncclGetUniqueId): rank 0 creates them, the host hands them to the other ranks."""
+        buf = C.create_string_buffer(128)
+        _check(self.lib.d2d_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_create(self, uid, rank, world):
+        """d2d_comm of this context's device (ncclCommInitRank): every rank, same uid."""
+        return Comm(self, uid, rank, world)
 
     # -- buffers --------------------------------------------------------------------
     def dev(self, a, dtype=None):
@@ -511,6 +552,12 @@ class FitPlan:
         """Scheduling hint for solve_groups over R scenarios: start the scenarios that swept longest in the LAST solve_groups
         of this plan first (enable=False clears it)."""
         _check(self.ctx.lib.d2d_fit_plan_set_group_order(self.ctx.h, self.h, R, 1 if enable else 0))
+
+    def group_report(self, R):
+        """(sweeps int32 [R], last-sweep largest relative move float64 [R]) of the last solve_groups over R scenarios."""
+        sw = np.zeros(R, np.int32); mv = np.zeros(R)
+        _check(self.ctx.lib.d2d_fit_group_report(self.ctx.h, self.h, R, _hptr(sw), _hptr(mv)))
+        return sw, mv
 
     def set_groups(self, n_ac):
         _check(self.ctx.lib.d2d_fit_plan_set_groups(self.h, n_ac))

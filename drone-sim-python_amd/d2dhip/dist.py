@@ -16,10 +16,21 @@ def shard_bounds(total, rank, world):
 class StatsReducer:
     """The convergence exchange.  `device` is where the backend wants its buffers (cuda:<local_rank> for nccl / RCCL, cpu for
     gloo).  Everything is allocated once: a pinned host staging tensor, the device send buffer and the gathered [world, 3]
-    tensor; a call is one host write, one collective, one read-back -- no tensors are built per call."""
+    tensor; a call is one host write, one collective, one read-back -- no tensors are built per call.
 
-    def __init__(self, dist=None, device='cpu'):
+    ctx (a d2dhip.Context) with the `nccl` backend: the collective that runs is the library's own C-ABI entry point,
+    d2d_allreduce_stats on a d2d_comm (include/d2d.h: ONE grouped RCCL exchange of sum / max / sum on the context's stream) --
+    rank 0 creates the 128-byte id (d2d_comm_unique_id) and torch.distributed only carries it to the other ranks.  If the
+    communicator cannot be created (e.g. librccl cannot be loaded) the exchange stays on torch.distributed and `self.collective`
+    says why.  `self.rccl_ranks` = the rank count the d2d_comm reports."""
+
+    def __init__(self, dist=None, device='cpu', ctx=None):
         self.dist = dist
+        self.comm = None
+        self.rccl_ranks = None
+        self.collective = 'none (one rank)' if dist is None else f'torch.distributed ({dist.get_backend()})'
+        if dist is not None and ctx is not None and dist.get_backend() == 'nccl':
+            self._make_comm(dist, ctx)
         if dist is not None:
             import torch
             self.torch = torch
@@ -32,11 +43,37 @@ class StatsReducer:
             self.run_host = torch.zeros(1, dtype=torch.float64, pin_memory=on_gpu)
             self.run_dev = torch.zeros(1, dtype=torch.float64, device=device)
 
+    def _make_comm(self, dist, ctx):
+        import torch
+        try:
+            rank, world = dist.get_rank(), dist.get_world_size()
+            uid = torch.zeros(128, dtype=torch.uint8, device=ctx.device)
+            if rank == 0:
+                uid.copy_(torch.frombuffer(bytearray(ctx.comm_unique_id()), dtype=torch.uint8))
+            dist.broadcast(uid, src=0)
+            self.comm = ctx.comm_create(bytes(uid.cpu().numpy().tobytes()), rank, world)
+            self.rccl_ranks = self.comm.info()[1]
+            self.collective = 'd2d_allreduce_stats (RCCL through the C-ABI, d2d_comm of %d ranks)' % self.rccl_ranks
+        except Exception as e:       # noqa: BLE001  (fall back to torch.distributed, say so)
+            self.comm = None
+            self.collective = f'torch.distributed ({dist.get_backend()}); d2d_comm not created: {e!r}'[:300]
+
+    def _abi(self, a, b, c):
+        """one d2d_allreduce_stats: (sum a, max b, sum c) over the ranks"""
+        self.host[0] = float(a); self.host[1] = float(b); self.host[2] = float(c)
+        self.send.copy_(self.host, non_blocking=True)
+        self.comm.allreduce_stats(self.send)
+        self.host.copy_(self.send)                 # (synchronises: the host needs the numbers)
+        return float(self.host[0]), float(self.host[1]), float(self.host[2])
+
     def __call__(self, cost_sum, gmax, running):
-        """(sum of costs, max |J^T r|, trajectories not converged) over all ranks: ONE collective (an all-gather of the three
-        scalars; sum and max are then taken locally)."""
+        """(sum of costs, max |J^T r|, trajectories not converged) over all ranks: ONE collective (d2d_allreduce_stats; over
+        torch.distributed an all-gather of the three scalars, sum and max then taken locally)."""
         if self.dist is None:
             return float(cost_sum), float(gmax), int(running)
+        if self.comm is not None:
+            s0, s1, s2 = self._abi(cost_sum, gmax, running)
+            return s0, s1, int(round(s2))
         self.host[0] = float(cost_sum); self.host[1] = float(gmax); self.host[2] = float(running)
         self.send.copy_(self.host, non_blocking=True)
         self.dist.all_gather(self.all_rows, self.send)
@@ -48,6 +85,8 @@ class StatsReducer:
         """The per-check exchange inside the iteration loop: one all-reduce of one scalar."""
         if self.dist is None:
             return int(running)
+        if self.comm is not None:
+            return int(round(self._abi(0.0, 0.0, running)[2]))
         self.run_host[0] = float(running)
         self.run_dev.copy_(self.run_host, non_blocking=True)
         self.dist.all_reduce(self.run_dev, op=self.dist.ReduceOp.SUM)

@@ -63,7 +63,8 @@ typedef struct d2d_comm d2d_comm;
 int d2d_comm_unique_id(void *id_out);
 int d2d_comm_create(d2d_ctx *ctx, const void *id, int rank, int world, d2d_comm **out);
 int d2d_comm_destroy(d2d_comm *comm);
-int d2d_allreduce_stats(d2d_ctx *ctx, d2d_comm *comm, double *stats);
+int d2d_comm_info(const d2d_comm *comm, int32_t *rank, int32_t *world);   /* what the communicator was created with (either may be NULL) */
+int d2d_allreduce_stats(d2d_ctx *ctx, d2d_comm *comm, double *stats);     /* D2D_EINVAL if stats is not device memory */
 
 /* ------------------------------------------------------------------------------------
  * Plant and guidance (fp64).  State components: x, y, psi, phi, v; inputs: phi_c, v_c.
@@ -423,6 +424,10 @@ int d2d_fit_plan_set_groups(d2d_fit_plan *plan, int n_ac);
 int d2d_fit_solve_groups(d2d_ctx *ctx, d2d_fit_plan *plan, int R, const double *scen, double *q,
                          const d2d_fit_opts *opts, int max_sweeps, int inner_iters, double tol,
                          double *cost, int32_t *sweeps_done, double *stats);
+/* Per-scenario report of the last d2d_fit_solve_groups of this plan (persistent-kernel path): sweeps HOST int32 [R] = sweeps each
+ * scenario used, moved HOST double [R] = its largest relative move in the last of them (<= tol: settled); either may be NULL.
+ * D2D_ESTATE if the plan holds no such solve over R scenarios.  Synchronous. */
+int d2d_fit_group_report(d2d_ctx *ctx, d2d_fit_plan *plan, int R, int32_t *sweeps, double *moved);
 
 /* Per-launch timing of the LM loop with HIP events on the context's stream: enable = 1
  * starts a fresh recording, 0 stops (d2d_fit_eval's kernel launch is recorded too, as a fit_eval launch).
