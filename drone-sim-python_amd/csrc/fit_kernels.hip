@@ -533,15 +533,24 @@ fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_cap,
       }
       if (t < 0) {
         // (fetch-adds only: a compare-and-swap on the head under 2048 waves that reach their slice boundary together is quadratic)
-        const int a = atomicAdd(queue + 4, -1);
-        if (a <= 0) atomicAdd(queue + 4, 1);                 // nothing there (or a concurrent taker's undo made it look so: harmless)
-        else {
-          const int h = atomicAdd(queue + 2, 1);              // an entry is ours: completed pushes >= successful takes
-          int32_t *slot = ring + (h & ring_mask);
-          int v;
-          while ((v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < 0) __builtin_amdgcn_s_sleep(1);
-          __hip_atomic_store(slot, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          t = v | 0x40000000;                                 // (bit 30: resumed from the ring)
+        // A failed taker's transient -1 on the count can hide an entry from a taker that comes between its two adds, so a wave only
+        // gives up when the ring is EMPTY by the tickets: no push begun (queue[3]) that a take has not begun for (queue[2]).
+        for (;;) {
+          const int a = atomicAdd(queue + 4, -1);
+          if (a > 0) {
+            const int h = atomicAdd(queue + 2, 1);              // an entry is ours: completed pushes >= successful takes
+            int32_t *slot = ring + (h & ring_mask);
+            int v;
+            while ((v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < 0) __builtin_amdgcn_s_sleep(1);
+            __hip_atomic_store(slot, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            t = v | 0x40000000;                                 // (bit 30: resumed from the ring)
+            break;
+          }
+          atomicAdd(queue + 4, 1);
+          const int pend = __hip_atomic_load(queue + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
+                           __hip_atomic_load(queue + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (pend <= 0) break;
+          __builtin_amdgcn_s_sleep(2);
         }
       }
     }
@@ -557,8 +566,10 @@ fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_cap,
   };
   if (STAMPS) st_last = __builtin_amdgcn_s_memtime();
   bool first_take = true;
+  int reserved = -1;                              // the fit a yielding wave secured BEFORE it gave its own to the ring
   for (;;) {
-    int b = take(first_take);
+    int b = reserved >= 0 ? reserved : take(first_take);
+    reserved = -1;
     first_take = false;
     if (b < 0) break;
     const bool resumed = (b & 0x40000000) != 0;
@@ -669,7 +680,12 @@ fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_cap,
             LM_STAMP(4)
           }
           if (iters >= iter_cap || iters >= opts.max_iter) break;
-          if (opts.slice > 0 && queue != nullptr && local >= opts.slice && ((local - opts.slice) & 3) == 0 && others_waiting()) { yield = true; break; }
+          if (opts.slice > 0 && queue != nullptr && local >= opts.slice && ((local - opts.slice) & 3) == 0 && others_waiting()) {
+            // reserve before giving: the wave pushes its own fit only once it HOLDS the next one (a position of the queue or an
+            // entry of the ring); if the waiting work went to others meanwhile it simply goes on with its fit
+            reserved = take(false);
+            if (reserved >= 0) { yield = true; break; }
+          }
           if (iters >= prio_at) __builtin_amdgcn_s_setprio(2);
           LM_STAMP(6)
           if (MODE == D2D_LM_MODE_MINPACK && phase == 0) {
@@ -2021,6 +2037,10 @@ static int launch_lm(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, double *q, con
   static const int slice_env = getenv("D2D_LM_SLICE") ? atoi(getenv("D2D_LM_SLICE")) : -1;         // (A/B switch: overrides opts.slice)
   d2d_fit_opts oo = o;
   if (slice_env >= 0) oo.slice = slice_env;
+  if (oo.slice > 0) {                    // time-sliced hand-out: every launch starts from an empty ring and zeroed tickets
+    D2D_CHECK_HIP(hipMemsetAsync(pl->d_ring, 0xff, (size_t)pl->ring_cap * sizeof(int32_t), ctx->stream));
+    D2D_CHECK_HIP(hipMemsetAsync(queue + 2, 0, 3 * sizeof(int32_t), ctx->stream));
+  }
   const int32_t *order = (pl->order_B == B) ? pl->d_order : nullptr;
 #define LAUNCH_LM(STAMPSV, MODEV)                                                                                                  \
   hipLaunchKernelGGL((fit_lm_kernel<3, 24, STAMPSV, MODEV>), dim3(blocks), dim3(64 * pl->wpb_lm), L.total, ctx->stream, B, gm, L, oo, iter_cap, \
@@ -2472,9 +2492,9 @@ int d2d_fit_iterate(d2d_ctx *ctx, d2d_fit_plan *pl, int B, const double *scen, d
     if (int rc = prof_end(ctx, pl)) return rc;
   }
   if (n_running) {
-    if (pl->it_done >= o.max_iter) {
+    if (pl->it_done >= o.max_iter && o.slice <= 0) {
       *n_running = 0;                    // the iteration budget is spent: nothing to count (d2d_fit_finish synchronises)
-    } else {
+    } else {                             // (with the time-sliced hand-out the flags are counted even then: a fit left in the ring would show)
       D2D_CHECK_HIP(hipMemsetAsync(ctx->counter_dev, 0, sizeof(int32_t), ctx->stream));
       hipLaunchKernelGGL(fit_count_kernel, g1, b1, 0, ctx->stream, B, pl->d_flags, ctx->counter_dev);
       D2D_LAUNCH_CHECK();

@@ -395,7 +395,7 @@ class Context:
         cost, feas = self.empty(B), self.empty(B)
         iters = torch.empty(B, dtype=torch.int32, device=self.device); status = torch.empty(B, dtype=torch.int32, device=self.device)
         mult = self.zeros(B, 3, N) if want_mult else None
-        assert bounds is None or (bounds.is_contiguous() and tuple(bounds.shape) == (B, 4))
+        assert bounds is None or (bounds.is_contiguous() and tuple(bounds.shape) == (B, 4) and bounds.dtype == _torch().float64)
         o = NlpOpts(rho0, mub0, mub_min, feas_tol, opt_tol, inner_max, outer_max, serial, 0, None if bounds is None else bounds.data_ptr())
         _check(self.lib.d2d_nlp_solve(self.h, B, N, float(h), _ptr(scen), C.byref(o), _ptr(W), _ptr(partner), _ptr(work), _ptr(mult),
                                       _ptr(cost), _ptr(feas), _ptr(iters), _ptr(status)))
@@ -417,7 +417,7 @@ class Context:
         cost, feas, moved = self.empty(B), self.empty(B), self.empty(R)
         iters = torch.empty(B, dtype=torch.int32, device=self.device); status = torch.empty(B, dtype=torch.int32, device=self.device)
         sweeps = torch.empty(R, dtype=torch.int32, device=self.device)
-        assert bounds is None or (bounds.is_contiguous() and tuple(bounds.shape) == (B, 4))
+        assert bounds is None or (bounds.is_contiguous() and tuple(bounds.shape) == (B, 4) and bounds.dtype == _torch().float64)
         o = NlpOpts(rho0, mub0, mub_min, feas_tol, opt_tol, inner_max, outer_max, serial, 0, None if bounds is None else bounds.data_ptr())
         _check(self.lib.d2d_nlp_solve_groups(self.h, R, n_ac, N, float(h), _ptr(scen), C.byref(o), int(max_sweeps), float(tol), _ptr(W), _ptr(work),
                                              None, _ptr(cost), _ptr(feas), _ptr(iters), _ptr(status), _ptr(sweeps), _ptr(moved)))

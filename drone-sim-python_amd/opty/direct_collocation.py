@@ -140,7 +140,7 @@ class Problem:
         # an asymmetric phi interval / a box on psi travel beside the rows (d2d_nlp_opts.bounds; lo >= hi: not set)
         bnd = None
         if any('psi' in bd or abs(bd['phi'][0] + bd['phi'][1]) > 1e-12 for bd in self.bounds):
-            bnd = ctx.dev(np.array([[bd['phi'][0], bd['phi'][1]] + list(bd.get('psi', (0.0, 0.0))) for bd in self.bounds]))
+            bnd = ctx.dev(np.array([[bd['phi'][0], bd['phi'][1]] + list(bd.get('psi', (0.0, 0.0))) for bd in self.bounds], dtype=np.float64))
         # one launch for the whole Problem: wavefront a of a workgroup solves aircraft a; the pair coupled by CostCollision
         # alternates on the device (block Gauss-Seidel, d2d_nlp_solve_groups) until neither aircraft moves
         if not coupled:

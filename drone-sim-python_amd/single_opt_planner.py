@@ -203,6 +203,9 @@ class Planner:
         if (st == 1).all():
             info['backend_used'] = 'nlp'
             self.solution, self.info = sol, info
+            # the polynomial of the rejected soft-bound fit no longer describes the plan that is returned (info['fit_info'] keeps
+            # its record): fit_q / fit_plan / fit_scen / fit_coefs are valid only when backend_used == 'fit'
+            self.fit_q = self.fit_plan = self.fit_scen = self.fit_coefs = None
         else:                              # (e.g. a scenario whose bounds cannot all hold: the soft-bound compromise is what there is)
             self.info['nlp_status'] = info['status']
 

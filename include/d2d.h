@@ -321,7 +321,8 @@ typedef struct {
                            quadratic.  0 = Gauss-Newton only; default D2D_LM_SO_LAMBDA.  Persistent LM
                            kernels only; the launch-pair path ignores it.  (The finish of MINPACK mode always
                            carries the term.)                                                          */
-  int32_t mode;         /* D2D_LM_MODE_*; persistent K <= 64 kernel (the other paths run FAST)         */
+  int32_t mode;         /* D2D_LM_MODE_*: both persistent kernels (K <= 64 fused, and the long-horizon / S != 6 one) honour it;
+                           the launch-pair path and coupled groups run FAST                              */
   int32_t mp_finish;    /* MINPACK mode: calm steps before the second-order finish (default D2D_LM_MP_FINISH; 0 = never) */
   double mp_ftol, mp_xtol, mp_gtol;   /* lmder's ftol / xtol / gtol (default 1e-15 each: what bench.py's scipy leg uses) */
   int32_t slice;        /* scheduling of the persistent kernel, > 0: a fit that has run this many iterations while other fits

@@ -65,3 +65,40 @@ def test_rccl_entry_point_single_rank():
         assert b'rank' in lib.d2d_last_error()
     finally:
         ctx.close()
+
+
+def test_sharded_solve_through_the_c_abi_collective_one_rank():
+    """The collective the nccl path of solve_sharded runs is the library's own entry point: a one-rank `nccl` process group (one
+    GPU per box), StatsReducer creates a d2d_comm from the id rank 0 made (d2d_comm_unique_id, carried by torch.distributed) and
+    every exchange of the solve goes through d2d_allreduce_stats -- same bits as the single-process solve; a host pointer and a
+    second context's wrong use are refused with a message."""
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    import d2dhip
+    import bench
+    from d2dhip.dist import StatsReducer, solve_sharded
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29617')
+    ctx = d2dhip.Context(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        red = StatsReducer(dist, ctx.device, ctx)
+        assert red.comm is not None and red.rccl_ranks == 1, red.collective
+        assert 'd2d_allreduce_stats' in red.collective
+        assert red(1.25, 7.0, 3) == (1.25, 7.0, 3) and red.running_only(5) == 5
+        dur, wref = bench._plan_consts()
+        plan = d2dhip.FitPlan(ctx, bench.S_, bench.K, dur, wref)
+        dsc = ctx.dev(bench.bench_scenarios(512, 0))
+        q1 = plan.init(dsc); q2 = q1.clone()
+        c1, i1, s1, st1, glob, checks = solve_sharded(plan, dsc, q1, red, 200, 150)
+        c2, i2, s2, st2 = plan.solve(dsc, q2, max_iter=150, check_every=200)
+        assert torch.equal(q1, q2) and torch.equal(c1, c2) and torch.equal(i1, i2)
+        assert abs(glob[0] - float(c2.sum().item())) <= 1e-12 * abs(glob[0]) and glob[2] == int((s2 != d2dhip.ST_CONVERGED).sum().item())
+        host = np.zeros(3)
+        assert ctx.lib.d2d_allreduce_stats(ctx.h, red.comm.h, host.ctypes.data_as(C.c_void_p)) == -1          # D2D_EINVAL
+        assert b'device memory' in ctx.lib.d2d_last_error()
+        plan.close()
+        red.comm.close()
+    finally:
+        dist.destroy_process_group()
+        ctx.close()

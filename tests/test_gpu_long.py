@@ -89,8 +89,8 @@ def test_long_kernel_vs_oracle_lm(ctx, K, mode):
                 same += int(ok)
                 if ok:
                     dit.append(abs(int(ih[i]) - it_or))
-        assert same >= 7, same                                         # (a basin flip on a rounding-level difference is allowed)
-        assert np.median(dit) <= (2 if mode == 'fast' else 4) and (np.array(dit) <= 3).mean() >= (0.7 if mode == 'fast' else 0.5), dit   # (long wandering fits drift apart in fp32; the segment
+        assert same >= 8, same                                         # (one basin flip on a rounding-level difference is allowed)
+        assert np.median(dit) <= (2 if mode == 'fast' else 4) and (np.array(dit) <= 3).mean() >= (0.7 if mode == 'fast' else 0.6), dit   # (long wandering fits drift apart in fp32; the segment
         # formulation's Hessian carries three fp32 products instead of one: 4e-7 .. 2e-6 against 2e-7 .. 5e-7 of its norm)
         # scipy polish from the GPU points must not move them
         from scipy.optimize import least_squares
