@@ -24,6 +24,7 @@
 struct NlpScen {
   double p0[3], p1[3];
   double skv, skphi, vsp, wx, wy;            // s*kv, s*kphi (s = obj_scale / N [/ n_ac]); wind as it enters the eom (+w)
+  double sbank;                              // CostBank(use_mean=False): obj_scale * kbank of the term sbank * max_i phi_i^2 (skphi = 0 then); 0 = mean mode
   double lo[NLP_NV], hi[NLP_NV];             // box (+-1e300: open)
   double wobs, wcol, kc2;                    // s*kobs, scol*kcol, (k / rcol)^2
   int n_obs, okind;
@@ -35,6 +36,7 @@ __device__ __forceinline__ NlpScen nlp_load_scen(const double *__restrict__ sc, 
   s.p1[0] = sc[D2D_SC_X1]; s.p1[1] = sc[D2D_SC_Y1]; s.p1[2] = sc[D2D_SC_PSI1];
   const double ss = sc[D2D_SC_S];
   s.skv = ss * sc[D2D_SC_KV]; s.skphi = ss * sc[D2D_SC_KPHI]; s.vsp = sc[D2D_SC_VSP];
+  s.sbank = 0.0;                             // (nlp_solve_one sets it for D2D_SC_BANKMAX rows: it needs the node count)
   s.wx = -sc[D2D_SC_WX]; s.wy = -sc[D2D_SC_WY];      // the row stores -w (planner convention, single_opt_planner.scen_row)
   s.lo[0] = -1e300; s.hi[0] = 1e300; s.lo[1] = -1e300; s.hi[1] = 1e300; s.lo[2] = -1e300; s.hi[2] = 1e300;
   if (sc[D2D_SC_XMIN] < sc[D2D_SC_XMAX]) { s.lo[0] = sc[D2D_SC_XMIN]; s.hi[0] = sc[D2D_SC_XMAX]; }
@@ -185,7 +187,7 @@ __device__ __forceinline__ bool nlp_fixed(int i, int N, int c) { return c < 3 &&
 __device__ double nlp_merit(const NlpProb &pb, const NlpScen &s, const double *__restrict__ sc, int lane, double a, double rho,
                             double mub, double *cost_ref_out, double *feas_out) {
   const int N = pb.N;
-  double val = 0.0, bar = 0.0, cref = 0.0, feas = 0.0;
+  double val = 0.0, bar = 0.0, cref = 0.0, feas = 0.0, phi2max = 0.0;
   int outside = 0;
   for (int i0 = 0; i0 < N; i0 += 64) {
     const int i = i0 + lane;
@@ -207,6 +209,7 @@ __device__ double nlp_merit(const NlpProb &pb, const NlpScen &s, const double *_
       bar += log(prod);               // one log per node: at most ten slacks in [1e-12, 1e3], their product stays in range
       const double dv = w[4] - s.vsp;
       double obj = s.skv * dv * dv + s.skphi * w[3] * w[3];
+      phi2max = fmax(phi2max, w[3] * w[3]);
       cref += obj;
       nlp_exp_terms(s, sc, pb.partner, i, N, w[0], w[1], obj, cref, nullptr, nullptr, nullptr, nullptr, nullptr);
       val += obj;
@@ -223,7 +226,12 @@ __device__ double nlp_merit(const NlpProb &pb, const NlpScen &s, const double *_
     }
   }
   val = wave_sum(val); bar = wave_sum(bar);
-  if (cost_ref_out) *cost_ref_out = wave_sum(cref);
+  cref = wave_sum(cref);
+  if (s.sbank > 0.0) {                       // CostBank max mode (src/d2d/opty_utils.py:68-82): obj_scale * kbank * max_i phi_i^2
+    const double bk = s.sbank * wave_max(phi2max);
+    val += bk; cref += bk;
+  }
+  if (cost_ref_out) *cost_ref_out = cref;
   if (feas_out) *feas_out = wave_max(feas);
   const bool any_out = __builtin_amdgcn_ballot_w64(outside != 0) != 0ull;
   if (any_out || !(fabs(val) <= 1.79e308)) return INFINITY;
@@ -244,8 +252,25 @@ __device__ __forceinline__ double nlp_rsqrt(double v) {
 // blocks D (diagonal) and E (i, i-1) of the barrier-AL Lagrangian incl. the constraint curvature, barrier diagonal, damping,
 // right-hand side; then the elimination of (phi, v) described below.  Returns the barrier KKT error of the inner problem
 // (wave-uniform; it does not depend on the damping); *pd_out = false if a 2x2 pivot is not positive.
+// node with the largest |phi| at the current iterate (first on ties), wave-uniform
+__device__ int nlp_bank_argmax(const NlpProb &pb, int lane) {
+  const int N = pb.N;
+  double best = -1.0;
+  int istar = 0;
+  for (int i0 = 0; i0 < N; i0 += 64) {
+    const int i = i0 + lane;
+    const double a = i < N ? fabs(NLP_W(3, i)) : -1.0;
+    const double m = wave_max(a);
+    if (m > best) { best = m; istar = i0 + (int)__builtin_ctzll(__ballot(a == m)); }
+  }
+  return __builtin_amdgcn_readfirstlane(istar);
+}
+
+// imax (CostBank max mode, s.sbank > 0): the node whose bank angle is the largest at the current iterate -- the reference's
+// cost_grad is one-hot there (2 obj_scale kbank phi_imax), the step's model carries the term sbank * phi_imax^2 on that node
+// alone (the maximiser frozen for the step; the merit function of the line search is the true max)
 __device__ double nlp_assemble(const NlpProb &pb, const NlpScen &s, const double *__restrict__ sc, int lane, double rho, double mub,
-                               double lam, bool *pd_out) {
+                               double lam, bool *pd_out, int imax) {
   const int N = pb.N;
   const double h = pb.h, ih = 1.0 / h;
   double err = 0.0;
@@ -283,6 +308,7 @@ __device__ double nlp_assemble(const NlpProb &pb, const NlpScen &s, const double
       for (int c = 0; c < NLP_NV; ++c) D[a][c] = 0.0;
     D[4][4] += s.skv; g[4] += s.skv * (wc[4] - s.vsp);
     D[3][3] += s.skphi; g[3] += s.skphi * wc[3];
+    if (i == imax) { D[3][3] += s.sbank; g[3] += s.sbank * wc[3]; }
     {
       double obj = 0.0, cref = 0.0;
       nlp_exp_terms(s, sc, pb.partner, i, N, wc[0], wc[1], obj, cref, &g[0], &g[1], &D[0][0], &D[0][1], &D[1][1]);
@@ -937,7 +963,8 @@ __device__ __forceinline__ void nlp_solve_one(int N, double h, const d2d_nlp_opt
 #define NLP_STAMP(k) if (st_on) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[k] += t_ - st_t; st_t = t_; }
   const bool st_on = stamps != nullptr;
   if (st_on) st_t = __builtin_amdgcn_s_memtime();
-  const NlpScen s = nlp_load_scen(sc, o, bnd);
+  NlpScen s = nlp_load_scen(sc, o, bnd);
+  if (sc[D2D_SC_BANKMAX] != 0.0) { s.sbank = s.skphi * (double)N; s.skphi = 0.0; }     // obj_scale * kbank (the row's S is obj_scale / N)
   NlpProb pb;
   pb.N = N; pb.h = h;
   pb.W = Wb;
@@ -999,9 +1026,10 @@ __device__ __forceinline__ void nlp_solve_one(int N, double h, const d2d_nlp_opt
       ++total_inner;
       bool converged = false;
       accepted = false;
+      const int imax = s.sbank > 0.0 ? nlp_bank_argmax(pb, lane) : -1;
       for (int tr = 0; tr < 30; ++tr) {
         bool pd;
-        err = nlp_assemble(pb, s, sc, lane, rho, mub, lam, &pd);        // (a retry with another damping assembles again: rare)
+        err = nlp_assemble(pb, s, sc, lane, rho, mub, lam, &pd, imax);  // (a retry with another damping assembles again: rare)
         nlp_phase_sync();
         NLP_STAMP(1)
         if (tr == 0 && err <= tol_in) { converged = true; break; }
@@ -1045,9 +1073,15 @@ __device__ __forceinline__ void nlp_solve_one(int N, double h, const d2d_nlp_opt
     (void)nlp_merit(pb, s, sc, lane, 0.0, rho, mub, &cost_ref, &feas);
     if (!(fabs(phi0) <= 1.79e308) || !(fabs(err) <= 1.79e308)) { status = D2D_ST_NONFINITE; break; }
     if (feas <= o.feas_tol && mub <= o.mub_min * 1.0001 && err <= tol_in) { status = D2D_ST_CONVERGED; break; }
+    // CostBank max mode: the one-hot cost_grad has no zero where two nodes share the maximum (they do at a min-max optimum): the
+    // solve ends converged IN VALUE -- feasible, barrier at its floor, a whole batch of steps that lowered the merit by no more
+    // than D2D_NLP_BANKMAX_VALUE_TOL of itself (oracle/nlp.py solve)
+    if (s.sbank > 0.0 && feas <= o.feas_tol && mub <= o.mub_min * 1.0001 && (phi_first - phi0) <= D2D_NLP_BANKMAX_VALUE_TOL * (1.0 + fabs(phi0))) {
+      status = D2D_ST_CONVERGED; break;
+    }
     // the inner problem is not solved yet and the batch still lowered the merit function by more than rounding: same multipliers,
     // penalty and barrier parameter, another batch of steps -- the schedule must not run ahead of the iterate
-    if (err > tol_in && accepted && (phi_first - phi0) > D2D_NLP_GATE_PROGRESS * (1.0 + fabs(phi0))) continue;
+    if (err > tol_in && accepted && (phi_first - phi0) > (s.sbank > 0.0 ? D2D_NLP_BANKMAX_VALUE_TOL : D2D_NLP_GATE_PROGRESS) * (1.0 + fabs(phi0))) continue;
     // an infeasible problem (e.g. end points too far apart for v_max) or an infeasible stationary point of the violation: the
     // penalty grows tenfold per solved inner problem and the violation no longer halves -- give up instead of running
     // outer_max x inner_max steps

@@ -114,8 +114,8 @@ class Problem:
         coupled = multi and n >= 2 and not np.isnan(low[5]) and low[5] > 0
         if coupled:
             rows[:2, d2dhip.SC_KCOL], rows[:2, d2dhip.SC_RCOL], rows[:2, d2dhip.SC_SCOL] = low[5], low[6], self.planner.obj_scale / N
-        if low[8]:
-            raise NotImplementedError('CostBank max mode has no collocation kernel (use the polynomial-fit backend)')
+        # (low[8]: CostBank(use_mean=False) travels as D2D_SC_BANKMAX -- obj_scale kbank max phi^2 with the maximiser frozen for the
+        # length of a Newton step, csrc/nlp_kernels.hip nlp_assemble / oracle/nlp.py)
         return rows, coupled
 
     def solve(self, x0):

@@ -480,6 +480,8 @@ int d2d_fit_sample(d2d_ctx *ctx, const d2d_fit_plan *plan, int B, const double *
 #define D2D_NLP_MUB_MIN 1e-9
 #define D2D_NLP_GRAD_FLOOR 1e-11   /* x rho: rounding floor of the penalty gradient */
 #define D2D_NLP_GATE_PROGRESS 1e-9  /* relative decrease of the merit function over inner_max steps below which an unsolved inner problem is left */
+#define D2D_NLP_BANKMAX_VALUE_TOL 1e-7   /* CostBank max mode (D2D_SC_BANKMAX rows): converged in value -- feasible, barrier at its floor, a batch of
+                                           inner_max steps lowered the merit function by no more than this fraction (the one-hot cost_grad has no zero) */
 #define D2D_NLP_STALL_OUTERS 5      /* solved inner problems in a row that did not halve the violation: D2D_ST_STALLED */
 typedef struct {
   double rho0;       /* initial penalty (D2D_NLP_RHO0)                                                        */

@@ -43,8 +43,13 @@ class Problem:
     """One aircraft: scenario data in plain attributes (what the device row carries)."""
 
     def __init__(self, N, h, p0, p1, vsp=12.0, kv=1.0, kphi=0.0, obj_scale=1.0, wind=(0.0, 0.0), phi_max=np.deg2rad(30.0),
-                 v_min=9.0, v_max=14.0, x_box=None, y_box=None, obstacles=(), kobs=0.0, obs_kind=1, partner=None, kcol=0.0, rcol=1.0):
+                 v_min=9.0, v_max=14.0, x_box=None, y_box=None, obstacles=(), kobs=0.0, obs_kind=1, partner=None, kcol=0.0, rcol=1.0,
+                 bank_max=False):
         self.N, self.h = int(N), float(h)
+        # CostBank(use_mean=False), src/d2d/opty_utils.py:68-82: cost = obj_scale * kbank * max_i phi_i^2 and cost_grad one-hot at
+        # the maximiser (2 obj_scale kbank phi_imax).  That is the gradient of no differentiable function; what is minimised is the
+        # max itself with the maximiser frozen for the length of a Newton step (model term on that node alone, true max in the merit)
+        self.bank_max = bool(bank_max)
         self.p0, self.p1 = np.asarray(p0, float)[:3], np.asarray(p1, float)[:3]
         self.vsp, self.kv, self.kphi = float(vsp), float(kv), float(kphi)
         self.s = obj_scale / N
@@ -79,7 +84,7 @@ def problem_from_row(row, N, h):
                  obj_scale=r[D.SC_S] * N, wind=(-r[D.SC_WX], -r[D.SC_WY]), phi_max=r[D.SC_PHIMAX], v_min=r[D.SC_VMIN], v_max=r[D.SC_VMAX],
                  x_box=(r[D.SC_XMIN], r[D.SC_XMAX]) if r[D.SC_XMIN] < r[D.SC_XMAX] else None,
                  y_box=(r[D.SC_YMIN], r[D.SC_YMAX]) if r[D.SC_YMIN] < r[D.SC_YMAX] else None,
-                 obstacles=obs, kobs=r[D.SC_KOBS], obs_kind=0 if (kinds and 1 in kinds) else 1)
+                 obstacles=obs, kobs=r[D.SC_KOBS], obs_kind=0 if (kinds and 1 in kinds) else 1, bank_max=r[D.SC_BANKMAX] != 0.0)
     if r[D.SC_KCOL] > 0.0 and r[D.SC_RCOL] > 0.0:        # CostCollision: scale SCOL * KCOL (no 1 / n_ac, src/d2d/multiopty_utils.py:132); set pb.partner
         pb.kcol, pb.rcol = r[D.SC_KCOL] * r[D.SC_SCOL] / r[D.SC_S], r[D.SC_RCOL]
     return pb
@@ -131,9 +136,16 @@ def _obst_terms(pb, W, quirk):
     return out
 
 
+def _bank_value(pb, W):
+    """the bank term of the cost: s kphi sum phi^2 (mean mode) or obj_scale kphi max phi^2 (max mode; pb.s = obj_scale / N)"""
+    if pb.bank_max:
+        return pb.s * pb.N * pb.kphi * float(np.max(W[:, 3] ** 2))
+    return pb.s * pb.kphi * float(np.sum(W[:, 3] ** 2))
+
+
 def cost(pb, W):
-    """The reference's cost() value (CostInput / CostAirVel / CostBank(mean) / CostComposit), src/d2d/opty_utils.py:55-165."""
-    c = pb.s * (pb.kv * np.sum((W[:, 4] - pb.vsp) ** 2) + pb.kphi * np.sum(W[:, 3] ** 2))
+    """The reference's cost() value (CostInput / CostAirVel / CostBank / CostComposit), src/d2d/opty_utils.py:55-165."""
+    c = pb.s * pb.kv * np.sum((W[:, 4] - pb.vsp) ** 2) + _bank_value(pb, W)
     for w, e, *_ in _obst_terms(pb, W, quirk=False):
         c += w * np.sum(e)
     return float(c)
@@ -142,7 +154,7 @@ def cost(pb, W):
 def objective(pb, W):
     """The objective whose gradient is the reference's cost_grad (kind-1 obstacle terms scaled by (r/k)^2; kind-0 terms continued
     over their clip by the paraboloid whose gradient cost_grad returns there -- see the header and _obst_terms)."""
-    c = pb.s * (pb.kv * np.sum((W[:, 4] - pb.vsp) ** 2) + pb.kphi * np.sum(W[:, 3] ** 2))
+    c = pb.s * pb.kv * np.sum((W[:, 4] - pb.vsp) ** 2) + _bank_value(pb, W)
     for w, e, dx, dy, k2, f in _obst_terms(pb, W, quirk=True):
         c += w * np.sum(f)
     return float(c)
@@ -152,7 +164,11 @@ def cost_grad(pb, W):
     """(N, 5): the reference's cost_grad (= gradient of objective())."""
     g = np.zeros_like(W)
     g[:, 4] = 2 * pb.s * pb.kv * (W[:, 4] - pb.vsp)
-    g[:, 3] = 2 * pb.s * pb.kphi * W[:, 3]
+    if pb.bank_max:                                   # one-hot at the maximiser (first on ties), :77-82
+        im = int(np.argmax(np.abs(W[:, 3])))
+        g[im, 3] = 2 * pb.s * pb.N * pb.kphi * W[im, 3]
+    else:
+        g[:, 3] = 2 * pb.s * pb.kphi * W[:, 3]
     for w, e, dx, dy, k2, _f in _obst_terms(pb, W, quirk=True):
         g[:, 0] += -2 * w * k2 * dx * e
         g[:, 1] += -2 * w * k2 * dy * e
@@ -175,7 +191,12 @@ def _normal_equations(pb, W, mu, rho, second_order=True):
     D = np.zeros((N, NV, NV)); E = np.zeros((N - 1, NV, NV)); g = np.zeros((N, NV))
     # cost rows r = sqrt(s kv)(v - vsp), sqrt(s kphi) phi
     D[:, 4, 4] += pb.s * pb.kv; g[:, 4] += pb.s * pb.kv * (v - pb.vsp)
-    D[:, 3, 3] += pb.s * pb.kphi; g[:, 3] += pb.s * pb.kphi * phi
+    if pb.bank_max:                                   # the maximiser of this iterate carries the whole term
+        im = int(np.argmax(np.abs(phi)))
+        sb = pb.s * pb.N * pb.kphi
+        D[im, 3, 3] += sb; g[im, 3] += sb * phi[im]
+    else:
+        D[:, 3, 3] += pb.s * pb.kphi; g[:, 3] += pb.s * pb.kphi * phi
     # exp rows r = sqrt(w e):  dr = -k2 (dx, dy) r   ->  J^T r = -k2 w e (dx, dy),  J^T J = k2^2 w e (dx, dy)(dx, dy)^T
     for w, e, dx, dy, k2, _f in _obst_terms(pb, W, quirk=True):
         we = w * e
@@ -253,6 +274,9 @@ def _merit(pb, W, mu, rho, mub, hasL, hasU):
     if (sl <= 0).any() or (su <= 0).any():
         return np.inf
     return _al_value(pb, W, mu, rho) - mub * float(np.sum(np.log(sl)) + np.sum(np.log(su)))
+
+
+BANKMAX_VALUE_TOL = 1e-7     # include/d2d.h D2D_NLP_BANKMAX_VALUE_TOL
 
 
 def solve(pb, W0, verbose=False, rho0=RHO0, inner_max=INNER_MAX, outer_max=OUTER_MAX, feas_tol=FEAS_TOL, opt_tol=OPT_TOL):
@@ -352,9 +376,16 @@ def solve(pb, W0, verbose=False, rho0=RHO0, inner_max=INNER_MAX, outer_max=OUTER
         if feas <= feas_tol and mub <= MUB_MIN * 1.0001 and err <= tol_in:
             status = 1
             break
+        # CostBank max mode: the one-hot cost_grad has no zero where two nodes share the maximum (they do at a min-max optimum), so
+        # the KKT error never meets its tolerance -- the solve ends "converged in value": feasible, barrier at its floor, and a whole
+        # batch of steps that no longer lowers the merit function by more than BANKMAX_VALUE_TOL of itself
+        if pb.bank_max and feas <= feas_tol and mub <= MUB_MIN * 1.0001 and phi_first is not None \
+                and (phi_first - phi_last) <= BANKMAX_VALUE_TOL * (1.0 + abs(phi_last)):
+            status = 1
+            break
         # the inner problem is not solved yet and the batch still lowered the merit function by more than rounding: same
         # multipliers, penalty and barrier parameter, another batch of steps -- the schedule must not run ahead of the iterate
-        if err > tol_in and accepted and (phi_first - phi_last) > GATE_PROGRESS * (1.0 + abs(phi_last)):
+        if err > tol_in and accepted and (phi_first - phi_last) > (BANKMAX_VALUE_TOL if pb.bank_max else GATE_PROGRESS) * (1.0 + abs(phi_last)):
             continue
         # an infeasible problem (or an infeasible stationary point of the violation): the penalty grows tenfold per solved inner problem
         # and the violation no longer shrinks: give up (status 4)

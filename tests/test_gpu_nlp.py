@@ -453,3 +453,47 @@ def test_asymmetric_phi_interval_and_psi_box_vs_oracle(ctx):
         p = sop.Planner(turn, initialize=True, backend='nlp')
         p.run(p.get_initial_guess('tri'))
     assert p.sol_phi.min() >= philo - 1e-12 and p.sol_phi.max() <= phihi + 1e-12 and (p.sol_phi > phihi - 1e-4).sum() >= 3
+
+
+def test_costbank_max_mode_vs_oracle(ctx):
+    """CostBank(use_mean=False), src/d2d/opty_utils.py:68-82 -- cost obj_scale * kbank * max phi^2, cost_grad one-hot at the maximiser --
+    on the collocation backend (D2D_SC_BANKMAX rows): the maximiser of an iterate carries the whole term for the length of a Newton
+    step, the merit function is the true max, the solve ends converged in value (the one-hot gradient has no zero where two nodes
+    share the maximum).  Kernel = oracle: same cost, same largest bank angle, feasible; the largest bank angle is clearly below the
+    mean-mode plan's, whose cost functional it does not minimise; and the reference's plug-point accepts the cost."""
+    import d2dhip as D
+    N, h = 41, 0.1
+    p0, p1 = (0., 0., 0.), (45., 12., 0.6)
+    pm = nlp.Problem(N, h, p0, p1, vsp=12., kv=1., kphi=1., obj_scale=1., phi_max=np.deg2rad(30.), v_min=9., v_max=14., bank_max=True)
+    pa = nlp.Problem(N, h, p0, p1, vsp=12., kv=1., kphi=1., obj_scale=1., phi_max=np.deg2rad(30.), v_min=9., v_max=14.)
+    t = np.linspace(0, 1, N)
+    W0 = np.stack([45 * t, 12 * t, 0.6 * t, np.zeros(N), 12 * np.ones(N)], 1)
+    rm = _row(pm); rm[D.SC_BANKMAX] = 1.0
+    W, out = _solve(ctx, [pm, pa], [W0, W0], [rm, _row(pa)])
+    assert (out['status'] == 1).all(), out['status']
+    Wm, Wa = W[:, :, 0], W[:, :, 1]
+    Wo, info = nlp.solve(pm, W0)
+    assert info['status'] == 1
+    assert abs(out['cost'][0] - nlp.cost(pm, Wm)) <= 1e-10 * out['cost'][0]          # the cost reported is the reference's cost()
+    assert abs(info['cost'] - out['cost'][0]) <= 1e-5 * info['cost'], (info['cost'], out['cost'][0])
+    assert abs(np.abs(Wm[:, 3]).max() - np.abs(Wo[:, 3]).max()) <= 1e-4
+    assert np.abs(nlp.constraints(pm, Wm)).max() <= 1e-8
+    assert np.abs(Wm[:, 3]).max() < 0.9 * np.abs(Wa[:, 3]).max()                      # min-max flattens the bank profile
+    assert (np.abs(Wm[:, 3]) > 0.999 * np.abs(Wm[:, 3]).max()).sum() >= 2              # ... at least two nodes share the maximum
+    # through opty.direct_collocation.Problem: a scenario whose cost is CostBank(use_mean=False) no longer raises
+    import contextlib, io
+    import d2d.opty_utils as d2ou
+    import d2d.optyplan_scenarios as sc
+    import single_opt_planner as sop
+
+    cb = d2ou.CostBank()
+    cb.use_mean = False                                  # (a class attribute in the reference, :69)
+
+    class bankmax(sc.exp_0):
+        t1, p0, p1 = 4.0, (0., 0., 0., 0., 12.), (45., 12., 0.6, 0., 12.)
+        cost = cb
+    with contextlib.redirect_stdout(io.StringIO()):
+        p = sop.Planner(bankmax, initialize=True, backend='nlp')
+        p.run(p.get_initial_guess('tri'))
+    assert np.isfinite(p.sol_phi).all() and p.info['feas'] <= 1e-8
+    assert abs(p.info['obj_val'] - bankmax.obj_scale * np.max(p.sol_phi ** 2)) <= 1e-12 + 1e-9 * p.info['obj_val']
