@@ -1119,11 +1119,14 @@ __device__ __forceinline__ void nlp_solve_one(int N, double h, const d2d_nlp_opt
 #undef NLP_STAMP
 }
 
+#ifndef NLP_WAVES_PER_SIMD
+#define NLP_WAVES_PER_SIMD 2       // (A/B: -DNLP_WAVES_PER_SIMD=1 gives the assembly 512 registers and no scratch)
+#endif
 // One wavefront per problem.  Node-parallel phases (merit, assembly, step statistics, update) run with lane = node; the two
 // block recursions are serial in the nodes and run wave-uniform.  Control flow is uniform: no lane waits for another problem.
 // Two waves per SIMD (the assembly spills ~280 registers for it, once per Newton step; the serial recursions are separate functions
 // and do not): measured +12 % problems/s at 4096 and 65 536 problems for +6 % latency of a lone one.
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NLP_WAVES_PER_SIMD, NLP_WAVES_PER_SIMD)))
 nlp_solve_kernel(int B, int N, double h, d2d_nlp_opts o, const double *__restrict__ scen, const double *partner, double *W,
                  double *work, double *mult, double *__restrict__ cost_out, double *__restrict__ feas_out,
                  int32_t *__restrict__ iters_out, int32_t *__restrict__ status_out, unsigned long long *stamps) {
@@ -1149,7 +1152,7 @@ nlp_solve_kernel(int B, int N, double h, d2d_nlp_opts o, const double *__restric
 // problem.  Sweep 0 solves every aircraft uncoupled, concurrently; then aircraft 0 and 1 take turns (workgroup barriers between
 // the turns; the partner's positions are read from its W in global memory, which its wave does not touch meanwhile) until neither
 // moved by more than tol in a sweep, or max_sweeps.  No host round trips.  prev [R][2][N] scratch.
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NLP_WAVES_PER_SIMD, NLP_WAVES_PER_SIMD)))
 nlp_groups_kernel(int R, int n_ac, int N, double h, d2d_nlp_opts o, int max_sweeps, double tol, const double *__restrict__ scen, double *W,
                   double *work, double *mult, double *prev, double *__restrict__ cost_out, double *__restrict__ feas_out,
                   int32_t *__restrict__ iters_out, int32_t *__restrict__ status_out, int32_t *__restrict__ sweeps_out,

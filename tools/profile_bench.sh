@@ -21,3 +21,7 @@ done
 timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_sim_fp64 -o bench -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-groups --config3-batch 0 --no-extra-modes > $OUT/pmc_sim_fp64.json 2> $OUT/pmc_sim_fp64.err || echo "pass sim fp64 failed"
 echo "pass sim fp64 done"
 ls -R $OUT | head -40
+# the headline alone (4096 fits, default solver, index order): every launch of fit_lm_kernel in this trace is a headline launch, so
+# the AverageNs of its kernel_stats row is the per-launch duration that bench.py's HIP events must agree with
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_headline -o bench -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-sim --no-nlp --no-groups --config3-batch 0 --no-extra-modes > $OUT/headline.json 2> $OUT/headline.err || echo "headline trace failed"
+echo "headline trace done"
