@@ -417,7 +417,7 @@ fit_step_kernel(int B, FitGeom g, StepLds L, d2d_fit_opts opts, GroupArgs ga,
 // Cholesky's registers), waves drift apart so that one wave's MFMA phase overlaps another's
 // fp64 VALU phases, and trajectories that converge early free their wave for the tail.
 #define FIT_LM_WPB_MAX 8
-#define GROUPS_AA_STRIDE 768    // doubles per aircraft of the Anderson history of fit_groups_kernel (three slots of (G, F) [2][48]; lives in d_H)
+#define GROUPS_LS_STRIDE 128    // doubles per aircraft of the line search of fit_groups_kernel (the unknowns before the sweep [48], the trial point [48] behind them; lives in d_H)
 struct FusedLds {
   int G64, G32, Wt, wave0, wave_stride;
   int qs, sp, big, cf, cfp; // inside a wave's block; `big` holds us + cf + cfp, then the image of J^T J / its factor
@@ -943,8 +943,9 @@ fit_groups_kernel(int R, int n_ac, int nds, FitGeom g, FusedLds L, d2d_fit_opts 
                   const float *__restrict__ gWt, const double *__restrict__ prep, double *q_io, double *pos,
                   double *__restrict__ cost_out, double *__restrict__ g_out, int32_t *__restrict__ flags,
                   int32_t *__restrict__ sweeps_out, double *__restrict__ moved_out, int32_t *__restrict__ queue,
-                  const int32_t *__restrict__ order, double *__restrict__ aa_hist, int aa_m, double aa_start) {
-  // aa_m > 0: Anderson acceleration of depth aa_m (<= 2) on the sweep map (see below); aa_hist [B][GROUPS_AA_STRIDE] doubles
+                  const int32_t *__restrict__ order, double *ls_hist, int ls_s0, double ls_r0) {
+  // ls_s0 > 0: line search on the joint cost along the direction of a slow sweep, from sweep ls_s0 on (see below); ls_hist
+  // [B][GROUPS_LS_STRIDE] doubles: per aircraft the unknowns before the sweep [48] and the trial point [48]
   // order != NULL: hand-out position i takes scenario order[i] (d2d_fit_plan_set_group_order: the scenarios that swept longest
   // in a previous solve start first, so the tail of the launch is not one late straggler)
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -975,11 +976,12 @@ fit_groups_kernel(int R, int n_ac, int nds, FitGeom g, FusedLds L, d2d_fit_opts 
     const int r = order ? __builtin_amdgcn_readfirstlane(order[ri]) : ri;
     const int gbase = r * n_ac;
     // sampled positions of every aircraft of the group (at the start, and after an extrapolated step)
-    auto publish_positions = [&]() {
+    // (src / sstride: the unknowns of trajectory b are src[b * sstride + 0 .. n) -- q_io, or the trial points of the line search)
+    auto publish_positions = [&](const double *src, size_t sstride) {
       for (int a = 0; a < n_ac; ++a) {
         const int b = gbase + a;
         const double *pkb = pk + (size_t)b * FIT_PK * g.K;
-        const double *qb = q_io + (size_t)b * n;
+        const double *qb = src + (size_t)b * sstride;
         double x = 0.0, y = 0.0;
         if (lane < g.K) {
           x = pkb[lane]; y = pkb[g.K + lane];
@@ -989,19 +991,42 @@ fit_groups_kernel(int R, int n_ac, int nds, FitGeom g, FusedLds L, d2d_fit_opts 
         }
       }
     };
-    publish_positions();
+    publish_positions(q_io, n);
     __threadfence_block();
     int sweep = 0, nev_total = 0;
     double moved = 0.0;
     bool settled = false;
-    // Anderson acceleration of the sweep map G (one block Gauss-Seidel sweep over the group): X_{k+1} = G_k - sum_j gamma_j (G_k - G_{k-j})
-    // with gamma = argmin || F_k - sum_j gamma_j (F_k - F_{k-j}) ||_2, F_k = G_k - X_k (depth aa_m <= 2).  The slow scenarios of
-    // BASELINE configs[2] converge LINEARLY at 0.9 .. 0.997 per sweep (tools/dev_groups_trace.py: 95 .. > 150 sweeps to 1e-6 where
-    // the median needs 9); the fixed point is the same -- the stop test is still the move of a PLAIN sweep.  History: three slots
-    // of (G, F) per aircraft in aa_hist, written by the visits; an extrapolated step after which the plain sweep moves MORE than
-    // the one before it clears the history and pauses the acceleration for two sweeps.
-    int aa_cur = 0, aa_nh = 0, aa_pause = 0, aa_fail = 0;
-    bool aa_applied = false;
+    // Line search on the JOINT cost along a slow sweep (oracle/fit.py bgs_solve, ls_s0 / ls_r0).  Block Gauss-Seidel is a descent
+    // method on F(X) = sum of the aircraft's own rows + every coupled pair once; the slow scenarios of BASELINE configs[2] converge
+    // LINEARLY at 0.9 .. 0.93 per sweep, and the slowest DRIFTS away from a saddle of F with moves that grow by 0.5 % per sweep for
+    // > 100 sweeps (tools/dev_groups_trace.py).  After a sweep (from sweep ls_s0 on) that moved at least ls_r0 x the move of the
+    // sweep before, F is evaluated along the sweep's own direction d = X_k - X_{k-1}: first length rho / (1 - rho) (the fixed point
+    // of a single linear mode; 8 when the moves grow), doubled while F falls (up to 64), one shorter try (x 1/4) when the first
+    // does not lower F; the best point with F below F(X_k) is taken, otherwise nothing changes.  The stop test stays the move of
+    // a PLAIN sweep, and the iteration stays a descent on F -- unlike the Anderson extrapolation of the sweep map (a root finder of
+    // G(X) - X, measured in round 4: attracted by the repelling fixed points that the plain sweeps leave), it cannot be drawn to
+    // a saddle.  F through the cost-only phase 1 of every aircraft against the published positions: c_a counts a's collision rows
+    // against all partners, so F = sum_a (c_a - coll_a / 2).
+    auto joint_merit = [&](const double *src, size_t sstride) -> double {
+      double F = 0.0;
+      for (int a = 0; a < n_ac; ++a) {
+        const int b = gbase + a;
+        const double *prow = prep + (size_t)b * FIT_PREP_STRIDE;
+        const double *pkb = pk + (size_t)b * FIT_PK * g.K;
+        const GroupCtx gc{pos, n_ac, a, gbase, nds};
+        if (act) qs[q_slot(lane, g.nq)] = src[(size_t)b * sstride + lane];
+        for (int i = lane; i < FIT_PREP_STRIDE; i += 64) sp[i] = prow[i];
+        double pkr[FIT_PK];
+#pragma unroll
+        for (int cc = 0; cc < FIT_PK; ++cc) pkr[cc] = lane < g.K ? pkb[(size_t)cc * g.K + lane] : 0.0;
+        wave_lds_sync();
+        double coll = 0.0;
+        const double c = uniform_d(eval_cost_grp<NQ>(g, G64, pkr, pkb, sp, qs, gc, lane, coll));
+        F += c - 0.5 * uniform_d(coll);
+        wave_lds_sync();
+      }
+      return F;
+    };
     double moved_prev = 1e300;
     for (sweep = 1; sweep <= max_sweeps; ++sweep) {
       moved = 0.0;
@@ -1093,10 +1118,7 @@ fit_groups_kernel(int R, int n_ac, int nds, FitGeom g, FusedLds L, d2d_fit_opts 
           const double dq = uniform_d(wave_max(fabs(qi - q_start))), qa = uniform_d(wave_max(fabs(q_start)));
           moved = fmax(moved, dq / (1.0 + qa));
           if (act) { q_io[(size_t)b * n + lane_io] = qi; qs[q_slot(lane, g.nq)] = qi; }
-          if (aa_m > 0 && act) {
-            double *h = aa_hist + (size_t)b * GROUPS_AA_STRIDE + aa_cur * 2 * N;
-            h[lane_io] = qi; h[N + lane_io] = qi - q_start;
-          }
+          if (ls_s0 > 0 && act) ls_hist[(size_t)b * GROUPS_LS_STRIDE + lane_io] = q_start;
         }
         wave_lds_sync();
         if (lane < g.K) {
@@ -1107,74 +1129,47 @@ fit_groups_kernel(int R, int n_ac, int nds, FitGeom g, FusedLds L, d2d_fit_opts 
         __threadfence_block();
       }
       if (moved <= tol) { settled = true; break; }
-      if (aa_m > 0) {
-        bool reverted = false;
-        if (aa_applied && moved > moved_prev) {
-          // the plain sweep from the extrapolated state moves MORE than the sweep before it: the extrapolation is thrown away --
-          // back to the plain result of the sweep it was built from (its G is the slot before this sweep's), history restarted,
-          // no acceleration for four sweeps; a scenario that rejects three extrapolations goes on without any
-          const int hp = (aa_cur + 2) % 3;
-          if (act) {
-            for (int a = 0; a < n_ac; ++a)
-              q_io[(size_t)(gbase + a) * n + lane] = aa_hist[(size_t)(gbase + a) * GROUPS_AA_STRIDE + hp * 2 * N + lane];
-          }
-          __threadfence_block();
-          publish_positions();
-          __threadfence_block();
-          aa_nh = 0; aa_pause = 4; ++aa_fail;
-          moved = moved_prev;                 // (the state is the one that had moved by moved_prev)
-          reverted = true;
-        }
-        aa_applied = false;
-        if (!reverted && aa_fail < 3 && aa_nh >= 1 && aa_pause == 0 && moved <= aa_start && sweep < max_sweeps) {
-          const int m = aa_nh < aa_m ? aa_nh : aa_m;
-          const int h1 = (aa_cur + 2) % 3, h2 = (aa_cur + 1) % 3;
-          double a11 = 0.0, a12 = 0.0, a22 = 0.0, b1 = 0.0, b2 = 0.0, ff = 0.0;
+      if (ls_s0 > 0 && sweep >= ls_s0 && sweep < max_sweeps && moved >= ls_r0 * moved_prev) {
+        const double rho = moved / moved_prev;
+        double al = rho < 1.0 ? rho / fmax(1.0 - rho, 1e-3) : D2D_GS_LS_FIRST_MAX;
+        al = fmin(fmax(al, 1.0), D2D_GS_LS_FIRST_MAX);
+        __threadfence_block();
+        double bestF = joint_merit(q_io, n), best_al = 0.0;      // (the published positions are those of q_io)
+        bool shrunk = false;
+        double *trial = ls_hist + N;                             // trajectory b: trial[b * GROUPS_LS_STRIDE + 0 .. n)
+        for (int t = 0; t < 5 && al <= D2D_GS_LS_MAX; ++t) {
           if (act) {
             for (int a = 0; a < n_ac; ++a) {
-              const double *h = aa_hist + (size_t)(gbase + a) * GROUPS_AA_STRIDE;
-              const double fc = h[aa_cur * 2 * N + N + lane];
-              const double d1 = fc - h[h1 * 2 * N + N + lane];
-              const double d2 = m > 1 ? fc - h[h2 * 2 * N + N + lane] : 0.0;
-              a11 = fma(d1, d1, a11); a12 = fma(d1, d2, a12); a22 = fma(d2, d2, a22); b1 = fma(d1, fc, b1); b2 = fma(d2, fc, b2);
-              ff = fma(fc, fc, ff);
+              const size_t b = (size_t)(gbase + a);
+              const double qk = q_io[b * n + lane];
+              trial[b * GROUPS_LS_STRIDE + lane] = fma(al, qk - ls_hist[b * GROUPS_LS_STRIDE + lane], qk);
             }
           }
-          a11 = uniform_d(wave_sum(a11)); a12 = uniform_d(wave_sum(a12)); a22 = uniform_d(wave_sum(a22));
-          b1 = uniform_d(wave_sum(b1)); b2 = uniform_d(wave_sum(b2)); ff = uniform_d(wave_sum(ff));
-          double g1 = 0.0, g2 = 0.0;
-          bool ok = a11 > 0.0;
-          if (ok) {
-            const double det = a11 * a22 - a12 * a12;
-            if (m > 1 && det > 0.2 * a11 * a22) { g1 = (b1 * a22 - b2 * a12) / det; g2 = (b2 * a11 - b1 * a12) / det; }
-            else g1 = b1 / a11;
-            // the least-squares residual || F - dF gamma ||^2 = ff - gamma . b must be a real reduction, the coefficients moderate
-            const double red = ff - (g1 * b1 + g2 * b2);
-            ok = fabs(g1) <= 1e3 && fabs(g2) <= 1e3 && red <= 0.81 * ff;         // (also false for NaN)
-          }
-          if (ok) {
-            if (act) {
-              for (int a = 0; a < n_ac; ++a) {
-                const double *h = aa_hist + (size_t)(gbase + a) * GROUPS_AA_STRIDE;
-                const double gc = h[aa_cur * 2 * N + lane];
-                double xn = gc - g1 * (gc - h[h1 * 2 * N + lane]);
-                if (g2 != 0.0) xn -= g2 * (gc - h[h2 * 2 * N + lane]);
-                q_io[(size_t)(gbase + a) * n + lane] = xn;
-              }
-            }
-            __threadfence_block();
-            publish_positions();
-            __threadfence_block();
-            aa_applied = true;
+          __threadfence_block();
+          publish_positions(trial, GROUPS_LS_STRIDE);
+          __threadfence_block();
+          const double Ft = joint_merit(trial, GROUPS_LS_STRIDE);
+          const bool better = Ft < bestF;                        // (false for NaN)
+          if (better) { bestF = Ft; best_al = al; }
+          if (t == 0) {
+            if (better) al *= 2.0; else { al *= 0.25; shrunk = true; }
+          } else {
+            if (shrunk || !better) break;
+            al *= 2.0;
           }
         }
-        if (aa_pause > 0) --aa_pause;
-        if (!reverted) {
-          aa_cur = (aa_cur + 1) % 3;
-          if (aa_nh < 2) ++aa_nh;
-          moved_prev = moved;
+        if (best_al > 0.0 && act) {
+          for (int a = 0; a < n_ac; ++a) {
+            const size_t b = (size_t)(gbase + a);
+            const double qk = q_io[b * n + lane];
+            q_io[b * n + lane] = fma(best_al, qk - ls_hist[b * GROUPS_LS_STRIDE + lane], qk);
+          }
         }
+        __threadfence_block();
+        publish_positions(q_io, n);
+        __threadfence_block();
       }
+      moved_prev = moved;
     }
     if (sweep > max_sweeps) sweep = max_sweeps;
     __builtin_amdgcn_s_setprio(0);
@@ -2643,18 +2638,21 @@ int d2d_fit_solve_groups(d2d_ctx *ctx, d2d_fit_plan *pl, int R, const double *sc
     const int32_t *gorder = (pl->gorder_R == R) ? pl->d_order : nullptr;
     double *d_moved = pl->d_lm;                           // [R] scratch
     const int blocks = R < pl->n_cu ? R : pl->n_cu;
-    // Anderson acceleration of the sweep map: OFF by default, D2D_GROUPS_AA=1|2 (depth) for experiments; its history lives in
-    // d_H (6 kB per trajectory, not used on this path).  Measured on configs[2] (tools/dev_groups_ab.sh): mean
-    // 10.5 -> 8.6 sweeps, p99 24 -> 15 at tol 1e-6 -- but the accelerated iteration is a quasi-Newton ROOT finder of G(X) - X and
-    // is attracted by REPELLING fixed points of the sweep map (saddles of the joint cost) that plain block Gauss-Seidel, a descent
-    // method, leaves: one scenario of the 8192 of tests/test_gpu_fullsize.py "settles" to 1e-8 in 13 sweeps at such a point and
-    // then drifts away from it for the next 140.  Wrong answers are not a price for fewer sweeps.
-    static const int aa_env = getenv("D2D_GROUPS_AA") ? atoi(getenv("D2D_GROUPS_AA")) : 0;
-    const int aa_m = aa_env < 0 ? 0 : (aa_env > 2 ? 2 : aa_env);
+    // Line search on the joint cost along slow sweeps (fit_groups_kernel): on from sweep 8 for sweeps that move >= 0.8 x the one
+    // before; D2D_GROUPS_LS=0 switches it off (plain block Gauss-Seidel), D2D_GROUPS_LS_S0 / D2D_GROUPS_LS_R0 move the thresholds
+    // (development).  Its per-trajectory scratch (the unknowns before the sweep, the trial point) lives in d_H, unused on this path.
+    // Measured on configs[2] (tools/dev_groups_accel.py, 8192 scenarios at tol 1e-6): the slowest scenario 200+ -> 39 sweeps, 19
+    // scenarios beyond 40 sweeps -> 0, 0.15 evaluations of F per scenario on average, the same fixed point as the plain sweeps
+    // in every scenario (F within 1e-12).  (The Anderson extrapolation of the sweep map tried before -- mean 10.5 -> 8.6 sweeps
+    // -- was attracted by repelling fixed points, saddles of F, and is gone: DESIGN.md 5.5b.)
+    const int ls_env = getenv("D2D_GROUPS_LS") ? atoi(getenv("D2D_GROUPS_LS")) : 1;
+    const int ls_s0_env = getenv("D2D_GROUPS_LS_S0") ? atoi(getenv("D2D_GROUPS_LS_S0")) : D2D_GS_LS_SWEEP0;
+    const double ls_r0_env = getenv("D2D_GROUPS_LS_R0") ? atof(getenv("D2D_GROUPS_LS_R0")) : D2D_GS_LS_RATIO;
+    const int ls_s0 = ls_env > 0 ? (ls_s0_env < 2 ? 2 : ls_s0_env) : 0;
     if (int rc = prof_begin(ctx, pl, 2)) return rc;
     hipLaunchKernelGGL((fit_groups_kernel<3, 24>), dim3(blocks), dim3(64 * wpb_g), L.total, ctx->stream, R, n_ac, pl->nds, gm, L, o,
                        max_sweeps, inner_iters, tol, pl->d_G, pl->d_pk, pl->d_G32, pl->d_W32, pl->d_prep, q, pl->d_pos, pl->d_cost,
-                       pl->d_g, pl->d_flags, d_sweeps, d_moved, queue, gorder, reinterpret_cast<double *>(pl->d_H), aa_m, 1e-3);
+                       pl->d_g, pl->d_flags, d_sweeps, d_moved, queue, gorder, reinterpret_cast<double *>(pl->d_H), ls_s0, ls_r0_env);
     D2D_LAUNCH_CHECK();
     if (int rc = prof_end(ctx, pl)) return rc;
     if (cost) D2D_CHECK_HIP(hipMemcpyAsync(cost, pl->d_cost, (size_t)B * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));

@@ -113,6 +113,29 @@ __device__ __forceinline__ double eval_phase1_grp(const FitGeom &g, const double
   return cost;
 }
 
+// The cost alone of a coupled aircraft at qs against the partners' published positions (the line search of fit_groups_kernel):
+// returns sum r^2 over all rows of the aircraft, coll = the part of its collision rows; both are per-lane copies of wave sums.
+template <int NQ>
+__device__ __forceinline__ double eval_cost_grp(const FitGeom &g, const double *G64, const double (&pkr)[FIT_PK],
+                                                const double *__restrict__ pkb, const double *sp, const double *qs,
+                                                const GroupCtx &gc, int lane, double &coll) {
+  double cacc = 0.0, ccol = 0.0;
+  LAUNDER(lane);
+  const int k = lane;
+  int kbank = -1;
+  if (sp[PR_CPHIMAX] > 0.0) kbank = bank_argmax<NQ>(g, G64, pkb, qs, load_scenp(sp), lane);
+  if (k < g.K) {
+    double Y[6], xin[6];
+    flat_outputs_pk<NQ>(g, G64, qs, pkr, k, Y);
+    const ScenP s = load_scenp(sp);
+    partner_sums(s, gc, g.K, k, Y[0], Y[1], xin);
+    cacc = sample_terms<false>(s, Y, pkr[6], pkr[7], nullptr, nullptr, k == kbank, nullptr, xin);
+    ccol = xin[0];
+  }
+  coll = wave_sum(ccol);
+  return wave_sum(cacc);
+}
+
 // phase 2 (lane = unknown): (J^T r)[lane] = sum_k G_k^T u_k, three independent fp64 accumulation chains.
 // NQ > 0: nq is a compile-time constant, so every LDS read of a chunk of five samples carries an
 // immediate offset and the whole chunk (15 basis values + 15 u's) is requested before its FMAs run.

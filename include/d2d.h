@@ -289,6 +289,14 @@ enum {
 #define D2D_LM_FAIL_MULT 8.0
 /* block Gauss-Seidel over coupled aircraft: a scenario still sweeping after GS_PRIO_AT sweeps raises its wave's priority */
 #define D2D_GS_PRIO_AT 40
+/* ... and its slow sweeps are followed by a line search on the JOINT cost (own rows of every aircraft + every coupled pair once) along
+ * the sweep's direction: from sweep GS_LS_SWEEP0 on, after a sweep that moved >= GS_LS_RATIO x the move of the sweep before it; first
+ * length rho / (1 - rho) clipped to [1, GS_LS_FIRST_MAX] (GS_LS_FIRST_MAX when the moves grow), doubled while the joint cost falls (up
+ * to GS_LS_MAX), one try at a quarter when the first does not lower it (oracle/fit.py bgs_solve; persistent kernel only) */
+#define D2D_GS_LS_SWEEP0 8
+#define D2D_GS_LS_RATIO 0.8
+#define D2D_GS_LS_FIRST_MAX 8.0
+#define D2D_GS_LS_MAX 64.0
 enum { D2D_ST_RUNNING = 0, D2D_ST_CONVERGED = 1, D2D_ST_MAXITER = 2, D2D_ST_NONFINITE = 3, D2D_ST_STALLED = 4 };
 
 /* Solver of d2d_fit_solve / d2d_fit_iterate (persistent LM kernel; oracle/fit.py states both on the CPU):

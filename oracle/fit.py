@@ -645,15 +645,40 @@ def group_residuals(basis, scs, qflat):
     return np.concatenate(out)
 
 
-def bgs_solve(basis, scs, q0s=None, sweeps=30, inner_iters=8, tol=1e-12, **lm_kw):
+GS_LS_SWEEP0, GS_LS_RATIO, GS_LS_FIRST_MAX, GS_LS_MAX = 8, 0.8, 8.0, 64.0      # include/d2d.h D2D_GS_LS_*
+
+
+def group_merit(basis, scs, qs):
+    """The joint cost as fit_groups_kernel's line search adds it up: every aircraft's cost against its partners' positions
+    (own rows + ITS collision rows) minus half of its collision part -- each coupled pair once; equals group_cost when the
+    masks and collision parameters of a group are symmetric."""
+    n = len(scs)
+    pos = group_positions(basis, scs, qs)
+    tot = 0.0
+    for i in range(n):
+        oth = [pos[j] for j in partners(scs[i], i, n)]
+        c_all = cost(basis, scs[i], qs[i], others=oth)
+        tot += c_all - 0.5 * (c_all - cost(basis, scs[i], qs[i]))
+    return tot
+
+
+def bgs_solve(basis, scs, q0s=None, sweeps=30, inner_iters=8, tol=1e-12, ls=False, ls_s0=GS_LS_SWEEP0, ls_r0=GS_LS_RATIO,
+              trace=None, **lm_kw):
     """Block Gauss-Seidel over the aircraft of one group -- the algorithm d2d_fit_solve_groups runs:
     visit aircraft 0..n-1 in order; each visit restarts the LM state and runs at most `inner_iters`
     damped solves on that aircraft's unknowns with the others' sampled positions frozen.  Stops when
-    a whole sweep changes no unknown by more than tol*(1+|q|)."""
+    a whole sweep changes no unknown by more than tol*(1+|q|).
+    ls (the persistent kernel fit_groups_kernel; include/d2d.h D2D_GS_LS_*): after a sweep -- from sweep ls_s0 on -- that moved at
+    least ls_r0 x the move of the sweep before it, a line search on the joint cost along the sweep's direction d = X_k - X_{k-1}:
+    first length rho / (1 - rho) clipped to [1, 8] (8 when the moves grow), doubled while the joint cost falls (<= 64), one try
+    at a quarter when the first does not lower it; the best point below F(X_k) is taken.  The sweeps stay a descent on the
+    joint cost and the stop test stays the move of a plain sweep.  trace: list that receives (sweep, moved, step length)."""
     n = len(scs)
     qs = [initial_guess(basis, scs[i]) if q0s is None else np.array(q0s[i], float) for i in range(n)]
+    moved_prev = 1e300
     for sw in range(1, sweeps + 1):
         moved = 0.0
+        q_before = [q.copy() for q in qs]
         for i in range(n):
             pos = group_positions(basis, scs, qs)
             oth = [pos[j] for j in partners(scs[i], i, n)]
@@ -661,7 +686,32 @@ def bgs_solve(basis, scs, q0s=None, sweeps=30, inner_iters=8, tol=1e-12, **lm_kw
             moved = max(moved, float(np.max(np.abs(qn - qs[i])) / (1.0 + np.max(np.abs(qs[i])))))
             qs[i] = qn
         if moved <= tol:
+            if trace is not None: trace.append((sw, moved, 0.0))
             break
+        best_al = 0.0
+        if ls and sw >= ls_s0 and sw < sweeps and moved >= ls_r0 * moved_prev:
+            rho = moved / moved_prev
+            al = rho / max(1.0 - rho, 1e-3) if rho < 1.0 else GS_LS_FIRST_MAX
+            al = min(max(al, 1.0), GS_LS_FIRST_MAX)
+            d = [qs[i] - q_before[i] for i in range(n)]
+            best_F, shrunk = group_merit(basis, scs, qs), False
+            for t in range(5):
+                if al > GS_LS_MAX:
+                    break
+                Ft = group_merit(basis, scs, [qs[i] + al * d[i] for i in range(n)])
+                better = Ft < best_F
+                if better:
+                    best_F, best_al = Ft, al
+                if t == 0:
+                    if better: al *= 2.0
+                    else: al *= 0.25; shrunk = True
+                else:
+                    if shrunk or not better: break
+                    al *= 2.0
+            if best_al > 0.0:
+                qs = [qs[i] + best_al * d[i] for i in range(n)]
+        if trace is not None: trace.append((sw, moved, best_al))
+        moved_prev = moved
     return np.array(qs), group_cost(basis, scs, qs), sw
 
 

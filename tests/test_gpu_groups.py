@@ -50,7 +50,8 @@ def test_groups_vs_oracle_bgs_and_joint_arbiter(env, n_ac, pair01):
         cj = F.group_cost(ob, sc[r], qh[r])
         assert abs(2 * pol.cost - cj) <= 1e-6 * cj
         # (b) the oracle's block Gauss-Seidel (same algorithm, fp64 Hessian)
-        qo, co, swo = F.bgs_solve(ob, sc[r], sweeps=80, inner_iters=8, tol=1e-12)
+        # (the persistent kernel follows its slow sweeps by a line search on the joint cost: ls=True)
+        qo, co, swo = F.bgs_solve(ob, sc[r], sweeps=80, inner_iters=8, tol=1e-12, ls=True)
         zo = np.array([F.coefficients(ob, sc[r, i], qo[i]) for i in range(n_ac)])
         assert np.abs(zg - zo).max() <= 1e-6 * np.abs(zo).max()
         assert abs(co - cj) <= 1e-6 * cj
@@ -70,6 +71,46 @@ def test_groups_vs_oracle_bgs_and_joint_arbiter(env, n_ac, pair01):
         # coupling must push apart the ones that come within the collision radius and never pull anybody closer
         rcol = sc[0, 0, F.SC_RCOL]
         assert d > d0 + 1.0 if d0 < 0.8 * rcol else d >= d0 - 1e-3, (d, d0)
+
+
+def test_line_search_on_slow_scenarios_vs_oracle(monkeypatch):
+    """The slow scenarios of BASELINE configs[2] (seed 1 of the bench: 96 and 90 plain sweeps to 1e-6): with the line search on the
+    joint cost (include/d2d.h D2D_GS_LS_*) the kernel settles them in a fraction of the sweeps, at the fixed point of the plain
+    sweeps, and does what the oracle's statement of the same rule does (sweep counts, coefficients, joint cost)."""
+    import d2dhip
+    from d2dhip import synth
+    ctx = d2dhip.Context(0)
+    plan = d2dhip.FitPlan(ctx, S_, K, DUR, synth.default_wref(1.0, K))
+    ob = F.FitBasis.from_arrays(S_, K, DUR, *plan.basis())
+    n_ac, ids = 8, [2171, 308]
+    sc = synth.circle_group_scenarios(n_ac, 8192, DUR, K, seed=1)[ids]
+    dsc = ctx.dev(sc.reshape(len(ids) * n_ac, -1))
+    try:
+        monkeypatch.setenv('D2D_GROUPS_LS', '0')
+        q0 = plan.init(dsc)
+        plan.solve_groups(dsc, q0, n_ac, max_sweeps=200, inner_iters=8, tol=1e-6)
+        sw_plain, _ = plan.group_report(len(ids))
+        monkeypatch.delenv('D2D_GROUPS_LS')
+        q = plan.init(dsc)
+        plan.solve_groups(dsc, q, n_ac, max_sweeps=200, inner_iters=8, tol=1e-6)
+        sw_ls, mv_ls = plan.group_report(len(ids))
+    finally:
+        plan.set_groups(1)
+    assert (sw_plain >= 80).all() and (sw_ls <= 40).all() and (mv_ls <= 1e-6).all(), (sw_plain, sw_ls, mv_ls)
+    qh, qp = q.cpu().numpy().reshape(len(ids), n_ac, -1), q0.cpu().numpy().reshape(len(ids), n_ac, -1)
+    for r in range(len(ids)):
+        cj, cp = F.group_cost(ob, sc[r], qh[r]), F.group_cost(ob, sc[r], qp[r])
+        assert abs(cj - cp) <= 1e-6 * cp, (cj, cp)                        # the same minimum as the plain sweeps ...
+        assert abs(F.group_merit(ob, sc[r], qh[r]) - cj) <= 1e-12 * cj     # (the merit the line search adds up IS the joint cost)
+        tr = []
+        qo, co, swo = F.bgs_solve(ob, sc[r], sweeps=200, inner_iters=8, tol=1e-6, ls=True, trace=tr)
+        assert abs(swo - sw_ls[r]) <= 2, (swo, sw_ls[r], tr)                # ... reached the way the oracle reaches it
+        assert any(al > 0 for _, _, al in tr)
+        zg = np.array([F.coefficients(ob, sc[r, i], qh[r, i]) for i in range(n_ac)])
+        zo = np.array([F.coefficients(ob, sc[r, i], qo[i]) for i in range(n_ac)])
+        assert np.abs(zg - zo).max() <= 1e-4 * np.abs(zo).max()             # (both stopped at a sweep that moved <= 1e-6)
+        assert abs(co - cj) <= 1e-6 * cj
+    plan.close(); ctx.close()
 
 
 def test_groups_config2_batch_properties(env):
