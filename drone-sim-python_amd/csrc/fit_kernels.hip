@@ -943,7 +943,7 @@ fit_groups_kernel(int R, int n_ac, int nds, FitGeom g, FusedLds L, d2d_fit_opts 
                   const float *__restrict__ gWt, const double *__restrict__ prep, double *q_io, double *pos,
                   double *__restrict__ cost_out, double *__restrict__ g_out, int32_t *__restrict__ flags,
                   int32_t *__restrict__ sweeps_out, double *__restrict__ moved_out, int32_t *__restrict__ queue,
-                  const int32_t *__restrict__ order, double *ls_hist, int ls_s0, double ls_r0) {
+                  const int32_t *__restrict__ order, double *ls_hist, int ls_s0, double ls_r0, int prio_at) {
   // ls_s0 > 0: line search on the joint cost along the direction of a slow sweep, from sweep ls_s0 on (see below); ls_hist
   // [B][GROUPS_LS_STRIDE] doubles: per aircraft the unknowns before the sweep [48] and the trial point [48]
   // order != NULL: hand-out position i takes scenario order[i] (d2d_fit_plan_set_group_order: the scenarios that swept longest
@@ -1030,7 +1030,7 @@ fit_groups_kernel(int R, int n_ac, int nds, FitGeom g, FusedLds L, d2d_fit_opts 
     double moved_prev = 1e300;
     for (sweep = 1; sweep <= max_sweeps; ++sweep) {
       moved = 0.0;
-      if (sweep == D2D_GS_PRIO_AT) __builtin_amdgcn_s_setprio(2);      // a scenario that is still sweeping decides when the launch ends
+      if (sweep == prio_at) __builtin_amdgcn_s_setprio(2);      // a scenario that is still sweeping decides when the launch ends
       for (int a = 0; a < n_ac; ++a) {
         const int b = gbase + a;
         const double *prow = prep + (size_t)b * FIT_PREP_STRIDE;
@@ -2652,7 +2652,8 @@ int d2d_fit_solve_groups(d2d_ctx *ctx, d2d_fit_plan *pl, int R, const double *sc
     if (int rc = prof_begin(ctx, pl, 2)) return rc;
     hipLaunchKernelGGL((fit_groups_kernel<3, 24>), dim3(blocks), dim3(64 * wpb_g), L.total, ctx->stream, R, n_ac, pl->nds, gm, L, o,
                        max_sweeps, inner_iters, tol, pl->d_G, pl->d_pk, pl->d_G32, pl->d_W32, pl->d_prep, q, pl->d_pos, pl->d_cost,
-                       pl->d_g, pl->d_flags, d_sweeps, d_moved, queue, gorder, reinterpret_cast<double *>(pl->d_H), ls_s0, ls_r0_env);
+                       pl->d_g, pl->d_flags, d_sweeps, d_moved, queue, gorder, reinterpret_cast<double *>(pl->d_H), ls_s0, ls_r0_env,
+                       getenv("D2D_GROUPS_PRIO_AT") ? atoi(getenv("D2D_GROUPS_PRIO_AT")) : D2D_GS_PRIO_AT);
     D2D_LAUNCH_CHECK();
     if (int rc = prof_end(ctx, pl)) return rc;
     if (cost) D2D_CHECK_HIP(hipMemcpyAsync(cost, pl->d_cost, (size_t)B * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));

@@ -22,6 +22,17 @@ static GlMesh make_mesh(double dt, double tau_phi, double tau_v) {
     m.row[p][9] = std::exp(-w / tau_phi);
     m.row[p][10] = std::exp(-w / tau_v);
   }
+  // the one-panel mesh of a step that starts close to its bank command (sim_device.h plant_step)
+  static_assert(D2D_GL_FAST_STAGES == 6, "the 6-stage Gauss nodes below");
+  static const double c6[6] = {0.033765242898423975, 0.16939530676686776, 0.3806904069584015, 0.6193095930415985, 0.8306046932331322,
+                               0.966234757101576};
+  m.fast[0] = dt;
+  for (int i = 0; i < 6; ++i) {
+    m.fast[1 + i] = std::exp(-c6[i] * dt / tau_phi);
+    m.fast[7 + i] = std::exp(-c6[i] * dt / tau_v);
+  }
+  m.fast[13] = std::exp(-dt / tau_phi);
+  m.fast[14] = std::exp(-dt / tau_v);
   return m;
 }
 

@@ -75,6 +75,10 @@ int d2d_allreduce_stats(d2d_ctx *ctx, d2d_comm *comm, double *stats);     /* D2D
  * a zero-order-hold input) are integrated exactly. */
 #define D2D_GL_STAGES 4
 #define D2D_GL_PANELS 5
+/* ... and a step that starts within D2D_GL_FAST_DPHI (rad) of its bank command -- every step of a settled guidance loop -- takes ONE
+ * panel of D2D_GL_FAST_STAGES stages over the whole step instead (the boundary layer it has to resolve is that small) */
+#define D2D_GL_FAST_STAGES 6
+#define D2D_GL_FAST_DPHI 0.02
 
 /* One batched plant step.  Replaces Aircraft.disc_dyn(Xk, Uk, W, t, dt)
  * (src/d2d/dynamic.py:25-28; model :14-23, heading wrap :27 / src/d2d/utils.py:7).

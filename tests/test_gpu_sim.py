@@ -47,6 +47,25 @@ def test_step_large_batch_matches_oracle(ctx):
     assert np.abs(d).max() < 1e-10
 
 
+def test_step_one_panel_and_graded_meshes_match_oracle(ctx):
+    """plant_step picks its mesh per drone by |phi - phi_c| (include/d2d.h D2D_GL_FAST_*): a batch that mixes both branches inside
+    every wavefront, with rows at and just beyond the threshold, against the oracle's statement of the same rule."""
+    rng = np.random.default_rng(5)
+    n = 4099
+    X = np.stack([rng.uniform(-100, 100, n), rng.uniform(-100, 100, n), rng.uniform(-np.pi, np.pi, n),
+                  rng.uniform(-0.9, 0.9, n), rng.uniform(8, 16, n)], 1)
+    dphi = np.where(rng.random(n) < 0.5, rng.uniform(-S.GL_FAST_DPHI, S.GL_FAST_DPHI, n), rng.uniform(-0.5, 0.5, n))
+    dphi[:8] = [S.GL_FAST_DPHI, -S.GL_FAST_DPHI, np.nextafter(S.GL_FAST_DPHI, 1), -np.nextafter(S.GL_FAST_DPHI, 1), 0.0, 1e-9, 0.3, -0.3]
+    U = np.stack([X[:, 3] - dphi, rng.uniform(9, 16, n)], 1)
+    fast = np.abs(X[:, 3] - U[:, 0]) <= S.GL_FAST_DPHI
+    assert 0.3 < fast.mean() < 0.8
+    for tau in (0.01, 0.9667):
+        o = ctx.step(ctx.dev(_planes(X)), ctx.dev(_planes(U)), (0.7, -0.4), tau, 1.0, 0.05).cpu().numpy().T
+        ora = S.disc_dyn_glrk(X, U, (0.7, -0.4), 0.05, tau, 1.0)
+        d = o - ora; d[:, 2] = S.norm_mpi_pi(d[:, 2])
+        assert np.abs(d).max() < 1e-10, (tau, np.abs(d).max(), np.abs(d[fast]).max(), np.abs(d[~fast]).max())
+
+
 def _gvf(ctx, g, n_rows, X0, n_form=1, **kw):
     c = np.tile(g['centres'], (n_form, 1)); N = 4 * n_form
     out = ctx.gvf_run(ctx.dev(_planes(np.tile(X0, (n_form, 1)))), ctx.dev(_planes(c)), ctx.dev(np.full(N, float(g['r']))),
