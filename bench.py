@@ -706,6 +706,20 @@ def main():
             if rep >= 2:
                 best = min(best, time.perf_counter() - tg)
         sw, mv = rep_cold
+        # the same solve with the line search on the joint cost switched off (plain block Gauss-Seidel), no hint: what the slow
+        # scenarios cost without it
+        plan_g.group_order_from_last(Rg, False)
+        os.environ['D2D_GROUPS_LS'] = '0'
+        try:
+            qg = q0g.clone()
+            torch.cuda.synchronize()
+            tg = time.perf_counter()
+            plan_g.solve_groups(dscg, qg, n_ac, max_sweeps=GSWEEPS, inner_iters=8, tol=GTOL)
+            torch.cuda.synchronize()
+            plain_s = time.perf_counter() - tg
+            sw_p, mv_p = plan_g.group_report(Rg)
+        finally:
+            del os.environ['D2D_GROUPS_LS']
         config2 = {'workload': '8-drone circular formation x 8192 replicas (65 536 coupled trajectories), CostCollision rows between all pairs '
                                '(BASELINE configs[2]); block Gauss-Seidel per scenario in one persistent launch (fit_groups_kernel)',
                    'tol': GTOL, 'max_sweeps': GSWEEPS,
@@ -717,6 +731,9 @@ def main():
                    'scenarios_beyond_40_sweeps': int((sw > 40).sum()),
                    'evaluations': float(resg[2][3]),
                    'jtj_frac_of_fp32_mfma_peak': ALG_FLOP_PER_EVAL * float(resg[2][3]) / best / 1e12 / FP32_PEAK_TFLOPS,
+                   'line_search': 'on the joint cost along slow sweeps (include/d2d.h D2D_GS_LS_*); same fixed points as the plain sweeps',
+                   'plain_sweeps': {'seconds': plain_s, 'sweeps_mean': float(sw_p.mean()), 'sweeps_p99': int(np.percentile(sw_p, 99)), 'sweeps_max': int(sw_p.max()),
+                                    'scenarios_beyond_40_sweeps': int((sw_p > 40).sum()), 'settled_frac': float((mv_p <= GTOL).mean())},
                    'round1_seconds': 0.80, 'round3_seconds_tol_1e-10_cap_120_unsettled': 0.107}
         plan_g.close()
         del dscg, q0g, qg

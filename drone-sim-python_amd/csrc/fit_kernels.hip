@@ -535,22 +535,30 @@ fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_cap,
         // (fetch-adds only: a compare-and-swap on the head under 2048 waves that reach their slice boundary together is quadratic)
         // A failed taker's transient -1 on the count can hide an entry from a taker that comes between its two adds, so a wave only
         // gives up when the ring is EMPTY by the tickets: no push begun (queue[3]) that a take has not begun for (queue[2]).
-        for (;;) {
-          const int a = atomicAdd(queue + 4, -1);
-          if (a > 0) {
-            const int h = atomicAdd(queue + 2, 1);              // an entry is ours: completed pushes >= successful takes
-            int32_t *slot = ring + (h & ring_mask);
-            int v;
-            while ((v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < 0) __builtin_amdgcn_s_sleep(1);
-            __hip_atomic_store(slot, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            t = v | 0x40000000;                                 // (bit 30: resumed from the ring)
-            break;
+        // The count is only decremented when a plain load shows it positive: waves that WAIT here (a push has begun, nothing is
+        // ready yet) must not keep the count negative with their own transient decrements -- with hundreds of idle waves cycling
+        // through (-1, +1) the one entry that then arrives is never seen positive by anybody, and the launch never ends
+        // (tests/test_gpu_fullsize.py::test_time_sliced_handout_is_bit_identical hung on exactly that, round 4).
+        // (the wait is bounded -- ~0.5 s -- so that the grid drains whatever happens: a fit left in the ring keeps D2D_ST_RUNNING,
+        // d2d_fit_solve / d2d_fit_iterate count those and launch again)
+        for (int spin = 0;; ++spin) {
+          if (__hip_atomic_load(queue + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0) {
+            const int a = atomicAdd(queue + 4, -1);
+            if (a > 0) {
+              const int h = atomicAdd(queue + 2, 1);            // an entry is ours: completed pushes >= successful takes
+              int32_t *slot = ring + (h & ring_mask);
+              int v;
+              while ((v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < 0) __builtin_amdgcn_s_sleep(1);
+              __hip_atomic_store(slot, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              t = v | 0x40000000;                               // (bit 30: resumed from the ring)
+              break;
+            }
+            atomicAdd(queue + 4, 1);
           }
-          atomicAdd(queue + 4, 1);
           const int pend = __hip_atomic_load(queue + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
                            __hip_atomic_load(queue + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (pend <= 0) break;
-          __builtin_amdgcn_s_sleep(2);
+          if (pend <= 0 || spin > (1 << 18)) break;
+          __builtin_amdgcn_s_sleep(16);
         }
       }
     }
@@ -2017,6 +2025,12 @@ static int launch_step(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, double *q, c
   return D2D_OK;
 }
 
+// the time slice of the fused kernel's hand-out: d2d_fit_opts.slice, or D2D_LM_SLICE (A/B switch of the development tools)
+static int lm_slice(const d2d_fit_opts &o) {
+  static const int slice_env = getenv("D2D_LM_SLICE") ? atoi(getenv("D2D_LM_SLICE")) : -1;
+  return slice_env >= 0 ? slice_env : o.slice;
+}
+
 static int launch_lm(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, double *q, const d2d_fit_opts &o, int iter_cap) {
   const FitGeom gm = geom_of(pl);
   const FusedLds L = fused_lds_layout(pl->K, pl->nq, 48, pl->wpb_lm);
@@ -2029,9 +2043,8 @@ static int launch_lm(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, double *q, con
   const int blocks = B < pl->n_cu ? B : pl->n_cu;     // persistent: one workgroup per CU
   int32_t *queue = ctx->counter_dev + 8;
   static const int prio_only = getenv("D2D_LM_PRIO_AT") ? atoi(getenv("D2D_LM_PRIO_AT")) : 48;     // (A/B switch; large = never)
-  static const int slice_env = getenv("D2D_LM_SLICE") ? atoi(getenv("D2D_LM_SLICE")) : -1;         // (A/B switch: overrides opts.slice)
   d2d_fit_opts oo = o;
-  if (slice_env >= 0) oo.slice = slice_env;
+  oo.slice = lm_slice(o);
   if (oo.slice > 0) {                    // time-sliced hand-out: every launch starts from an empty ring and zeroed tickets
     D2D_CHECK_HIP(hipMemsetAsync(pl->d_ring, 0xff, (size_t)pl->ring_cap * sizeof(int32_t), ctx->stream));
     D2D_CHECK_HIP(hipMemsetAsync(queue + 2, 0, 3 * sizeof(int32_t), ctx->stream));
@@ -2471,11 +2484,15 @@ int d2d_fit_iterate(d2d_ctx *ctx, d2d_fit_plan *pl, int B, const double *scen, d
   if ((pl->use_lm || pl->use_long) && pl->n_group <= 1) {
     int budget = o.max_iter - pl->it_done;
     if (budget > n_iters) budget = n_iters;
-    if (budget > 0) {
+    // Time-sliced hand-out: a fit that a launch left in its ring keeps D2D_ST_RUNNING with its own iteration count below the
+    // cap.  Once the plan's budget is spent such fits are finished by further launches under the full cap (every fit stops at
+    // max_iter iterations of its own) -- without them the caller's `while (running > 0)` would spin on a count that cannot fall.
+    const bool sweep_up = budget <= 0 && pl->use_lm && lm_slice(o) > 0;
+    if (budget > 0 || sweep_up) {
       if (int rc = prof_begin(ctx, pl, 2)) return rc;
-      if (int rc = pl->use_lm ? launch_lm(ctx, pl, B, q, o, pl->it_done + budget) : launch_lm_long(ctx, pl, B, q, o, budget)) return rc;
+      if (int rc = pl->use_lm ? launch_lm(ctx, pl, B, q, o, sweep_up ? o.max_iter : pl->it_done + budget) : launch_lm_long(ctx, pl, B, q, o, budget)) return rc;
       if (int rc = prof_end(ctx, pl)) return rc;
-      pl->it_done += budget;
+      if (budget > 0) pl->it_done += budget;
     }
   } else
   for (int i = 0; i < n_iters && pl->it_done < o.max_iter; ++i, ++pl->it_done) {
@@ -2487,7 +2504,7 @@ int d2d_fit_iterate(d2d_ctx *ctx, d2d_fit_plan *pl, int B, const double *scen, d
     if (int rc = prof_end(ctx, pl)) return rc;
   }
   if (n_running) {
-    if (pl->it_done >= o.max_iter && o.slice <= 0) {
+    if (pl->it_done >= o.max_iter && !(pl->use_lm && lm_slice(o) > 0)) {
       *n_running = 0;                    // the iteration budget is spent: nothing to count (d2d_fit_finish synchronises)
     } else {                             // (with the time-sliced hand-out the flags are counted even then: a fit left in the ring would show)
       D2D_CHECK_HIP(hipMemsetAsync(ctx->counter_dev, 0, sizeof(int32_t), ctx->stream));
@@ -2542,8 +2559,13 @@ int d2d_fit_solve(d2d_ctx *ctx, const d2d_fit_plan *plc, int B, const double *sc
   // the persistent LM kernel masks finished trajectories itself and ends when its last one stops: one
   // launch for the whole solve; the split path counts the running trajectories every check_every iterations
   const int per_call = ((pl->use_lm || pl->use_long) && pl->n_group <= 1) ? o.max_iter : o.check_every;
-  while (running > 0)
+  for (int calls = 0; running > 0; ++calls) {
+    if (calls > o.max_iter + 64) {        // (cannot happen: every call either spends budget or finishes fits a sliced launch left behind)
+      d2d_set_error("d2d_fit_solve: %d trajectories still running after %d launches", (int)running, calls);
+      return D2D_ESTATE;
+    }
     if (int rc = d2d_fit_iterate(ctx, pl, B, scen, q, &o, per_call, &running)) return rc;
+  }
   return d2d_fit_finish(ctx, pl, B, scen, q, cost, iters, status, stats);
 }
 
