@@ -92,6 +92,7 @@ gvf_run_kernel(d2d_gvf_params p, GlMesh mesh, int fpb, const double *__restrict_
   int my_stop = p.n_rows;      // formation-uniform
   bool prev_all_ok = false;    // result of the stop test at the end of the previous step
   int n_true = 0, first_true = -1;   // phase-error rule (use_stop == 2): steps on which it held so far, loop index i-1 of the first one
+  double sin_psi = 0.0, cos_psi = 1.0;
   for (int i = 1; i < p.n_rows; ++i) {
     // src/11_full_sim_case1.py:140 -- `if np.all(stop)==1 and t>0: break` at the top of step i
     if (p.use_stop) {
@@ -119,10 +120,13 @@ gvf_run_kernel(d2d_gvf_params p, GlMesh mesh, int fpb, const double *__restrict_
     for (int m = 0; m < nm; ++m) Ur += sh_B[a * nm + m] * sh_e[base + m];
     Ur *= -p.kr;
     const double Rr = Ur + R;
-    double sin_psi, cos_psi;                               // one sincos per step, shared by the guidance law and the plant
-    sincos(s.psi, &sin_psi, &cos_psi);
-    const double phi_c = gvf_bank_cmd(s, sin_psi, cos_psi, cx, cy, Rr, p.ke, p.kd, nullptr, nullptr);
-    State5 sn = plant_step(s, phi_c, p.v_c, p.wx, p.wy, mesh, sin_psi, cos_psi);
+    // (sin, cos) of the heading, shared by the guidance law and the plant: the plant step hands the pair of its new heading on
+    // (rotations by the turn of a panel: one rounding each), a sincos refreshes it every 16th step
+    if ((i & 15) == 1) sincos(s.psi, &sin_psi, &cos_psi);
+    double tan_c;
+    const double phi_c = gvf_bank_cmd(s, sin_psi, cos_psi, cx, cy, Rr, p.ke, p.kd, nullptr, nullptr, &tan_c);
+    double sn_n = sin_psi, cs_n = cos_psi;
+    State5 sn = plant_step<true>(s, phi_c, p.v_c, p.wx, p.wy, mesh, sn_n, cs_n, tan_c);
     if (run) {
       if (U_hist && ((i - 1) % rs == 0)) {
         const long r = (long)((i - 1) / rs) * 2 * N;
@@ -139,6 +143,7 @@ gvf_run_kernel(d2d_gvf_params p, GlMesh mesh, int fpb, const double *__restrict_
         if (eth_hist && a < nm) eth_hist[row * (long)p.n_form * nm + (long)f * nm + a] = e * (180.0 / D2D_PI);
       }
       s = sn;
+      sin_psi = sn_n; cos_psi = cs_n;
     }
     if (p.use_stop) {
       // :170-175 -- |X[0:3]-X0f[0:3]| <= tol for every aircraft of the formation
