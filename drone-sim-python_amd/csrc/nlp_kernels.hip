@@ -1014,7 +1014,11 @@ __device__ __forceinline__ void nlp_solve_one(int N, double h, const d2d_nlp_opt
   int total_inner = 0, status = D2D_ST_MAXITER;
   double err = 0.0, cost_ref = 0.0, feas = 0.0;
   int n_stalled = 0;                        // outer iterations in a row at the largest penalty without feasibility progress
-  for (int outer = 1; outer <= o.outer_max; ++outer) {
+  // CostBank max mode ends "converged in value": a whole batch of steps that no longer lowers the merit function.  That test needs
+  // a window of its own length, whatever the batch of the schedule is: D2D_NLP_BANKMAX_BATCHES batches in one (same step budget).
+  const int inner_n = s.sbank > 0.0 ? D2D_NLP_BANKMAX_BATCHES * o.inner_max : o.inner_max;
+  const int outer_n = s.sbank > 0.0 ? (o.outer_max + D2D_NLP_BANKMAX_BATCHES - 1) / D2D_NLP_BANKMAX_BATCHES : o.outer_max;
+  for (int outer = 1; outer <= outer_n; ++outer) {
     const double tol_in = fmax(fmax(o.opt_tol, fmin(1e-1, 10.0 * mub)), D2D_NLP_GRAD_FLOOR * rho);
     // merit value of the current point for this (mub, rho, mu): one pass here, afterwards the accepted trial's value
     NLP_STAMP(7)
@@ -1022,7 +1026,7 @@ __device__ __forceinline__ void nlp_solve_one(int N, double h, const d2d_nlp_opt
     const double phi_first = phi0;
     NLP_STAMP(0)
     bool accepted = false;
-    for (int it = 0; it < o.inner_max; ++it) {
+    for (int it = 0; it < inner_n; ++it) {
       ++total_inner;
       bool converged = false;
       accepted = false;

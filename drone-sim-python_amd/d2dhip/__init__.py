@@ -64,6 +64,7 @@ class FitOpts(C.Structure):
 
 
 SO_LAMBDA = 1e-4          # D2D_LM_SO_LAMBDA: damping below which the evaluations carry the second-order term (FAST mode)
+NLP_INNER_MAX, NLP_OUTER_MAX = 20, 120     # include/d2d.h D2D_NLP_INNER_MAX / D2D_NLP_OUTER_MAX (tests/test_abi.py compares)
 MODE_MINPACK, MODE_FAST = 0, 1     # D2D_LM_MODE_*: MINPACK's lmder path (what scipy least_squares('lm') follows) / rounds 1-2's loop
 MP_FINISH = 3             # D2D_LM_MP_FINISH: calm lmder steps before the second-order finish (0 = pure lmder)
 MP_SLOW = 8               # D2D_LM_MP_SLOW: stagnating lmder trials (cost change <= 1e-4 of itself) in a row before the finish (0 = never)
@@ -383,8 +384,8 @@ class Context:
                                          _ptr(out['Xr']), _ptr(out['X_final'])))
         return out
 
-    def nlp_solve(self, scen, W, h, partner=None, rho0=10.0, mub0=0.1, mub_min=1e-9, feas_tol=1e-9, opt_tol=1e-7, inner_max=60,
-                  outer_max=40, want_mult=False, serial=0, bounds=None):
+    def nlp_solve(self, scen, W, h, partner=None, rho0=10.0, mub0=0.1, mub_min=1e-9, feas_tol=1e-9, opt_tol=1e-7, inner_max=NLP_INNER_MAX,
+                  outer_max=NLP_OUTER_MAX, want_mult=False, serial=0, bounds=None):
         """Direct-collocation NLP in node variables (d2d_nlp_solve): scen dev [B][SCEN_STRIDE], W dev [B][5][N] in/out (initial
         guess -> solution), partner dev [B][2][N] or None, bounds dev [B][4] = (phi_lo, phi_hi, psi_lo, psi_hi) or None (d2d_nlp_opts.bounds).
         Returns dict(cost, feas, iters, status[, mult [B][3][N]]) of device tensors."""
@@ -405,7 +406,7 @@ class Context:
         return out
 
     def nlp_solve_groups(self, scen, W, h, n_ac, max_sweeps=12, tol=1e-7, rho0=10.0, mub0=0.1, mub_min=1e-9, feas_tol=1e-9, opt_tol=1e-7,
-                         inner_max=60, outer_max=40, serial=0, bounds=None):
+                         inner_max=NLP_INNER_MAX, outer_max=NLP_OUTER_MAX, serial=0, bounds=None):
         """The reference's multi-aircraft Problem for R scenarios in one launch (d2d_nlp_solve_groups): scen dev [R*n_ac][SCEN_STRIDE],
         W dev [R*n_ac][5][N] in/out, the aircraft of a scenario consecutive; CostCollision couples aircraft 0 and 1 (rows' KCOL > 0).
         Returns dict(cost, feas, iters, status per aircraft; sweeps, moved per scenario) of device tensors."""

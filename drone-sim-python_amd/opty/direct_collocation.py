@@ -128,8 +128,10 @@ class Problem:
         W = np.stack([np.stack([get(sl._slice_x, a), get(sl._slice_y, a), get(sl._slice_psi, a), get(sl._slice_phi, a),
                                 get(sl._slice_v, a)], 0) for a in range(n)], 0)                       # (n, 5, N)
         rows, coupled = self._rows()
-        # IPOPT's max_iter counts Newton steps; here they are grouped as outer (multiplier / barrier updates) x inner (<= 60)
-        kw = dict(inner_max=60, outer_max=int(min(max(self.options.get('max_iter', 3000) // 60, 12), 60)))
+        # IPOPT's max_iter counts Newton steps; here they are grouped as outer (multiplier / barrier updates) x inner (<= D2D_NLP_INNER_MAX):
+        # between 720 and 3600 steps in all, as in rounds 2-3 (12 .. 60 batches of 60)
+        _im = d2dhip.NLP_INNER_MAX
+        kw = dict(inner_max=_im, outer_max=int(min(max(self.options.get('max_iter', 3000) // _im, 720 // _im), 3600 // _im)))
         # IPOPT's `tol` (the reference sets 1e-5 .. 1e-8) bounds its scaled KKT error.  This backend's own tolerances -- barrier KKT
         # error of the last inner problem 1e-7, collocation residual 1e-9 -- are at least as tight as every value the reference
         # uses, so a looser `tol` changes nothing; a tighter one tightens them with it.

@@ -32,7 +32,8 @@ NV = 5                      # variables per node: x, y, psi, phi, v
 RHO0, RHO_MAX, RHO_GROW = 10.0, 1e8, 10.0
 LAM0, LAM_MIN, LAM_MAX = 1e-3, 1e-12, 1e12
 FEAS_TOL, OPT_TOL = 1e-9, 1e-7
-INNER_MAX, OUTER_MAX = 60, 40
+INNER_MAX, OUTER_MAX = 20, 120      # include/d2d.h D2D_NLP_INNER_MAX / D2D_NLP_OUTER_MAX
+BANKMAX_BATCHES = 3                 # D2D_NLP_BANKMAX_BATCHES
 MUB0, MUB_MIN = 1e-1, 1e-9   # barrier parameter: start, floor
 GATE_PROGRESS = 1e-9      # relative decrease of the merit function over a batch of inner_max steps below which an unsolved inner problem is left
 STALL_OUTERS = 5          # solved inner problems in a row (each with a tenfold penalty) that did not halve the violation: give up
@@ -303,6 +304,8 @@ def solve(pb, W0, verbose=False, rho0=RHO0, inner_max=INNER_MAX, outer_max=OUTER
     total_inner = 0
     status = 2
     n_stalled = 0
+    if pb.bank_max:                 # the value test of the max mode needs a window of its own length (include/d2d.h D2D_NLP_BANKMAX_BATCHES)
+        inner_max, outer_max = BANKMAX_BATCHES * inner_max, (outer_max + BANKMAX_BATCHES - 1) // BANKMAX_BATCHES
     for outer in range(1, outer_max + 1):
         tol_in = max(opt_tol, min(1e-1, 10.0 * mub), GRAD_FLOOR * rho)
         phi_first = phi_last = None

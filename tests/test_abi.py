@@ -38,6 +38,13 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(d2dhip.TrackParams) == 2 * 4 + 5 * 8 + 5 * 8 + 3 * 8 + 7 * 8
     assert ctypes.sizeof(d2dhip.FitOpts) == 2 * 4 + 4 * 8 + 2 * 4 + 3 * 8 + 2 * 4     # + mode, mp_finish, mp_ftol/xtol/gtol, slice, mp_slow
     assert d2dhip.SCEN_STRIDE == 80 and d2dhip.MAX_OBS == 16
+    # defaults that the binding and the oracle repeat from the header
+    hdr = open(os.path.join(ROOT, 'include', 'd2d.h')).read()
+    from oracle import nlp as NL, fit as F, sim as S
+    val = lambda name: float(re.search(r'#define %s ([-+0-9.eE]+)' % name, hdr).group(1))       # noqa: E731
+    assert (d2dhip.NLP_INNER_MAX, d2dhip.NLP_OUTER_MAX) == (val('D2D_NLP_INNER_MAX'), val('D2D_NLP_OUTER_MAX')) == (NL.INNER_MAX, NL.OUTER_MAX)
+    assert (F.GS_LS_SWEEP0, F.GS_LS_RATIO, F.GS_LS_FIRST_MAX, F.GS_LS_MAX) == tuple(val('D2D_GS_LS_' + k) for k in ('SWEEP0', 'RATIO', 'FIRST_MAX', 'MAX'))
+    assert (S.GL_FAST_STAGES, S.GL_FAST_DPHI) == (val('D2D_GL_FAST_STAGES'), val('D2D_GL_FAST_DPHI'))
 
 
 def test_missing_library_fails_loudly(monkeypatch):
