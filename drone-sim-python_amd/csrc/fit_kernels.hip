@@ -1358,7 +1358,7 @@ fit_lm_long_kernel(int B, FitGeom g, LongLds L, d2d_fit_opts opts, int iter_budg
     const GroupCtx gc{ga.pos, ga.n_ac, ga.n_ac > 0 ? b % ga.n_ac : 0, ga.n_ac > 0 ? (b / ga.n_ac) * ga.n_ac : 0, ga.pos ? ga.nds : 0};
     const double *pkb = pk + (size_t)b * FIT_PK * g.K;
     double qi = act ? q_io[(size_t)b * n + lane] : 0.0;
-    double lam = lm[LM_STRIDE * b + 0], nu = lm[LM_STRIDE * b + 1];
+    double lam = uniform_d(lm[LM_STRIDE * b + 0]), nu = uniform_d(lm[LM_STRIDE * b + 1]);      // (wave-uniform: scalar registers)
     int iters = flags[4 * b + FL_ITERS];
     int nev = 0, local = 0, status = D2D_ST_RUNNING;
     bool so_rows = uniform_i(lm[LM_STRIDE * b + 3] != 0.0 ? 1 : 0) != 0;
@@ -1578,7 +1578,7 @@ fit_lm_long_kernel(int B, FitGeom g, LongLds L, d2d_fit_opts opts, int iter_budg
       }
       const StepOutcome so = lm_update(ok != 0, fin, accept, accept ? alpha : 1.0, c, ct, pred, pred_s, dmax, qmax, lam, nu, opts);
       ++iters; ++local;
-      lam = so.lam; nu = so.nu; status = so.status;
+      lam = uniform_d(so.lam); nu = uniform_d(so.nu); status = so.status;
       if (so.accept) {
         qi += alpha * delta;
         need_eval = true;                                // (also when converged: cost and J^T r at the final point)
