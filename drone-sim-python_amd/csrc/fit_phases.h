@@ -911,7 +911,7 @@ __device__ __forceinline__ int mp_trial(MpState &s, const d2d_fit_opts &o, doubl
     const bool ok = solve(gn ? 0.0 : par, gn ? 1 : (it + 1 < 10 ? 2 : 0), s.delta, dls, dxn, t2);
     ++s.nfac;
     if (gn) {
-      s.gn_ok = ok ? 1 : 0; s.p_gn = dls; s.dx_gn = dxn; s.t2_gn = t2; s.gn_valid = 1;
+      s.gn_ok = ok ? 1 : 0; s.p_gn = dls; s.dx_gn = uniform_d(dxn); s.t2_gn = uniform_d(t2); s.gn_valid = 1;      // (state that lives across trials: scalar registers)
       done = gn_post();
       continue;
     }
@@ -930,7 +930,7 @@ __device__ __forceinline__ int mp_trial(MpState &s, const d2d_fit_opts &o, doubl
     par = fmax(parl, par + parc);
   }
   // ---- the trial point and lmder's updates ----
-  if (s.first) { s.delta = fmin(s.delta, pn); s.first = 0; }
+  if (s.first) { s.delta = uniform_d(fmin(s.delta, pn)); s.first = 0; }
   const double ct = trial(dl);
   const bool ctfin = fabs(ct) <= 1.79e308;
   const double fnorm1 = ctfin ? sqrt(ct) : 1.79e308;
@@ -944,13 +944,13 @@ __device__ __forceinline__ int mp_trial(MpState &s, const d2d_fit_opts &o, doubl
   if (ratio <= 0.25) {
     double temp = actred >= 0.0 ? 0.5 : 0.5 * dirder / (dirder + 0.5 * actred);
     if (0.1 * fnorm1 >= fnorm || temp < 0.1) temp = 0.1;
-    s.delta = temp * fmin(s.delta, pn / 0.1);
+    s.delta = uniform_d(temp * fmin(s.delta, pn / 0.1));
     par = par / temp;
   } else if (par == 0.0 || ratio >= 0.75) {
-    s.delta = pn / 0.5;
+    s.delta = uniform_d(pn / 0.5);
     par = 0.5 * par;
   }
-  s.par = par;
+  s.par = uniform_d(par);
   accepted = ratio >= 1e-4;
   if (accepted) {
     qi += (double)dl; c = ct;
