@@ -33,6 +33,7 @@ static GlMesh make_mesh(double dt, double tau_phi, double tau_v) {
   }
   m.fast[13] = std::exp(-dt / tau_phi);
   m.fast[14] = std::exp(-dt / tau_v);
+  m.fast_dphi = (dt <= D2D_GL_FAST_RATIO * tau_phi) ? D2D_GL_FAST_DPHI : -1.0;
   return m;
 }
 

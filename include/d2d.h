@@ -79,6 +79,8 @@ int d2d_allreduce_stats(d2d_ctx *ctx, d2d_comm *comm, double *stats);     /* D2D
  * panel of D2D_GL_FAST_STAGES stages over the whole step instead (the boundary layer it has to resolve is that small) */
 #define D2D_GL_FAST_STAGES 6
 #define D2D_GL_FAST_DPHI 0.02
+#define D2D_GL_FAST_RATIO 6.0      /* ... and only while dt <= GL_FAST_RATIO * tau_phi: the one panel integrates exp(-t / tau_phi) over the whole step
+                                      (error at the threshold: 2e-10 at dt = 5 tau_phi, 7e-8 at 10 tau_phi, 8e-6 at 20 tau_phi; the graded panels: <= 1e-9) */
 
 /* One batched plant step.  Replaces Aircraft.disc_dyn(Xk, Uk, W, t, dt)
  * (src/d2d/dynamic.py:25-28; model :14-23, heading wrap :27 / src/d2d/utils.py:7).

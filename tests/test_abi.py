@@ -44,7 +44,7 @@ def test_struct_layouts_match_header():
     val = lambda name: float(re.search(r'#define %s ([-+0-9.eE]+)' % name, hdr).group(1))       # noqa: E731
     assert (d2dhip.NLP_INNER_MAX, d2dhip.NLP_OUTER_MAX) == (val('D2D_NLP_INNER_MAX'), val('D2D_NLP_OUTER_MAX')) == (NL.INNER_MAX, NL.OUTER_MAX)
     assert (F.GS_LS_SWEEP0, F.GS_LS_RATIO, F.GS_LS_FIRST_MAX, F.GS_LS_MAX) == tuple(val('D2D_GS_LS_' + k) for k in ('SWEEP0', 'RATIO', 'FIRST_MAX', 'MAX'))
-    assert (S.GL_FAST_STAGES, S.GL_FAST_DPHI) == (val('D2D_GL_FAST_STAGES'), val('D2D_GL_FAST_DPHI'))
+    assert (S.GL_FAST_STAGES, S.GL_FAST_DPHI, S.GL_FAST_RATIO) == (val('D2D_GL_FAST_STAGES'), val('D2D_GL_FAST_DPHI'), val('D2D_GL_FAST_RATIO'))
 
 
 def test_missing_library_fails_loudly(monkeypatch):

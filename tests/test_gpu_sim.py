@@ -59,11 +59,11 @@ def test_step_one_panel_and_graded_meshes_match_oracle(ctx):
     U = np.stack([X[:, 3] - dphi, rng.uniform(9, 16, n)], 1)
     fast = np.abs(X[:, 3] - U[:, 0]) <= S.GL_FAST_DPHI
     assert 0.3 < fast.mean() < 0.8
-    for tau in (0.01, 0.9667):
-        o = ctx.step(ctx.dev(_planes(X)), ctx.dev(_planes(U)), (0.7, -0.4), tau, 1.0, 0.05).cpu().numpy().T
-        ora = S.disc_dyn_glrk(X, U, (0.7, -0.4), 0.05, tau, 1.0)
+    for tau, dt in ((0.01, 0.05), (0.9667, 0.05), (0.01, 0.2), (0.01, 0.06), (0.01, 0.061)):      # (dt > GL_FAST_RATIO tau: graded panels only)
+        o = ctx.step(ctx.dev(_planes(X)), ctx.dev(_planes(U)), (0.7, -0.4), tau, 1.0, dt).cpu().numpy().T
+        ora = S.disc_dyn_glrk(X, U, (0.7, -0.4), dt, tau, 1.0)
         d = o - ora; d[:, 2] = S.norm_mpi_pi(d[:, 2])
-        assert np.abs(d).max() < 1e-10, (tau, np.abs(d).max(), np.abs(d[fast]).max(), np.abs(d[~fast]).max())
+        assert np.abs(d).max() < 1e-10, (tau, dt, np.abs(d).max(), np.abs(d[fast]).max(), np.abs(d[~fast]).max())
 
 
 def _gvf(ctx, g, n_rows, X0, n_form=1, **kw):

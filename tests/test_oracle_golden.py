@@ -55,6 +55,13 @@ def test_plant_glrk_both_meshes_against_a_tight_lsoda():
     assert fast.sum() >= 30 and (~fast).sum() >= 28
     assert err[fast].max() < 2e-9, err[fast].max()
     assert err[~fast].max() < 5e-8, err[~fast].max()
+    # a step much longer than tau_phi (dt = 20 tau_phi > GL_FAST_RATIO tau_phi) never takes the one panel, however close the bank is to its
+    # command: its error there would be 8e-6 (the graded panels: 1e-9)
+    for i in np.nonzero(fast)[0][:8]:
+        ref = S.disc_dyn_odeint(X[i], U[i], W, 0.0, 0.2, 0.01, rtol=1e-13, atol=1e-13)
+        d = S.disc_dyn_glrk(X[i], U[i], W, 0.2, 0.01) - ref
+        d[2] = S.norm_mpi_pi(d[2])
+        assert np.abs(d).max() < 2e-8, np.abs(d).max()
     # the two meshes agree where they meet: no jump of the trajectory at the threshold
     Xs, Us = X[:4].copy(), U[:4].copy()
     for sgn in (1.0, -1.0):
