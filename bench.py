@@ -451,6 +451,51 @@ def sim_records(ctx, torch, cpu_g, cpu_t, drones=65536, steps=10000, track_steps
 
 
 # ---------------------------------------------------------------------------------------
+# The line the driver parses is the LAST stdout line and stays small (round 4's 20.9 kB line was not parsed): contract keys +
+# `roofline` + `cpu_baseline` + the hoisted scalars.  Everything else goes to the side file and to an EARLIER, prefixed stdout line.
+LINE_LIMIT = 4096
+ROOF_KEYS = ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'alg_flop_per_unit', 'units_per_launch_avg', 'avg_launch_us', 'launches')
+CPU_KEYS = ('value', 'unit', 'cores', 'kind', 'sample', 'host_cpu_count')
+DETAIL_PREFIX = 'BENCH_DETAIL '
+
+
+def _clip(v, n):
+    return v if not isinstance(v, str) or len(v) <= n else v[:n - 3] + '...'
+
+
+def compact_line(line, roof, cpu, detail_file=None):
+    """The final JSON line: `line` (scalars and the small `config` object only) + the contract's `roofline` and `cpu_baseline`
+    objects reduced to the keys the contract names.  Strings are clipped (harder if needed) so that the line never exceeds LINE_LIMIT."""
+    for n in (400, 160, 80, 40):
+        out = {k: _clip(v, n) for k, v in line.items() if not isinstance(v, (dict, list))}
+        out['config'] = {k: _clip(v, n) for k, v in line.get('config', {}).items()}
+        for k, v in line.items():
+            if isinstance(v, list):
+                out[k] = v
+        out['roofline'] = {k: _clip(roof[k], n) for k in ROOF_KEYS if k in roof} if roof else None
+        out['cpu_baseline'] = {k: _clip(cpu[k], n) for k in CPU_KEYS if k in cpu} if cpu else None
+        out['detail'] = detail_file
+        s = json.dumps(out)
+        if len(s) <= LINE_LIMIT:
+            return s
+    raise ValueError(f'bench line is {len(s)} bytes, limit {LINE_LIMIT}: too many hoisted keys')
+
+
+def emit(line, detail, roof, cpu):
+    """Side file (gpurun_out/ when it exists, so that it travels back from a GPU box) + prefixed detail line, THEN the small line."""
+    d = os.path.join(ROOT, 'gpurun_out')
+    path = os.path.join(d if os.path.isdir(d) and os.access(d, os.W_OK) else ROOT, 'bench_detail.json')
+    try:
+        with open(path, 'w') as f:
+            json.dump(detail, f, indent=1)
+        rel = os.path.relpath(path, ROOT)
+    except OSError:
+        rel = None
+    print(DETAIL_PREFIX + json.dumps(detail), flush=True)
+    print(compact_line(line, roof, cpu, rel), flush=True)
+
+
+# ---------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -703,6 +748,7 @@ def main():
             if rep == 1:
                 cold = time.perf_counter() - tg
                 rep_cold = plan_g.group_report(Rg)
+                evals_cold = float(resg[2][3])
             if rep >= 2:
                 best = min(best, time.perf_counter() - tg)
         sw, mv = rep_cold
@@ -729,8 +775,9 @@ def main():
                    'settled_frac': float((mv <= GTOL).mean()), 'last_sweep_max_rel_move': float(mv.max()),
                    'sweeps_mean': float(sw.mean()), 'sweeps_p50': int(np.percentile(sw, 50)), 'sweeps_p99': int(np.percentile(sw, 99)), 'sweeps_max': int(sw.max()),
                    'scenarios_beyond_40_sweeps': int((sw > 40).sum()),
-                   'evaluations': float(resg[2][3]),
-                   'jtj_frac_of_fp32_mfma_peak': ALG_FLOP_PER_EVAL * float(resg[2][3]) / best / 1e12 / FP32_PEAK_TFLOPS,
+                   'target_seconds': 0.06, 'meets_target': bool(cold <= 0.06),
+                   'evaluations': evals_cold,           # of the same cold solve as `seconds`
+                   'jtj_frac_of_fp32_mfma_peak': ALG_FLOP_PER_EVAL * evals_cold / cold / 1e12 / FP32_PEAK_TFLOPS,
                    'line_search': 'on the joint cost along slow sweeps (include/d2d.h D2D_GS_LS_*); same fixed points as the plain sweeps',
                    'plain_sweeps': {'seconds': plain_s, 'sweeps_mean': float(sw_p.mean()), 'sweeps_p99': int(np.percentile(sw_p, 99)), 'sweeps_max': int(sw_p.max()),
                                     'scenarios_beyond_40_sweeps': int((sw_p > 40).sum()), 'settled_frac': float((mv_p <= GTOL).mean())},
@@ -849,10 +896,10 @@ def main():
             # -- multi-GPU: which collective ran, on how many RCCL ranks, and the per-rank spread of the solver kernel --
             'collective': reducer.collective, 'rccl_ranks': reducer.rccl_ranks,
             'rank_kernel_ms_per_step_min_max': list(head_rank_ms),
-            'variants': variants,      # same batch, same timing discipline: the other solver (fast_mode), pure lmder, and the order hint
-            'roofline': roof, 'roofline_isolated': roof_iso, 'config2': config2, 'config3': config3, 'parity': parity, 'sim': sim, 'nlp': nlp, 'long_horizon': longh, 'cpu_baseline': cpu,
         }
-        print(json.dumps(line))
+        detail = dict(line, variants=variants, roofline=roof, roofline_isolated=roof_iso, config2=config2, config3=config3, parity=parity, sim=sim, nlp=nlp,
+                      long_horizon=longh, cpu_baseline=cpu)
+        emit(line, detail, roof, cpu)
     if dist is not None:
         dist.destroy_process_group()
 
