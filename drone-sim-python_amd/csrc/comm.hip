@@ -17,6 +17,7 @@ typedef int (*CommDestroyFn)(Comm);
 typedef int (*AllReduceFn)(const void *, void *, size_t, int, int, Comm, hipStream_t);
 typedef int (*GroupFn)(void);
 typedef const char *(*ErrStrFn)(int);
+typedef int (*CommQueryFn)(const Comm, int *);      // ncclCommCount, ncclCommUserRank
 struct Rccl {
   void *h = nullptr;
   GetUniqueIdFn get_id = nullptr;
@@ -25,6 +26,7 @@ struct Rccl {
   AllReduceFn all_reduce = nullptr;
   GroupFn group_start = nullptr, group_end = nullptr;
   ErrStrFn err = nullptr;
+  CommQueryFn count = nullptr, user_rank = nullptr;
 };
 Rccl g_rccl;
 
@@ -43,7 +45,9 @@ int load_rccl() {
   r.group_start = reinterpret_cast<GroupFn>(dlsym(h, "ncclGroupStart"));
   r.group_end = reinterpret_cast<GroupFn>(dlsym(h, "ncclGroupEnd"));
   r.err = reinterpret_cast<ErrStrFn>(dlsym(h, "ncclGetErrorString"));
-  if (!r.get_id || !r.init_rank || !r.destroy || !r.all_reduce || !r.group_start || !r.group_end) {
+  r.count = reinterpret_cast<CommQueryFn>(dlsym(h, "ncclCommCount"));
+  r.user_rank = reinterpret_cast<CommQueryFn>(dlsym(h, "ncclCommUserRank"));
+  if (!r.get_id || !r.init_rank || !r.destroy || !r.all_reduce || !r.group_start || !r.group_end || !r.count || !r.user_rank) {
     d2d_set_error("librccl is missing an expected symbol");
     return D2D_ESTATE;
   }
@@ -104,8 +108,17 @@ int d2d_comm_destroy(d2d_comm *comm) {
 
 int d2d_comm_info(const d2d_comm *comm, int32_t *rank, int32_t *world) {
   D2D_REQUIRE(comm != nullptr, "d2d_comm_info: comm is NULL");
-  if (rank) *rank = comm->rank;
-  if (world) *world = comm->world;
+  // what the COMMUNICATOR says (ncclCommUserRank / ncclCommCount), not what the caller passed to d2d_comm_create: the caller's
+  // values are only the cross-check -- a communicator that disagrees with them is not the one the caller thinks it has
+  int r = -1, w = -1;
+  D2D_CHECK_NCCL(g_rccl.user_rank(comm->comm, &r));
+  D2D_CHECK_NCCL(g_rccl.count(comm->comm, &w));
+  if (r != comm->rank || w != comm->world) {
+    d2d_set_error("d2d_comm_info: RCCL reports rank %d of %d, d2d_comm_create was given rank %d of %d", r, w, comm->rank, comm->world);
+    return D2D_ESTATE;
+  }
+  if (rank) *rank = r;
+  if (world) *world = w;
   return D2D_OK;
 }
 

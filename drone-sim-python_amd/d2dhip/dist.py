@@ -24,12 +24,13 @@ class StatsReducer:
     communicator cannot be created (e.g. librccl cannot be loaded) the exchange stays on torch.distributed and `self.collective`
     says why.  `self.rccl_ranks` = the rank count the d2d_comm reports."""
 
-    def __init__(self, dist=None, device='cpu', ctx=None):
+    def __init__(self, dist=None, device='cpu', ctx=None, force_comm=False):
         self.dist = dist
         self.comm = None
         self.rccl_ranks = None
         self.collective = 'none (one rank)' if dist is None else f'torch.distributed ({dist.get_backend()})'
-        if dist is not None and ctx is not None and dist.get_backend() == 'nccl':
+        # (force_comm: tests drive the agreement protocol of _make_comm over gloo with a stand-in context)
+        if dist is not None and ctx is not None and (dist.get_backend() == 'nccl' or force_comm):
             self._make_comm(dist, ctx)
         if dist is not None:
             import torch
@@ -44,19 +45,47 @@ class StatsReducer:
             self.run_dev = torch.zeros(1, dtype=torch.float64, device=device)
 
     def _make_comm(self, dist, ctx):
+        """Every step that can fail on ONE rank is followed by a collective agreement, so that all ranks end on the same
+        collective: rank 0 always takes part in the broadcast of the id (129 bytes: the id + an ok flag, zero when it could not
+        be created), and after d2d_comm_create every rank all-reduces (MIN) its own ok flag over torch.distributed -- if any rank
+        failed, every rank closes its d2d_comm and the exchange stays on torch.distributed."""
         import torch
-        try:
-            rank, world = dist.get_rank(), dist.get_world_size()
-            uid = torch.zeros(128, dtype=torch.uint8, device=ctx.device)
-            if rank == 0:
-                uid.copy_(torch.frombuffer(bytearray(ctx.comm_unique_id()), dtype=torch.uint8))
-            dist.broadcast(uid, src=0)
-            self.comm = ctx.comm_create(bytes(uid.cpu().numpy().tobytes()), rank, world)
-            self.rccl_ranks = self.comm.info()[1]
-            self.collective = 'd2d_allreduce_stats (RCCL through the C-ABI, d2d_comm of %d ranks)' % self.rccl_ranks
-        except Exception as e:       # noqa: BLE001  (fall back to torch.distributed, say so)
+        rank, world = dist.get_rank(), dist.get_world_size()
+        why = None
+        msg = torch.zeros(129, dtype=torch.uint8, device=ctx.device)
+        if rank == 0:
+            try:
+                buf = bytearray(ctx.comm_unique_id()) + bytearray([1])
+                msg.copy_(torch.frombuffer(buf, dtype=torch.uint8))
+            except Exception as e:       # noqa: BLE001  (msg stays zero: flag 0 tells the others)
+                why = f'd2d_comm_unique_id: {e!r}'
+        dist.broadcast(msg, src=0)
+        raw = bytes(msg.cpu().numpy().tobytes())
+        comm = None
+        if raw[128] == 1:
+            try:
+                comm = ctx.comm_create(raw[:128], rank, world)
+                info = comm.info()           # ncclCommUserRank / ncclCommCount, cross-checked against (rank, world) by the library
+                if tuple(info) != (rank, world):
+                    raise RuntimeError(f'd2d_comm reports rank {info[0]} of {info[1]}, expected {rank} of {world}')
+            except Exception as e:       # noqa: BLE001
+                why = f'd2d_comm_create: {e!r}'
+                if comm is not None:
+                    comm.close()
+                comm = None
+        elif why is None:
+            why = 'rank 0 could not create the RCCL id'
+        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=ctx.device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 1:
+            self.comm = comm
+            self.rccl_ranks = comm.info()[1]
+            self.collective = 'd2d_allreduce_stats (RCCL through the C-ABI, d2d_comm of %d ranks by ncclCommCount)' % self.rccl_ranks
+        else:
+            if comm is not None:
+                comm.close()
             self.comm = None
-            self.collective = f'torch.distributed ({dist.get_backend()}); d2d_comm not created: {e!r}'[:300]
+            self.collective = (f'torch.distributed ({dist.get_backend()}); d2d_comm not used: ' + (why or 'another rank could not create it'))[:300]
 
     def _abi(self, a, b, c):
         """one d2d_allreduce_stats: (sum a, max b, sum c) over the ranks"""

@@ -63,7 +63,7 @@ typedef struct d2d_comm d2d_comm;
 int d2d_comm_unique_id(void *id_out);
 int d2d_comm_create(d2d_ctx *ctx, const void *id, int rank, int world, d2d_comm **out);
 int d2d_comm_destroy(d2d_comm *comm);
-int d2d_comm_info(const d2d_comm *comm, int32_t *rank, int32_t *world);   /* what the communicator was created with (either may be NULL) */
+int d2d_comm_info(const d2d_comm *comm, int32_t *rank, int32_t *world);   /* ncclCommUserRank / ncclCommCount of the communicator (either may be NULL); D2D_ESTATE if they differ from what d2d_comm_create was given */
 int d2d_allreduce_stats(d2d_ctx *ctx, d2d_comm *comm, double *stats);     /* D2D_EINVAL if stats is not device memory */
 
 /* ------------------------------------------------------------------------------------

@@ -107,6 +107,81 @@ def test_two_rank_gloo_sharded_solve():
     np.testing.assert_allclose(np.concatenate([r0['cost'], r1['cost']]), ref, rtol=1e-9)
 
 
+class _FakeComm:
+    """stand-in for d2dhip.Comm over gloo: same surface (info / allreduce_stats / close)"""
+
+    def __init__(self, dist, rank, world, log):
+        self.dist, self.rank, self.world, self.log = dist, rank, world, log
+
+    def info(self):
+        return self.rank, self.world
+
+    def allreduce_stats(self, t):
+        self.log.append('abi')
+        a, b, c = t[0:1].clone(), t[1:2].clone(), t[2:3].clone()
+        self.dist.all_reduce(a, op=self.dist.ReduceOp.SUM); self.dist.all_reduce(b, op=self.dist.ReduceOp.MAX); self.dist.all_reduce(c, op=self.dist.ReduceOp.SUM)
+        t[0], t[1], t[2] = a[0], b[0], c[0]
+
+    def close(self):
+        self.log.append('closed')
+
+
+class _FakeCtx:
+    """stand-in context: fails where `case` says so, on the rank it says"""
+    device = 'cpu'
+
+    def __init__(self, dist, rank, case, log):
+        self.dist, self.rank, self.case, self.log = dist, rank, case, log
+
+    def comm_unique_id(self):
+        if self.case == 'uid_fails_on_rank0':
+            raise OSError('librccl.so.1 cannot be loaded')
+        return bytes(range(128))
+
+    def comm_create(self, uid, rank, world):
+        assert uid == bytes(range(128))
+        if self.case == 'create_fails_on_rank1' and rank == 1:
+            raise RuntimeError('ncclCommInitRank failed')
+        return _FakeComm(self.dist, rank, world, self.log)
+
+
+def _agree_worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    res = {}
+    for case in ('uid_fails_on_rank0', 'create_fails_on_rank1', 'all_fine'):
+        log = []
+        red = StatsReducer(dist, 'cpu', _FakeCtx(dist, rank, case, log), force_comm=True)
+        # the exchange after the decision must be the SAME collective on both ranks: it completes and agrees
+        tot = red(1.0 + rank, 10.0 * (rank + 1), 3 + rank)
+        run = red.running_only(rank)
+        res[case] = dict(uses_comm=red.comm is not None, collective=red.collective, rccl_ranks=red.rccl_ranks, tot=tot, run=run, log=log)
+    out[rank] = res
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_comm_fallback_is_decided_collectively():
+    """a d2d_comm that only SOME ranks could create must not leave the ranks on different collectives (hang).  Rank 0
+    failing to make the id, and rank 1 failing to join, both end with every rank on torch.distributed; no failure ends on the d2d_comm."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_agree_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    for case, uses in (('uid_fails_on_rank0', False), ('create_fails_on_rank1', False), ('all_fine', True)):
+        a, b = out[0][case], out[1][case]
+        assert a['uses_comm'] == b['uses_comm'] == uses, (case, a['collective'], b['collective'])
+        assert a['tot'] == b['tot'] == (3.0, 20.0, 7) and a['run'] == b['run'] == 1
+        assert ('abi' in a['log']) == uses and ('abi' in b['log']) == uses
+        if uses:
+            assert a['rccl_ranks'] == b['rccl_ranks'] == 2 and 'd2d_allreduce_stats' in a['collective']
+        else:
+            assert 'd2d_comm not used' in a['collective'] and 'd2d_comm not used' in b['collective']
+    # rank 0 had created its communicator when rank 1 failed: it was closed, not leaked or used
+    assert out[0]['create_fails_on_rank1']['log'] == ['closed']
+
+
 def test_bench_self_spawns_its_ranks():
     """`python bench.py --gpus 2` with no launcher in the environment starts two ranks itself (before touching any GPU) and
     returns their exit code; D2D_BENCH_SPAWN_TEST makes every rank report and leave before the GPU part."""

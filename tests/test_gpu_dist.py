@@ -56,6 +56,10 @@ def test_rccl_entry_point_single_rank():
         assert any(b != b'\x00' for b in uid)
         comm = C.c_void_p()
         assert lib.d2d_comm_create(ctx.h, uid, 0, 1, C.byref(comm)) == 0, lib.d2d_last_error()
+        # d2d_comm_info answers from the communicator itself (ncclCommUserRank / ncclCommCount), not from the arguments above
+        r, w = C.c_int32(-7), C.c_int32(-7)
+        assert lib.d2d_comm_info(comm, C.byref(r), C.byref(w)) == 0, lib.d2d_last_error()
+        assert (r.value, w.value) == (0, 1)
         stats = torch.tensor([1.5, 2.5, 3.0], dtype=torch.float64, device=ctx.device)
         assert lib.d2d_allreduce_stats(ctx.h, comm, C.c_void_p(stats.data_ptr())) == 0, lib.d2d_last_error()
         ctx.sync()
@@ -83,8 +87,8 @@ def test_sharded_solve_through_the_c_abi_collective_one_rank():
     dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
     try:
         red = StatsReducer(dist, ctx.device, ctx)
-        assert red.comm is not None and red.rccl_ranks == 1, red.collective
-        assert 'd2d_allreduce_stats' in red.collective
+        assert red.comm is not None and red.rccl_ranks == 1 and red.comm.info() == (0, 1), red.collective
+        assert 'd2d_allreduce_stats' in red.collective and 'ncclCommCount' in red.collective
         assert red(1.25, 7.0, 3) == (1.25, 7.0, 3) and red.running_only(5) == 5
         dur, wref = bench._plan_consts()
         plan = d2dhip.FitPlan(ctx, bench.S_, bench.K, dur, wref)

