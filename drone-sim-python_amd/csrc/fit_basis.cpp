@@ -160,6 +160,25 @@ int fit_basis_build(d2d_fit_plan *pl) {
   for (int i = 0; i < nq; ++i)
     for (int j = i + 1; j < nq; ++j) { const double s = 0.5 * (Gram(i, j) + Gram(j, i)); Gram(i, j) = s; Gram(j, i) = s; }
   if (!cholesky(Gram)) { d2d_set_error("fit_basis_build: whitening metric not positive definite (wref, K, S?)"); return D2D_EINVAL; }
+  pl->Lw = Gram.a;                                        // lower Cholesky factor L of Nf^T Mref Nf (fit_basis_knots)
+  {
+    // Pe = -(L L^T)^-1 Nf^T M Nx: the free knot data of q = 0 per unit end datum (Zp = Nx + Nf Pe)
+    Dense R = matmul(Nf, matmul(M, Nx), true);            // nq x 4
+    pl->Pe.assign((size_t)nq * 4, 0.0);
+    std::vector<double> y(nq);
+    for (int c = 0; c < 4; ++c) {
+      for (int i = 0; i < nq; ++i) {
+        double v = -R(i, c);
+        for (int j = 0; j < i; ++j) v -= Gram(i, j) * y[j];
+        y[i] = v / Gram(i, i);
+      }
+      for (int i = nq - 1; i >= 0; --i) {
+        double v = y[i];
+        for (int j = i + 1; j < nq; ++j) v -= Gram(j, i) * pl->Pe[(size_t)j * 4 + c];
+        pl->Pe[(size_t)i * 4 + c] = v / Gram(i, i);
+      }
+    }
+  }
   // Z = Nf L^-T  <=>  Z L^T = Nf : forward substitution over columns
   Dense Z(nz, nq);
   for (int i = 0; i < nz; ++i)
@@ -274,5 +293,135 @@ int fit_basis_segments(d2d_fit_plan *pl) {
     if (chunks(s) > pl->seg_nchunk) pl->seg_nchunk = chunks(s);
   }
   for (int s = S; s < D2D_FIT_MAX_S; ++s) pl->seg_l0[s + 1] = pl->seg_l0[S];
+  return D2D_OK;
+}
+
+// The knot-space statement of the fit (oracle/fit_knot.py; kernel: fit_knot.hip): unknowns = the Taylor-scaled knot data
+//   u[8 j + 4 a + k] = T^k / k! * Y_a^(k)(t_j),  j = 0..S (knots), a = axis, k = 0..3    ((j in {0, S}, k < 2): the end conditions)
+// in which a sample touches the 16 entries of its segment's two knots only: J^T J is block tridiagonal in 8 x 8 blocks.
+// q = B (u_free - u0) per axis with B = L^T diag(1 / dsc), u0 = Pu e; the reference metric Mu = B^T B is banded.
+int fit_basis_knots(d2d_fit_plan *pl) {
+  const int S = pl->S, K = pl->K, nq = pl->nq, NE = 8 * (S + 1);
+  const double T = pl->T;
+  if (nq != 4 * S || (int)pl->Lw.size() != nq * nq) { d2d_set_error("fit_basis_knots: plan without the whitening factor"); return D2D_EINVAL; }
+  auto &kn = pl->kn;
+  kn.NE = NE;
+  double dsc[4] = {1.0, T, T * T / 2.0, T * T * T / 6.0};
+  // free knot-data columns of one axis (fit_basis_build: everything but (pos, vel) at the first and last knot), in knot order
+  std::vector<int> freec;
+  for (int i = 0; i < 4 * (S + 1); ++i)
+    if (i != 0 && i != 1 && i != 4 * S && i != 4 * S + 1) freec.push_back(i);
+  // axis-vector index (28 = 4 (S+1) entries: knot data of one axis) of free index i: freec[i]; full entry of (axis a, axis index v): 8 (v / 4) + 4 a + v % 4
+  const int NV = 4 * (S + 1);
+  kn.NV = NV;
+  std::vector<int> vfree(NV, -1);
+  for (int i = 0; i < nq; ++i) vfree[freec[i]] = i;
+  // Hermite basis of one segment in the scaled coordinates on x in [0, 1]: coefficients c = Hu v
+  Dense A(8, 8);
+  for (int k = 0; k < 4; ++k) {
+    A(k, k) = 1.0;
+    for (int p = k; p < 8; ++p) {
+      double c = 1.0;                                       // C(p, k)
+      for (int i = 0; i < k; ++i) c = c * (p - i) / (i + 1);
+      A(4 + k, p) = c;
+    }
+  }
+  if (!invert(A)) { d2d_set_error("fit_basis_knots: singular Hermite block"); return D2D_EINVAL; }
+  kn.Hb64.assign((size_t)K * KN_HB_STRIDE, 0.0);
+  kn.Hb32.assign((size_t)K * 32, 0.f);
+  for (int k = 0; k < K; ++k) {
+    const double x = pl->tau[k] / T;
+    const int s = pl->seg[k];
+    for (int d = 0; d < 3; ++d)
+      for (int m = 0; m < 8; ++m) {
+        double v = 0.0;
+        for (int p = d; p < 8; ++p) v += arr(d, p) * std::pow(x, p - d) * A(p, m);
+        v /= std::pow(T, d);
+        kn.Hb64[(size_t)k * KN_HB_STRIDE + 4 * m + d] = v;
+        // the MFMA operands leave out the columns of the end conditions (they are not unknowns)
+        const bool fixed = (s == 0 && m < 2) || (s == S - 1 && m >= 4 && m < 6);
+        kn.Hb32[(size_t)k * 32 + 4 * m + d] = fixed ? 0.f : (float)v;
+      }
+  }
+  for (int s = 0; s <= S; ++s) kn.k0[s] = s < S ? pl->seg_k0[s] : K;
+  for (int s = 0; s < S; ++s)
+    if (pl->seg_Ks[s] == 0) kn.k0[s] = s + 1 < S ? pl->seg_k0[s + 1] : K;     // (an empty segment: empty range)
+  for (int s = S + 1; s <= D2D_FIT_MAX_S; ++s) kn.k0[s] = K;
+  // waypoint rows' constant J^T J: per segment sum_k Hb0_k^T Hb0_k on the (x, x) and (y, y) columns, in the MFMA accumulator layout
+  kn.Wseg.assign((size_t)S * 4 * 64, 0.f);
+  for (int s = 0; s < S; ++s)
+    for (int r = 0; r < 4; ++r)
+      for (int l = 0; l < 64; ++l) {
+        const int R = 4 * (l >> 4) + r, C = l & 15;
+        const int aR = (R >> 2) & 1, aC = (C >> 2) & 1, mR = 4 * (R >> 3) + (R & 3), mC = 4 * (C >> 3) + (C & 3);
+        if (aR != aC) continue;
+        double v = 0.0;
+        for (int k = kn.k0[s]; k < kn.k0[s + 1]; ++k) v += (double)kn.Hb32[(size_t)k * 32 + 4 * mR] * (double)kn.Hb32[(size_t)k * 32 + 4 * mC];
+        kn.Wseg[((size_t)s * 4 + r) * 64 + l] = (float)v;
+      }
+  // per axis: B = L^T / dsc, Binv = dsc L^-T, Mu = B^T B = L L^T / (dsc dsc), Mu^-1
+  Dense L(nq, nq), Bm(nq, nq), Bi(nq, nq), Mu(nq, nq);
+  for (int i = 0; i < nq; ++i)
+    for (int j = 0; j < nq; ++j) L(i, j) = pl->Lw[(size_t)i * nq + j];
+  std::vector<double> ds(nq);
+  for (int i = 0; i < nq; ++i) ds[i] = dsc[freec[i] % 4];
+  for (int j = 0; j < nq; ++j)
+    for (int i = 0; i < nq; ++i) Bm(j, i) = L(i, j) / ds[i];
+  Bi = Bm;
+  if (!invert(Bi)) { d2d_set_error("fit_basis_knots: singular map"); return D2D_EINVAL; }
+  Mu = matmul(Bm, Bm, true);
+  Dense Mi = Mu;
+  if (!invert(Mi)) { d2d_set_error("fit_basis_knots: singular metric"); return D2D_EINVAL; }
+  // rows per full entry e = 8 j + 4 a + k (both axes carry the same numbers); zero rows / columns for the end conditions
+  kn.Bq.assign((size_t)2 * nq * NV, 0.0);      // [q index (axis-major: a nq + jq)][NV]: q = sum_v Bq[.][v] (u - u0)[axis vector]
+  kn.BiT.assign((size_t)2 * nq * NV, 0.0);     // [q index][NV]: (J^T r in q) = sum_v BiT[.][v] g_u[axis vector]   (g_q = Binv^T g_u)
+  kn.Md32.assign((size_t)2 * nq * 2 * nq, 0.f);   // dense rows of Mu in the order of the free entries (knot-major, axes interleaved)
+  kn.Mrow32.assign((size_t)NE * 12, 0.f);
+  kn.Binv.assign((size_t)NE * nq, 0.0);        // [e][nq]: (u - u0)_e = sum_j Binv[e][j] q[a nq + j]
+  kn.Minv.assign((size_t)NE * NV, 0.0);        // [e][NV]: (Mu^-1 g)_e = sum_v Minv[e][v] g[axis vector]
+  kn.Mrow.assign((size_t)NE * 12, 0.0);        // [e][3 knots (j-1, j, j+1)][4]: the same-axis entries of row e of Mu
+  kn.Pu.assign((size_t)NE * 4, 0.0);           // [e][4]: u0_e = Pu[e] . (pos0, vel0, pos1, vel1) of its axis
+  kn.msc.assign((size_t)NE, 1.0);
+  for (int a = 0; a < 2; ++a)
+    for (int jq = 0; jq < nq; ++jq)
+      for (int i = 0; i < nq; ++i) {
+        kn.Bq[((size_t)a * nq + jq) * NV + freec[i]] = Bm(jq, i);
+        kn.BiT[((size_t)a * nq + jq) * NV + freec[i]] = Bi(i, jq);
+      }
+  for (int e = 0; e < NE; ++e) {
+    const int j = e >> 3, k = e & 3, v = 4 * j + k, i = vfree[v];
+    if (i < 0) {                                           // an end condition: u_e = dsc_k * datum
+      kn.Pu[(size_t)e * 4 + (j == 0 ? k : 2 + k)] = dsc[k];
+      continue;
+    }
+    for (int c = 0; c < 4; ++c) kn.Pu[(size_t)e * 4 + c] = ds[i] * pl->Pe[(size_t)i * 4 + c];
+    for (int jq = 0; jq < nq; ++jq) kn.Binv[(size_t)e * nq + jq] = Bi(i, jq);
+    for (int i2 = 0; i2 < nq; ++i2) kn.Minv[(size_t)e * NV + freec[i2]] = Mi(i, i2);
+    for (int dj = -1; dj <= 1; ++dj)
+      for (int k2 = 0; k2 < 4; ++k2) {
+        const int v2 = 4 * (j + dj) + k2;
+        if (v2 < 0 || v2 >= NV || vfree[v2] < 0) continue;
+        kn.Mrow[(size_t)e * 12 + 4 * (dj + 1) + k2] = Mu(i, vfree[v2]);
+      }
+    for (int i2 = 0; i2 < nq; ++i2)
+      if (Mu(i, i2) != 0.0 && std::abs(freec[i2] / 4 - j) > 1 && std::fabs(Mu(i, i2)) > 1e-12 * std::sqrt(Mu(i, i) * Mu(i2, i2))) {
+        d2d_set_error("fit_basis_knots: the metric couples knots that are not neighbours");
+        return D2D_EINVAL;
+      }
+    kn.msc[e] = std::sqrt(Mu(i, i));
+  }
+  for (size_t t = 0; t < kn.Mrow.size(); ++t) kn.Mrow32[t] = (float)kn.Mrow[t];
+  kn.Mi32.assign(kn.Minv.size(), 0.f);
+  for (size_t t = 0; t < kn.Minv.size(); ++t) kn.Mi32[t] = (float)kn.Minv[t];
+  // dense index of the free entries: full entries in ascending order without the eight end conditions
+  std::vector<int> efree;
+  for (int e = 0; e < NE; ++e)
+    if (vfree[4 * (e >> 3) + (e & 3)] >= 0) efree.push_back(e);
+  for (int i = 0; i < 2 * nq; ++i)
+    for (int i2 = 0; i2 < 2 * nq; ++i2) {
+      const int e = efree[i], e2 = efree[i2];
+      if (((e >> 2) & 1) != ((e2 >> 2) & 1)) continue;
+      kn.Md32[(size_t)i * 2 * nq + i2] = (float)Mu(vfree[4 * (e >> 3) + (e & 3)], vfree[4 * (e2 >> 3) + (e2 & 3)]);
+    }
   return D2D_OK;
 }

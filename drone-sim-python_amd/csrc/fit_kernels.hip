@@ -27,11 +27,7 @@
 #define FIT_THREADS (64 * FIT_WPB_MAX)
 #define FIT_LDS_BYTES (160 * 1024)
 
-// flags[b][4] = status, iters, need_eval, evaluations (half-units: 2 per Gauss-Newton, 3 per second-order one); lm[b][LM_STRIDE], below
-enum { FL_STATUS = 0, FL_ITERS = 1, FL_NEED = 2, FL_NEVAL = 3 };
-// lm[b][LM_STRIDE]: 0 lambda, 1 nu, 2 gmax, 3 second-order mode of the pending evaluation; MINPACK mode: 4 par, 5 trust-region radius,
-// 6 phase | first << 1 | calm << 2, 7 factorisations so far
-#define LM_STRIDE 8
+// (flags[b][4] and lm[b][LM_STRIDE]: fit_plan.h)
 
 struct FitLds {
   // byte offsets into dynamic LDS
@@ -557,7 +553,8 @@ fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_cap,
           }
           const int pend = __hip_atomic_load(queue + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
                            __hip_atomic_load(queue + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (pend <= 0 || spin > (1 << 18)) break;
+          if (pend <= 0) break;
+          if (spin > (1 << 18)) { atomicAdd(queue + 5, 1); break; }      // gave up with a push pending: counted, d2d_fit_finish reports it
           __builtin_amdgcn_s_sleep(16);
         }
       }
@@ -1705,7 +1702,7 @@ __global__ void __launch_bounds__(256)
 fit_state_init_kernel(int B, int off, int stride, double *__restrict__ lm, int32_t *__restrict__ flags,
                       int32_t *__restrict__ queue) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == 0 && queue) { queue[0] = 0; queue[1] = 0; queue[2] = 0; queue[3] = 0; queue[4] = 0; }     // work queue + ring counters of the persistent LM kernel (fit_lm_kernel)
+  if (i == 0 && queue) { queue[0] = 0; queue[1] = 0; queue[2] = 0; queue[3] = 0; queue[4] = 0; queue[5] = 0; }     // work queue + ring counters of the persistent LM kernel (fit_lm_kernel); [5] = bounded waits that gave up, over the whole solve
   if (i >= B) return;
   const int b = off + i * stride;
   lm[LM_STRIDE * b + 0] = D2D_LM_LAMBDA0; lm[LM_STRIDE * b + 1] = 2.0; lm[LM_STRIDE * b + 2] = 0.0; lm[LM_STRIDE * b + 3] = 0.0;
@@ -1779,6 +1776,15 @@ __global__ void __launch_bounds__(256)
 fit_count_kernel(int B, const int32_t *__restrict__ flags, int32_t *__restrict__ counter) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   const int run = (b < B && flags[4 * b + FL_STATUS] == D2D_ST_RUNNING) ? 1 : 0;
+  const unsigned long long m = __ballot(run);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(counter, (int)__popcll(m));
+}
+
+// counts trajectories still running with fewer than `cap` iterations of their own (time-sliced hand-out: left in the ring) -> counter[0]
+__global__ void __launch_bounds__(256)
+fit_count_below_kernel(int B, const int32_t *__restrict__ flags, int cap, int32_t *__restrict__ counter) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int run = (b < B && flags[4 * b + FL_STATUS] == D2D_ST_RUNNING && flags[4 * b + FL_ITERS] < cap) ? 1 : 0;
   const unsigned long long m = __ballot(run);
   if ((threadIdx.x & 63) == 0 && m) atomicAdd(counter, (int)__popcll(m));
 }
@@ -1961,6 +1967,7 @@ static int ensure_scratch(d2d_fit_plan *pl, int B) {
   SCRATCH_ALLOC(d_lm, (size_t)B * LM_STRIDE * sizeof(double))
   SCRATCH_ALLOC(d_flags, (size_t)B * 4 * sizeof(int32_t))
 #undef SCRATCH_ALLOC
+  if (int rc = fit_knot_ensure(pl, B)) { free_scratch(pl); return rc; }
   pl->cap_B = B;
   return D2D_OK;
 }
@@ -2050,6 +2057,17 @@ static int launch_lm(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, double *q, con
     D2D_CHECK_HIP(hipMemsetAsync(queue + 2, 0, 3 * sizeof(int32_t), ctx->stream));
   }
   const int32_t *order = (pl->order_B == B) ? pl->d_order : nullptr;
+  // the default solver of the headline shape runs in knot coordinates (fit_knot.hip); the time-sliced hand-out and the FAST loop
+  // stay on fit_lm_kernel
+  if (pl->kn.wpb > 0 && oo.mode == D2D_LM_MODE_MINPACK && oo.slice <= 0) {
+    if (int rc = fit_knot_launch(ctx, const_cast<d2d_fit_plan *>(pl), B, q, oo, iter_cap, order, prio_only)) return rc;
+    if (want_times) {
+      D2D_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+      const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+      fprintf(stderr, "[fit_lm_knot launch] B=%d iter_cap=%d: %.1f us\n", B, iter_cap, us);
+    }
+    return D2D_OK;
+  }
 #define LAUNCH_LM(STAMPSV, MODEV)                                                                                                  \
   hipLaunchKernelGGL((fit_lm_kernel<3, 24, STAMPSV, MODEV>), dim3(blocks), dim3(64 * pl->wpb_lm), L.total, ctx->stream, B, gm, L, oo, iter_cap, \
                      pl->d_G, pl->d_pk, pl->d_G32, pl->d_W32, pl->d_prep, q, pl->d_cost, pl->d_g, pl->d_lm, pl->d_flags, queue,   \
@@ -2167,6 +2185,7 @@ int d2d_fit_plan_create(d2d_ctx *ctx, int S, int K, double duration, const doubl
   if (int rc = fit_basis_build(pl)) { delete pl; return rc; }
   if (int rc = fit_basis_segments(pl)) { delete pl; return rc; }
   const int nq = pl->nq, gstr = nq + 1;
+  D2D_CHECK_HIP(hipSetDevice(ctx->device));
   // the split-path kernels (public d2d_fit_eval, coupled groups) stage the whole basis block in LDS: K <~ 229 at S = 6
   pl->split_ok = pick_eval_layout(K, nq, &pl->g32_lds, &pl->wpb_eval, 0) &&
                  pick_step_layout(K, nq, 16 * ((2 * nq + 15) / 16), &pl->wpb_step);
@@ -2177,6 +2196,9 @@ int d2d_fit_plan_create(d2d_ctx *ctx, int S, int K, double duration, const doubl
   pl->use_long = !pl->use_lm && (!getenv("D2D_FIT_SPLIT") || !pl->split_ok);
   if (getenv("D2D_FIT_LONG") && !getenv("D2D_FIT_SPLIT")) { pl->use_lm = false; pl->use_long = true; }
   if (pl->use_long) pl->wpb_lm = FIT_LM_WPB_MAX;
+  // the headline shape (S = 6, K <= 64) runs the default solver in knot coordinates (fit_knot.hip); D2D_FIT_KNOT=0: in q
+  if (pl->use_lm)
+    if (int rc = fit_knot_plan_init(pl)) { delete pl; return rc; }
   if (!pl->split_ok && !pl->use_long) {
     d2d_set_error("d2d_fit_plan_create: K=%d, S=%d does not fit the 160 KiB LDS image of the basis block", K, S);
     delete pl;
@@ -2265,6 +2287,7 @@ int d2d_fit_plan_destroy(d2d_fit_plan *pl) {
   for (void *p : ptrs)
     if (p) hipFree(p);
   free_scratch(pl);
+  fit_knot_plan_free(pl);
   delete pl;
   return D2D_OK;
 }
@@ -2467,6 +2490,8 @@ int d2d_fit_begin(d2d_ctx *ctx, d2d_fit_plan *pl, int B) {
   pl->active_B = B;
   pl->prep_valid_for = nullptr;
   pl->rows_B = 0;              // (a solve rewrites d_prep and, on the launch-pair path, d_H)
+  pl->last_slice = 0; pl->last_running = -1;
+  pl->gsweeps_R = 0;           // (... and d_lm: the sweeps / moves of an earlier d2d_fit_solve_groups are gone -- d2d_fit_group_report says D2D_ESTATE)
   return D2D_OK;
 }
 
@@ -2487,7 +2512,9 @@ int d2d_fit_iterate(d2d_ctx *ctx, d2d_fit_plan *pl, int B, const double *scen, d
     // Time-sliced hand-out: a fit that a launch left in its ring keeps D2D_ST_RUNNING with its own iteration count below the
     // cap.  Once the plan's budget is spent such fits are finished by further launches under the full cap (every fit stops at
     // max_iter iterations of its own) -- without them the caller's `while (running > 0)` would spin on a count that cannot fall.
-    const bool sweep_up = budget <= 0 && pl->use_lm && lm_slice(o) > 0;
+    pl->last_slice = pl->use_lm ? lm_slice(o) : 0;
+    pl->last_opts = o;
+    const bool sweep_up = budget <= 0 && pl->last_slice > 0 && pl->last_running != 0;     // (nothing left RUNNING by the last count: no launch)
     if (budget > 0 || sweep_up) {
       if (int rc = prof_begin(ctx, pl, 2)) return rc;
       if (int rc = pl->use_lm ? launch_lm(ctx, pl, B, q, o, sweep_up ? o.max_iter : pl->it_done + budget) : launch_lm_long(ctx, pl, B, q, o, budget)) return rc;
@@ -2513,9 +2540,35 @@ int d2d_fit_iterate(d2d_ctx *ctx, d2d_fit_plan *pl, int B, const double *scen, d
       D2D_CHECK_HIP(hipMemcpyAsync(ctx->counter_host, ctx->counter_dev, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
       D2D_CHECK_HIP(hipStreamSynchronize(ctx->stream));
       *n_running = ctx->counter_host[0];
+      pl->last_running = *n_running;
     }
   }
   return D2D_OK;
+}
+
+// Time-sliced hand-out only: fits a launch left in its ring (a bounded wait that gave up) keep D2D_ST_RUNNING below their cap.  The
+// caller may never look at n_running (one d2d_fit_iterate, then d2d_fit_finish), so d2d_fit_finish sweeps them up itself: launches
+// under the cap the plan has reached (it_done: a fit that is RUNNING with that many iterations of its own was stopped by the
+// caller's budget, not left behind) until no fit below it is RUNNING; if that does not happen it says so instead of reporting them.
+static int sweep_up_sliced(d2d_ctx *ctx, d2d_fit_plan *pl, int B, double *q) {
+  const dim3 g1((B + 255) / 256), b1(256);
+  for (int tries = 0;; ++tries) {
+    D2D_CHECK_HIP(hipMemsetAsync(ctx->counter_dev, 0, sizeof(int32_t), ctx->stream));
+    const int cap = pl->it_done < pl->last_opts.max_iter ? pl->it_done : pl->last_opts.max_iter;
+    hipLaunchKernelGGL(fit_count_below_kernel, g1, b1, 0, ctx->stream, B, pl->d_flags, cap, ctx->counter_dev);
+    D2D_LAUNCH_CHECK();
+    D2D_CHECK_HIP(hipMemcpyAsync(ctx->counter_host, ctx->counter_dev, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    D2D_CHECK_HIP(hipMemcpyAsync(ctx->counter_host + 1, ctx->counter_dev + 8 + 5, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    D2D_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    const int left = ctx->counter_host[0], gave_up = ctx->counter_host[1];
+    if (left == 0) return D2D_OK;
+    if (tries >= 8) {
+      d2d_set_error("d2d_fit_finish: %d fits are still RUNNING below the iteration cap after %d sweep-up launches of the time-sliced hand-out "
+                    "(%d bounded ring waits gave up during this solve)", left, tries, gave_up);
+      return D2D_ESTATE;
+    }
+    if (int rc = launch_lm(ctx, pl, B, q, pl->last_opts, cap)) return rc;
+  }
 }
 
 int d2d_fit_finish(d2d_ctx *ctx, d2d_fit_plan *pl, int B, const double *scen, const double *q,
@@ -2528,6 +2581,8 @@ int d2d_fit_finish(d2d_ctx *ctx, d2d_fit_plan *pl, int B, const double *scen, co
     if (int rc = launch_prep(ctx, pl, B, scen)) return rc;
     pl->prep_valid_for = scen;
   }
+  if (pl->use_lm && pl->n_group <= 1 && pl->last_slice > 0 && pl->it_done > 0)
+    if (int rc = sweep_up_sliced(ctx, pl, B, const_cast<double *>(q))) return rc;
   // (the persistent LM kernel leaves cost and J^T r of every trajectory evaluated at its final point)
   if (!((pl->use_lm || pl->use_long) && pl->n_group <= 1 && pl->it_done > 0))
     if (int rc = launch_eval(ctx, pl, B, q, nullptr, pl->d_cost, pl->d_g, nullptr)) return rc;
@@ -2647,6 +2702,7 @@ int d2d_fit_solve_groups(d2d_ctx *ctx, d2d_fit_plan *pl, int R, const double *sc
   if (int rc = launch_prep(ctx, pl, B, scen)) return rc;
   pl->prep_valid_for = nullptr;
   pl->active_B = 0;
+  pl->gsweeps_R = 0;           // only the persistent-kernel path below leaves a report; the launch-pair paths overwrite d_lm
   // ---- one persistent launch: a wavefront per scenario runs the whole block Gauss-Seidel of its group (fit_groups_kernel)
   int wpb_g = 0;
   if (pl->nq == 24 && !getenv("D2D_FIT_SPLIT") && pick_fused_layout(pl->K, pl->nq, 48, &wpb_g)) {

@@ -615,11 +615,17 @@ __device__ __forceinline__ float lanes_above(float v, int j, unsigned long long 
   return r;
 }
 
-template <int N, bool MP = false, bool FULL = false>
+// Metric (fit_knot.hip: the solve in knot coordinates, where lmder's norm is ||s||_M and the damping is lam M): an object with
+//   apply(delta) -> (M delta)[lane]      dxnorm = sqrt(delta^T M delta), isq = || L^-1 (M delta / dxnorm) ||^2
+//   damp(j0)     -> lam * M[lane][j0 .. j0+3]   added to the lane's matrix row where the panel of columns j0 .. j0+3 reads it (zero on
+//                                               the lanes that are not rows of the system: lane N carries the right-hand side)
+// The default (int) is the Euclidean norm with the damping on the pivots.
+template <int N, bool MP = false, bool FULL = false, class Metric = int>
 __device__ __forceinline__ bool damped_solve(const f32x2 (&hrow)[N / 2], double lam, bool act, int lane,
                                              float *Lm, float &dgi, float &delta, unsigned long long *tt = nullptr,
                                              bool unit = false, int isq_mode = 0, double tr_delta = 0.0,
-                                             double *dxnorm = nullptr, double *isq = nullptr, float hd = 0.f, bool have_hd = false) {
+                                             double *dxnorm = nullptr, double *isq = nullptr, float hd = 0.f, bool have_hd = false,
+                                             Metric metric = Metric()) {
   constexpr int LS = CHOL_LS, NBK = N / 16;
   // tt (diagnostics, fused kernel with D2D_LM_STAMPS): cycles of setup, block columns [0,N/3), [N/3,2N/3), [2N/3,N), substitution
   unsigned long long tl = 0;
@@ -684,6 +690,8 @@ __device__ __forceinline__ bool damped_solve(const f32x2 (&hrow)[N / 2], double 
       const int j0 = c0 + 4 * sp;
       __builtin_amdgcn_sched_barrier(0);
       const f32x4 dq = lds_get<f32x4>(damp + j0);
+      f32x4 mq = f32x4{0.f, 0.f, 0.f, 0.f};             // (requested here, with the panel's other reads: used after the dot products)
+      if constexpr (!__is_same(Metric, int)) mq = metric.damp(j0);
       // the newest chunk (published by the panel before); the older ones were requested before that panel's diagonal block
       if (sp > 0) {
 #pragma unroll
@@ -718,6 +726,7 @@ __device__ __forceinline__ bool damped_solve(const f32x2 (&hrow)[N / 2], double 
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         float a = HEL(j0 + c);
+        if constexpr (!__is_same(Metric, int)) a += mq[c];
         if (!FULL) a = live ? a : 0.f;
         if (I > 0) a -= dv[sp][c];
         s[c] = sp > 0 ? a - (acc[c].x + acc[c].y) : a;
@@ -781,7 +790,9 @@ __device__ __forceinline__ bool damped_solve(const f32x2 (&hrow)[N / 2], double 
 #endif
   delta = act ? dl : 0.f;
   if (MP) {
-    const double dn2 = uniform_d(wave_sum((double)delta * (double)delta));
+    float mdl = delta;                                   // (M delta)[lane]
+    if constexpr (!__is_same(Metric, int)) mdl = metric.apply(delta);
+    const double dn2 = uniform_d(wave_sum((double)delta * (double)mdl));
     const double dn = sqrt(dn2);
     *dxnorm = dn;
     *isq = 0.0;
@@ -790,7 +801,7 @@ __device__ __forceinline__ bool damped_solve(const f32x2 (&hrow)[N / 2], double 
       f32x4 lrow[N / 4];                                 // this lane's row of the factor, zero on and above the diagonal
 #pragma unroll
       for (int t = 0; t < N / 4; ++t) lrow[t] = lds_get<f32x4>(Lm + li * LS + 4 * t);
-      float wcur = delta * (float)(1.0 / dn);
+      float wcur = mdl * (float)(1.0 / dn);
 #pragma unroll
       for (int j = 0; j < N - 1; ++j) {
         const float zj = lane_value(wcur * myinv, j);

@@ -4,6 +4,27 @@
 
 #include "common.h"
 
+// per-trajectory solver state shared by the persistent kernels (fit_kernels.hip, fit_knot.hip):
+// flags[b][4] = status, iters, need_eval, evaluations (half-units: 2 per Gauss-Newton, 3 per second-order one)
+enum { FL_STATUS = 0, FL_ITERS = 1, FL_NEED = 2, FL_NEVAL = 3 };
+// lm[b][LM_STRIDE]: 0 lambda, 1 nu, 2 gmax, 3 second-order mode of the pending evaluation; MINPACK mode: 4 par, 5 trust-region radius,
+// 6 phase | first << 1 | calm << 2 | slow << 16, 7 factorisations so far
+#define LM_STRIDE 8
+
+// Tables of the knot-space statement (fit_basis.cpp fit_basis_knots; kernel: fit_knot.hip)
+#define KN_HB_STRIDE 34          // doubles per sample of the fp64 Hermite table [K][8][4] (+2: conflict-free 16-byte rows)
+struct KnotTables {
+  int NE = 0, NV = 0;            // full entries 8 (S+1); entries of one axis 4 (S+1)
+  int k0[D2D_FIT_MAX_S + 2] = {0};   // first sample of every segment, k0[S] = K
+  std::vector<double> Hb64, Bq, BiT, Binv, Minv, Mrow, Pu, msc;
+  std::vector<float> Hb32, Wseg, Md32, Mrow32, Mi32;
+  // device copies (one allocation each)
+  double *d_Hb64 = nullptr, *d_Bq = nullptr, *d_BiT = nullptr, *d_Binv = nullptr, *d_Minv = nullptr, *d_Pu = nullptr, *d_msc = nullptr;
+  float *d_Hb32 = nullptr, *d_Wseg = nullptr, *d_Md32 = nullptr, *d_Mrow32 = nullptr, *d_Mi32 = nullptr;
+  double *d_u = nullptr;         // [cap_B][64] the knot vector of every fit between launches (bit-exact resume)
+  int wpb = 0;                   // wavefronts per workgroup of fit_lm_knot_kernel (0: the plan does not use it)
+};
+
 struct d2d_fit_plan {
   int device;
   int S, K, nq;        // segments, samples, reduced unknowns per axis (4*S)
@@ -11,6 +32,8 @@ struct d2d_fit_plan {
   double wref[3];
   // host copies (fp64)
   std::vector<double> G, Gp, Z, Zp, Pinit, G0tG0;
+  std::vector<double> Lw, Pe;       // whitening factor L (nq x nq, lower) and the free knot data of q = 0 per unit end datum (nq x 4)
+  KnotTables kn;
   // segment formulation of the long-horizon kernel (fit_seg.h; fit_basis.cpp fit_basis_segments)
   std::vector<int> seg;             // [K]  segment of every sample
   std::vector<double> tau;          // [K]  its local time
@@ -57,6 +80,8 @@ struct d2d_fit_plan {
   bool split_ok = true;     // the split-path kernels' LDS image holds this K (d2d_fit_eval, coupled groups)
   int n_cu = 256;
   int it_done = 0, active_B = 0;   // LM loop state between d2d_fit_begin / iterate / finish
+  int last_slice = 0, last_running = -1;   // ... slice of the last d2d_fit_iterate (0: no time-sliced hand-out), its count of RUNNING fits (-1: not counted)
+  d2d_fit_opts last_opts = {};     // ... and its options (d2d_fit_finish sweeps up what a sliced launch left in the ring)
   // optional per-launch timing (d2d_fit_profile)
   bool prof_on = false;
   std::vector<hipEvent_t> prof_ev;   // start/stop pairs
@@ -65,3 +90,9 @@ struct d2d_fit_plan {
 
 int fit_basis_build(d2d_fit_plan *pl);   // fills the host vectors
 int fit_basis_segments(d2d_fit_plan *pl);   // ... of the segment formulation (after fit_basis_build)
+int fit_basis_knots(d2d_fit_plan *pl);      // ... of the knot-space statement (after fit_basis_segments)
+// fit_knot.hip: the persistent LM kernel in knot coordinates (S = 6, K <= 64, default solver)
+int fit_knot_plan_init(d2d_fit_plan *pl);
+void fit_knot_plan_free(d2d_fit_plan *pl);
+int fit_knot_ensure(d2d_fit_plan *pl, int cap_B);
+int fit_knot_launch(d2d_ctx *ctx, d2d_fit_plan *pl, int B, double *q, const d2d_fit_opts &o, int iter_cap, const int32_t *order, int prio_at);
