@@ -283,9 +283,17 @@ def nlp_record(ctx, torch, cpu, B=4096):
     # (x ~1.1 with the retries), cyclic reduction 21 read + 6 written (the reduced records live in the LDS), recovery 40 read + 5
     # written, update 20 read + 15 written = 118 doubles read + 70 written = 114 kB + 68 kB per step at N = 121
     alg = float(it.sum()) * (114e3 + 68e3) * (W0.shape[2] / 121.0)
+    # what a launch MUST move: the scenario row in, the node values in and out (5 x N doubles each way) and the four result words per
+    # problem -- everything else of `alg` is the algorithm's own workspace, streamed through HBM / L2 once per Newton step because it
+    # does not fit beside two waves' registers.  `workspace_stream_frac` is therefore a utilisation of self-inflicted traffic, NOT a
+    # roofline fraction; the roofline fraction of the irreducible bytes is `irreducible_frac` (latency-bound kernel: tiny by construction)
+    irr = float(B) * (rows.shape[1] * 8 + 2 * W0.shape[1] * W0.shape[2] * 8 + 4 * 8)
     rec['roofline'] = {'bound': 'hbm', 'kernel': 'nlp_solve_kernel', 'achieved': alg / best / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                       'frac': alg / best / 1e9 / HBM_PEAK_GBS, 'traffic': rec['hbm_traffic_per_launch'], 'alg_bytes_per_launch': alg,
-                       'note': 'latency-bound (dependent fp64 chains of the assembly and of the seven cyclic-reduction levels, one wavefront per problem, two waves per SIMD); traffic = FETCH_SIZE + WRITE_SIZE of the committed PMC passes (FETCH_SIZE uncalibrated for 8-B-per-lane loads)'}
+                       'workspace_stream_frac': alg / best / 1e9 / HBM_PEAK_GBS, 'traffic': rec['hbm_traffic_per_launch'],
+                       'workspace_bytes_per_launch': alg, 'irreducible_bytes_per_launch': irr,
+                       'irreducible_frac': irr / best / 1e9 / HBM_PEAK_GBS,
+                       'traffic_over_irreducible': (rec['hbm_traffic_per_launch'] / irr) if rec['hbm_traffic_per_launch'] else None,
+                       'note': 'latency-bound (dependent fp64 chains of the assembly and of the seven cyclic-reduction levels, one wavefront per problem, two waves per SIMD); `achieved` prices the workspace stream of the algorithm (182 kB per Newton step), not a roofline: see irreducible_*; traffic = FETCH_SIZE + WRITE_SIZE of the committed PMC passes (FETCH_SIZE uncalibrated for 8-B-per-lane loads)'}
     if cpu is not None:
         rec['verdicts_vs_oracle'] = nlp_verify(rows, W0, h, st, cost, feas)
         n = len(cpu['cost'])
@@ -430,6 +438,22 @@ def sim_records(ctx, torch, cpu_g, cpu_t, drones=65536, steps=10000, track_steps
                    'roofline_valu': pmc_valu('gvf_run_kernel', dte), 'cpu_baseline': cpu_g}
     del out
     torch.cuda.empty_cache()
+    # occupancy scaling of the GVF loop: the same history volume (drones x steps) with 2 x and 4 x the drones, i.e. two and four waves
+    # per SIMD instead of one -- is configs[4] (65 536 drones = 1024 waves = ONE wave per SIMD) latency-bound by construction?
+    scaling = [{'drones': N, 'steps': steps, 'waves_per_simd': N / 64 / 1024, 'value': recs['gvf']['value'], 'launch_s': dte}]
+    for mult in (2, 4):
+        N2, st2 = N * mult, steps // mult
+        nf2 = N2 // n_ac
+        c2 = np.tile(np.array([[0, -20], [25, -20], [25, -100], [0, -100.0]]), (nf2, 1)) + np.repeat(rng.uniform(-5, 5, (nf2, 2)), n_ac, 0)
+        X2 = np.tile([20, 30, -np.pi / 2, 0, 10.0], (N2, 1)) + np.concatenate([rng.uniform(-3, 3, (N2, 2)), np.zeros((N2, 3))], 1)
+        dX2, dC2, dR2 = ctx.dev(np.ascontiguousarray(X2.T)), ctx.dev(np.ascontiguousarray(c2.T)), ctx.dev(np.full(N2, 60.0))
+        o2, dt2 = timed(lambda o: ctx.gvf_run(dX2, dC2, dR2, n_ac, st2 + 1, 0.05, 15.0, record=('X', 'U'), out=o))
+        scaling.append({'drones': N2, 'steps': st2, 'waves_per_simd': N2 / 64 / 1024, 'value': N2 * st2 / dt2, 'launch_s': dt2})
+        del o2, dX2, dC2, dR2
+        torch.cuda.empty_cache()
+    recs['gvf']['occupancy_scaling'] = scaling
+    recs['gvf']['speedup_2_waves_per_simd'] = scaling[1]['value'] / scaling[0]['value']
+    recs['gvf']['speedup_4_waves_per_simd'] = scaling[2]['value'] / scaling[0]['value']
     T = track_steps + 1
     t = np.arange(T) * 0.1
     ph = rng.uniform(0, 2 * np.pi, N)
@@ -892,6 +916,7 @@ def main():
             'nlp_value': nlp['value'] if nlp else None,
             'long_horizon_value_121': longh['value'] if longh else None,
             'sim_gvf_value': sim['gvf']['value'] if sim else None, 'sim_track_value': sim['track']['value'] if sim else None,
+            'sim_gvf_value_2_waves_per_simd': sim['gvf']['occupancy_scaling'][1]['value'] if sim else None,
             'cpu_baseline_value': cpu['value'] if cpu else None, 'cpu_baseline_cores': cpu['cores'] if cpu else None,
             # -- multi-GPU: which collective ran, on how many RCCL ranks, and the per-rank spread of the solver kernel --
             'collective': reducer.collective, 'rccl_ranks': reducer.rccl_ranks,
