@@ -62,8 +62,8 @@ def pmc_traffic(kernel):
     corrected as MI355X_MICROARCH.md prescribes).  bench.py cannot read hardware counters itself; None when the file is absent."""
     try:
         import glob
-        files = (sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r04', '*_traffic.json'))) or sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r03', '*_traffic.json')))
-                 or [os.path.join(ROOT, 'profiles', 'r02', '06_bench_final_traffic.json')])
+        files = next((fs for fs in (sorted(glob.glob(os.path.join(ROOT, 'profiles', r, '*_traffic.json'))) for r in ('r05', 'r04', 'r03')) if fs),
+                     [os.path.join(ROOT, 'profiles', 'r02', '06_bench_final_traffic.json')])
         t = json.load(open(files[-1]))[kernel][0]
         t['file'] = os.path.relpath(files[-1], ROOT)
     except (OSError, KeyError, IndexError, ValueError):
@@ -75,7 +75,7 @@ def pmc_valu(kernel, launch_s):
     """roofline against the fp64 vector pipe for the kernels it bounds (the simulation loops): executed fp64 flop per launch from the
     committed rocprofv3 pass of THIS command (profiles/r04/*_valu.json, tools/condense_profile.py) over the launch time measured
     here.  None when the file is absent."""
-    for rnd in ('r04', 'r03'):
+    for rnd in ('r05', 'r04', 'r03'):
         try:
             import glob
             f = sorted(glob.glob(os.path.join(ROOT, 'profiles', rnd, '*_valu.json')))[-1]
