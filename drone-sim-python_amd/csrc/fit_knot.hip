@@ -37,7 +37,7 @@ namespace {
 #define LAUNDER_S(v) do { (v) = __builtin_amdgcn_readfirstlane(v); asm volatile("" : "+s"(v)); } while (0)
 
 struct KnotGeom {
-  int K, S, lmax;               // samples, segments, longest run of samples of two adjacent segments
+  int K, S, smax;               // samples, segments, samples of the longest segment
   int k0[D2D_FIT_MAX_S + 2];    // first sample of every segment; k0[S] = K
 };
 
@@ -152,34 +152,30 @@ __device__ __forceinline__ double knot_phase1(int K, const double *Hb64, const d
 // ---- phase 2 (lane = entry): (J_u^T r)[e] over the samples of the entry's two segments ------------------------------------------
 // kb / km / ke: first sample of segment j-1 (or j at the first knot), of segment j, and the end of segment j (j-1 at the last knot);
 // a sample before km sees the entry as the END knot of its segment (Hermite function 4 + kd), one after as the START knot (kd).
+// Two counted loops over at most KN_SEG_MAX samples each; a lane is masked out of the iterations beyond its own range.
 __device__ __forceinline__ double knot_phase2(const KnotGeom &kg, const double *Hb64, const double *us, int kb, int km, int ke,
                                               int a, int kd, bool live, int lane) {
   typedef double __attribute__((ext_vector_type(2), may_alias)) f64x2a;
   LAUNDER(lane);
   LAUNDER(kb);
   double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-  int lmax = kg.lmax;
-  LAUNDER_S(lmax);
-  for (int t = 0; t < lmax; t += 3) {                 // chunks of three samples: the twelve reads of a chunk, then its nine FMAs
-    f64x2a h01[3], u01[3];
-    double h2[3], u2[3], sel[3];
+  int smax = kg.smax;
+  LAUNDER_S(smax);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int k = kb + t + i;
-      const bool ok = live && k < ke;
-      const int kc = ok ? k : 0;
-      const int m = (k < km ? 4 : 0) + kd;
-      const double *hb = Hb64 + (size_t)kc * KN_HB_STRIDE + 4 * m;
-      const double *uk = us + kc * KN_US + 4 * a;
-      h01[i] = *reinterpret_cast<const f64x2a *>(hb); u01[i] = *reinterpret_cast<const f64x2a *>(uk);
-      h2[i] = hb[2]; u2[i] = uk[2];
-      sel[i] = ok ? 1.0 : 0.0;
-    }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      a0 = fma(h01[i].x * sel[i], u01[i].x, a0);
-      a1 = fma(h01[i].y * sel[i], u01[i].y, a1);
-      a2 = fma(h2[i] * sel[i], u2[i], a2);
+  for (int half = 0; half < 2; ++half) {
+    const int k0 = half ? km : kb, k1 = half ? ke : km;
+    const double *hb = Hb64 + (size_t)k0 * KN_HB_STRIDE + 4 * ((half ? 0 : 4) + kd);
+    const double *uk = us + k0 * KN_US + 4 * a;
+    const int n = live ? k1 - k0 : 0;
+    for (int t = 0; t < smax; ++t) {
+      if (t < n) {
+        const f64x2a h01 = *reinterpret_cast<const f64x2a *>(hb), u01 = *reinterpret_cast<const f64x2a *>(uk);
+        const double h2 = hb[2], u2 = uk[2];
+        a0 = fma(h01.x, u01.x, a0);
+        a1 = fma(h01.y, u01.y, a1);
+        a2 = fma(h2, u2, a2);
+      }
+      hb += KN_HB_STRIDE; uk += KN_US;
     }
   }
   return (a0 + a1) + a2;
@@ -260,28 +256,50 @@ __device__ __forceinline__ void knot_mfma_so(const KnotGeom &kg, const unsigned 
 }
 
 // ---- the segment blocks -> the dense image of J_u^T J_u over the 48 free entries (fit_phases.h tiles_to_image's layout) ---------------
-// lane (c, g4) holds B_s[4 g4 + rr][c]: global row 8 s + 4 g4 + rr, column 8 s + c.  The image is zeroed, then every block entry is
-// added (consecutive segments overlap on the 8 x 8 block of their common knot); entries of the end conditions are left out.
-__device__ __forceinline__ void knot_blocks_to_image(const f32x4 (&acc)[D2D_FIT_MAX_S], float *Hs, int lane) {
+// lane (c, g4) holds B_s[4 g4 + rr][c]: full-entry row 8 s + 4 g4 + rr, column 8 s + c.  Consecutive segments overlap on the 8 x 8
+// block of their common knot: the upper-knot quadrant of B_{s-1} (lanes c >= 8, g4 >= 2) is fetched into the lower-knot quadrant of
+// B_s (lanes c < 8, g4 < 2: lane + 40) with ds_bpermute and added in registers, so every image entry has ONE writer: plain stores
+// after the image is zeroed (LDS atomics on 64 lanes cost several times a store).  ic0 / ic5, rv0 / rv5: dense column of this
+// lane and validity of its rows in the first / last segment, where the end conditions' entries are left out (-1 / false).
+__device__ __forceinline__ void knot_blocks_to_image(f32x4 (&acc)[D2D_FIT_MAX_S], float *Hs, int lane) {
   LAUNDER(lane);
   constexpr int LS = KN_IMG_LS;
-#ifndef KN_ABL_NOZERO
   for (int i = lane; i < KN_N * LS / 4; i += 64) lds_put<f32x4>(Hs + 4 * i, f32x4{0.f, 0.f, 0.f, 0.f});
-#endif
-  wave_lds_sync();
   const int c = lane & 15, g4 = lane >> 4;
+  const bool lowq = c < 8 && g4 < 2, highq = c >= 8 && g4 >= 2;
+  const int src = ((lane + 40) & 63) << 2;
+  auto fetch = [&](float v) -> float {
+    const float up = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, v)));
+    return lowq ? up : 0.f;
+  };
+#pragma unroll
+  for (int s = D2D_FIT_MAX_S - 1; s >= 1; --s) {
+    // (component by component: with a loop over the vector subscript the compiler fetched component 0 for all four)
+    const float u0 = fetch(acc[s - 1].x), u1 = fetch(acc[s - 1].y), u2 = fetch(acc[s - 1].z), u3 = fetch(acc[s - 1].w);
+    acc[s].x += u0; acc[s].y += u1; acc[s].z += u2; acc[s].w += u3;
+  }
+  wave_lds_sync();
+  // dense index = full entry - 4 for the knots 1 .. 5; knot 0: entries 2, 3, 6, 7 -> 0 .. 3; knot 6: entries 50, 51, 54, 55 -> 44 .. 47
+  const int cq = c & 7, cd = 2 * (cq >> 2) + (cq & 3) - 2;            // dense offset of an end knot's column, valid if (cq & 3) >= 2
+  const bool cv = (cq & 3) >= 2;
 #pragma unroll
   for (int s = 0; s < D2D_FIT_MAX_S; ++s) {
-    const int iC = (s >= 1 && s <= 4) ? 8 * s + c - 4 : kn_dense_of(8 * s + c);
+    // column
+    int iC = 8 * s + c - 4;
+    bool okc = true;
+    if (s == 0) { iC = c < 8 ? cd : c - 4; okc = c >= 8 || cv; }
+    if (s == D2D_FIT_MAX_S - 1) { iC = c < 8 ? 8 * s + c - 4 : 44 + cd; okc = c < 8 || cv; }
+    // the upper-knot quadrant of every segment but the last went into the next segment's accumulators
+    const bool mine = okc && !(highq && s < D2D_FIT_MAX_S - 1);
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
-      const int R = 8 * s + 4 * g4 + rr;
-      const int iR = (s >= 1 && s <= 4) ? R - 4 : kn_dense_of(R);
-#ifdef KN_ABL_STORE
-      if (iR >= 0 && iC >= 0) Hs[iR * LS + iC] = acc[s][rr];
-#else
-      if (iR >= 0 && iC >= 0) atomicAdd(Hs + iR * LS + iC, acc[s][rr]);
-#endif
+      int iR = 8 * s + 4 * g4 + rr - 4;
+      bool okr = true;
+      if (s == 0 && rr < 2) okr = g4 >= 2;                               // rows 0, 1, 4, 5 of knot 0: end conditions
+      if (s == 0 && rr >= 2) iR = g4 < 2 ? 2 * g4 + rr - 2 : 4 * g4 + rr - 4;
+      if (s == D2D_FIT_MAX_S - 1 && rr < 2) okr = g4 < 2;                // rows 48, 49, 52, 53
+      if (s == D2D_FIT_MAX_S - 1 && rr >= 2) iR = g4 < 2 ? 8 * s + 4 * g4 + rr - 4 : 44 + 2 * (g4 - 2) + rr - 2;
+      if (mine && okr) Hs[iR * LS + iC] = acc[s][rr];
     }
   }
   wave_lds_sync();
@@ -371,8 +389,9 @@ fit_lm_knot_kernel(int B, KnotGeom kg, KnotLds L, d2d_fit_opts opts, int iter_ca
 #ifdef KN_ABL_DAMP
       return f32x4{lam, lam, lam, lam};
 #endif
-      return lds_get<f32x4>(mdrow + j0) * lam;
+      return lam != 0.f ? lds_get<f32x4>(mdrow + j0) : f32x4{0.f, 0.f, 0.f, 0.f};     // (unscaled: damped_solve multiplies by `scale`)
     }
+    float scale;                  // = lam (wave-uniform copy for the rows of the system: 0 elsewhere through `lam`)
   };
   KnotMetric metric;
   metric.sfull = sfull; metric.mdrow = Md32 + (lane < N ? lane : 0) * N; metric.lam = 0.f;
@@ -471,17 +490,18 @@ fit_lm_knot_kernel(int B, KnotGeom kg, KnotLds L, d2d_fit_opts opts, int iter_ca
     }
     if (phase == 0) { V_mp_par = uniform_d(lmb[4]); V_mp_delta = uniform_d(lmb[5]); }
     else { V_lam = uniform_d(lmb[0]); V_nu = uniform_d(lmb[1]); }
-    double c = 0.0, gi = 0.0, gnrm = -1.0;
+    double c = 0.0, gi = 0.0, gnrm = -1.0, xub = 0.0;
     float hdiag = 0.f;
     f32x2 hrow[N / 2];
 #pragma unroll
     for (int m = 0; m < N / 2; ++m) hrow[m] = f32x2{0.f, 0.f};
     wave_lds_sync();
-    if (phase == 0 && mp.first && V_mp_delta <= 0.0) {              // lmder's first radius: factor * ||x||, ||x|| = ||u - u0||_M
+    if (phase == 0) {                                               // ||x|| = ||u - u0||_M: lmder's first radius is factor * ||x||
       const float dv = act ? (float)(ui - u0i) : 0.f;
       const float mv = metric.apply(dv);
-      const double xn = sqrt(uniform_d(wave_sum((double)dv * (double)mv)));
-      V_mp_delta = xn > 0.0 ? 100.0 * xn : 100.0;
+      const double xn = sqrt(fmax(uniform_d(wave_sum((double)dv * (double)mv)), 0.0));
+      xub = xn * (1.0 + 1e-6);
+      if (mp.first && V_mp_delta <= 0.0) V_mp_delta = xn > 0.0 ? 100.0 * xn : 100.0;
     }
     KN_STAMP(0)
     for (bool reenter = true; reenter;) {
@@ -555,7 +575,7 @@ fit_lm_knot_kernel(int B, KnotGeom kg, KnotLds L, d2d_fit_opts opts, int iter_ca
           double dxn = 0.0, t2 = 0.0;
           float dls, dgi;
           // the damped matrix H_u + lam Mu: the metric's row is added where the factorisation reads the lane's row (damped_solve)
-          metric.lam = lane < N ? (float)solve_lam : 0.f;
+          metric.lam = lane < N ? (float)solve_lam : 0.f; metric.scale = metric.lam;
           ok = uniform_i(damped_solve<N, true, true>(hrow, 0.0, act, lane, big, dgi, dls, nullptr, true, isq_mode, V_mp_delta, &dxn, &t2,
                                                      hdiag, true, metric) ? 1 : 0) != 0;
           KN_STAMP(5)
@@ -672,9 +692,16 @@ fit_lm_knot_kernel(int B, KnotGeom kg, KnotLds L, d2d_fit_opts opts, int iter_ca
           mp.slow = fabs(actred) <= D2D_LM_MP_SLOW_TOL ? mp.slow + 1 : 0;
           ++iters;
           sub = 0;
-          const float dv = act ? (float)(ui - u0i) : 0.f;
-          const float mv = metric.apply(dv);
-          const double xnorm = sqrt(fmax(uniform_d(wave_sum((double)dv * (double)mv)), 0.0));
+          // ||x|| = ||u - u0||_M enters only through  radius <= xtol ||x||  (xtol, eps ~ 1e-15): xub >= ||x|| (triangle inequality,
+          // grown by every accepted step) tells when those tests cannot fire, and the norm itself is computed only otherwise
+          if (taken) xub += V_pn;
+          double xnorm = xub;
+          if (V_mp_delta <= fmax(opts.mp_xtol, MP_EPSMCH) * xub) {
+            const float dv = act ? (float)(ui - u0i) : 0.f;
+            const float mv = metric.apply(dv);
+            xnorm = sqrt(fmax(uniform_d(wave_sum((double)dv * (double)mv)), 0.0));
+            xub = xnorm * (1.0 + 1e-6);
+          }
           int info = 0;
           if (fabs(actred) <= opts.mp_ftol && prered <= opts.mp_ftol && 0.5 * ratio <= 1.0) info = 1;
           if (V_mp_delta <= opts.mp_xtol * xnorm) info = 2;
@@ -810,14 +837,12 @@ int upload(T **dst, const std::vector<T> &src) {
 
 }  // namespace
 
-// D2D_FIT_KNOT=1 at plan creation selects the knot kernel for the headline shape: S = 6 (seven knots, 48 free entries), K <= 64.
-// It is NOT the default: with the dense factorisation of fit_phases.h it runs at the speed of fit_lm_kernel (the evaluation
-// phases are cheaper, the metric costs the solve what they save: DESIGN.md 5.3c) -- the default stays the q-coordinate kernel
-// until the banded factorisation this formulation allows exists.
+// The headline shape -- S = 6 (seven knots, 48 free entries), K <= 64, default solver -- runs on the knot kernel; D2D_FIT_KNOT=0 at
+// plan creation keeps the q-coordinate kernel (fit_lm_kernel) for A/B runs and for the tests that compare the two.
 int fit_knot_plan_init(d2d_fit_plan *pl) {
   pl->kn.wpb = 0;
   if (pl->S != 6 || pl->nq != 24 || pl->K > 64) return D2D_OK;
-  if (!getenv("D2D_FIT_KNOT") || atoi(getenv("D2D_FIT_KNOT")) != 1) return D2D_OK;
+  if (getenv("D2D_FIT_KNOT") && atoi(getenv("D2D_FIT_KNOT")) == 0) return D2D_OK;
   if (int rc = fit_basis_knots(pl)) return rc;
   for (int s2 = 0; s2 < pl->S; ++s2)
     if (pl->kn.k0[s2 + 1] - pl->kn.k0[s2] > KN_SEG_MAX) return D2D_OK;      // (cannot happen at K <= 64, S = 6)
@@ -866,12 +891,10 @@ int fit_knot_ensure(d2d_fit_plan *pl, int cap_B) {
 int fit_knot_launch(d2d_ctx *ctx, d2d_fit_plan *pl, int B, double *q, const d2d_fit_opts &o, int iter_cap, const int32_t *order, int prio_at) {
   auto &kn = pl->kn;
   KnotGeom kg;
-  kg.K = pl->K; kg.S = pl->S; kg.lmax = 0;
+  kg.K = pl->K; kg.S = pl->S; kg.smax = 0;
   for (int s = 0; s <= D2D_FIT_MAX_S + 1; ++s) kg.k0[s] = kn.k0[s < D2D_FIT_MAX_S + 2 ? s : D2D_FIT_MAX_S + 1];
-  for (int j = 0; j <= pl->S; ++j) {
-    const int len = kn.k0[j < pl->S ? j + 1 : pl->S] - kn.k0[j > 0 ? j - 1 : 0];
-    if (len > kg.lmax) kg.lmax = len;
-  }
+  for (int j = 0; j < pl->S; ++j)
+    if (kn.k0[j + 1] - kn.k0[j] > kg.smax) kg.smax = kn.k0[j + 1] - kn.k0[j];
   const KnotLds L = knot_lds_layout(pl->K, kn.wpb);
   KnotDev T{kn.d_Hb64, kn.d_Bq, kn.d_BiT, kn.d_Binv, kn.d_Minv, kn.d_Pu, kn.d_msc, kn.d_Hb32, kn.d_Wseg, kn.d_Md32, kn.d_Mrow32, kn.d_Mi32};
   static const bool want_stamps = getenv("D2D_LM_STAMPS") != nullptr;

@@ -617,8 +617,8 @@ __device__ __forceinline__ float lanes_above(float v, int j, unsigned long long 
 
 // Metric (fit_knot.hip: the solve in knot coordinates, where lmder's norm is ||s||_M and the damping is lam M): an object with
 //   apply(delta) -> (M delta)[lane]      dxnorm = sqrt(delta^T M delta), isq = || L^-1 (M delta / dxnorm) ||^2
-//   damp(j0)     -> lam * M[lane][j0 .. j0+3]   added to the lane's matrix row where the panel of columns j0 .. j0+3 reads it (zero on
-//                                               the lanes that are not rows of the system: lane N carries the right-hand side)
+//   damp(j0), scale -> M[lane][j0 .. j0+3] and lam: scale * damp is added to the lane's matrix row where the panel of columns
+//                      j0 .. j0+3 reads it (scale = 0 on the lanes that are not rows of the system: lane N carries the right-hand side)
 // The default (int) is the Euclidean norm with the damping on the pivots.
 template <int N, bool MP = false, bool FULL = false, class Metric = int>
 __device__ __forceinline__ bool damped_solve(const f32x2 (&hrow)[N / 2], double lam, bool act, int lane,
@@ -726,7 +726,7 @@ __device__ __forceinline__ bool damped_solve(const f32x2 (&hrow)[N / 2], double 
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         float a = HEL(j0 + c);
-        if constexpr (!__is_same(Metric, int)) a += mq[c];
+        if constexpr (!__is_same(Metric, int)) a = fmaf(metric.scale, mq[c], a);
         if (!FULL) a = live ? a : 0.f;
         if (I > 0) a -= dv[sp][c];
         s[c] = sp > 0 ? a - (acc[c].x + acc[c].y) : a;
