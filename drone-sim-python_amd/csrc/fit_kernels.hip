@@ -2294,7 +2294,7 @@ int d2d_fit_plan_destroy(d2d_fit_plan *pl) {
 
 int d2d_fit_plan_kernel(const d2d_fit_plan *pl) {
   if (!pl) return D2D_EINVAL;
-  return pl->use_lm ? D2D_FIT_KERNEL_FUSED : (pl->use_long ? D2D_FIT_KERNEL_LONG : D2D_FIT_KERNEL_SPLIT);
+  return pl->use_lm ? (pl->kn.wpb > 0 ? D2D_FIT_KERNEL_KNOT : D2D_FIT_KERNEL_FUSED) : (pl->use_long ? D2D_FIT_KERNEL_LONG : D2D_FIT_KERNEL_SPLIT);
 }
 
 int d2d_fit_plan_get(const d2d_fit_plan *pl, double *G, double *Gp, double *Z, double *Zp, double *Pinit) {

@@ -26,6 +26,7 @@
 #define KN_NE 56                // entries with the end conditions
 #define KN_WV_KNOT 10           // doubles per knot of a wave's knot vector (80 B: the six segments' reads fall into different banks)
 #define KN_US 10                // doubles per sample of the u records [axis][4] (80 B)
+#define KN_GTOL_SCALE 0.1        // the finish's gradient test in the metric's diagonal scaling: a tenth of gtol (oracle/fit_knot.py GTOL_SCALE)
 #define KN_SEG_MAX 11            // samples of one segment at K <= 64, S = 6
 #define KN_IMG_LS (KN_N + 4)    // row stride of the dense image (fit_phases.h CHOL_LS)
 
@@ -561,7 +562,7 @@ fit_lm_knot_kernel(int B, KnotGeom kg, KnotLds L, d2d_fit_opts opts, int iter_ca
             else sub = 3;
           } else {
             const double gmax = uniform_d(wave_max(act ? fabs(gi) / *msc_l : 0.0));
-            if (gmax <= opts.gtol) { status = D2D_ST_CONVERGED; break; }
+            if (gmax <= KN_GTOL_SCALE * opts.gtol) { status = D2D_ST_CONVERGED; break; }
             do_solve = true; solve_lam = V_lam;
           }
         } else if (sub == 1) {

@@ -472,8 +472,9 @@ class FitPlan:
 
     @property
     def kernel(self):
-        """'fused' | 'long' | 'split': the kernel d2d_fit_solve runs for this plan (include/d2d.h D2D_FIT_KERNEL_*)."""
-        return ('split', 'fused', 'long')[self.ctx.lib.d2d_fit_plan_kernel(self.h)]
+        """'fused' | 'long' | 'split' | 'knot': the kernel d2d_fit_solve runs for this plan with the default solver (include/d2d.h
+        D2D_FIT_KERNEL_*; 'knot' = the fused shape in knot coordinates, csrc/fit_knot.hip)."""
+        return ('split', 'fused', 'long', 'knot')[self.ctx.lib.d2d_fit_plan_kernel(self.h)]
 
     def basis(self):
         """Host copies: G (3,K,nq), Gp (3,K,4), Z (8S,nq), Zp (8S,4), Pinit (nq,K)."""

@@ -361,8 +361,12 @@ int d2d_fit_plan_destroy(d2d_fit_plan *plan);
  * the launch-pair path (D2D_FIT_SPLIT=1 in the environment).  d2d_fit_eval uses the launch-pair evaluation kernel
  * while the basis block fits the LDS (K <~ 229 at S = 6) and the segment formulation beyond; coupled groups run on the group
  * kernels up to that K and on the long-horizon kernel beyond; d2d_fit_rows / d2d_fit_jtj (the contraction-only pair of the
- * bench) keep the LDS limit (D2D_EINVAL beyond). */
-enum { D2D_FIT_KERNEL_SPLIT = 0, D2D_FIT_KERNEL_FUSED = 1, D2D_FIT_KERNEL_LONG = 2 };
+ * bench) keep the LDS limit (D2D_EINVAL beyond).
+ * D2D_FIT_KERNEL_KNOT (round 5): the fused shape (S = 6, K <= 64) with the DEFAULT solver runs in knot coordinates -- the reference's
+ * local parameterisation CompositeTraj([MinSnapPoly...]) (src/d2d/trajectory.py:166-208), J^T J block tridiagonal, one MFMA per sample
+ * (csrc/fit_knot.hip, oracle/fit_knot.py); D2D_LM_MODE_FAST and the time-sliced hand-out of such a plan stay on the fused q kernel.
+ * D2D_FIT_KNOT=0 in the environment at plan creation keeps the q kernel for the default solver too (then: D2D_FIT_KERNEL_FUSED). */
+enum { D2D_FIT_KERNEL_SPLIT = 0, D2D_FIT_KERNEL_FUSED = 1, D2D_FIT_KERNEL_LONG = 2, D2D_FIT_KERNEL_KNOT = 3 };
 int d2d_fit_plan_kernel(const d2d_fit_plan *plan);
 
 /* Copy the basis to host buffers (any may be NULL): G [3][K][nq], Gp [3][K][4],

@@ -29,6 +29,8 @@ import numpy as np
 from . import fit as F
 
 NK = 8           # entries per knot: 2 axes x (pos, vel, acc, jerk)
+GTOL_SCALE = 0.1  # the finish's gradient test max_j |g_u,j| / sqrt(Mu_jj) <= GTOL_SCALE * gtol: in the metric's diagonal scaling the
+                  # test is looser than max |g_q| <= gtol of the q statement by up to the spread of that scaling (csrc/fit_knot.hip KN_GTOL_SCALE)
 
 
 def hermite_unit():
@@ -292,7 +294,7 @@ def finish_knot(kb, sc, u, max_iter=200, ftol=1e-14, gtol=1e-9, xtol=1e-11, hess
     c, g, H = kb.eval_normal(sc, u, wp, second_order=True, hess_dtype=hess_dtype)
     it = 0
     for it in range(1, max_iter + 1):
-        if np.max(np.abs(g) / kb.msc) <= gtol:
+        if np.max(np.abs(g) / kb.msc) <= GTOL_SCALE * gtol:
             status = F.ST_CONVERGED
             break
         Dg = kb.Mu if scaling == 'M' else np.diag(np.maximum(np.abs(np.diag(H)), F.LM_DIAG_FLOOR))

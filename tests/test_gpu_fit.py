@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from oracle import fit as F
+from oracle import fit as F, fit_knot as FK
 
 pytestmark = pytest.mark.gpu
 
@@ -205,10 +205,16 @@ def test_solve_vs_oracle_and_scipy(ctx, plan, obasis, mode):
     assert np.isin(status, (F.ST_CONVERGED, F.ST_STALLED)).all(), status
     assert stats[2] == 0 and abs(stats[0] - cost.sum()) < 1e-9 * cost.sum()
     n_same_oracle = n_same_scipy = n_same_iters = 0
+    kbasis = FK.KnotBasis(obasis) if plan.kernel == 'knot' else None
     for i in range(B):
         # (a) the oracle running the same algorithm: same basin -> 1e-6
         if mode == 'fast':
             qo, co, ito, sto = F.lm_solve(obasis, sc[i])
+        elif plan.kernel == 'knot':
+            # the default solver of this shape runs in knot coordinates: its CPU statement is oracle/fit_knot.py (the same trial
+            # points as the q statement in exact arithmetic; the rounding of the fp32 factorisation differs)
+            qo, co, ito, sto, _ = FK.solve_minpack_knot(kbasis, sc[i], finish=0 if mode == 'minpack_pure' else F.MP_FINISH,
+                                                        max_iter=kw.get('max_iter', 200), hess_dtype=np.float32, chol_dtype=np.float32)
         else:
             qo, co, ito, sto, _ = F.solve_minpack(obasis, sc[i], finish=0 if mode == 'minpack_pure' else F.MP_FINISH, max_iter=kw.get('max_iter', 200),
                                                   hess_dtype=np.float32, chol_dtype=np.float32)
@@ -235,7 +241,9 @@ def test_solve_vs_oracle_and_scipy(ctx, plan, obasis, mode):
         assert n_same_scipy >= int(0.75 * B), n_same_scipy  # another LM variant picks other local minima
     else:
         assert n_same_scipy >= B - 1, n_same_scipy          # the path scipy follows
-        assert n_same_iters >= int(0.7 * B), n_same_iters   # (rounding ties in lmder's ratio tests shift a path by a trial or two)
+        # (rounding ties in lmder's ratio tests shift a path by a trial or two; pure lmder in knot coordinates ends on ftol = 1e-15
+        # in a linearly converging Gauss-Newton tail, where the last trials are decided at the level of the fp32 factorisation's rounding)
+        assert n_same_iters >= int((0.5 if (mode == 'minpack_pure' and plan.kernel == 'knot') else 0.7) * B), n_same_iters
 
 
 def test_solve_full_batch_properties(ctx, plan, obasis):
@@ -253,7 +261,9 @@ def test_solve_full_batch_properties(ctx, plan, obasis):
     c1, g1, _ = plan.eval(dsc, q, want_H=False)
     ok = np.isin(st, (F.ST_CONVERGED, F.ST_STALLED))
     assert np.abs(g1.cpu().numpy()[ok]).max() < 1e-5
-    np.testing.assert_allclose(c1.cpu().numpy(), cost.cpu().numpy(), rtol=1e-12)
+    # (the default solver evaluates the polynomial through the knot data and a Hermite table, d2d_fit_eval through the dense basis:
+    # two summation orders of the same flat outputs)
+    np.testing.assert_allclose(c1.cpu().numpy(), cost.cpu().numpy(), rtol=2e-11)
     q2 = q.clone()
     cost2, *_ = plan.solve(dsc, q2, max_iter=20)
     assert (np.abs((q2 - q).cpu().numpy()).max(1)[ok] < 1e-5).all()

@@ -87,7 +87,7 @@ def test_32768_fits_properties_and_order_invariance(ctx, plan, obasis):
     c1, g1, _ = plan.eval(dsc, q, want_H=False)
     c0h, c1h, ch = c0.cpu().numpy(), c1.cpu().numpy(), cost.cpu().numpy()
     assert (ch <= c0h * (1 + 1e-12)).all()
-    assert np.abs(c1h - ch).max() <= 1e-12 * np.abs(ch).max()
+    assert np.abs(c1h - ch).max() <= 2e-11 * np.abs(ch).max()        # (knot / Hermite evaluation in the solver, dense basis in d2d_fit_eval)
     # stationarity: |J^T r|_inf tiny relative to the scale of the gradient at the start, at every converged fit
     _, g0, _ = plan.eval(dsc, q0, want_H=False)
     gn1 = g1.abs().max(1).values.cpu().numpy(); gn0 = g0.abs().max(1).values.cpu().numpy()
@@ -235,8 +235,26 @@ def test_collocation_batch_16384_properties(ctx):
         assert info['status'] == 1 and abs(info['cost'] - cost[b]) <= 1e-7 * cost[b], (b, info['cost'], cost[b])
 
 
+@pytest.fixture(scope='module')
+def plan_q(ctx):
+    """the same plan with the default solver on the q-coordinate kernel (D2D_FIT_KNOT=0): the time-sliced hand-out lives there"""
+    import os
+    import d2dhip
+    old = os.environ.get('D2D_FIT_KNOT')
+    os.environ['D2D_FIT_KNOT'] = '0'
+    try:
+        p = d2dhip.FitPlan(ctx, S_, K, DUR, WREF)
+    finally:
+        if old is None:
+            del os.environ['D2D_FIT_KNOT']
+        else:
+            os.environ['D2D_FIT_KNOT'] = old
+    yield p
+    p.close()
+
+
 @pytest.mark.parametrize('mode', ['minpack', 'fast'])
-def test_time_sliced_handout_is_bit_identical(ctx, plan, mode):
+def test_time_sliced_handout_is_bit_identical(ctx, plan_q, mode):
     """d2d_fit_opts.slice > 0: fits that have run `slice` iterations while others wait go to the back of the device-wide ring and are
     resumed by whichever wavefront pops them (state through device-scope atomics, fetch-add tickets).  Scheduling only: every result
     bit for bit what the run-to-completion hand-out gives, every fit handled exactly once, on a batch that makes the ring work
@@ -244,6 +262,7 @@ def test_time_sliced_handout_is_bit_identical(ctx, plan, mode):
     import torch
     import d2dhip
     from d2dhip import synth
+    plan = plan_q
     kw = {} if mode == 'minpack' else {'mode': d2dhip.MODE_FAST}
     for B, sl in ((4500, 8), (2049, 4), (300, 4), (1, 4)):
         dsc = ctx.dev(synth.synth_scenarios(B, seed=31, obj_scale=0.1, K=K))

@@ -110,7 +110,7 @@ def test_long_kernel_equals_fused_kernel_at_K50(ctx):
     iteration counts within rounding-level differences of the two summation orders."""
     import d2dhip
     K = 50
-    pf, dur = _plan(ctx, K)
+    pf, dur = _plan(ctx, K, env={'D2D_FIT_KNOT': '0'})            # (the two q-coordinate copies of lmder; the knot kernel: tests/test_gpu_knot.py)
     pl, _ = _plan(ctx, K, env={'D2D_FIT_LONG': '1'})
     try:
         assert pf.kernel == 'fused' and pl.kernel == 'long'

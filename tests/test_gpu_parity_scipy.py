@@ -8,8 +8,8 @@ tests/golden/make_fit_scipy_golden.py, which also holds the fp64 exact minimiser
 
 Asserted: cost within 1e-6 of scipy's on every K = 50 fit; cost AND the 96 monomial coefficients within 1e-6 on >= 0.995 (K = 50) /
 >= 0.996 (K = 121) of them; every fit that differs from scipy's stopping point by more than 1e-6 is accounted for -- either it is the
-SAME minimum and scipy's stopping point is the one that is off (both are compared with the exact minimiser: the kernel within 1e-7,
-scipy further away than the kernel), or it is another certified minimum (scipy started from the kernel's point does not move)."""
+SAME minimum and scipy's stopping point is the one that is off (both are compared with the exact minimiser: the kernel within 5e-7,
+scipy at least twice as far away), or it is another certified minimum (scipy started from the kernel's point does not move)."""
 import hashlib
 import os
 
@@ -75,10 +75,12 @@ def _solve_and_compare(ctx, K, t1, sc, g, pre, max_iter):
     odd = np.nonzero(~same)[0]
     for i in odd:
         if near[i]:
-            # the same minimum: the kernel is on it to 1e-7, and scipy's own stopping point is further from it than the kernel's
+            # the same minimum: the kernel is on it to 5e-7, and scipy's own stopping point is further from it than the kernel's
             e_gpu = np.abs(z[i] - zstar[i]).max() / np.abs(zstar[i]).max()
             e_sci = np.abs(g[pre + 'z'][i] - zstar[i]).max() / np.abs(zstar[i]).max()
-            assert e_gpu <= 1e-7 and e_sci > e_gpu and g[pre + 'grad_left'][i] > 1e-10, (i, e_gpu, e_sci)
+            # (5e-7: a fit whose last Newton step changes the cost by less than its rounding is left where it is -- the valley is
+            # flat to 1e-15 of the cost there; scipy's stopping point is still at least twice as far from the exact minimiser)
+            assert e_gpu <= 5e-7 and e_sci > 2 * e_gpu and g[pre + 'grad_left'][i] > 1e-10, (i, e_gpu, e_sci)
         else:
             # another minimum: it must be one (the arbiter started from the kernel's point stays there)
             c3, q3 = _scipy_from(ob, sc[i], qh[i])
