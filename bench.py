@@ -687,13 +687,22 @@ def main():
         if lm_n > 0:
             # the whole LM loop runs in one persistent kernel per convergence check: it IS the hot path
             ach = ALG_FLOP_PER_EVAL * n_evals / (lm_ms * 1e-3) / 1e12
-            roof = {'bound': 'mfma', 'kernel': 'fit_lm_kernel<3,24> (fused solver loop: fp64 residual/J^T r, J^T J on v_mfma_f32_16x16x4_f32, fp32 Cholesky), solver = ' + a.mode,
+            knot = plan.kernel == 'knot' and a.mode == 'minpack'
+            kname = 'fit_lm_knot_kernel' if knot else 'fit_lm_kernel'
+            roof = {'bound': 'mfma',
+                    'kernel': (kname + ' (fused solver loop in knot coordinates: J^T J block tridiagonal, ONE v_mfma_f32_16x16x4_f32 per sample; fp64 residual / J^T r, fp32 Cholesky), solver = ' + a.mode) if knot
+                    else (kname + '<3,24> (fused solver loop: fp64 residual/J^T r, J^T J on v_mfma_f32_16x16x4_f32, fp32 Cholesky), solver = ' + a.mode),
                     'achieved': ach, 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / FP32_PEAK_TFLOPS,
-                    'traffic': pmc_traffic('fit_lm_kernel')[0], 'traffic_source': pmc_traffic('fit_lm_kernel')[1],
+                    'traffic': pmc_traffic(kname)[0], 'traffic_source': pmc_traffic(kname)[1],
                     'alg_flop_per_unit': ALG_FLOP_PER_EVAL, 'units_per_launch_avg': n_evals / lm_n,
                     'avg_launch_us': 1e3 * lm_ms / lm_n, 'launches': int(lm_n), 'kernel_ms_total': lm_ms,
-                    'note': 'achieved counts only the J^T J contraction (M*P*(P+1) per evaluation); the same kernel also does the '
-                            'fp64 residual/gradient phases, the Cholesky solves and the trial costs'}
+                    'note': 'achieved = the ALGORITHMIC count of SURVEY 8d, M*P*(P+1) = 200*48*49 flop per J^T J evaluation (variant R, symmetric, dense), per '
+                            'kernel time; the same kernel also does the fp64 residual / gradient phases, the Cholesky solves and the trial costs'
+                            + ('.  The knot kernel EXECUTES the block-sparse form SURVEY 8d allows (each sample touches the 16 columns of its segment): '
+                               '50-66 MFMAs of 2048 flop per evaluation instead of 300 -- executed_mfma_flop_per_unit says what the matrix cores really did' if knot else '')}
+            if knot:
+                roof['executed_mfma_flop_per_unit'] = 66 * 2048
+                roof['frac_of_executed_flop'] = 66 * 2048 * n_evals / (lm_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS
         else:
             ach = ALG_FLOP_PER_EVAL * n_evals / (ev_ms * 1e-3) / 1e12
             roof = {'bound': 'mfma', 'kernel': 'fit_eval_kernel (J^T J, v_mfma_f32_16x16x4_f32)', 'achieved': ach,
@@ -900,6 +909,7 @@ def main():
                        'check_every': a.check_every,
                        'solver': 'MINPACK lmder path on the normal equations + second-order finish (d2d_fit_opts.mode = D2D_LM_MODE_MINPACK, the library default)'
                                  if a.mode == 'minpack' else 'D2D_LM_MODE_FAST',
+                       'kernel': plan.kernel,
                        'handout': 'longest-first by the iteration counts of the previous solve of the same batch (warmup)' if a.order_hint else 'index order (no foreknowledge)',
                        'parallelism': f'trajectory-sharded x{world}'},
             'converged_frac': headline['converged_frac'], 'stalled_frac': headline['stalled_frac'], 'mean_iters': headline['mean_iters'],

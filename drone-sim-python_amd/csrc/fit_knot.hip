@@ -306,6 +306,43 @@ __device__ __forceinline__ void knot_blocks_to_image(f32x4 (&acc)[D2D_FIT_MAX_S]
   wave_lds_sync();
 }
 
+struct KnotMetric {
+  float *sfull;
+  const float *mdrow;           // this lane's row of the dense metric (shared table); lanes that are not rows: unused
+  const float *mrow;            // ... its twelve same-axis entries around the own knot (shared table)
+  float lam;                    // lam on the rows of the system, 0 elsewhere (lane N carries the right-hand side)
+  int e, ej, ea;
+  bool act;
+  __device__ __forceinline__ float apply(float v) const {
+#ifdef KN_ABL_APPLY
+    return v;
+#endif
+    wave_lds_sync();
+    if (act) sfull[8 + e] = v;
+    wave_lds_sync();
+    const float *bq = sfull + 8 * ej + 4 * ea;                 // knot j-1 (8 floats of padding in front)
+    const f32x4 s0 = lds_get<f32x4>(bq), s1 = lds_get<f32x4>(bq + 8), s2 = lds_get<f32x4>(bq + 16);
+    const f32x4 m0 = lds_get<f32x4>(mrow), m1 = lds_get<f32x4>(mrow + 4), m2 = lds_get<f32x4>(mrow + 8);
+    float r = m0.x * s0.x;
+    r = fmaf(m0.y, s0.y, r); r = fmaf(m0.z, s0.z, r); r = fmaf(m0.w, s0.w, r);
+    r = fmaf(m1.x, s1.x, r); r = fmaf(m1.y, s1.y, r); r = fmaf(m1.z, s1.z, r); r = fmaf(m1.w, s1.w, r);
+    r = fmaf(m2.x, s2.x, r); r = fmaf(m2.y, s2.y, r); r = fmaf(m2.z, s2.z, r); r = fmaf(m2.w, s2.w, r);
+    return act ? r : 0.f;
+  }
+  __device__ __forceinline__ f32x4 damp(int j0) const {
+#ifdef KN_ABL_DAMP
+    return f32x4{lam, lam, lam, lam};
+#endif
+    return lam != 0.f ? lds_get<f32x4>(mdrow + j0) : f32x4{0.f, 0.f, 0.f, 0.f};     // (unscaled: damped_solve multiplies by `scale`)
+  }
+  float scale;                  // = lam (wave-uniform copy for the rows of the system: 0 elsewhere through `lam`)
+};
+
+}  // namespace
+// (the factorisation may leave out the tiles a half-bandwidth <= 15 keeps zero: fit_phases.h damped_solve)
+template <> struct nd_is_banded<KnotMetric> { static constexpr bool value = true; };
+namespace {
+
 template <bool STAMPS>
 __global__ void __launch_bounds__(64 * KN_WPB_MAX)
 fit_lm_knot_kernel(int B, KnotGeom kg, KnotLds L, d2d_fit_opts opts, int iter_cap, KnotDev T, const double *__restrict__ pk,
@@ -363,37 +400,6 @@ fit_lm_knot_kernel(int B, KnotGeom kg, KnotLds L, d2d_fit_opts opts, int iter_ca
   for (int i = lane; i < 9 * 8; i += 64) sfull[i] = 0.f;
   // (M v)[lane] for a vector given lane-wise on the free entries: scattered to the [knot][axis][4] layout, the three same-axis
   // quads around the own knot read back (the metric is banded: one knot to either side); damp: lam * (row of M) for the solve
-  struct KnotMetric {
-    float *sfull;
-    const float *mdrow;           // this lane's row of the dense metric (shared table); lanes that are not rows: unused
-    const float *mrow;            // ... its twelve same-axis entries around the own knot (shared table)
-    float lam;                    // lam on the rows of the system, 0 elsewhere (lane N carries the right-hand side)
-    int e, ej, ea;
-    bool act;
-    __device__ __forceinline__ float apply(float v) const {
-#ifdef KN_ABL_APPLY
-      return v;
-#endif
-      wave_lds_sync();
-      if (act) sfull[8 + e] = v;
-      wave_lds_sync();
-      const float *bq = sfull + 8 * ej + 4 * ea;                 // knot j-1 (8 floats of padding in front)
-      const f32x4 s0 = lds_get<f32x4>(bq), s1 = lds_get<f32x4>(bq + 8), s2 = lds_get<f32x4>(bq + 16);
-      const f32x4 m0 = lds_get<f32x4>(mrow), m1 = lds_get<f32x4>(mrow + 4), m2 = lds_get<f32x4>(mrow + 8);
-      float r = m0.x * s0.x;
-      r = fmaf(m0.y, s0.y, r); r = fmaf(m0.z, s0.z, r); r = fmaf(m0.w, s0.w, r);
-      r = fmaf(m1.x, s1.x, r); r = fmaf(m1.y, s1.y, r); r = fmaf(m1.z, s1.z, r); r = fmaf(m1.w, s1.w, r);
-      r = fmaf(m2.x, s2.x, r); r = fmaf(m2.y, s2.y, r); r = fmaf(m2.z, s2.z, r); r = fmaf(m2.w, s2.w, r);
-      return act ? r : 0.f;
-    }
-    __device__ __forceinline__ f32x4 damp(int j0) const {
-#ifdef KN_ABL_DAMP
-      return f32x4{lam, lam, lam, lam};
-#endif
-      return lam != 0.f ? lds_get<f32x4>(mdrow + j0) : f32x4{0.f, 0.f, 0.f, 0.f};     // (unscaled: damped_solve multiplies by `scale`)
-    }
-    float scale;                  // = lam (wave-uniform copy for the rows of the system: 0 elsewhere through `lam`)
-  };
   KnotMetric metric;
   metric.sfull = sfull; metric.mdrow = Md32 + (lane < N ? lane : 0) * N; metric.lam = 0.f;
   metric.e = e; metric.ej = ej; metric.ea = ea; metric.act = act;

@@ -615,6 +615,8 @@ __device__ __forceinline__ float lanes_above(float v, int j, unsigned long long 
   return r;
 }
 
+template <class M> struct nd_is_banded { static constexpr bool value = false; };
+
 // Metric (fit_knot.hip: the solve in knot coordinates, where lmder's norm is ||s||_M and the damping is lam M): an object with
 //   apply(delta) -> (M delta)[lane]      dxnorm = sqrt(delta^T M delta), isq = || L^-1 (M delta / dxnorm) ||^2
 //   damp(j0), scale -> M[lane][j0 .. j0+3] and lam: scale * damp is added to the lane's matrix row where the panel of columns
@@ -757,8 +759,12 @@ __device__ __forceinline__ bool damped_solve(const f32x2 (&hrow)[N / 2], double 
     // block column I is complete: its contribution to the tiles of the block columns behind it
     if (I + 1 < NBK) {
       f32x4 op[NBK + 1];               // op[J]: L[16 J + m][c0 + 4 g .. + 3]; the rows behind N (block NBK) are not used
+      // (a Metric that says `banded`: the matrix has half-bandwidth <= 15, so block column I has no entries in the rows of the
+      // block columns beyond I + 1 -- their operands are zero and their tiles are left alone: 16 MFMAs per factorisation instead of 28)
+      constexpr bool BANDED = nd_is_banded<Metric>::value;
 #pragma unroll
       for (int J = I + 1; J <= NBK; ++J) {
+        if (BANDED && J > I + 1 && J < NBK) continue;
         const int rowi = (J < NBK) ? 16 * J + m16 : (N + (m16 & 3));
         op[J] = lds_get<f32x4>(Lm + rowi * LS + c0 + 4 * g4);
       }
@@ -766,6 +772,7 @@ __device__ __forceinline__ bool damped_solve(const f32x2 (&hrow)[N / 2], double 
       for (int ip = I + 1; ip < NBK; ++ip)
 #pragma unroll
         for (int J = ip; J <= NBK; ++J)
+          if (!(BANDED && (ip > I + 1 || (J > I + 1 && J < NBK))))
 #pragma unroll
 #ifndef ABL_NOMFMA
           for (int q = 0; q < 4; ++q) T[ip][J] = __builtin_amdgcn_mfma_f32_16x16x4f32(op[J][q], op[ip][q], T[ip][J], 0, 0, 0);

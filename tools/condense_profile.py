@@ -34,7 +34,7 @@ with open(prefix + '_pmc_summary.txt', 'w') as out:
 traffic = {}
 for k, cs in acc.items():
     if 'FETCH_SIZE' in cs and 'WRITE_SIZE' in cs:
-        name = next((n for n in ('fit_lm_kernel', 'fit_jtj_kernel', 'gvf_run_kernel', 'track_run_kernel', 'nlp_solve_kernel') if n in k), None)
+        name = next((n for n in ('fit_lm_knot_kernel', 'fit_lm_kernel', 'fit_jtj_kernel', 'gvf_run_kernel', 'track_run_kernel', 'nlp_solve_kernel') if n in k), None)
         if name is None:
             continue
         fetch_kib = sum(cs['FETCH_SIZE']) / len(cs['FETCH_SIZE'])
