@@ -168,15 +168,24 @@ __device__ __forceinline__ double knot_phase2(const KnotGeom &kg, const double *
     const double *hb = Hb64 + (size_t)k0 * KN_HB_STRIDE + 4 * ((half ? 0 : 4) + kd);
     const double *uk = us + k0 * KN_US + 4 * a;
     const int n = live ? k1 - k0 : 0;
-    for (int t = 0; t < smax; ++t) {
-      if (t < n) {
-        const f64x2a h01 = *reinterpret_cast<const f64x2a *>(hb), u01 = *reinterpret_cast<const f64x2a *>(uk);
-        const double h2 = hb[2], u2 = uk[2];
-        a0 = fma(h01.x, u01.x, a0);
-        a1 = fma(h01.y, u01.y, a1);
-        a2 = fma(h2, u2, a2);
+    for (int t = 0; t < smax; t += 3) {                   // three samples per iteration: their twelve reads, then their nine FMAs
+      f64x2a h01[3], u01[3];
+      double h2[3], u2[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+        if (t + i < n) {
+          h01[i] = *reinterpret_cast<const f64x2a *>(hb + i * KN_HB_STRIDE); u01[i] = *reinterpret_cast<const f64x2a *>(uk + i * KN_US);
+          h2[i] = hb[i * KN_HB_STRIDE + 2]; u2[i] = uk[i * KN_US + 2];
+        } else {
+          h01[i] = f64x2a{0.0, 0.0}; u01[i] = f64x2a{0.0, 0.0}; h2[i] = 0.0; u2[i] = 0.0;
+        }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        a0 = fma(h01[i].x, u01[i].x, a0);
+        a1 = fma(h01[i].y, u01[i].y, a1);
+        a2 = fma(h2[i], u2[i], a2);
       }
-      hb += KN_HB_STRIDE; uk += KN_US;
+      hb += 3 * KN_HB_STRIDE; uk += 3 * KN_US;
     }
   }
   return (a0 + a1) + a2;
@@ -187,6 +196,7 @@ __device__ __forceinline__ double knot_phase2(const KnotGeom &kg, const double *
 // J[row r][col c] = cA * TA + cB * TB from one 8-byte read of the fp32 Hermite table (d1, d2 for the v / phi rows, d0, d1 for the
 // position rows whose cB is zero) and one of the row record.  The end conditions' columns are zero in the table.  The waypoint rows'
 // constant block (w^2 sum Hb0^T Hb0, per segment) is the accumulators' start value.
+template <int SEGMAX>
 __device__ __forceinline__ void knot_mfma(const KnotGeom &kg, const unsigned char *lds, int hb32_off, int cf_off, const float *Wseg,
                                           float ww, int lane, f32x4 (&acc)[D2D_FIT_MAX_S]) {
   LAUNDER(lane);
@@ -194,25 +204,33 @@ __device__ __forceinline__ void knot_mfma(const KnotGeom &kg, const unsigned cha
   const int m = 4 * (c >> 3) + (c & 3), a = (c >> 2) & 1;
   const int tab = hb32_off + (4 * m + (r < 2 ? 1 : 0)) * 4;
   const int cfo = cf_off + r * 16 + a * 8;
+  // three segments at a time: their operands first -- 2 x 8-byte reads per sample, all in flight together (clamped past the end
+  // of a segment) -- then their k-steps round-robin over the three accumulators
 #pragma unroll
-  for (int s = 0; s < D2D_FIT_MAX_S; ++s) {
+  for (int s0 = 0; s0 < D2D_FIT_MAX_S; s0 += 3) {
+    float v[3][SEGMAX];
+    int n[3];
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) acc[s][rr] = ww * Wseg[(s * 4 + rr) * 64 + lane];
-    // the whole segment's operands first (<= KN_SEG_MAX samples: 2 x 8-byte reads each, clamped past the end), then its k-steps:
-    // the reads of a segment are in flight together instead of one round trip per sample
-    int kb = kg.k0[s], n = kg.k0[s + 1] - kg.k0[s];
-    LAUNDER_S(kb); LAUNDER_S(n);
-    float v[KN_SEG_MAX];
+    for (int j = 0; j < 3; ++j) {
+      const int s = s0 + j;
+      int kb = kg.k0[s];
+      n[j] = kg.k0[s + 1] - kg.k0[s];
+      LAUNDER_S(kb); LAUNDER_S(n[j]);
 #pragma unroll
-    for (int i = 0; i < KN_SEG_MAX; ++i) {
-      const int kk = kb + (i < n ? i : (n > 0 ? n - 1 : 0));
-      const float2 t = lds_get<float2>(lds + tab + kk * 128);
-      const float2 cc = lds_get<float2>(lds + cfo + kk * 64);
-      v[i] = fmaf(cc.y, t.y, cc.x * t.x);
+      for (int i = 0; i < SEGMAX; ++i) {
+        const int kk = kb + (i < n[j] ? i : (n[j] > 0 ? n[j] - 1 : 0));
+        const float2 t = lds_get<float2>(lds + tab + kk * 128);
+        const float2 cc = lds_get<float2>(lds + cfo + kk * 64);
+        v[j][i] = fmaf(cc.y, t.y, cc.x * t.x);
+      }
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) acc[s][rr] = ww * Wseg[(s * 4 + rr) * 64 + lane];
     }
 #pragma unroll
-    for (int i = 0; i < KN_SEG_MAX; ++i)
-      if (i < n) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[i], v[i], acc[s], 0, 0, 0);
+    for (int i = 0; i < SEGMAX; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        if (i < n[j]) acc[s0 + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[j][i], v[j][i], acc[s0 + j], 0, 0, 0);
   }
 }
 
@@ -343,7 +361,8 @@ struct KnotMetric {
 template <> struct nd_is_banded<KnotMetric> { static constexpr bool value = true; };
 namespace {
 
-template <bool STAMPS>
+// SEG9: no segment holds more than nine samples (K <= 54 at S = 6: the bench's K = 50) -- the MFMA pass keeps 27 operands, not 33
+template <bool STAMPS, bool SEG9>
 __global__ void __launch_bounds__(64 * KN_WPB_MAX)
 fit_lm_knot_kernel(int B, KnotGeom kg, KnotLds L, d2d_fit_opts opts, int iter_cap, KnotDev T, const double *__restrict__ pk,
                    const double *__restrict__ prep, double *q_io, double *cost_io, double *g_io, double *lm, int32_t *flags,
@@ -535,7 +554,8 @@ fit_lm_knot_kernel(int B, KnotGeom kg, KnotLds L, d2d_fit_opts opts, int iter_ca
             const float ww = (float)(sp[PR_WWP] * sp[PR_WWP]);
             const int wbase = L.wave0 + wave * L.wave_stride;
             if (so_rows) knot_mfma_so(kg, lds, L.Hb32, wbase + L.cf, wbase + L.cfp, Wseg, ww, lane, acc);
-            else knot_mfma(kg, lds, L.Hb32, wbase + L.cf, Wseg, ww, lane, acc);
+            else if (SEG9) knot_mfma<9>(kg, lds, L.Hb32, wbase + L.cf, Wseg, ww, lane, acc);
+            else knot_mfma<KN_SEG_MAX>(kg, lds, L.Hb32, wbase + L.cf, Wseg, ww, lane, acc);
             nev += so_rows ? 3 : 2;
             wave_lds_sync();
             KN_STAMP(3)
@@ -871,8 +891,10 @@ int fit_knot_plan_init(d2d_fit_plan *pl) {
   if (!rc) rc = upload(&kn.d_Pu, kn.Pu);
   if (!rc) rc = upload(&kn.d_msc, kn.msc);
   if (rc) return rc;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fit_lm_knot_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, KN_LDS_BYTES);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fit_lm_knot_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, KN_LDS_BYTES);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fit_lm_knot_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, KN_LDS_BYTES);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fit_lm_knot_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, KN_LDS_BYTES);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fit_lm_knot_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, KN_LDS_BYTES);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fit_lm_knot_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, KN_LDS_BYTES);
   kn.wpb = wpb;
   return D2D_OK;
 }
@@ -911,12 +933,13 @@ int fit_knot_launch(d2d_ctx *ctx, d2d_fit_plan *pl, int B, double *q, const d2d_
   int32_t *queue = ctx->counter_dev + 8;
   float *dbg = nullptr;                  // development: D2D_KNOT_DEBUG=<file> dumps the first evaluation (H_u rows, g_u, u) of every fit
   if (getenv("D2D_KNOT_DEBUG")) D2D_CHECK_HIP(hipMalloc(&dbg, (size_t)B * (KN_N * KN_N + 4 * KN_N) * sizeof(float)));
-  if (want_stamps)
-    hipLaunchKernelGGL((fit_lm_knot_kernel<true>), dim3(blocks), dim3(64 * kn.wpb), L.total, ctx->stream, B, kg, L, o, iter_cap, T, pl->d_pk,
-                       pl->d_prep, q, pl->d_cost, pl->d_g, pl->d_lm, pl->d_flags, queue, order, prio_at, kn.d_u, stamps, dbg);
-  else
-    hipLaunchKernelGGL((fit_lm_knot_kernel<false>), dim3(blocks), dim3(64 * kn.wpb), L.total, ctx->stream, B, kg, L, o, iter_cap, T, pl->d_pk,
-                       pl->d_prep, q, pl->d_cost, pl->d_g, pl->d_lm, pl->d_flags, queue, order, prio_at, kn.d_u, stamps, dbg);
+#define KN_LAUNCH(ST, S9)                                                                                                                  \
+  hipLaunchKernelGGL((fit_lm_knot_kernel<ST, S9>), dim3(blocks), dim3(64 * kn.wpb), L.total, ctx->stream, B, kg, L, o, iter_cap, T, pl->d_pk, \
+                     pl->d_prep, q, pl->d_cost, pl->d_g, pl->d_lm, pl->d_flags, queue, order, prio_at, kn.d_u, stamps, dbg)
+  const bool seg9 = kg.smax <= 9;
+  if (want_stamps) { if (seg9) KN_LAUNCH(true, true); else KN_LAUNCH(true, false); }
+  else { if (seg9) KN_LAUNCH(false, true); else KN_LAUNCH(false, false); }
+#undef KN_LAUNCH
   D2D_LAUNCH_CHECK();
   if (dbg) {
     std::vector<float> h((size_t)B * (KN_N * KN_N + 4 * KN_N));

@@ -122,3 +122,41 @@ def test_knot_kernel_wind_bankmax_box_and_extra_obstacles(ctx):
         assert g1.abs().max(1).values.cpu().numpy()[smooth].max() <= 1e-5
     finally:
         pk.close(); pq.close()
+
+
+@pytest.mark.parametrize('K2', [64, 40, 57])
+def test_knot_kernel_other_sample_counts(ctx, K2):
+    """K = 64 (eleven samples in the longest segment: the kernel's general instantiation), K = 40 and an odd K: the same minima as the
+    q-coordinate kernel, the reported cost is the oracle's at the returned point."""
+    import d2dhip
+    from d2dhip import synth
+    dur = synth.planner_timing(0, (K2 - 1) / 10.0, 10)[2]
+    wref = synth.default_wref(0.1, K2)
+    sc = synth.synth_scenarios(96, seed=5, obj_scale=0.1, K=K2, dist_range=(30. * dur / 4.9, 55. * dur / 4.9))
+    dsc = ctx.dev(sc)
+    plans = []
+    for knot in ('1', '0'):
+        old = os.environ.get('D2D_FIT_KNOT')
+        os.environ['D2D_FIT_KNOT'] = knot
+        try:
+            plans.append(d2dhip.FitPlan(ctx, S_, K2, dur, wref))
+        finally:
+            if old is None:
+                del os.environ['D2D_FIT_KNOT']
+            else:
+                os.environ['D2D_FIT_KNOT'] = old
+    pk, pq = plans
+    try:
+        assert pk.kernel == 'knot' and pq.kernel == 'fused'
+        q0 = pk.init(dsc)
+        qk, qq = q0.clone(), q0.clone()
+        ck, ik, sk, _ = pk.solve(dsc, qk)
+        cq, iq, sq, _ = pq.solve(dsc, qq)
+        assert np.isin(sk.cpu().numpy(), (d2dhip.ST_CONVERGED, d2dhip.ST_STALLED)).all()
+        ckh, cqh = ck.cpu().numpy(), cq.cpu().numpy()
+        assert (np.abs(ckh - cqh) <= 1e-6 * cqh).mean() >= 0.97
+        ob = F.FitBasis.from_arrays(S_, K2, dur, *pk.basis())
+        for i in range(8):
+            assert abs(F.cost(ob, sc[i], qk.cpu().numpy()[i]) - ckh[i]) <= 1e-10 * ckh[i]
+    finally:
+        pk.close(); pq.close()
