@@ -116,12 +116,24 @@ def _cpu_fit_one(args):
     return 2 * res.cost, res.x
 
 
+KNOT_DEFAULT = os.environ.get('D2D_FIT_KNOT', '1') != '0'      # the headline shape's default solver runs in knot coordinates (csrc/fit_knot.hip)
+_KB = {}
+
+
 def _cpu_oracle_lm_one(args):
-    """oracle/fit.py solve_minpack: the CPU statement of the kernel's default algorithm (lmder on the normal equations + second-order
-    finish) with the kernel's precision split (fp32 Hessian and Cholesky, fp64 residuals / cost / J^T r)."""
+    """The CPU statement of the kernel's default algorithm (lmder on the normal equations + second-order finish) with the kernel's
+    precision split (fp32 Hessian and Cholesky, fp64 residuals / cost / J^T r): oracle/fit_knot.py solve_minpack_knot for the knot
+    kernel (the same trial points as oracle/fit.py solve_minpack in exact arithmetic), solve_minpack with D2D_FIT_KNOT=0."""
     from oracle import fit as F
     basis, sc = args
-    q, c, it, st, info = F.solve_minpack(basis, sc, hess_dtype=np.float32, chol_dtype=np.float32)
+    if KNOT_DEFAULT:
+        from oracle import fit_knot as FK
+        kb = _KB.get(id(basis))
+        if kb is None:
+            kb = _KB[id(basis)] = FK.KnotBasis(basis)
+        q, c, it, st, info = FK.solve_minpack_knot(kb, sc, hess_dtype=np.float32, chol_dtype=np.float32)
+    else:
+        q, c, it, st, info = F.solve_minpack(basis, sc, hess_dtype=np.float32, chol_dtype=np.float32)
     return c, q, it
 
 
@@ -168,7 +180,7 @@ def cpu_baseline(batch, n_sample=1024, n_oracle=1024):
            # the pool is that size (D2D_BENCH_CORES overrides) and the whole-host figure is an EXTRAPOLATION, labelled as such
            'extrapolated_to_host_cpu_count': n_sample / dt / cores * (os.cpu_count() or cores),
            'oracle_lm': {'value': len(ores) / dto, 'unit': 'trajectory-optimisations/s',
-                         'sample': f'oracle/fit.py solve_minpack (the CPU statement of the kernel\'s default algorithm, fp32 Hessian / Cholesky like the kernel) '
+                         'sample': f'{"oracle/fit_knot.py solve_minpack_knot" if KNOT_DEFAULT else "oracle/fit.py solve_minpack"} (the CPU statement of the kernel\'s default algorithm, fp32 Hessian / Cholesky like the kernel) '
                                    f'on the first {len(ores)} of them, same pool, {dto:.1f} s wall', 'mean_iters': float(np.mean([r[2] for r in ores]))}}
     keep = {'basis': basis, 'sc': sc, 'cost': costs, 'q': qs, 'z': z,
             'o_cost': np.array([r[0] for r in ores]), 'o_q': np.array([r[1] for r in ores])}
@@ -871,7 +883,7 @@ def main():
                   'coeff_rel_le_1e-6_frac': float((rel_z <= 1e-6).mean()),
                   'others': four_numbers(a.mode, cg, qg, same, a.mode),
                   'mean_cost_gpu': float(cg.mean()), 'mean_cost_cpu': float(keep['cost'].mean()),
-                  'vs_oracle_lm': {'scenarios': no, 'what': 'GPU vs oracle/fit.py solve_minpack (the CPU statement of the same algorithm with the same precision split)'
+                  'vs_oracle_lm': {'scenarios': no, 'what': ('GPU vs oracle/fit_knot.py solve_minpack_knot' if KNOT_DEFAULT else 'GPU vs oracle/fit.py solve_minpack') + ' (the CPU statement of the same algorithm with the same precision split)'
                                                             if a.mode == 'minpack' else 'GPU (fast mode) vs oracle/fit.py solve_minpack: different algorithms',
                                    'same_minimum_frac': float(((rel_co <= 1e-6) & (rel_qo <= 1e-6)).mean())},
                   'polish': {'scenarios': npol, 'what': 'scipy LM (tol 1e-15) started from the GPU solutions: largest relative move',
