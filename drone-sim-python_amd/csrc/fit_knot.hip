@@ -407,14 +407,25 @@ fit_lm_knot_kernel(int B, KnotGeom kg, KnotLds L, d2d_fit_opts opts, int iter_ca
   const int ej = e >> 3, ea = (e >> 2) & 1, ekd = e & 3;
   const int wv_slot = ej * KN_WV_KNOT + 4 * ea + ekd;
   // samples of the entry's two segments (phase 2)
-  int p2_kb = 0, p2_km = 0, p2_ke = 0;
+  // (recomputed where they are used -- a dozen selects -- rather than held in registers across the whole launch)
+  auto p2_ranges = [&](int &kb, int &km, int &ke) {
+    int lj = lane;
+    LAUNDER(lj);
+    const int e2 = lj < N ? kn_entry_of(lj) : 0, j2 = e2 >> 3;
+    kb = 0; km = 0; ke = 0;
 #pragma unroll
-  for (int j = 0; j <= D2D_FIT_MAX_S; ++j)
-    if (j == ej) { p2_kb = kg.k0[j > 0 ? j - 1 : 0]; p2_km = kg.k0[j]; p2_ke = kg.k0[j < kg.S ? j + 1 : kg.S]; }
+    for (int j = 0; j <= D2D_FIT_MAX_S; ++j)
+      if (j == j2) { kb = kg.k0[j > 0 ? j - 1 : 0]; km = kg.k0[j]; ke = kg.k0[j < kg.S ? j + 1 : kg.S]; }
+  };
   // the sample's segment (phase 1)
-  int seg = 0;
+  auto seg_of_lane = [&]() -> int {
+    int lj = lane;
+    LAUNDER(lj);
+    int sg = 0;
 #pragma unroll
-  for (int s = 1; s < D2D_FIT_MAX_S; ++s) seg += (lane >= kg.k0[s] && s < kg.S) ? 1 : 0;
+    for (int s = 1; s < D2D_FIT_MAX_S; ++s) sg += (lj >= kg.k0[s] && s < kg.S) ? 1 : 0;
+    return sg;
+  };
   const double *msc_l = reinterpret_cast<const double *>(lds + L.Msc) + (act ? e : 0);      // sqrt(Mu_ee): the finish's max-norm scaling
   for (int i = lane; i < 9 * 8; i += 64) sfull[i] = 0.f;
   // (M v)[lane] for a vector given lane-wise on the free entries: scattered to the [knot][axis][4] layout, the three same-axis
@@ -532,7 +543,7 @@ fit_lm_knot_kernel(int B, KnotGeom kg, KnotLds L, d2d_fit_opts opts, int iter_ca
     KN_STAMP(0)
     for (bool reenter = true; reenter;) {
       reenter = false;
-      c = uniform_d(knot_phase1(kg.K, Hb64, sp, wv, seg, wpx, wpy, us, cf, cfp, so_rows, lane));
+      c = uniform_d(knot_phase1(kg.K, Hb64, sp, wv, seg_of_lane(), wpx, wpy, us, cf, cfp, so_rows, lane));
       KN_STAMP(1)
       bool fresh = true;
       if (!(fabs(c) <= 1.79e308)) { status = D2D_ST_NONFINITE; fresh = false; }
@@ -546,6 +557,8 @@ fit_lm_knot_kernel(int B, KnotGeom kg, KnotLds L, d2d_fit_opts opts, int iter_ca
         int isq_mode = 0;
         if (sub == 0) {
           if (fresh) {
+            int p2_kb, p2_km, p2_ke;
+            p2_ranges(p2_kb, p2_km, p2_ke);
             gi = knot_phase2(kg, Hb64, us, p2_kb, p2_km, p2_ke, ea, ekd, act, lane);
             KN_STAMP(2)
             fresh = false;
@@ -686,7 +699,7 @@ fit_lm_knot_kernel(int B, KnotGeom kg, KnotLds L, d2d_fit_opts opts, int iter_ca
         const bool so_trial = phase != 0;
         if (act) wv[wv_slot] = ui + V_alpha * (double)dl;
         wave_lds_sync();
-        const double ca = uniform_d(knot_phase1(kg.K, Hb64, sp, wv, seg, wpx, wpy, us, cf, cfp, so_trial, lane));
+        const double ca = uniform_d(knot_phase1(kg.K, Hb64, sp, wv, seg_of_lane(), wpx, wpy, us, cf, cfp, so_trial, lane));
         KN_STAMP(1)
         if (phase == 0) {
           const double fnorm = sqrt(c);
@@ -813,7 +826,7 @@ fit_lm_knot_kernel(int B, KnotGeom kg, KnotLds L, d2d_fit_opts opts, int iter_ca
         gq = a0 + a1;
         q_io[(size_t)b * N + lane_io] = qv;
         g_io[(size_t)b * N + lane_io] = gq;
-        u_io[(size_t)b * 64 + lane_io] = ui;
+        if (status == D2D_ST_RUNNING) u_io[(size_t)b * 64 + lane_io] = ui;      // (only a fit that will be resumed needs its knot vector kept)
       }
       const double gmax = uniform_d(wave_max(fabs(gq)));
       if (lane == 0) {
