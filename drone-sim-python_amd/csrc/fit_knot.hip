@@ -44,7 +44,7 @@ struct KnotGeom {
 
 struct KnotLds {
   int Hb64, Hb32, Wseg, Md32, Mi32, Mr32, Msc, wave0, wave_stride;
-  int wv, sp, sfull, gfull, big, cf, cfp;   // inside a wave's block; `big`: the u records, then cf, cfp -- overlaid by the image
+  int wv, sp, sfull, gfull, park, big, cf, cfp;   // inside a wave's block; `big`: the u records, then cf, cfp -- overlaid by the image
   int total;
 };
 
@@ -66,6 +66,7 @@ KnotLds knot_lds_layout(int K, int wpb) {
   L.sp = w; w = align16(w + FIT_PREP_STRIDE * 8);
   L.sfull = w; w = align16(w + 9 * 8 * 4);            // one padding knot on either side of the 7 x 8 floats
   L.gfull = w; w = align16(w + KN_NE * 8);
+  L.park = w; w = align16(w + 3 * 64 * 8);           // per-fit lane constants: the two waypoint coordinates of the lane's sample, u0 of its entry
   L.big = w;
   const int us_bytes = align16(K * KN_US * 8), cf_bytes = (K + 1) * 4 * 16, cfp_bytes = align16((K + 1) * 2 * 8);
   L.cf = w + us_bytes;
@@ -91,6 +92,10 @@ __device__ __forceinline__ void stage(void *dst, const void *src, int bytes) {
 
 // dense index (0 .. 47) of the free entries in ascending order <-> full entry (0 .. 55)
 __device__ __forceinline__ int kn_entry_of(int i) { return i < 4 ? (i < 2 ? 2 + i : 4 + i) : (i < 44 ? i + 4 : (i < 46 ? i + 6 : i + 8)); }
+// ... with lanes 48 .. 55 on the eight end conditions (entries 0, 1, 4, 5, 48, 49, 52, 53)
+__device__ __forceinline__ int kn_entry_all(int l) {
+  return l < 48 ? kn_entry_of(l) : (l < 56 ? (l < 52 ? 0 : 48) + ((l & 2) ? 4 : 0) + (l & 1) : 0);
+}
 __device__ __forceinline__ int kn_dense_of(int e) {          // -1: an end condition
   if (e >= 8 && e < 48) return e - 4;
   if ((e & 3) < 2) return -1;
@@ -100,8 +105,8 @@ __device__ __forceinline__ int kn_dense_of(int e) {          // -1: an end condi
 // ---- phase 1 (lane = sample): flat outputs from the 16 knot values of the sample's segment, rows, records -------------------------
 // wv: the wave's knot vector [7][KN_WV_KNOT] (knot j: x (4), y (4)); seg: this lane's segment.  Records: us [K][KN_US] = u_k as
 // [axis][d] (d = 0..2: position, velocity, acceleration part of D_k^T r_k), cf / cfp as fit_phases.h eval_phase1_reg.
-__device__ __forceinline__ double knot_phase1(int K, const double *Hb64, const double *sp, const double *wv, int seg, double wpx,
-                                              double wpy, double *us, f32x4 *cf, float2 *cfp, bool so, int lane) {
+__device__ __forceinline__ double knot_phase1(int K, const double *Hb64, const double *sp, const double *wv, int seg, const double *park,
+                                              double *us, f32x4 *cf, float2 *cfp, bool so, int lane) {
   typedef double __attribute__((ext_vector_type(2), may_alias)) f64x2a;
   double cacc = 0.0;
   LAUNDER(lane);
@@ -132,6 +137,7 @@ __device__ __forceinline__ double knot_phase1(int K, const double *Hb64, const d
     double u[6] = {0, 0, 0, 0, 0, 0};
     f32x4 coef[4];
     const ScenP s = load_scenp(sp);
+    const double wpx = park[k], wpy = park[64 + k];       // the 'tri' waypoint of this sample (parked per fit)
     if (so) {
       float2 pos[2];
       cacc = sample_terms<true>(s, Y, wpx, wpy, u, coef, k == kbank, pos);
@@ -325,20 +331,27 @@ __device__ __forceinline__ void knot_blocks_to_image(f32x4 (&acc)[D2D_FIT_MAX_S]
 }
 
 struct KnotMetric {
-  float *sfull;
-  const float *mdrow;           // this lane's row of the dense metric (shared table); lanes that are not rows: unused
-  const float *mrow;            // ... its twelve same-axis entries around the own knot (shared table)
+  // everything addressed as byte offsets from the workgroup's LDS base (wave-uniform bases, lane-dependent parts recomputed from
+  // the lane where they are used): held as per-lane pointers across the solver loop they were a dozen VGPRs that went to scratch
+  unsigned char *lds;
+  int sfull_off, md32_off, mr32_off;   // the wave's scatter buffer; the shared tables of the dense metric rows and of the banded ones
+  int lane;
   float lam;                    // lam on the rows of the system, 0 elsewhere (lane N carries the right-hand side)
-  int e, ej, ea;
-  bool act;
+  float scale;                  // = lam
   __device__ __forceinline__ float apply(float v) const {
 #ifdef KN_ABL_APPLY
     return v;
 #endif
+    int l = lane;
+    LAUNDER(l);
+    const bool act = l < KN_N;
+    const int e = act ? kn_entry_of(l) : 0;
+    float *sf = reinterpret_cast<float *>(lds + sfull_off);
     wave_lds_sync();
-    if (act) sfull[8 + e] = v;
+    if (act) sf[8 + e] = v;
     wave_lds_sync();
-    const float *bq = sfull + 8 * ej + 4 * ea;                 // knot j-1 (8 floats of padding in front)
+    const float *bq = sf + 8 * (e >> 3) + 4 * ((e >> 2) & 1);        // knot j-1 (8 floats of padding in front)
+    const float *mrow = reinterpret_cast<const float *>(lds + mr32_off) + e * 12;
     const f32x4 s0 = lds_get<f32x4>(bq), s1 = lds_get<f32x4>(bq + 8), s2 = lds_get<f32x4>(bq + 16);
     const f32x4 m0 = lds_get<f32x4>(mrow), m1 = lds_get<f32x4>(mrow + 4), m2 = lds_get<f32x4>(mrow + 8);
     float r = m0.x * s0.x;
@@ -351,9 +364,11 @@ struct KnotMetric {
 #ifdef KN_ABL_DAMP
     return f32x4{lam, lam, lam, lam};
 #endif
+    int l = lane;
+    LAUNDER(l);
+    const float *mdrow = reinterpret_cast<const float *>(lds + md32_off) + (l < KN_N ? l : 0) * KN_N;
     return lam != 0.f ? lds_get<f32x4>(mdrow + j0) : f32x4{0.f, 0.f, 0.f, 0.f};     // (unscaled: damped_solve multiplies by `scale`)
   }
-  float scale;                  // = lam (wave-uniform copy for the rows of the system: 0 elsewhere through `lam`)
 };
 
 }  // namespace
@@ -397,13 +412,14 @@ fit_lm_knot_kernel(int B, KnotGeom kg, KnotLds L, d2d_fit_opts opts, int iter_ca
   double *sp = reinterpret_cast<double *>(wl + L.sp);
   float *sfull = reinterpret_cast<float *>(wl + L.sfull);
   double *gfull = reinterpret_cast<double *>(wl + L.gfull);
+  double *park = reinterpret_cast<double *>(wl + L.park);
   double *us = reinterpret_cast<double *>(wl + L.big);
   f32x4 *cf = reinterpret_cast<f32x4 *>(wl + L.cf);
   float2 *cfp = reinterpret_cast<float2 *>(wl + L.cfp);
   float *big = reinterpret_cast<float *>(wl + L.big);
   const bool act = lane < N;
   // this lane's entry: dense index `lane` -> full entry e = 8 j + 4 a + kd; lanes 48 .. 55 own the eight end conditions
-  const int e = act ? kn_entry_of(lane) : (lane < KN_NE ? (lane < 52 ? 0 : 48) + ((lane & 2) ? 4 : 0) + (lane & 1) : 0);
+  const int e = kn_entry_all(lane);
   const int ej = e >> 3, ea = (e >> 2) & 1, ekd = e & 3;
   const int wv_slot = ej * KN_WV_KNOT + 4 * ea + ekd;
   // samples of the entry's two segments (phase 2)
@@ -426,14 +442,17 @@ fit_lm_knot_kernel(int B, KnotGeom kg, KnotLds L, d2d_fit_opts opts, int iter_ca
     for (int s = 1; s < D2D_FIT_MAX_S; ++s) sg += (lj >= kg.k0[s] && s < kg.S) ? 1 : 0;
     return sg;
   };
-  const double *msc_l = reinterpret_cast<const double *>(lds + L.Msc) + (act ? e : 0);      // sqrt(Mu_ee): the finish's max-norm scaling
+  auto msc_of_lane = [&]() -> double {      // sqrt(Mu_ee): the finish's max-norm scaling (shared table)
+    int l = lane;
+    LAUNDER(l);
+    return reinterpret_cast<const double *>(lds + L.Msc)[l < N ? kn_entry_of(l) : 0];
+  };
   for (int i = lane; i < 9 * 8; i += 64) sfull[i] = 0.f;
   // (M v)[lane] for a vector given lane-wise on the free entries: scattered to the [knot][axis][4] layout, the three same-axis
   // quads around the own knot read back (the metric is banded: one knot to either side); damp: lam * (row of M) for the solve
   KnotMetric metric;
-  metric.sfull = sfull; metric.mdrow = Md32 + (lane < N ? lane : 0) * N; metric.lam = 0.f;
-  metric.e = e; metric.ej = ej; metric.ea = ea; metric.act = act;
-  metric.mrow = reinterpret_cast<const float *>(lds + L.Mr32) + (act ? e : 0) * 12;
+  metric.lds = lds; metric.sfull_off = L.wave0 + wave * L.wave_stride + L.sfull; metric.md32_off = L.Md32; metric.mr32_off = L.Mr32;
+  metric.lane = lane; metric.lam = 0.f; metric.scale = 0.f;
 
   const int stride = gridDim.x * (blockDim.x >> 6);
   auto take = [&](bool first) -> int {
@@ -457,27 +476,32 @@ fit_lm_knot_kernel(int B, KnotGeom kg, KnotLds L, d2d_fit_opts opts, int iter_ca
     if (b < 0) break;
     if (flags[4 * b + FL_STATUS] != D2D_ST_RUNNING) continue;
     const double *prow = prep + (size_t)b * FIT_PREP_STRIDE;
-    double *lmb = lm + (size_t)b * LM_STRIDE;
+    double *lmb = lm + (size_t)b * LM_STRIDE;       // (formed again from the scalar b in the epilogue: not held across the solver loop)
     int iters = uniform_i(flags[4 * b + FL_ITERS]);
     for (int i = lane; i < FIT_PREP_STRIDE; i += 64) sp[i] = prow[i];
-    double wpx = 0.0, wpy = 0.0;
     {
       int lane_ld = lane;
       LAUNDER(lane_ld);
+      double wpx = 0.0, wpy = 0.0;
       if (lane_ld < kg.K) { wpx = pk[((size_t)b * FIT_PK + 6) * kg.K + lane_ld]; wpy = pk[((size_t)b * FIT_PK + 7) * kg.K + lane_ld]; }
+      park[lane_ld] = wpx; park[64 + lane_ld] = wpy;
     }
     wave_lds_sync();
     // u0 (the knot data of q = 0; for the end conditions: the scaled datum itself) and the start point
-    double u0i = 0.0, ui = 0.0;
+    double ui = 0.0;
+    auto u0_of_lane = [&]() -> double { int l = lane; LAUNDER(l); return park[128 + l]; };
     {
+      double u0i = 0.0;
       int lane_ld = lane;
       LAUNDER(lane_ld);
+      const int e_ld = kn_entry_all(lane_ld);        // (from the laundered lane: the per-lane table pointers are not kept across fits)
       if (lane_ld < KN_NE) {
-        const double *pu = T.Pu + (size_t)e * 4;
-        const double *ed = sp + (ea ? PR_DY : PR_DX);
+        const double *pu = T.Pu + (size_t)e_ld * 4;
+        const double *ed = sp + (((e_ld >> 2) & 1) ? PR_DY : PR_DX);
         u0i = fma(pu[0], ed[0], fma(pu[1], ed[1], fma(pu[2], ed[2], pu[3] * ed[3])));
       }
       ui = u0i;
+      park[128 + lane_ld] = u0i;
       if (iters > 0) {
         if (lane_ld < N) ui = u_io[(size_t)b * 64 + lane_ld];
       } else {
@@ -485,8 +509,8 @@ fit_lm_knot_kernel(int B, KnotGeom kg, KnotLds L, d2d_fit_opts opts, int iter_ca
         if (lane_ld < N) qb[lane_ld] = q_io[(size_t)b * N + lane_ld];
         wave_lds_sync();
         if (lane_ld < N) {
-          const double *bi = T.Binv + (size_t)e * (N / 2);
-          const double *qa = qb + ea * (N / 2);
+          const double *bi = T.Binv + (size_t)e_ld * (N / 2);
+          const double *qa = qb + ((e_ld >> 2) & 1) * (N / 2);
           double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll 4
           for (int j = 0; j < N / 2; j += 2) { acc0 = fma(bi[j], qa[j], acc0); acc1 = fma(bi[j + 1], qa[j + 1], acc1); }
@@ -534,7 +558,7 @@ fit_lm_knot_kernel(int B, KnotGeom kg, KnotLds L, d2d_fit_opts opts, int iter_ca
     for (int m = 0; m < N / 2; ++m) hrow[m] = f32x2{0.f, 0.f};
     wave_lds_sync();
     if (phase == 0) {                                               // ||x|| = ||u - u0||_M: lmder's first radius is factor * ||x||
-      const float dv = act ? (float)(ui - u0i) : 0.f;
+      const float dv = act ? (float)(ui - u0_of_lane()) : 0.f;
       const float mv = metric.apply(dv);
       const double xn = sqrt(fmax(uniform_d(wave_sum((double)dv * (double)mv)), 0.0));
       xub = xn * (1.0 + 1e-6);
@@ -543,7 +567,7 @@ fit_lm_knot_kernel(int B, KnotGeom kg, KnotLds L, d2d_fit_opts opts, int iter_ca
     KN_STAMP(0)
     for (bool reenter = true; reenter;) {
       reenter = false;
-      c = uniform_d(knot_phase1(kg.K, Hb64, sp, wv, seg_of_lane(), wpx, wpy, us, cf, cfp, so_rows, lane));
+      c = uniform_d(knot_phase1(kg.K, Hb64, sp, wv, seg_of_lane(), park, us, cf, cfp, so_rows, lane));
       KN_STAMP(1)
       bool fresh = true;
       if (!(fabs(c) <= 1.79e308)) { status = D2D_ST_NONFINITE; fresh = false; }
@@ -578,7 +602,7 @@ fit_lm_knot_kernel(int B, KnotGeom kg, KnotLds L, d2d_fit_opts opts, int iter_ca
             image_row<N>(big, lane, hrow);
             hdiag = image_diag<N>(big, lane);
             wave_lds_sync();
-            if (dbg != nullptr && iters == 0 && act) {            // development: the first evaluation's H_u row and g_u of every fit
+            if (STAMPS && dbg != nullptr && iters == 0 && act) {            // development: the first evaluation's H_u row and g_u of every fit
               float *d = dbg + (size_t)b * (N * N + 4 * N) + lane * N;
 #pragma unroll
               for (int m = 0; m < N / 2; ++m) { d[2 * m] = hrow[m].x; d[2 * m + 1] = hrow[m].y; }
@@ -600,7 +624,7 @@ fit_lm_knot_kernel(int B, KnotGeom kg, KnotLds L, d2d_fit_opts opts, int iter_ca
             if (!mp.gn_valid) { do_solve = true; is_gn = true; solve_lam = 0.0; isq_mode = 1; }
             else sub = 3;
           } else {
-            const double gmax = uniform_d(wave_max(act ? fabs(gi) / *msc_l : 0.0));
+            const double gmax = uniform_d(wave_max(act ? fabs(gi) / msc_of_lane() : 0.0));
             if (gmax <= KN_GTOL_SCALE * opts.gtol) { status = D2D_ST_CONVERGED; break; }
             do_solve = true; solve_lam = V_lam;
           }
@@ -619,7 +643,7 @@ fit_lm_knot_kernel(int B, KnotGeom kg, KnotLds L, d2d_fit_opts opts, int iter_ca
           ok = uniform_i(damped_solve<N, true, true>(hrow, 0.0, act, lane, big, dgi, dls, nullptr, true, isq_mode, V_mp_delta, &dxn, &t2,
                                                      hdiag, true, metric) ? 1 : 0) != 0;
           KN_STAMP(5)
-          if (dbg != nullptr && iters == 0 && mp.nfac == 0 && phase == 0 && act) {
+          if (STAMPS && dbg != nullptr && iters == 0 && mp.nfac == 0 && phase == 0 && act) {
             dbg[(size_t)b * (N * N + 4 * N) + N * N + 2 * N + lane] = dls;
             float *x = dbg + (size_t)b * (N * N + 4 * N) + N * N + 3 * N;
             if (lane == 0) { x[0] = (float)dxn; x[1] = (float)t2; x[2] = (float)gnrm; x[3] = ok ? 1.f : 0.f; x[4] = (float)V_mp_delta; x[5] = (float)solve_lam; }
@@ -651,8 +675,8 @@ fit_lm_knot_kernel(int B, KnotGeom kg, KnotLds L, d2d_fit_opts opts, int iter_ca
             dl = dls;
             const double delta = (double)dl;
             V_pred = V_lam * dxn * dxn - uniform_d(wave_sum(delta * gi));
-            const double msci = *msc_l;
-            V_dmax = uniform_d(wave_max(act ? fabs(delta) * msci : 0.0)); V_qmax = uniform_d(wave_max(act ? fabs(ui - u0i) * msci : 0.0));
+            const double msci = msc_of_lane();
+            V_dmax = uniform_d(wave_max(act ? fabs(delta) * msci : 0.0)); V_qmax = uniform_d(wave_max(act ? fabs(ui - u0_of_lane()) * msci : 0.0));
             V_ct = 0.0; V_pred_s = V_pred; V_alpha = 1.0; V_bt_a = 0.0; V_bt_b = 0.0; fin = false; accept = false; att = 0;
             if (ok) do_trial = true;
           }
@@ -699,7 +723,7 @@ fit_lm_knot_kernel(int B, KnotGeom kg, KnotLds L, d2d_fit_opts opts, int iter_ca
         const bool so_trial = phase != 0;
         if (act) wv[wv_slot] = ui + V_alpha * (double)dl;
         wave_lds_sync();
-        const double ca = uniform_d(knot_phase1(kg.K, Hb64, sp, wv, seg_of_lane(), wpx, wpy, us, cf, cfp, so_trial, lane));
+        const double ca = uniform_d(knot_phase1(kg.K, Hb64, sp, wv, seg_of_lane(), park, us, cf, cfp, so_trial, lane));
         KN_STAMP(1)
         if (phase == 0) {
           const double fnorm = sqrt(c);
@@ -737,7 +761,7 @@ fit_lm_knot_kernel(int B, KnotGeom kg, KnotLds L, d2d_fit_opts opts, int iter_ca
           if (taken) xub += V_pn;
           double xnorm = xub;
           if (V_mp_delta <= fmax(opts.mp_xtol, MP_EPSMCH) * xub) {
-            const float dv = act ? (float)(ui - u0i) : 0.f;
+            const float dv = act ? (float)(ui - u0_of_lane()) : 0.f;
             const float mv = metric.apply(dv);
             xnorm = sqrt(fmax(uniform_d(wave_sum((double)dv * (double)mv)), 0.0));
             xub = xnorm * (1.0 + 1e-6);
@@ -796,7 +820,7 @@ fit_lm_knot_kernel(int B, KnotGeom kg, KnotLds L, d2d_fit_opts opts, int iter_ca
       int lane_io = lane;
       LAUNDER(lane_io);
       wave_lds_sync();
-      if (lane_io < KN_NE) gfull[e] = act ? ui - u0i : 0.0;
+      if (lane_io < KN_NE) gfull[e] = act ? ui - u0_of_lane() : 0.0;
       wave_lds_sync();
       double qv = 0.0, gq = 0.0;
       const int qa = lane_io >= N / 2 ? 1 : 0;
@@ -830,13 +854,17 @@ fit_lm_knot_kernel(int B, KnotGeom kg, KnotLds L, d2d_fit_opts opts, int iter_ca
       }
       const double gmax = uniform_d(wave_max(fabs(gq)));
       if (lane == 0) {
-        cost_io[b] = c;
+        int bs = b;
+        LAUNDER_S(bs);
+        double *lmb = lm + (size_t)bs * LM_STRIDE;
+        int *flags_b = flags + 4 * (size_t)bs;
+        cost_io[bs] = c;
         lmb[2] = gmax; lmb[3] = so_rows ? 1.0 : 0.0;
         if (phase == 0) { lmb[4] = V_mp_par; lmb[5] = V_mp_delta; } else { lmb[0] = V_lam; lmb[1] = V_nu; }
         lmb[6] = (double)(phase | (mp.first << 1) | ((mp.calm & 0x3fff) << 2) | (mp.slow << 16));
         lmb[7] = lmb[7] + (double)mp.nfac;
-        flags[4 * b + FL_STATUS] = status; flags[4 * b + FL_ITERS] = iters; flags[4 * b + FL_NEED] = 1;
-        flags[4 * b + FL_NEVAL] = flags[4 * b + FL_NEVAL] + nev;
+        flags_b[FL_STATUS] = status; flags_b[FL_ITERS] = iters; flags_b[FL_NEED] = 1;
+        flags_b[FL_NEVAL] = flags_b[FL_NEVAL] + nev;
       }
     }
     __builtin_amdgcn_s_setprio(0);
@@ -939,7 +967,7 @@ int fit_knot_launch(d2d_ctx *ctx, d2d_fit_plan *pl, int B, double *q, const d2d_
     if (kn.k0[j + 1] - kn.k0[j] > kg.smax) kg.smax = kn.k0[j + 1] - kn.k0[j];
   const KnotLds L = knot_lds_layout(pl->K, kn.wpb);
   KnotDev T{kn.d_Hb64, kn.d_Bq, kn.d_BiT, kn.d_Binv, kn.d_Minv, kn.d_Pu, kn.d_msc, kn.d_Hb32, kn.d_Wseg, kn.d_Md32, kn.d_Mrow32, kn.d_Mi32};
-  static const bool want_stamps = getenv("D2D_LM_STAMPS") != nullptr;
+  static const bool want_stamps = getenv("D2D_LM_STAMPS") != nullptr || getenv("D2D_KNOT_DEBUG") != nullptr;     // (the dump lives in the stamped build)
   unsigned long long *stamps = want_stamps ? reinterpret_cast<unsigned long long *>(ctx->stats_dev + 8) : nullptr;
   if (want_stamps) D2D_CHECK_HIP(hipMemsetAsync(stamps, 0, 8 * sizeof(unsigned long long), ctx->stream));
   const int blocks = B < pl->n_cu ? B : pl->n_cu;
