@@ -618,6 +618,7 @@ fit_lm_kernel(int B, FitGeom g, FusedLds L, d2d_fit_opts opts, int iter_cap,
     bool so_rows = uniform_i(ld_dev(lmb + 3) != 0.0 ? 1 : 0) != 0;      // mode of the rows in us / cf (and of hrow after the MFMA pass)
     int phase = 1;
     MpState mp;
+    mp.pgn_lds = nullptr;
     mp.dx_gn = 0.0; mp.t2_gn = 0.0; mp.p_gn = 0.f; mp.gn_valid = 0; mp.gn_ok = 0; mp.first = 0; mp.calm = 0; mp.slow = 0; mp.nfac = 0;
     if (MODE == D2D_LM_MODE_MINPACK) {
       const int pw = uniform_i((int)ld_dev(lmb + 6));                   // phase | first << 1 | calm << 2 | slow << 16
@@ -1264,7 +1265,7 @@ static SegLds seg_lds_layout(int N, int nq, int S, int wpb) {
   L.qs = w; w = align16(w + N * 8);
   L.sp = w; w = align16(w + FIT_PREP_STRIDE * 8);
   L.zc = w; w = align16(w + 8 * D2D_FIT_MAX_S * 2 * 8);
-  L.park = w; w = align16(w + 5 * 64 * 8);          // per-lane constants of the running fit (fit_lm_long_kernel), [5][64]
+  L.park = w; w = align16(w + 5 * 64 * 8 + 2 * 64 * 4);   // per-lane constants of the running fit (fit_lm_long_kernel), [5][64], + [2][64] floats of lmder's state
   L.big = w;
   L.cf = w;
   L.cfp = L.cf + SEG_ROWS * 4 * 16;
@@ -1354,13 +1355,16 @@ fit_lm_long_kernel(int B, FitGeom g, LongLds L, d2d_fit_opts opts, int iter_budg
     if (flags[4 * b + FL_STATUS] != D2D_ST_RUNNING) continue;
     const GroupCtx gc{ga.pos, ga.n_ac, ga.n_ac > 0 ? b % ga.n_ac : 0, ga.n_ac > 0 ? (b / ga.n_ac) * ga.n_ac : 0, ga.pos ? ga.nds : 0};
     const double *pkb = pk + (size_t)b * FIT_PK * g.K;
-    double qi = act ? q_io[(size_t)b * n + lane] : 0.0;
+    int lp = lane;                     // (the per-fit loads and stores below address with a re-made lane index: the per-lane pointers of the
+    LAUNDER(lp);                       // loop's prologue are otherwise formed once per launch and held -- in scratch -- across every fit)
+    double qi = lp < n ? q_io[(size_t)b * n + lp] : 0.0;
     double lam = uniform_d(lm[LM_STRIDE * b + 0]), nu = uniform_d(lm[LM_STRIDE * b + 1]);      // (wave-uniform: scalar registers)
     int iters = flags[4 * b + FL_ITERS];
     int nev = 0, local = 0, status = D2D_ST_RUNNING;
     bool so_rows = uniform_i(lm[LM_STRIDE * b + 3] != 0.0 ? 1 : 0) != 0;
     int phase = 1;
     MpState mp;
+    mp.pgn_lds = SEG ? reinterpret_cast<float *>(wl + sa.L.park + 5 * 64 * 8) : nullptr;      // (the cached Gauss-Newton step: one register fewer across the trials)
     mp.par = 0.0; mp.delta = 0.0; mp.dx_gn = 0.0; mp.t2_gn = 0.0; mp.p_gn = 0.f; mp.gn_valid = 0; mp.gn_ok = 0; mp.first = 0; mp.calm = 0; mp.slow = 0; mp.nfac = 0;
     if (MODE == D2D_LM_MODE_MINPACK) {
       const int pw = uniform_i((int)lm[LM_STRIDE * b + 6]);            // phase | first << 1 | calm << 2 | slow << 16
@@ -1376,7 +1380,7 @@ fit_lm_long_kernel(int B, FitGeom g, LongLds L, d2d_fit_opts opts, int iter_budg
     f32x2 hrow[N / 2];
 #pragma unroll
     for (int m = 0; m < N / 2; ++m) hrow[m] = f32x2{0.f, 0.f};
-    for (int i = lane; i < FIT_PREP_STRIDE; i += 64) sp[i] = prep[(size_t)b * FIT_PREP_STRIDE + i];
+    for (int i = lp; i < FIT_PREP_STRIDE; i += 64) sp[i] = prep[(size_t)b * FIT_PREP_STRIDE + i];
     wave_lds_sync();
 
     // segment formulation: the end-condition part of this lane's Legendre coefficient pair (lane = (segment, degree)) and chunk 0's
@@ -1386,15 +1390,15 @@ fit_lm_long_kernel(int B, FitGeom g, LongLds L, d2d_fit_opts opts, int iter_budg
     double *park = reinterpret_cast<double *>(wl + sa.L.park);
     if (SEG) {
       double zpx = 0.0, zpy = 0.0;
-      if (lane < 8 * sa.m.S) {
+      if (lp < 8 * sa.m.S) {
 #pragma unroll
         for (int mm_ = 0; mm_ < 4; ++mm_) {
-          const double zv = sa.Zlp[lane * 4 + mm_];
+          const double zv = sa.Zlp[lp * 4 + mm_];
           zpx = fma(zv, sp[PR_DX + mm_], zpx); zpy = fma(zv, sp[PR_DY + mm_], zpy);
         }
       }
-      const SegIn i0 = segment_inputs(ls, g.K, sa.sx, pkb, 0);
-      park[lane] = zpx; park[64 + lane] = zpy; park[128 + lane] = i0.x; park[192 + lane] = i0.wpx; park[256 + lane] = i0.wpy;
+      const SegIn i0 = segment_inputs(lane_segment(sa.m, lp), g.K, sa.sx, pkb, 0);
+      park[lp] = zpx; park[64 + lp] = zpy; park[128 + lp] = i0.x; park[192 + lp] = i0.wpx; park[256 + lp] = i0.wpy;
     }
     double mom_none[16];
 
@@ -1502,10 +1506,12 @@ fit_lm_long_kernel(int B, FitGeom g, LongLds L, d2d_fit_opts opts, int iter_budg
       c = uniform_d(ca); gi = ga;
       if (want_H) {
         const float ww = (float)(sp[PR_WWP] * sp[PR_WWP]);
+        int lw = lane;
+        LAUNDER(lw);
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) acc[t][r] = fmaf(ww, Wt[(t * 4 + r) * 64 + lane], acc[t][r]);
+          for (int r = 0; r < 4; ++r) acc[t][r] = fmaf(ww, Wt[(t * 4 + r) * 64 + lw], acc[t][r]);
         tiles_to_image<N>(acc, big, lane);
         image_put_rhs<N>(big, lane, gi);
         wave_lds_sync();

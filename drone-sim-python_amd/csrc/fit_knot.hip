@@ -360,13 +360,13 @@ struct KnotMetric {
     r = fmaf(m2.x, s2.x, r); r = fmaf(m2.y, s2.y, r); r = fmaf(m2.z, s2.z, r); r = fmaf(m2.w, s2.w, r);
     return act ? r : 0.f;
   }
+  int row_off;                  // byte offset of this lane's row of the dense metric: formed by prepare() inside the solve, dead outside it
+  __device__ __forceinline__ void prepare(int l) { row_off = md32_off + (l < KN_N ? l : 0) * (KN_N * 4); }
   __device__ __forceinline__ f32x4 damp(int j0) const {
 #ifdef KN_ABL_DAMP
     return f32x4{lam, lam, lam, lam};
 #endif
-    int l = lane;
-    LAUNDER(l);
-    const float *mdrow = reinterpret_cast<const float *>(lds + md32_off) + (l < KN_N ? l : 0) * KN_N;
+    const float *mdrow = reinterpret_cast<const float *>(lds + row_off);
     return lam != 0.f ? lds_get<f32x4>(mdrow + j0) : f32x4{0.f, 0.f, 0.f, 0.f};     // (unscaled: damped_solve multiplies by `scale`)
   }
 };
@@ -452,7 +452,7 @@ fit_lm_knot_kernel(int B, KnotGeom kg, KnotLds L, d2d_fit_opts opts, int iter_ca
   // quads around the own knot read back (the metric is banded: one knot to either side); damp: lam * (row of M) for the solve
   KnotMetric metric;
   metric.lds = lds; metric.sfull_off = L.wave0 + wave * L.wave_stride + L.sfull; metric.md32_off = L.Md32; metric.mr32_off = L.Mr32;
-  metric.lane = lane; metric.lam = 0.f; metric.scale = 0.f;
+  metric.lane = lane; metric.lam = 0.f; metric.scale = 0.f; metric.row_off = 0;
 
   const int stride = gridDim.x * (blockDim.x >> 6);
   auto take = [&](bool first) -> int {
@@ -462,8 +462,10 @@ fit_lm_knot_kernel(int B, KnotGeom kg, KnotLds L, d2d_fit_opts opts, int iter_ca
       return order ? __builtin_amdgcn_readfirstlane(order[bi]) : bi;
     }
     int t = -1;
-    if (lane == 0 && stride + __hip_atomic_load(queue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < B) {
-      const int p = stride + atomicAdd(queue, 1);
+    int32_t *qp = queue;
+    asm volatile("" : "+s"(qp));        // (re-made from the scalar argument here: its vector copy is not held across the fits)
+    if (lane == 0 && stride + __hip_atomic_load(qp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < B) {
+      const int p = stride + atomicAdd(qp, 1);
       if (p < B) t = order ? order[p] : p;
     }
     return __builtin_amdgcn_readfirstlane(t);
@@ -478,10 +480,10 @@ fit_lm_knot_kernel(int B, KnotGeom kg, KnotLds L, d2d_fit_opts opts, int iter_ca
     const double *prow = prep + (size_t)b * FIT_PREP_STRIDE;
     double *lmb = lm + (size_t)b * LM_STRIDE;       // (formed again from the scalar b in the epilogue: not held across the solver loop)
     int iters = uniform_i(flags[4 * b + FL_ITERS]);
-    for (int i = lane; i < FIT_PREP_STRIDE; i += 64) sp[i] = prow[i];
     {
       int lane_ld = lane;
       LAUNDER(lane_ld);
+      for (int i = lane_ld; i < FIT_PREP_STRIDE; i += 64) sp[i] = prow[i];
       double wpx = 0.0, wpy = 0.0;
       if (lane_ld < kg.K) { wpx = pk[((size_t)b * FIT_PK + 6) * kg.K + lane_ld]; wpy = pk[((size_t)b * FIT_PK + 7) * kg.K + lane_ld]; }
       park[lane_ld] = wpx; park[64 + lane_ld] = wpy;
@@ -544,6 +546,7 @@ fit_lm_knot_kernel(int B, KnotGeom kg, KnotLds L, d2d_fit_opts opts, int iter_ca
     bool so_rows = uniform_i(lmb[3] != 0.0 ? 1 : 0) != 0;
     int phase = 1;
     MpState mp;
+    mp.pgn_lds = nullptr;
     mp.dx_gn = 0.0; mp.t2_gn = 0.0; mp.p_gn = 0.f; mp.gn_valid = 0; mp.gn_ok = 0; mp.first = 0; mp.calm = 0; mp.slow = 0; mp.nfac = 0;
     {
       const int pw = uniform_i((int)lmb[6]);

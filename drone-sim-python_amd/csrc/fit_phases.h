@@ -545,6 +545,7 @@ __device__ __forceinline__ void tiles_to_image(const f32x4 (&acc)[(N / 16) * (N 
 // [[A, b], [b^T, .]] is y^T with L y = b).
 template <int N>
 __device__ __forceinline__ void image_put_rhs(float *Hs, int lane, double gi) {
+  LAUNDER(lane);
   if (lane < N) Hs[N * CHOL_LS + lane] = (float)(-gi);
 }
 
@@ -619,7 +620,7 @@ template <class M> struct nd_is_banded { static constexpr bool value = false; };
 
 // Metric (fit_knot.hip: the solve in knot coordinates, where lmder's norm is ||s||_M and the damping is lam M): an object with
 //   apply(delta) -> (M delta)[lane]      dxnorm = sqrt(delta^T M delta), isq = || L^-1 (M delta / dxnorm) ||^2
-//   damp(j0), scale -> M[lane][j0 .. j0+3] and lam: scale * damp is added to the lane's matrix row where the panel of columns
+//   prepare(lane); damp(j0), scale -> M[lane][j0 .. j0+3] and lam: scale * damp is added to the lane's matrix row where the panel of columns
 //                      j0 .. j0+3 reads it (scale = 0 on the lanes that are not rows of the system: lane N carries the right-hand side)
 // The default (int) is the Euclidean norm with the damping on the pivots.
 template <int N, bool MP = false, bool FULL = false, class Metric = int>
@@ -634,6 +635,7 @@ __device__ __forceinline__ bool damped_solve(const f32x2 (&hrow)[N / 2], double 
 #define DS_STAMP(i) if (tt) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tt[i] += t_ - tl; tl = t_; }
   if (tt) tl = __builtin_amdgcn_s_memtime();
   LAUNDER(lane);
+  if constexpr (!__is_same(Metric, int)) metric.prepare(lane);       // (per-solve addressing of the metric's rows, from the re-made lane)
   const bool live = act || lane == N;           // rows of the system + the right-hand side row
   float d = hd;
   if (!have_hd) {
@@ -883,6 +885,13 @@ struct MpState {
   double par, delta;        // damping of the last lmpar, trust-region radius
   double dx_gn, t2_gn;      // cached Gauss-Newton step of the current point: its norm, || L^-1 (p / ||p||) ||^2
   float p_gn;               // ... and the step itself (this lane's entry)
+  float *pgn_lds;           // (optional, wave-uniform) [64] floats of the wave's LDS block that hold p_gn instead of a register
+  __device__ __forceinline__ void put_pgn(float v) {
+    if (pgn_lds) pgn_lds[__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u))] = v; else p_gn = v;
+  }
+  __device__ __forceinline__ float get_pgn() const {
+    return pgn_lds ? pgn_lds[__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u))] : p_gn;
+  }
   int gn_valid, gn_ok;      // the cache holds the step of the current J^T J / it could be factorised
   int first, calm, nfac;    // first trial of the fit (Delta = min(Delta, ||p||)); accepted steps in a row with par = 0 and ratio >= 0.75
   int slow;                 // trials in a row (accepted or not) that changed the cost by no more than D2D_LM_MP_SLOW_TOL of itself
@@ -911,7 +920,7 @@ __device__ __forceinline__ int mp_trial(MpState &s, const d2d_fit_opts &o, doubl
   int it = 0;
   bool done = false;
   auto gn_post = [&]() -> bool {
-    if (s.gn_ok && s.dx_gn - s.delta <= 0.1 * s.delta) { dl = s.p_gn; pn = s.dx_gn; par = 0.0; return true; }
+    if (s.gn_ok && s.dx_gn - s.delta <= 0.1 * s.delta) { dl = s.get_pgn(); pn = s.dx_gn; par = 0.0; return true; }
     fp = s.gn_ok ? s.dx_gn - s.delta : 1.79e308;
     parl = (s.gn_ok && s.t2_gn > 0.0) ? (fp / s.delta) / s.t2_gn : 0.0;
     paru = gnrm / s.delta;
@@ -929,7 +938,7 @@ __device__ __forceinline__ int mp_trial(MpState &s, const d2d_fit_opts &o, doubl
     const bool ok = solve(gn ? 0.0 : par, gn ? 1 : (it + 1 < 10 ? 2 : 0), s.delta, dls, dxn, t2);
     ++s.nfac;
     if (gn) {
-      s.gn_ok = ok ? 1 : 0; s.p_gn = dls; s.dx_gn = uniform_d(dxn); s.t2_gn = uniform_d(t2); s.gn_valid = 1;      // (state that lives across trials: scalar registers)
+      s.gn_ok = ok ? 1 : 0; s.put_pgn(dls); s.dx_gn = uniform_d(dxn); s.t2_gn = uniform_d(t2); s.gn_valid = 1;      // (state that lives across trials: scalar registers)
       done = gn_post();
       continue;
     }
@@ -949,7 +958,10 @@ __device__ __forceinline__ int mp_trial(MpState &s, const d2d_fit_opts &o, doubl
   }
   // ---- the trial point and lmder's updates ----
   if (s.first) { s.delta = uniform_d(fmin(s.delta, pn)); s.first = 0; }
+  // (with the LDS slots: the step sits out the trial evaluation -- the kernel's register peak -- in the wave's block)
+  if (s.pgn_lds) s.pgn_lds[64 + __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u))] = dl;
   const double ct = trial(dl);
+  if (s.pgn_lds) dl = s.pgn_lds[64 + __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u))];
   const bool ctfin = fabs(ct) <= 1.79e308;
   const double fnorm1 = ctfin ? sqrt(ct) : 1.79e308;
   double actred = -1.0;
