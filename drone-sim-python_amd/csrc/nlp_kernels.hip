@@ -192,13 +192,21 @@ __device__ double nlp_merit(const NlpProb &pb, const NlpScen &s, const double *_
   for (int i0 = 0; i0 < N; i0 += 64) {
     const int i = i0 + lane;
     if (i < N) {
-      double w[NLP_NV], wp[3] = {0, 0, 0};
+      // (every value the node needs is requested up front, from clamped indices where a neighbour does not exist: a load inside a
+      // branch is a memory round trip of its own -- the compiler does not speculate loads -- and a Newton step had forty of those)
+      const int im = i >= 1 ? i - 1 : 0;
+      double w[NLP_NV], wp[3], dwl[NLP_NV], dwp[3], muv[3];
 #pragma unroll
-      for (int c = 0; c < NLP_NV; ++c) w[c] = NLP_W(c, i) + (a != 0.0 ? a * NLP_DW(c, i) : 0.0);
-      if (i >= 1) {
+      for (int c = 0; c < NLP_NV; ++c) { w[c] = NLP_W(c, i); dwl[c] = NLP_DW(c, i); }
 #pragma unroll
-        for (int c = 0; c < 3; ++c) wp[c] = NLP_W(c, i - 1) + (a != 0.0 ? a * NLP_DW(c, i - 1) : 0.0);
+      for (int c = 0; c < 3; ++c) { wp[c] = NLP_W(c, im); dwp[c] = NLP_DW(c, im); muv[c] = NLP_MU(c, i); }
+      if (a != 0.0) {
+#pragma unroll
+        for (int c = 0; c < NLP_NV; ++c) w[c] += a * dwl[c];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) wp[c] += a * dwp[c];
       }
+      if (i < 1) { wp[0] = 0.0; wp[1] = 0.0; wp[2] = 0.0; }
       double prod = 1.0;
 #pragma unroll
       for (int c = 0; c < NLP_NV; ++c) {
@@ -218,7 +226,7 @@ __device__ double nlp_merit(const NlpProb &pb, const NlpScen &s, const double *_
         nlp_constraint(s, pb.h, wp, w, c3);
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-          const double cm = c3[k] + NLP_MU(k, i);
+          const double cm = c3[k] + muv[k];
           val += rho * cm * cm;
           feas = fmax(feas, fabs(c3[k]));
         }
@@ -287,18 +295,20 @@ __device__ double nlp_assemble(const NlpProb &pb, const NlpScen &s, const double
     double rhsv[NLP_NV];
     double wp[3] = {0, 0, 0}, wc[NLP_NV], wn[NLP_NV] = {0, 0, 0, 0, 1};
     double cc[3] = {0, 0, 0}, cn[3] = {0, 0, 0};     // (c + mu) of the constraint that ends at this node / at the next one
+    // (all loads of the node up front, neighbours from clamped indices: see nlp_merit)
+    const int im = i >= 1 ? i - 1 : 0, ip = has_next ? i + 1 : i;
+    double zlv[NLP_NV], zuv[NLP_NV], mu_c[3], mu_n[3];
 #pragma unroll
-    for (int c = 0; c < NLP_NV; ++c) wc[c] = NLP_W(c, i);
-    if (i >= 1) {
+    for (int c = 0; c < NLP_NV; ++c) { wc[c] = NLP_W(c, i); wn[c] = NLP_W(c, ip); zlv[c] = NLP_P(WS_ZL + c, i); zuv[c] = NLP_P(WS_ZU + c, i); }
 #pragma unroll
-      for (int c = 0; c < 3; ++c) wp[c] = NLP_W(c, i - 1);
-    }
+    for (int c = 0; c < 3; ++c) { wp[c] = NLP_W(c, im); mu_c[c] = NLP_MU(c, i); mu_n[c] = NLP_MU(c, ip); }
+    if (i < 1) { wp[0] = 0.0; wp[1] = 0.0; wp[2] = 0.0; }
     if (has_next) {
-#pragma unroll
-      for (int c = 0; c < NLP_NV; ++c) wn[c] = NLP_W(c, i + 1);
       nlp_constraint(s, h, wc, wn, cn);
 #pragma unroll
-      for (int k = 0; k < 3; ++k) cn[k] += NLP_MU(k, i + 1);
+      for (int k = 0; k < 3; ++k) cn[k] += mu_n[k];
+    } else {
+      wn[0] = 0.0; wn[1] = 0.0; wn[2] = 0.0; wn[3] = 0.0; wn[4] = 1.0;
     }
     double g[NLP_NV] = {0, 0, 0, 0, 0};
     double D[NLP_NV][NLP_NV];
@@ -321,9 +331,9 @@ __device__ double nlp_assemble(const NlpProb &pb, const NlpScen &s, const double
       double sp, cp;
       sincos(wc[2], &sp, &cp);
       const double tp = tan(wc[3]), vi = wc[4], sec2 = 1.0 + tp * tp;
-      cc[0] = (wc[0] - wp[0]) * ih - vi * cp + s.wx + NLP_MU(0, i);
-      cc[1] = (wc[1] - wp[1]) * ih - vi * sp + s.wy + NLP_MU(1, i);
-      cc[2] = (wc[2] - wp[2]) * ih - FIT_G / vi * tp + NLP_MU(2, i);
+      cc[0] = (wc[0] - wp[0]) * ih - vi * cp + s.wx + mu_c[0];
+      cc[1] = (wc[1] - wp[1]) * ih - vi * sp + s.wy + mu_c[1];
+      cc[2] = (wc[2] - wp[2]) * ih - FIT_G / vi * tp + mu_c[2];
       double Ac[3][NLP_NV];                     // Jacobian of the constraint wrt this node
 #pragma unroll
       for (int k = 0; k < 3; ++k)
@@ -360,12 +370,12 @@ __device__ double nlp_assemble(const NlpProb &pb, const NlpScen &s, const double
       const bool fx = nlp_fixed(i, N, c);
       double sig = 0.0, r = -2.0 * g[c], st = 2.0 * g[c];
       if (!fx && s.lo[c] > -1e299) {
-        const double sl = wc[c] - s.lo[c], z = NLP_P(WS_ZL + c, i), isl = 1.0 / sl;
+        const double sl = wc[c] - s.lo[c], z = zlv[c], isl = 1.0 / sl;
         sig += z * isl; r += mub * isl; st -= z;
         err = fmax(err, fabs(z * sl - mub));
       }
       if (!fx && s.hi[c] < 1e299) {
-        const double su = s.hi[c] - wc[c], z = NLP_P(WS_ZU + c, i), isu = 1.0 / su;
+        const double su = s.hi[c] - wc[c], z = zuv[c], isu = 1.0 / su;
         sig += z * isu; r -= mub * isu; st += z;
         err = fmax(err, fabs(z * su - mub));
       }
@@ -571,9 +581,19 @@ __device__ __attribute__((noinline)) bool nlp_bcr_t(double *sin_generic, double 
   RT *pq = in_lds ? (RT *)lds_generic : (RT *)sf_generic;        // P (9), Q (9) of an eliminated node [node][ps]
   constexpr int ps = in_lds ? NLP_BCR_STRIDE : SF_N;
   if (in_lds) {
-    for (int e = lane; e < N * SIN_N; e += 64) {
-      const int node = e / SIN_N;
-      lds[node * NLP_BCR_STRIDE + (e - node * SIN_N)] = sin_g[e];
+    // (batches of 12 rows of 64: every load of a batch is in flight before its first LDS store -- as a plain loop the compiler waited
+    // for each load before storing it, 34 memory round trips in a row at 121 nodes, the longest serial stretch of a Newton step)
+    const int total = N * SIN_N;
+    for (int e0 = 0; e0 < total; e0 += 12 * 64) {
+      double v[12];
+#pragma unroll
+      for (int q = 0; q < 12; ++q) { const int e = e0 + q * 64 + lane; v[q] = e < total ? (double)sin_g[e] : 0.0; }
+#pragma unroll
+      for (int q = 0; q < 12; ++q) {
+        const int e = e0 + q * 64 + lane;
+        const int node = e / SIN_N;
+        if (e < total) lds[node * NLP_BCR_STRIDE + (e - node * SIN_N)] = v[q];
+      }
     }
     nlp_phase_sync();
   }
@@ -657,6 +677,18 @@ __device__ __attribute__((noinline)) bool nlp_bcr_t(double *sin_generic, double 
   // the way back: the unknowns of a level from those of the coarser ones (in the LDS path x_j takes the place of P_j)
   const RT *xs = in_lds ? (const RT *)lds_generic : (const RT *)ds_generic;
   constexpr int xst = in_lds ? NLP_BCR_STRIDE : 3;
+  // LDS path (one chunk per level: N <= 121): r_j sits in global memory -- the only global read of a level, a round trip of its own
+  // on the serial chain of seven levels.  The lane that will need r_j of the NEXT level is known (node s/2 (2 lane + 1)): its three
+  // values are requested one level ahead and arrive behind the current level's arithmetic.
+  double rn[3] = {0.0, 0.0, 0.0};
+  auto request_r = [&](int sl) {
+    if (!in_lds || sl < 1) return;
+    const int n_l = (N - 1 - sl) / (2 * sl) + 1;
+    const int jl = lane < n_l ? sl * (2 * lane + 1) : sl;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) rn[u] = ds_g[(size_t)jl * 3 + u];
+  };
+  request_r(s >> 1);
   for (s >>= 1; s >= 1; s >>= 1) {
     const int n_el = (N - 1 - s) / (2 * s) + 1;
     for (int m0 = 0; m0 < n_el; m0 += 64) {
@@ -664,7 +696,10 @@ __device__ __attribute__((noinline)) bool nlp_bcr_t(double *sin_generic, double 
       const bool act = m < n_el;
       const int j = act ? s * (2 * m + 1) : s, a = j - s, b = j + s;
       const bool has_b = act && b < N;
-      double x[3];
+      double x[3], rj[3];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) rj[u] = in_lds ? rn[u] : (act ? (double)ds_g[(size_t)j * 3 + u] : 0.0);
+      request_r(s >> 1);
       if (act) {
         const RT *o = pq + (size_t)j * ps;
         const RT *xa = xs + (size_t)a * xst, *xb = xs + (size_t)(has_b ? b : a) * xst;
@@ -672,7 +707,7 @@ __device__ __attribute__((noinline)) bool nlp_bcr_t(double *sin_generic, double 
         const double b0 = has_b ? xb[0] : 0.0, b1 = has_b ? xb[1] : 0.0, b2 = has_b ? xb[2] : 0.0;
 #pragma unroll
         for (int u = 0; u < 3; ++u)
-          x[u] = ds_g[(size_t)j * 3 + u] - (o[u * 3] * a0 + o[u * 3 + 1] * a1 + o[u * 3 + 2] * a2)
+          x[u] = rj[u] - (o[u * 3] * a0 + o[u * 3 + 1] * a1 + o[u * 3 + 2] * a2)
                  - (o[9 + u * 3] * b0 + o[9 + u * 3 + 1] * b1 + o[9 + u * 3 + 2] * b2);
       }
       nlp_phase_sync();                       // (every P_j of the chunk has been read before an x_j overwrites one)
@@ -884,36 +919,41 @@ __device__ void nlp_recover_stats(const NlpProb &pb, const NlpScen &s, int lane,
   for (int i0 = 0; i0 < N; i0 += 64) {
     const int i = i0 + lane;
     if (i >= N) continue;
-    double dwv[NLP_NV], dsp[3] = {0, 0, 0};
+    // (all loads of the node up front: see nlp_merit)
+    const int im = i >= 1 ? i - 1 : 0;
+    double dwv[NLP_NV], dsp[3], wv[NLP_NV], rhv[NLP_NV], zlv[NLP_NV], zuv[NLP_NV], elq[6], elr[6], ellp[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) dwv[c] = NLP_DS(c, i);
-    if (i >= 1) {
-#pragma unroll
-      for (int c = 0; c < 3; ++c) dsp[c] = NLP_DS(c, i - 1);
-    }
+    for (int c = 0; c < 3; ++c) { dwv[c] = NLP_DS(c, i); dsp[c] = NLP_DS(c, im); }
+    if (i < 1) { dsp[0] = 0.0; dsp[1] = 0.0; dsp[2] = 0.0; }
     double z0 = NLP_EL(EL_T + 0, i), z1 = NLP_EL(EL_T + 1, i);
 #pragma unroll
+    for (int k = 0; k < 6; ++k) { elq[k] = NLP_EL(EL_Q + k, i); elr[k] = NLP_EL(EL_R + k, i); }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) ellp[k] = NLP_EL(EL_LP + k, i);
+#pragma unroll
+    for (int c = 0; c < NLP_NV; ++c) { wv[c] = NLP_W(c, i); rhv[c] = NLP_RHS(c, i); zlv[c] = NLP_P(WS_ZL + c, i); zuv[c] = NLP_P(WS_ZU + c, i); }
+#pragma unroll
     for (int k = 0; k < 3; ++k) {
-      z0 -= NLP_EL(EL_Q + k, i) * dwv[k] + NLP_EL(EL_R + k, i) * dsp[k];
-      z1 -= NLP_EL(EL_Q + 3 + k, i) * dwv[k] + NLP_EL(EL_R + 3 + k, i) * dsp[k];
+      z0 -= elq[k] * dwv[k] + elr[k] * dsp[k];
+      z1 -= elq[3 + k] * dwv[k] + elr[3 + k] * dsp[k];
     }
-    dwv[4] = z1 * NLP_EL(EL_LP + 2, i);
-    dwv[3] = (z0 - NLP_EL(EL_LP + 1, i) * dwv[4]) * NLP_EL(EL_LP + 0, i);
+    dwv[4] = z1 * ellp[2];
+    dwv[3] = (z0 - ellp[1] * dwv[4]) * ellp[0];
 #pragma unroll
     for (int c = 0; c < NLP_NV; ++c) {
       const double dw = dwv[c];
       NLP_DW(c, i) = dw;
-      dphi -= NLP_RHS(c, i) * dw;
+      dphi -= rhv[c] * dw;
       if (nlp_fixed(i, N, c)) continue;
-      const double w = NLP_W(c, i);
+      const double w = wv[c];
       if (s.lo[c] > -1e299) {
-        const double sl = w - s.lo[c], z = NLP_P(WS_ZL + c, i);
+        const double sl = w - s.lo[c], z = zlv[c];
         if (-dw * amax > tau * sl) amax = -tau * sl / dw;          // (divide only when the bound is the binding one so far)
         const double dz = (mub - z * dw) / sl - z;
         if (-dz * az > tau * z) az = -tau * z / dz;
       }
       if (s.hi[c] < 1e299) {
-        const double su = s.hi[c] - w, z = NLP_P(WS_ZU + c, i);
+        const double su = s.hi[c] - w, z = zuv[c];
         if (dw * amax > tau * su) amax = tau * su / dw;
         const double dz = (mub + z * dw) / su - z;
         if (-dz * az > tau * z) az = -tau * z / dz;
@@ -929,20 +969,24 @@ __device__ void nlp_apply(const NlpProb &pb, const NlpScen &s, int lane, double 
   for (int i0 = 0; i0 < N; i0 += 64) {
     const int i = i0 + lane;
     if (i >= N) continue;
+    // (all loads of the node up front: see nlp_merit)
+    double wv[NLP_NV], dwl[NLP_NV], zlv[NLP_NV], zuv[NLP_NV];
+#pragma unroll
+    for (int c = 0; c < NLP_NV; ++c) { wv[c] = NLP_W(c, i); dwl[c] = NLP_DW(c, i); zlv[c] = NLP_P(WS_ZL + c, i); zuv[c] = NLP_P(WS_ZU + c, i); }
 #pragma unroll
     for (int c = 0; c < NLP_NV; ++c) {
       if (nlp_fixed(i, N, c)) continue;
-      const double w = NLP_W(c, i), dw = NLP_DW(c, i);
+      const double w = wv[c], dw = dwl[c];
       const double wn = w + a * dw;
       NLP_W(c, i) = wn;
       if (s.lo[c] > -1e299) {
-        const double sl = w - s.lo[c], z = NLP_P(WS_ZL + c, i), mn = mub / (wn - s.lo[c]);
+        const double sl = w - s.lo[c], z = zlv[c], mn = mub / (wn - s.lo[c]);
         double zn = z + az * ((mub - z * dw) / sl - z);
         zn = fmin(fmax(zn, 1e-10 * mn), 1e10 * mn);
         NLP_P(WS_ZL + c, i) = zn;
       }
       if (s.hi[c] < 1e299) {
-        const double su = s.hi[c] - w, z = NLP_P(WS_ZU + c, i), mn = mub / (s.hi[c] - wn);
+        const double su = s.hi[c] - w, z = zuv[c], mn = mub / (s.hi[c] - wn);
         double zn = z + az * ((mub + z * dw) / su - z);
         zn = fmin(fmax(zn, 1e-10 * mn), 1e10 * mn);
         NLP_P(WS_ZU + c, i) = zn;
@@ -1130,22 +1174,32 @@ __device__ __forceinline__ void nlp_solve_one(int N, double h, const d2d_nlp_opt
 // block recursions are serial in the nodes and run wave-uniform.  Control flow is uniform: no lane waits for another problem.
 // Two waves per SIMD (the assembly spills ~280 registers for it, once per Newton step; the serial recursions are separate functions
 // and do not): measured +12 % problems/s at 4096 and 65 536 problems for +6 % latency of a lone one.
+// Persistent: the grid is one wavefront per wave slot of the chip (or per problem, if there are fewer), problems are handed out through
+// a device counter, and the WORKSPACE BELONGS TO THE SLOT (work + blockIdx.x * WS_TOTAL * N), not to the problem: nothing in it
+// outlives a solve, and with one workspace per problem every solve streamed its 100+ kB through cold lines while the ones it
+// followed were written back -- slots keep the chip's working set at (resident waves) x (workspace) whatever the batch.
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NLP_WAVES_PER_SIMD, NLP_WAVES_PER_SIMD)))
 nlp_solve_kernel(int B, int N, double h, d2d_nlp_opts o, const double *__restrict__ scen, const double *partner, double *W,
                  double *work, double *mult, double *__restrict__ cost_out, double *__restrict__ feas_out,
-                 int32_t *__restrict__ iters_out, int32_t *__restrict__ status_out, unsigned long long *stamps) {
-  const int b = blockIdx.x, lane = threadIdx.x;
-  if (b >= B) return;
+                 int32_t *__restrict__ iters_out, int32_t *__restrict__ status_out, unsigned long long *stamps, int32_t *queue) {
+  const int lane = threadIdx.x;
   extern __shared__ __attribute__((aligned(16))) double nlp_lds[];
-  NlpOut out;
-  nlp_solve_one(N, h, o, scen + (size_t)b * D2D_SCEN_STRIDE, partner ? partner + (size_t)b * 2 * N : nullptr, W + (size_t)b * NLP_NV * N,
-                work + (size_t)b * WS_TOTAL * N, mult ? mult + (size_t)b * 3 * N : nullptr, lane, out, b == 0 ? stamps : nullptr, nlp_lds,
-                o.bounds ? o.bounds + (size_t)b * 4 : nullptr);
-  if (lane == 0) {
-    cost_out[b] = out.cost;
-    feas_out[b] = out.feas;
-    if (iters_out) iters_out[b] = out.iters;
-    if (status_out) status_out[b] = out.status;
+  double *wsb = work + (size_t)blockIdx.x * WS_TOTAL * N;
+  for (int b = blockIdx.x; b < B;) {
+    NlpOut out;
+    nlp_solve_one(N, h, o, scen + (size_t)b * D2D_SCEN_STRIDE, partner ? partner + (size_t)b * 2 * N : nullptr, W + (size_t)b * NLP_NV * N,
+                  wsb, mult ? mult + (size_t)b * 3 * N : nullptr, lane, out, b == 0 ? stamps : nullptr, nlp_lds,
+                  o.bounds ? o.bounds + (size_t)b * 4 : nullptr);
+    if (lane == 0) {
+      cost_out[b] = out.cost;
+      feas_out[b] = out.feas;
+      if (iters_out) iters_out[b] = out.iters;
+      if (status_out) status_out[b] = out.status;
+    }
+    nlp_phase_sync();                        // (the next problem's first stores to the workspace follow this one's last loads)
+    int t = 0;
+    if (lane == 0) t = (int)gridDim.x + atomicAdd(queue, 1);
+    b = __builtin_amdgcn_readfirstlane(t);
   }
 }
 
@@ -1232,8 +1286,16 @@ int d2d_nlp_solve(d2d_ctx *ctx, int B, int N, double h, const double *scen, cons
   D2D_REQUIRE(o.inner_max >= 1 && o.outer_max >= 1 && o.rho0 > 0 && o.mub0 > 0 && o.mub_min > 0, "d2d_nlp_solve: bad options");
   unsigned long long *stamps = nullptr;
   if (getenv("D2D_NLP_STAMPS")) D2D_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&stamps), 16 * sizeof(unsigned long long)));
-  hipLaunchKernelGGL(nlp_solve_kernel, dim3(B), dim3(64), NLP_LDS_DOUBLES * sizeof(double), ctx->stream, B, N, h, o, scen, partner, W, work, mult, cost, feas, iters,
-                     status, stamps);
+  // one wavefront per wave slot (D2D_NLP_SLOTS: development override of the slot count)
+  static int n_cu = 0;
+  if (n_cu == 0) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256; }
+  int slots = n_cu * 4 * NLP_WAVES_PER_SIMD;
+  if (getenv("D2D_NLP_SLOTS")) slots = atoi(getenv("D2D_NLP_SLOTS"));
+  const int grid = B < slots ? B : (slots < 1 ? 1 : slots);
+  int32_t *queue = ctx->counter_dev + 2;
+  D2D_CHECK_HIP(hipMemsetAsync(queue, 0, sizeof(int32_t), ctx->stream));
+  hipLaunchKernelGGL(nlp_solve_kernel, dim3(grid), dim3(64), NLP_LDS_DOUBLES * sizeof(double), ctx->stream, B, N, h, o, scen, partner, W, work, mult, cost, feas, iters,
+                     status, stamps, queue);
   D2D_LAUNCH_CHECK();
   if (stamps) {                                            // diagnostics: synchronous
     unsigned long long hs[9];
