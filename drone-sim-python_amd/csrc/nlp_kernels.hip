@@ -151,6 +151,7 @@ struct NlpProb {
 #define NLP_BCR_STRIDE 19                 // odd: a lane per node reads its record without 8-way bank conflicts
 #define NLP_BCR_LDS_NODES 121
 #define NLP_LDS_DOUBLES 2304              // >= 65 * 9 + 64 * NLP_REC_STRIDE (assembly) and >= NLP_BCR_LDS_NODES * NLP_BCR_STRIDE (cyclic reduction)
+static_assert(64 * NLP_BCR_STRIDE >= 65 * 9 && NLP_REC_STRIDE == NLP_BCR_STRIDE, "nlp_assemble rec_lds: records of the chunks above the first lie behind the hand-over rows");
 #define NLP_W(c, i) pb.W[(c) * pb.N + (i)]
 #define NLP_P(plane, i) pb.ws[(plane) * pb.N + (i)]
 #define NLP_MU(k, i) pb.mu[(k) * pb.N + (i)]
@@ -278,7 +279,7 @@ __device__ int nlp_bank_argmax(const NlpProb &pb, int lane) {
 // cost_grad is one-hot there (2 obj_scale kbank phi_imax), the step's model carries the term sbank * phi_imax^2 on that node
 // alone (the maximiser frozen for the step; the merit function of the line search is the true max)
 __device__ double nlp_assemble(const NlpProb &pb, const NlpScen &s, const double *__restrict__ sc, int lane, double rho, double mub,
-                               double lam, bool *pd_out, int imax) {
+                               double lam, bool *pd_out, int imax, bool rec_lds) {
   const int N = pb.N;
   const double h = pb.h, ih = 1.0 / h;
   double err = 0.0;
@@ -447,6 +448,23 @@ __device__ double nlp_assemble(const NlpProb &pb, const NlpScen &s, const double
 #pragma unroll
       for (int a = 0; a < 3; ++a) sinv[SIN_T + a] -= nb[UP_RT + a];
     }
+    if (rec_lds) {
+      // The cyclic reduction that follows works in this wave's LDS block on records [node][NLP_BCR_STRIDE] (N <= NLP_BCR_LDS_NODES):
+      // the records go there directly -- no store to the workspace, no load back (three memory round trips of a Newton step).
+      // Chunks above the first lie behind the hand-over rows (64 * 19 >= 65 * 9); the first chunk's own records overwrite the
+      // hand-over rows once every neighbour has read them.
+      nlp_phase_sync();
+      if (lane == 0 && i0 > 0) {                            // this chunk's first node for the chunk below
+#pragma unroll
+        for (int k = 0; k < 9; ++k) lds_up[64 * 9 + k] = upv[k];
+      }
+      if (live) {
+#pragma unroll
+        for (int k = 0; k < SIN_N; ++k) pb.lds[(size_t)i * NLP_BCR_STRIDE + k] = sinv[k];
+      }
+      nlp_phase_sync();
+      continue;
+    }
     if (live) {
 #pragma unroll
       for (int k = 0; k < SIN_N; ++k) lds_rec[lane * NLP_REC_STRIDE + k] = sinv[k];
@@ -571,7 +589,8 @@ __device__ __forceinline__ void nlp_solve3(const double (&L)[6], const double b0
 // (through generic pointers they were flat_ ones: 51 k cycles per Newton step instead of the 30 k of this version)
 typedef __attribute__((address_space(3))) double ldouble;
 template <typename RT, bool in_lds>
-__device__ __attribute__((noinline)) bool nlp_bcr_t(double *sin_generic, double *sf_generic, double *ds_generic, double *lds_generic, int N) {
+__device__ __attribute__((noinline)) bool nlp_bcr_t(double *sin_generic, double *sf_generic, double *ds_generic, double *lds_generic, int N,
+                                                    bool preloaded) {
   const int lane = threadIdx.x & 63;
   gdouble *sin_g = (gdouble *)sin_generic;
   gdouble *ds_g = (gdouble *)ds_generic;
@@ -580,7 +599,7 @@ __device__ __attribute__((noinline)) bool nlp_bcr_t(double *sin_generic, double 
   constexpr int rs = in_lds ? NLP_BCR_STRIDE : SIN_N;
   RT *pq = in_lds ? (RT *)lds_generic : (RT *)sf_generic;        // P (9), Q (9) of an eliminated node [node][ps]
   constexpr int ps = in_lds ? NLP_BCR_STRIDE : SF_N;
-  if (in_lds) {
+  if (in_lds && !preloaded) {
     // (batches of 12 rows of 64: every load of a batch is in flight before its first LDS store -- as a plain loop the compiler waited
     // for each load before storing it, 34 memory round trips in a row at 121 nodes, the longest serial stretch of a Newton step)
     const int total = N * SIN_N;
@@ -720,9 +739,10 @@ __device__ __attribute__((noinline)) bool nlp_bcr_t(double *sin_generic, double 
   }
   return true;
 }
-__device__ __forceinline__ bool nlp_bcr(double *sin_g, double *sf_g, double *ds_g, double *lds, int N) {
-  if (N <= NLP_BCR_LDS_NODES) return nlp_bcr_t<ldouble, true>(sin_g, sf_g, ds_g, lds, N);
-  return nlp_bcr_t<gdouble, false>(sin_g, sf_g, ds_g, lds, N);
+// preloaded: the records are in the LDS block already (nlp_assemble with rec_lds; only for N <= NLP_BCR_LDS_NODES)
+__device__ __forceinline__ bool nlp_bcr(double *sin_g, double *sf_g, double *ds_g, double *lds, int N, bool preloaded) {
+  if (N <= NLP_BCR_LDS_NODES) return nlp_bcr_t<ldouble, true>(sin_g, sf_g, ds_g, lds, N, preloaded);
+  return nlp_bcr_t<gdouble, false>(sin_g, sf_g, ds_g, lds, N, false);
 }
 
 // mid: 9 doubles of scratch for the second coupling block of the middle node (its coupling to node m+1)
@@ -1054,6 +1074,7 @@ __device__ __forceinline__ void nlp_solve_one(int N, double h, const d2d_nlp_opt
     for (int k = 0; k < 3; ++k) NLP_MU(k, i) = 0.0;
   }
   nlp_phase_sync();
+  const bool rec_lds = !o.serial && N <= NLP_BCR_LDS_NODES;       // the reduced records go from the assembly to the cyclic reduction through the LDS
   double rho = o.rho0, lam = D2D_LM_LAMBDA0, feas_prev = INFINITY;
   int total_inner = 0, status = D2D_ST_MAXITER;
   double err = 0.0, cost_ref = 0.0, feas = 0.0;
@@ -1077,13 +1098,13 @@ __device__ __forceinline__ void nlp_solve_one(int N, double h, const d2d_nlp_opt
       const int imax = s.sbank > 0.0 ? nlp_bank_argmax(pb, lane) : -1;
       for (int tr = 0; tr < 30; ++tr) {
         bool pd;
-        err = nlp_assemble(pb, s, sc, lane, rho, mub, lam, &pd, imax);  // (a retry with another damping assembles again: rare)
+        err = nlp_assemble(pb, s, sc, lane, rho, mub, lam, &pd, imax, rec_lds);  // (a retry with another damping assembles again: rare)
         nlp_phase_sync();
         NLP_STAMP(1)
         if (tr == 0 && err <= tol_in) { converged = true; break; }
         if (pd) {
           if (o.serial) pd = nlp_factor(pb.ws + (size_t)WS_SIN * N, pb.ws + (size_t)WS_SF * N, pb.ws + (size_t)WS_UP * N, N);   // (UP is free by now)
-          else pd = nlp_bcr(pb.ws + (size_t)WS_SIN * N, pb.ws + (size_t)WS_SF * N, pb.ws + (size_t)WS_DS * N, pb.lds, N);
+          else pd = nlp_bcr(pb.ws + (size_t)WS_SIN * N, pb.ws + (size_t)WS_SF * N, pb.ws + (size_t)WS_DS * N, pb.lds, N, rec_lds);
         }
         NLP_STAMP(2)
         if (!pd) { lam = fmin(lam * 8.0, D2D_LM_LAMBDA_MAX); continue; }
