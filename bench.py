@@ -293,8 +293,10 @@ def nlp_record(ctx, torch, cpu, B=4096):
     # algorithmic HBM bytes per node and Newton step of the round-3 algorithm (every value a phase needs read once, every
     # value it produces written once, neighbours from the cache): merit 13 doubles read x ~1.3 calls, assembly 18 read + 40 written
     # (x ~1.1 with the retries), cyclic reduction 21 read + 6 written (the reduced records live in the LDS), recovery 40 read + 5
-    # written, update 20 read + 15 written = 118 doubles read + 70 written = 114 kB + 68 kB per step at N = 121
-    alg = float(it.sum()) * (114e3 + 68e3) * (W0.shape[2] / 121.0)
+    # written, update 20 read + 15 written = 118 doubles read + 70 written = 114 kB + 68 kB per step at N = 121.  Round 5: the 18
+    # doubles of a reduced record go from the assembly to the cyclic reduction through the LDS (N <= 121): 100 read + 52 written
+    # = 97 kB + 50 kB per step
+    alg = float(it.sum()) * (97e3 + 50e3) * (W0.shape[2] / 121.0)
     # what a launch MUST move: the scenario row in, the node values in and out (5 x N doubles each way) and the four result words per
     # problem -- everything else of `alg` is the algorithm's own workspace, streamed through HBM / L2 once per Newton step because it
     # does not fit beside two waves' registers.  `workspace_stream_frac` is therefore a utilisation of self-inflicted traffic, NOT a
@@ -305,7 +307,7 @@ def nlp_record(ctx, torch, cpu, B=4096):
                        'workspace_bytes_per_launch': alg, 'irreducible_bytes_per_launch': irr,
                        'irreducible_frac': irr / best / 1e9 / HBM_PEAK_GBS,
                        'traffic_over_irreducible': (rec['hbm_traffic_per_launch'] / irr) if rec['hbm_traffic_per_launch'] else None,
-                       'note': 'latency-bound (dependent fp64 chains of the assembly and of the seven cyclic-reduction levels, one wavefront per problem, two waves per SIMD); `achieved` prices the workspace stream of the algorithm (182 kB per Newton step), not a roofline: see irreducible_*; traffic = FETCH_SIZE + WRITE_SIZE of the committed PMC passes (FETCH_SIZE uncalibrated for 8-B-per-lane loads)'}
+                       'note': 'latency-bound (dependent fp64 chains of the assembly and of the seven cyclic-reduction levels, one wavefront per problem, two waves per SIMD; round 5: every per-node load of a phase requested up front -- loads inside branches were forty serial memory round trips per Newton step -- and the reduced records handed over through the LDS: 121 k -> 160 k problems/s); `achieved` prices the workspace stream of the algorithm (147 kB per Newton step), not a roofline: see irreducible_*; traffic = FETCH_SIZE + WRITE_SIZE of the committed PMC passes (FETCH_SIZE uncalibrated for 8-B-per-lane loads)'}
     if cpu is not None:
         rec['verdicts_vs_oracle'] = nlp_verify(rows, W0, h, st, cost, feas)
         n = len(cpu['cost'])
