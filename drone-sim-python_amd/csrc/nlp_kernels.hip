@@ -1193,8 +1193,10 @@ __device__ __forceinline__ void nlp_solve_one(int N, double h, const d2d_nlp_opt
 #endif
 // One wavefront per problem.  Node-parallel phases (merit, assembly, step statistics, update) run with lane = node; the two
 // block recursions are serial in the nodes and run wave-uniform.  Control flow is uniform: no lane waits for another problem.
-// Two waves per SIMD (the assembly spills ~280 registers for it, once per Newton step; the serial recursions are separate functions
-// and do not): measured +12 % problems/s at 4096 and 65 536 problems for +6 % latency of a lone one.
+// Two waves per SIMD: the assembly spills for it (640-708 B / lane, once per Newton step; the serial recursions are separate functions
+// and do not).  Round 2 measured +12 % problems/s for it; since round 4's schedule change, and again after round 5's, one
+// wave per SIMD (-DNLP_WAVES_PER_SIMD=1: no spill in the kernel) runs at the SAME speed at 512, 4096 and 65 536 problems -- the
+// spills are off the critical path, and so is the second wave.
 // Persistent: the grid is one wavefront per wave slot of the chip (or per problem, if there are fewer), problems are handed out through
 // a device counter, and the WORKSPACE BELONGS TO THE SLOT (work + blockIdx.x * WS_TOTAL * N), not to the problem: nothing in it
 // outlives a solve, and with one workspace per problem every solve streamed its 100+ kB through cold lines while the ones it
