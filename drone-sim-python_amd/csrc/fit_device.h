@@ -488,23 +488,14 @@ __device__ __forceinline__ double sample_terms(const ScenP &s, const double Y[6]
 
 // The collision rows of sample k against the coupled aircraft of the group as SUMS (cost, D^T r and the 2x2 Gauss-Newton
 // position block): out = {sum h^2, sum o_x h, sum o_y h, sum o_x^2, sum o_x o_y, sum o_y^2} -- sample_terms' xin.
-#define D2D_GROUP_MAX_AC 8          // d2d_fit_plan_set_groups: 1 <= n_ac <= 8
 __device__ __forceinline__ void partner_sums(const ScenP &s, const GroupCtx &gc, int K, int k, double x, double y, double out[6]) {
 #pragma unroll
   for (int i = 0; i < 6; ++i) out[i] = 0.0;
   if (gc.pos && s.ccol > 0.0) {
-    // every partner's position is requested before the first is used (groups hold at most D2D_GROUP_MAX_AC aircraft): inside the
-    // loop each pair of loads was a memory round trip in front of an exp -- seven in a row per evaluation of an 8-aircraft group
-    double px[D2D_GROUP_MAX_AC], py[D2D_GROUP_MAX_AC];
-#pragma unroll
-    for (int m = 0; m < D2D_GROUP_MAX_AC; ++m) {
-      const double *pm = gc.pos + (size_t)(gc.gbase + (m < gc.n_ac ? m : 0)) * 2 * K;
-      px[m] = pm[k]; py[m] = pm[K + k];
-    }
-#pragma unroll
-    for (int m = 0; m < D2D_GROUP_MAX_AC; ++m) {
-      if (m >= gc.n_ac || m == gc.self || !((s.pmask >> m) & 1)) continue;
-      const double ex = (x - px[m]) * s.kc, ey = (y - py[m]) * s.kc;
+    for (int m = 0; m < gc.n_ac; ++m) {
+      if (m == gc.self || !((s.pmask >> m) & 1)) continue;
+      const double *pm = gc.pos + (size_t)(gc.gbase + m) * 2 * K;
+      const double ex = (x - pm[k]) * s.kc, ey = (y - pm[K + k]) * s.kc;
       const double h = s.ccol * exp(-0.5 * (ex * ex + ey * ey));
       const double ox = -h * ex * s.kc, oy = -h * ey * s.kc;
       out[0] = fma(h, h, out[0]); out[1] = fma(ox, h, out[1]); out[2] = fma(oy, h, out[2]);
@@ -522,16 +513,10 @@ __device__ __forceinline__ double partner_terms(const ScenP &s, const GroupCtx &
   double cost = 0.0;
   int slot = 0;
   if (gc.pos && s.ccol > 0.0) {
-    double px[D2D_GROUP_MAX_AC], py[D2D_GROUP_MAX_AC];        // (all partners requested up front: see partner_sums)
-#pragma unroll
-    for (int m = 0; m < D2D_GROUP_MAX_AC; ++m) {
-      const double *pm = gc.pos + (size_t)(gc.gbase + (m < gc.n_ac ? m : 0)) * 2 * K;
-      px[m] = pm[k]; py[m] = pm[K + k];
-    }
-#pragma unroll
-    for (int m = 0; m < D2D_GROUP_MAX_AC; ++m) {
-      if (m >= gc.n_ac || m == gc.self || !((s.pmask >> m) & 1)) continue;
-      const double ex = (x - px[m]) * s.kc, ey = (y - py[m]) * s.kc;
+    for (int m = 0; m < gc.n_ac; ++m) {
+      if (m == gc.self || !((s.pmask >> m) & 1)) continue;
+      const double *pm = gc.pos + (size_t)(gc.gbase + m) * 2 * K;
+      const double ex = (x - pm[k]) * s.kc, ey = (y - pm[K + k]) * s.kc;
       const double h = s.ccol * exp(-0.5 * (ex * ex + ey * ey));
       cost += h * h;
       if (WANT_JAC) {

@@ -794,8 +794,33 @@ __device__ __forceinline__ bool damped_solve(const f32x2 (&hrow)[N / 2], double 
   const float *col = Lm + li;
   float dl = col[N * LS] * myinv;                        // running (y_i - sum_{k>i} L[k][i] delta_k) / L[i][i]
 #ifndef ABL_NOSUB
+#ifndef ABL_SUB_LAZY
+  // the lane's column of the factor, in blocks of 16 rows, each block requested one block AHEAD of the dependent chain that uses it
+  // (two blocks in flight at the start; 32 registers): left to the scheduler the reads were issued two at a time inside the chain,
+  // each pair behind a full LDS wait -- 23 exposed LDS latencies on a chain of 47 readlane + fma steps
+  {
+    constexpr int NBS = N / 16;
+    float cm[2][16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cm[(NBS - 1) & 1][r] = col[(16 * (NBS - 1) + r) * LS];
+#pragma unroll
+    for (int bk = NBS - 1; bk >= 0; --bk) {
+      if (bk > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cm[(bk - 1) & 1][r] = col[(16 * (bk - 1) + r) * LS];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) cm[bk & 1][r] *= -myinv;
+#pragma unroll
+      for (int r = 15; r >= 0; --r)
+        if (16 * bk + r >= 1) dl = fmaf(cm[bk & 1][r], lane_value(dl, 16 * bk + r), dl);      // L[i][lane] = 0 for i <= lane
+    }
+  }
+#else
 #pragma unroll
   for (int i = N - 1; i >= 1; --i) dl = fmaf(-col[i * LS] * myinv, lane_value(dl, i), dl);   // L[i][lane] = 0 for i <= lane
+#endif
 #endif
   delta = act ? dl : 0.f;
   if (MP) {
@@ -810,6 +835,15 @@ __device__ __forceinline__ bool damped_solve(const f32x2 (&hrow)[N / 2], double 
       f32x4 lrow[N / 4];                                 // this lane's row of the factor, zero on and above the diagonal
 #pragma unroll
       for (int t = 0; t < N / 4; ++t) lrow[t] = lds_get<f32x4>(Lm + li * LS + 4 * t);
+#ifndef ABL_ISQ_LAZY
+      // (the row scaled by 1 / L[lane][lane] off the chain: the chain itself is readlane + fma per column, no multiply)
+#pragma unroll
+      for (int t = 0; t < N / 4; ++t) lrow[t] *= -myinv;
+      float wcur = mdl * (float)(1.0 / dn) * myinv;      // z_lane so far: (w_lane - sum_{j < lane} L[lane][j] z_j) / L[lane][lane]
+#pragma unroll
+      for (int j = 0; j < N - 1; ++j) wcur = fmaf(lrow[j >> 2][j & 3], lane_value(wcur, j), wcur);
+      const float z = act ? wcur : 0.f;
+#else
       float wcur = mdl * (float)(1.0 / dn);
 #pragma unroll
       for (int j = 0; j < N - 1; ++j) {
@@ -817,6 +851,7 @@ __device__ __forceinline__ bool damped_solve(const f32x2 (&hrow)[N / 2], double 
         wcur = fmaf(-lrow[j >> 2][j & 3], zj, wcur);
       }
       const float z = act ? wcur * myinv : 0.f;
+#endif
       *isq = uniform_d(wave_sum((double)z * (double)z));
     }
   }
