@@ -104,16 +104,26 @@ __global__ void __launch_bounds__(BENCH_THREADS) k_bench(const float *H, const f
   const float hd = image_diag<N>(img, lane);
   wave_lds_sync();
   float acc = 0.f;
+#ifdef BENCH_STAMPS     // -DBENCH_STAMPS: cycles of setup, block columns 0 / 1 / 2, substitutions (damped_solve's tt) of wave 0 of block 0
+  unsigned long long tt[5] = {0, 0, 0, 0, 0};
+  unsigned long long *ttp = tt;
+#else
+  unsigned long long *ttp = nullptr;
+#endif
   for (int r = 0; r < reps; ++r) {
     float dgi, delta;
     double dxn = 0.0, isq = 0.0;
-    SOLVE(N, MP, FULL, hrow, lam * (1 + r), lane < N, lane, img, dgi, delta, nullptr, true, MP ? 2 : 0, 1e30, &dxn, &isq);
+    SOLVE(N, MP, FULL, hrow, lam * (1 + r), lane < N, lane, img, dgi, delta, ttp, true, MP ? 2 : 0, 1e30, &dxn, &isq);
     acc += delta;
 #ifdef USE_ISQ
     acc += (float)isq;
 #endif
   }
   out[blockIdx.x * BENCH_THREADS + threadIdx.x] = acc;
+#ifdef BENCH_STAMPS
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    printf("  stamps (cycles per solve): setup %llu, block columns %llu %llu %llu, substitutions %llu\n", tt[0] / reps, tt[1] / reps, tt[2] / reps, tt[3] / reps, tt[4] / reps);
+#endif
 }
 
 template <int N, bool MP, bool FULL>
