@@ -737,18 +737,42 @@ __device__ __forceinline__ bool damped_solve(const f32x2 (&hrow)[N / 2], double 
       }
       // 4x4 diagonal block across lanes j0 .. j0+3; l[c] = L[lane][j0+c] (valid on the lanes below the pivot)
       float l[4], inv[4];
+#if defined(ABL_NODIAG)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { inv[c] = dq[c] + 1.f; l[c] = s[c] * inv[c]; }
+#elif !defined(DS_DIAG_UNIFORM)
+      // every broadcast on the dependent chain: readlane, add, rsq, mul, readlane, fma per column
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-#ifndef ABL_NODIAG
         const float piv = lane_value(s[c], j0 + c) + dq[c];
         inv[c] = __builtin_amdgcn_rsqf(piv);
         l[c] = s[c] * inv[c];
 #pragma unroll
         for (int c2 = c + 1; c2 < 4; ++c2) s[c2] = fmaf(-l[c], lane_value(l[c], j0 + c2), s[c2]);
-#else
-        inv[c] = dq[c] + 1.f; l[c] = s[c] * inv[c];
-#endif
       }
+#else
+      // -DDS_DIAG_UNIFORM (measured in round 5, not the default): the ten entries of the diagonal block broadcast FIRST (independent
+      // lane reads), its 4 x 4 factor formed redundantly in every lane from wave-uniform values, the lane's own four entries after
+      // it -- the same operations in the same order as the chain above (bit-identical) with a dependent chain of rsq -> mul -> fma
+      // per column.  A lone wave per SIMD: 3.87 -> 3.67 us per solve; two waves per SIMD, where the solve is bound by issue
+      // slots and this form has 16 more vector instructions per panel: 5.40 -> 5.75 us.
+      {
+        const float a00 = lane_value(s[0], j0), a10 = lane_value(s[0], j0 + 1), a20 = lane_value(s[0], j0 + 2), a30 = lane_value(s[0], j0 + 3);
+        const float a11 = lane_value(s[1], j0 + 1), a21 = lane_value(s[1], j0 + 2), a31 = lane_value(s[1], j0 + 3);
+        const float a22 = lane_value(s[2], j0 + 2), a32 = lane_value(s[2], j0 + 3), a33 = lane_value(s[3], j0 + 3);
+        inv[0] = __builtin_amdgcn_rsqf(a00 + dq[0]);
+        const float L10 = a10 * inv[0], L20 = a20 * inv[0], L30 = a30 * inv[0];
+        inv[1] = __builtin_amdgcn_rsqf(fmaf(-L10, L10, a11) + dq[1]);
+        const float L21 = fmaf(-L20, L10, a21) * inv[1], L31 = fmaf(-L30, L10, a31) * inv[1];
+        inv[2] = __builtin_amdgcn_rsqf(fmaf(-L21, L21, fmaf(-L20, L20, a22)) + dq[2]);
+        const float L32 = fmaf(-L31, L21, fmaf(-L30, L20, a32)) * inv[2];
+        inv[3] = __builtin_amdgcn_rsqf(fmaf(-L32, L32, fmaf(-L31, L31, fmaf(-L30, L30, a33))) + dq[3]);
+        l[0] = s[0] * inv[0];
+        l[1] = fmaf(-l[0], L10, s[1]) * inv[1];
+        l[2] = fmaf(-l[1], L21, fmaf(-l[0], L20, s[2])) * inv[2];
+        l[3] = fmaf(-l[2], L32, fmaf(-l[1], L31, fmaf(-l[0], L30, s[3]))) * inv[3];
+      }
+#endif
       float lm[4];
 #pragma unroll
       for (int c = 0; c < 4; ++c) lm[c] = lanes_above(l[c], j0 + c, ones);      // strictly lower
