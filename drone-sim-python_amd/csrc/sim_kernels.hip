@@ -53,7 +53,7 @@ __global__ void __launch_bounds__(256) step_kernel(int n, const double *__restri
 // ------------------------------------------------------------------------------------
 // Circular formation: block = fpb formations of n_ac consecutive threads.
 // LDS: theta[256] | e[256] | ok[256 ints] | B[n_ac*(n_ac-1)] | zdes[n_ac-1]
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))      // (two waves per SIMD for 131 072 drones and more: DESIGN 5.6)
 gvf_run_kernel(d2d_gvf_params p, GlMesh mesh, int fpb, const double *__restrict__ X0,
                const double *__restrict__ centres, const double *__restrict__ radius,
                const double *__restrict__ Bz, const double *__restrict__ X0f,
@@ -94,6 +94,13 @@ gvf_run_kernel(d2d_gvf_params p, GlMesh mesh, int fpb, const double *__restrict_
   bool prev_all_ok = false;    // result of the stop test at the end of the previous step
   int n_true = 0, first_true = -1;   // phase-error rule (use_stop == 2): steps on which it held so far, loop index i-1 of the first one
   double sin_psi = 0.0, cos_psi = 1.0;
+  // Formations of up to GVF_FA = 4 aircraft (what the reference flies): a step requests all its partners' angles / errors and the
+  // matrix entries that go with them AT ONCE.  As loops over the shared arrays every term was an LDS round trip of its own in front
+  // of its fma (the trip count is a run-time number): seven in a row per step at four aircraft, a tenth of a step that is one
+  // dependent chain from end to end.  The sums keep their order (terms beyond n_ac add 0 * x): bit-identical.  (Held in registers
+  // across the steps instead, the matrix entries put the kernel at one wave per SIMD.)
+  constexpr int GVF_FA = 4;
+  const bool small_form = n_ac <= GVF_FA;
   for (int i = 1; i < p.n_rows; ++i) {
     // src/11_full_sim_case1.py:140 -- `if np.all(stop)==1 and t>0: break` at the top of step i
     if (p.use_stop) {
@@ -108,7 +115,21 @@ gvf_run_kernel(d2d_gvf_params p, GlMesh mesh, int fpb, const double *__restrict_
     sh_theta[t] = atan2(s.y - cy, s.x - cx);
     __syncthreads();
     double e = 0.0;
-    if (a < nm) {
+    if (small_form) {
+      double th[GVF_FA], bc[GVF_FA];
+      const int ac = a < nm ? a : 0;
+#pragma unroll
+      for (int k = 0; k < GVF_FA; ++k) { const int kk = k < n_ac ? k : 0; th[k] = sh_theta[base + kk]; bc[k] = sh_B[kk * nm + ac]; }
+      const double zd = sh_z[ac];
+      double z = 0.0;
+#pragma unroll
+      for (int k = 0; k < GVF_FA; ++k) z += (k < n_ac ? bc[k] : 0.0) * th[k];
+      if (a < nm) {
+        e = z - zd;
+        if (e > D2D_PI) e -= D2D_TWO_PI;
+        if (e <= -D2D_PI) e += D2D_TWO_PI;
+      }
+    } else if (a < nm) {
       double z = 0.0;
       for (int k = 0; k < n_ac; ++k) z += sh_B[k * nm + a] * sh_theta[base + k];
       e = z - sh_z[a];
@@ -118,7 +139,15 @@ gvf_run_kernel(d2d_gvf_params p, GlMesh mesh, int fpb, const double *__restrict_
     sh_e[t] = e;
     __syncthreads();
     double Ur = 0.0;
-    for (int m = 0; m < nm; ++m) Ur += sh_B[a * nm + m] * sh_e[base + m];
+    if (small_form) {
+      double ev[GVF_FA - 1], br[GVF_FA - 1];
+#pragma unroll
+      for (int m = 0; m < GVF_FA - 1; ++m) { const int mm = m < nm ? m : 0; ev[m] = sh_e[base + mm]; br[m] = nm > 0 ? sh_B[a * nm + mm] : 0.0; }
+#pragma unroll
+      for (int m = 0; m < GVF_FA - 1; ++m) Ur += (m < nm ? br[m] : 0.0) * ev[m];
+    } else {
+      for (int m = 0; m < nm; ++m) Ur += sh_B[a * nm + m] * sh_e[base + m];
+    }
     Ur *= -p.kr;
     const double Rr = Ur + R;
     // (sin, cos) of the heading, shared by the guidance law and the plant: the plant step hands the pair of its new heading on
@@ -155,7 +184,15 @@ gvf_run_kernel(d2d_gvf_params p, GlMesh mesh, int fpb, const double *__restrict_
       sh_ok[t] = ok ? 1 : 0;
       __syncthreads();
       bool all_ok = true;
-      for (int k = 0; k < n_ac; ++k) all_ok = all_ok && (sh_ok[base + k] != 0);
+      if (small_form) {
+        int oks[GVF_FA];
+#pragma unroll
+        for (int k = 0; k < GVF_FA; ++k) oks[k] = sh_ok[base + (k < n_ac ? k : 0)];
+#pragma unroll
+        for (int k = 0; k < GVF_FA; ++k) all_ok = all_ok && (oks[k] != 0);
+      } else {
+        for (int k = 0; k < n_ac; ++k) all_ok = all_ok && (sh_ok[base + k] != 0);
+      }
       if (p.use_stop == 2) {
         // ... and the loop goes on for stop_hold more steps on which the rule holds (the time the planner needs, case 3)
         if (all_ok && my_stop == p.n_rows) {
