@@ -14,7 +14,7 @@ struct d2d_ctx {
   // scratch owned by the context
   double *Bmat_dev = nullptr;   // incidence matrix + z_des of the last gvf run
   size_t Bmat_cap = 0;
-  int32_t *counter_dev = nullptr;  // small device counters (fit convergence poll)
+  int32_t *counter_dev = nullptr;  // 16 small device counters: [0] fit convergence poll, [2] hand-out counter of nlp_solve_kernel, [8 .. 15] queue words of the fit kernels
   int32_t *counter_host = nullptr; // pinned mirror
   double *stats_dev = nullptr;
   double *stats_host = nullptr;
