@@ -486,7 +486,8 @@ int d2d_fit_sample(d2d_ctx *ctx, const d2d_fit_plan *plan, int B, const double *
  * scen dev [B][D2D_SCEN_STRIDE]: the fit's scenario rows (end poses, VSP, KV, KPHI, KOBS, S, wind, obstacles + OKIND, PHIMAX,
  * VMIN/VMAX, the x/y box, KCOL/RCOL/SCOL); W dev [B][5][N] node values (problem, component, node), in: the initial guess (e.g.
  * Planner.get_initial_guess), out: the solution; partner dev [B][2][N] frozen positions of the CostCollision partner or NULL;
- * work dev double[d2d_nlp_workspace_doubles(N) * B]; mult dev [B][3][N] or NULL: out, scaled multiplier estimates (node 0 unused;
+ * work dev double[d2d_nlp_workspace_doubles(N) * B] (scratch: the launch is persistent and uses one workspace per resident wavefront, the
+ * first min(B, wave slots) of them; nothing in it is an output); mult dev [B][3][N] or NULL: out, scaled multiplier estimates (node 0 unused;
  * Lagrange multiplier = 2 rho mu);  cost dev [B] (the reference's cost() at the solution), feas dev [B] (largest collocation
  * residual, in the reference's form), iters / status dev int32 [B] or NULL (Newton steps; D2D_ST_CONVERGED / D2D_ST_MAXITER /
  * D2D_ST_STALLED: no feasible point found -- the violation stopped shrinking at the largest penalty).
