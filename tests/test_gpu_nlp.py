@@ -497,3 +497,29 @@ def test_costbank_max_mode_vs_oracle(ctx):
         p.run(p.get_initial_guess('tri'))
     assert np.isfinite(p.sol_phi).all() and p.info['feas'] <= 1e-8
     assert abs(p.info['obj_val'] - bankmax.obj_scale * np.max(p.sol_phi ** 2)) <= 1e-12 + 1e-9 * p.info['obj_val']
+
+
+def test_persistent_handout_is_independent_of_the_batch(ctx):
+    """nlp_solve_kernel is persistent (one wavefront per wave slot, problems from a device counter) and a wavefront keeps ONE workspace for
+    every problem it takes: nothing of a solve may leak into the next one through it.  2560 problems in one launch -- more than the 2048
+    slots of an MI355X, so the slots that finish first take a second problem -- against the same problems solved in small launches of
+    their own (first, last and a middle block): status, Newton steps, cost and node values bit-identical."""
+    import d2dhip
+    from d2dhip import synth
+    B = 2560
+    rows, W0, h = synth.nlp_problems(B, seed=3)
+    dsc = ctx.dev(rows)
+    W = ctx.dev(np.ascontiguousarray(W0))
+    big = ctx.nlp_solve(dsc, W, h)
+    ctx.sync()
+    st, it, co, Wb = big['status'].cpu().numpy(), big['iters'].cpu().numpy(), big['cost'].cpu().numpy(), W.cpu().numpy()
+    assert (st == 1).mean() > 0.9
+    for lo in (0, 1200, B - 40):
+        sl = slice(lo, lo + 40)
+        Ws = ctx.dev(np.ascontiguousarray(W0[sl]))
+        small = ctx.nlp_solve(ctx.dev(np.ascontiguousarray(rows[sl])), Ws, h)
+        ctx.sync()
+        assert (small['status'].cpu().numpy() == st[sl]).all()
+        assert (small['iters'].cpu().numpy() == it[sl]).all()
+        np.testing.assert_array_equal(small['cost'].cpu().numpy(), co[sl])
+        np.testing.assert_array_equal(Ws.cpu().numpy(), Wb[sl])
