@@ -62,7 +62,7 @@ def pmc_traffic(kernel):
     corrected as MI355X_MICROARCH.md prescribes).  bench.py cannot read hardware counters itself; None when the file is absent."""
     try:
         import glob
-        files = next((fs for fs in (sorted(glob.glob(os.path.join(ROOT, 'profiles', r, '*_traffic.json'))) for r in ('r05', 'r04', 'r03')) if fs),
+        files = next((fs for fs in (sorted(glob.glob(os.path.join(ROOT, 'profiles', r, '*_traffic.json'))) for r in ('r06', 'r05', 'r04', 'r03')) if fs),
                      [os.path.join(ROOT, 'profiles', 'r02', '06_bench_final_traffic.json')])
         t = json.load(open(files[-1]))[kernel][0]
         t['file'] = os.path.relpath(files[-1], ROOT)
@@ -71,11 +71,27 @@ def pmc_traffic(kernel):
     return t['fetch_bytes_per_launch'] + t['write_bytes_per_launch'], t
 
 
+def pmc_issue(kernel):
+    """What the SIMDs did during a launch of the fused solver kernel, from the committed rocprofv3 PMC passes of THIS command
+    (tools/profile_bench.sh -> tools/condense_profile.py -> profiles/rNN/*_issue.json): MFMA instructions per evaluation unit, the
+    fraction of SIMD cycles the MFMA pipe was busy, the fraction of issue slots used, wave slots occupied (of 2).  None if absent."""
+    import glob
+    for rnd in ('r06', 'r05'):
+        for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', rnd, '*_issue.json')), reverse=True):
+            try:
+                v = json.load(open(f))[kernel]
+                v['file'] = os.path.relpath(f, ROOT)
+                return v
+            except (OSError, KeyError, ValueError):
+                continue
+    return None
+
+
 def pmc_valu(kernel, launch_s):
     """roofline against the fp64 vector pipe for the kernels it bounds (the simulation loops): executed fp64 flop per launch from the
     committed rocprofv3 pass of THIS command (profiles/r04/*_valu.json, tools/condense_profile.py) over the launch time measured
     here.  None when the file is absent."""
-    for rnd in ('r05', 'r04', 'r03'):
+    for rnd in ('r06', 'r05', 'r04', 'r03'):
         try:
             import glob
             f = sorted(glob.glob(os.path.join(ROOT, 'profiles', rnd, '*_valu.json')))[-1]
@@ -116,14 +132,14 @@ def _cpu_fit_one(args):
     return 2 * res.cost, res.x
 
 
-KNOT_DEFAULT = os.environ.get('D2D_FIT_KNOT', '1') != '0'      # the headline shape's default solver runs in knot coordinates (csrc/fit_knot.hip)
+KNOT_DEFAULT = True      # the headline shape's default solver runs in knot coordinates (csrc/fit_knot.hip); --kernel fused: the q kernel
 _KB = {}
 
 
 def _cpu_oracle_lm_one(args):
     """The CPU statement of the kernel's default algorithm (lmder on the normal equations + second-order finish) with the kernel's
     precision split (fp32 Hessian and Cholesky, fp64 residuals / cost / J^T r): oracle/fit_knot.py solve_minpack_knot for the knot
-    kernel (the same trial points as oracle/fit.py solve_minpack in exact arithmetic), solve_minpack with D2D_FIT_KNOT=0."""
+    kernel (the same trial points as oracle/fit.py solve_minpack in exact arithmetic), solve_minpack with --kernel fused."""
     from oracle import fit as F
     basis, sc = args
     if KNOT_DEFAULT:
@@ -318,13 +334,13 @@ def nlp_record(ctx, torch, cpu, B=4096):
     return rec
 
 
-def long_horizon_record(ctx, torch, d2dhip, B=4096, K=121, t1=12.0, more=LONG_HORIZONS[1:], cpu_long=None, large_B=32768):
+def long_horizon_record(ctx, torch, d2dhip, B=4096, K=121, t1=12.0, more=LONG_HORIZONS[1:], cpu_long=None, large_B=32768, long_tables=-1):
     """The reference's own planner horizons (101 .. 151 nodes at 10 Hz: exp_14 = 121; its 50 Hz scenarios: 211 .. 601) on the chunked
     persistent kernel (fit_lm_long_kernel, K > 64; the segment formulation of csrc/fit_seg.h): B independent fits of K nodes, same
     solver as the headline.  `more`: further (nodes, seconds) horizons reported under 'horizons'."""
     from d2dhip import synth
     dur = synth.planner_timing(0, t1, 10)[2]
-    plan = d2dhip.FitPlan(ctx, S_, K, dur, synth.default_wref(OBJ_SCALE, K))
+    plan = d2dhip.FitPlan(ctx, S_, K, dur, synth.default_wref(OBJ_SCALE, K), long_tables=long_tables)
     dsc = ctx.dev(_long_scenarios(B, K, t1))
     q0 = plan.init(dsc)
     q_first = q0.clone()
@@ -492,7 +508,8 @@ def sim_records(ctx, torch, cpu_g, cpu_t, drones=65536, steps=10000, track_steps
 # The line the driver parses is the LAST stdout line and stays small (round 4's 20.9 kB line was not parsed): contract keys +
 # `roofline` + `cpu_baseline` + the hoisted scalars.  Everything else goes to the side file and to an EARLIER, prefixed stdout line.
 LINE_LIMIT = 4096
-ROOF_KEYS = ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'alg_flop_per_unit', 'units_per_launch_avg', 'avg_launch_us', 'launches')
+ROOF_KEYS = ('bound', 'priced_against', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'alg_flop_per_unit', 'units_per_launch_avg', 'avg_launch_us', 'launches',
+             'executed_mfma_flop_per_unit', 'frac_of_executed_flop', 'mfma_busy_frac', 'issue_slot_frac', 'wave_slots_occupied', 'pmc_source')
 CPU_KEYS = ('value', 'unit', 'cores', 'kind', 'sample', 'host_cpu_count')
 DETAIL_PREFIX = 'BENCH_DETAIL '
 
@@ -554,6 +571,11 @@ def main():
     ap.add_argument('--no-sim', action='store_true', help='skip the simulation records (BASELINE configs[4])')
     ap.add_argument('--no-nlp', action='store_true', help='skip the collocation-NLP record (SURVEY 8 f-1)')
     ap.add_argument('--no-groups', action='store_true', help='skip the coupled-groups record (BASELINE configs[2])')
+    ap.add_argument('--kernel', choices=['auto', 'fused'], default='auto',
+                    help='d2d_fit_plan_opts.kernel of the headline plan: auto = the knot kernel for the default solver, fused = the q-coordinate kernel of rounds 1-4')
+    ap.add_argument('--handout', choices=['predicted', 'index'], default='predicted',
+                    help='d2d_fit_opts.handout of the headline: predicted = longest-first by the trial count the device predicts from each scenario row inside the '
+                         'solve (the library default; nothing is known from earlier solves), index = index order (always reported beside it)')
     ap.add_argument('--order-hint', action='store_true',
                     help='headline with the fits handed out longest-first by the iteration counts of the previous (warm-up) solve of the same '
                          'batch -- the replanning pattern; default: index order, no foreknowledge (the hinted figure is always reported beside it)')
@@ -600,7 +622,9 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
     ctx = d2dhip.Context(dev_index)
     dur, wref = _plan_consts()
-    plan = d2dhip.FitPlan(ctx, S_, K, dur, wref)
+    plan = d2dhip.FitPlan(ctx, S_, K, dur, wref, kernel=a.kernel)
+    global KNOT_DEFAULT
+    KNOT_DEFAULT = plan.kernel == 'knot'
     from d2dhip.dist import StatsReducer, solve_sharded
     red_dev = ctx.device if backend == 'nccl' else 'cpu'
     reducer = StatsReducer(dist, red_dev, ctx if backend == 'nccl' else None)
@@ -619,8 +643,13 @@ def main():
         dist.all_reduce(t, op=getattr(dist.ReduceOp, op))
         return [float(v) for v in t.cpu()]
 
-    MODES = {'minpack': {'mode': d2dhip.MODE_MINPACK}, 'fast': {'mode': d2dhip.MODE_FAST},
-             'minpack_pure': {'mode': d2dhip.MODE_MINPACK, 'mp_finish': 0}}
+    HO = {'predicted': d2dhip.HANDOUT_PREDICTED, 'index': d2dhip.HANDOUT_INDEX}
+    MODES = {'minpack': {'mode': d2dhip.MODE_MINPACK, 'handout': HO[a.handout]}, 'fast': {'mode': d2dhip.MODE_FAST},
+             'minpack_pure': {'mode': d2dhip.MODE_MINPACK, 'mp_finish': 0},
+             'minpack_index': {'mode': d2dhip.MODE_MINPACK, 'handout': d2dhip.HANDOUT_INDEX},
+             'minpack_predicted': {'mode': d2dhip.MODE_MINPACK, 'handout': d2dhip.HANDOUT_PREDICTED}}
+    HANDOUT_TXT = {'predicted': 'longest-first by the trial count predicted on the device from each scenario row, inside the timed solve (d2d_fit_opts.handout = '
+                                'D2D_HANDOUT_PREDICTED, the default: no foreknowledge of this batch)', 'index': 'index order (no foreknowledge)'}
 
     def timed_solves(Bn, steps, warmup, order, mode='minpack', max_iter=None, keep=True):
         """warmup + `steps` timed full solves of this rank's Bn resident scenarios with the global convergence check; barrier
@@ -683,14 +712,19 @@ def main():
     variants = {}
     gpu_sol = {}
     if not a.no_extra_modes:
+        other = 'index' if a.handout == 'predicted' else 'predicted'
         for name, (mode_v, order_v, mi) in {'default_with_order_hint': (a.mode, not a.order_hint, None),
+                                            'default_' + other + '_handout': ('minpack_' + other, False, None),
                                             'fast_mode': ('fast', False, None), 'fast_mode_with_order_hint': ('fast', True, None),
                                             'minpack_pure': ('minpack_pure', False, 600)}.items():
             if mode_v == a.mode and name == 'fast_mode':
                 continue
+            if a.mode != 'minpack' and name.endswith('_handout'):
+                continue
             dtv, rv, nev, prv, gv = timed_solves(B, max(3, a.steps // 2), 1, order_v, mode_v, mi)
             variants[name] = summary(B, max(3, a.steps // 2), dtv, gv, prv, nev)
-            variants[name]['handout'] = 'longest-first by the previous solve\'s iteration counts' if order_v else 'index order'
+            variants[name]['handout'] = ('longest-first by the previous solve\'s iteration counts' if order_v else
+                                         (HANDOUT_TXT[other] if name.endswith('_handout') else (HANDOUT_TXT[a.handout] if mode_v == 'minpack' else 'index order')))
             if keep is not None:
                 gpu_sol[name] = (rv[0][:a.cpu_sample].cpu().numpy(), rv[4][:a.cpu_sample].cpu().numpy(),
                                  plan.coeffs(rv[5][:a.cpu_sample], rv[4][:a.cpu_sample]).cpu().numpy())
@@ -703,7 +737,7 @@ def main():
             ach = ALG_FLOP_PER_EVAL * n_evals / (lm_ms * 1e-3) / 1e12
             knot = plan.kernel == 'knot' and a.mode == 'minpack'
             kname = 'fit_lm_knot_kernel' if knot else 'fit_lm_kernel'
-            roof = {'bound': 'mfma',
+            roof = {'bound': 'issue' if knot else 'mfma', 'priced_against': 'mfma',
                     'kernel': (kname + ' (fused solver loop in knot coordinates: J^T J block tridiagonal, ONE v_mfma_f32_16x16x4_f32 per sample; fp64 residual / J^T r, fp32 Cholesky), solver = ' + a.mode) if knot
                     else (kname + '<3,24> (fused solver loop: fp64 residual/J^T r, J^T J on v_mfma_f32_16x16x4_f32, fp32 Cholesky), solver = ' + a.mode),
                     'achieved': ach, 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / FP32_PEAK_TFLOPS,
@@ -715,8 +749,17 @@ def main():
                             + ('.  The knot kernel EXECUTES the block-sparse form SURVEY 8d allows (each sample touches the 16 columns of its segment): '
                                '50-66 MFMAs of 2048 flop per evaluation instead of 300 -- executed_mfma_flop_per_unit says what the matrix cores really did' if knot else '')}
             if knot:
-                roof['executed_mfma_flop_per_unit'] = 66 * 2048
-                roof['frac_of_executed_flop'] = 66 * 2048 * n_evals / (lm_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS
+                # what the matrix cores really executed: the MFMA instructions of the committed PMC pass of this command (J^T J blocks: one per
+                # sample and evaluation, two in second-order mode; + the 16 tile updates of every Cholesky factorisation), 2048 flop each
+                iss = pmc_issue(kname)
+                if iss:
+                    ex = iss['mfma_insts_per_unit'] * 2048.0
+                    roof.update({'executed_mfma_flop_per_unit': ex, 'frac_of_executed_flop': ex * n_evals / (lm_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
+                                 'mfma_busy_frac': iss['mfma_busy_frac'], 'issue_slot_frac': iss['issue_slot_frac'],
+                                 'wave_slots_occupied': iss['wave_slots_occupied'], 'pmc_source': iss['file']})
+                roof['bound_note'] = ('the fused kernel is bound by instruction ISSUE (VALU + LDS + SALU of the fp64 residual phases and the fp32 Cholesky), not by the '
+                                      'matrix cores: `frac` prices the algorithmic J^T J flop against the MFMA peak as the contract asks, frac_of_executed_flop / '
+                                      'mfma_busy_frac say what the MFMA pipe did, issue_slot_frac / wave_slots_occupied (of 2) what bounds the kernel')
         else:
             ach = ALG_FLOP_PER_EVAL * n_evals / (ev_ms * 1e-3) / 1e12
             roof = {'bound': 'mfma', 'kernel': 'fit_eval_kernel (J^T J, v_mfma_f32_16x16x4_f32)', 'achieved': ach,
@@ -732,26 +775,29 @@ def main():
             for _ in range(3):
                 plan.jtj(Bi, want_H=False)
             torch.cuda.synchronize()
-            plan.profile(True)
+            # nit back-to-back launches between ONE event pair on the library's stream (an event pair per launch adds its own ~3 us
+            # to a 28 us kernel: the rocprofv3 kernel trace of the same launches is the cross-check in profiles/)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(ctx.stream)
             for _ in range(nit):
                 plan.jtj(Bi, want_H=False)
-            pr = plan.profile_read()
-            plan.profile(False)
-            us = 1e3 * pr[6] / pr[7]
+            e1.record(ctx.stream)
+            torch.cuda.synchronize()
+            us = 1e3 * e0.elapsed_time(e1) / nit
             tf = ALG_FLOP_PER_EVAL * Bi / (us * 1e-6) / 1e12
-            return {'units_per_launch': Bi, 'avg_launch_us': us, 'launches': int(pr[7]), 'achieved': tf, 'frac': tf / FP32_PEAK_TFLOPS,
+            return {'units_per_launch': Bi, 'avg_launch_us': us, 'launches': int(nit), 'achieved': tf, 'frac': tf / FP32_PEAK_TFLOPS,
                     'alg_hbm_gbs': JTJ_BYTES_PER_UNIT * Bi / (us * 1e-6) / 1e9}
-        i4 = iso(dsc, q0, 20)
+        i4 = iso(dsc, q0, 40)
         roof_iso = {'bound': 'mfma', 'kernel': 'fit_jtj_kernel<3,24> (contraction only: fp32 row records HBM -> LDS, J^T J on v_mfma_f32_16x16x4_f32, '
                                                'tile-major store)', 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                     'alg_flop_per_unit': ALG_FLOP_PER_EVAL, 'alg_bytes_per_unit': JTJ_BYTES_PER_UNIT,
                     'traffic': pmc_traffic('fit_jtj_kernel')[0], 'traffic_source': pmc_traffic('fit_jtj_kernel')[1],
                     'alg_bytes_per_launch': JTJ_BYTES_PER_UNIT * B, **i4,
-                    'note': 'the whole kernel is the contraction (HIP events around the kernel only; rocprofv3 kernel trace in profiles/); '
+                    'note': 'the whole kernel is the contraction (one HIP event pair around back-to-back launches; rocprofv3 kernel trace in profiles/); '
                             'ceiling of frac = 0.766: the three diagonal 16x16 tiles are computed whole'}
         if world == 1 and a.config3_batch > B:
             dsci = ctx.dev(bench_scenarios(a.config3_batch, 0))
-            roof_iso['large'] = iso(dsci, plan.init(dsci), 10)
+            roof_iso['large'] = iso(dsci, plan.init(dsci), 20)
             del dsci
             torch.cuda.empty_cache()
 
@@ -763,7 +809,7 @@ def main():
         tot3 = B3 * world
         config3 = {'workload': f'{B3} fits per GPU ({tot3} in total), sharded by trajectory, convergence all-reduce (BASELINE configs[3])',
                    'unit': 'trajectory-optimisations/s', 'n_gpus': world, 'per_gpu_batch': B3, 'steps': a.config3_steps, 'solver': a.mode,
-                   'handout': 'longest-first by the previous solve\'s iteration counts' if a.order_hint else 'index order',
+                   'handout': 'longest-first by the previous solve\'s iteration counts' if a.order_hint else HANDOUT_TXT[a.handout],
                    **summary(B3, a.config3_steps, dt3, glob3, prof3, ne3)}
         if not a.no_extra_modes:
             dt3f, _, ne3f, prof3f, glob3f = timed_solves(B3, a.config3_steps, 1, False, 'fast', keep=False)
@@ -802,17 +848,13 @@ def main():
         # the same solve with the line search on the joint cost switched off (plain block Gauss-Seidel), no hint: what the slow
         # scenarios cost without it
         plan_g.group_order_from_last(Rg, False)
-        os.environ['D2D_GROUPS_LS'] = '0'
-        try:
-            qg = q0g.clone()
-            torch.cuda.synchronize()
-            tg = time.perf_counter()
-            plan_g.solve_groups(dscg, qg, n_ac, max_sweeps=GSWEEPS, inner_iters=8, tol=GTOL)
-            torch.cuda.synchronize()
-            plain_s = time.perf_counter() - tg
-            sw_p, mv_p = plan_g.group_report(Rg)
-        finally:
-            del os.environ['D2D_GROUPS_LS']
+        qg = q0g.clone()
+        torch.cuda.synchronize()
+        tg = time.perf_counter()
+        plan_g.solve_groups(dscg, qg, n_ac, max_sweeps=GSWEEPS, inner_iters=8, tol=GTOL, gs_ls=0)       # d2d_fit_opts.gs_ls = 0
+        torch.cuda.synchronize()
+        plain_s = time.perf_counter() - tg
+        sw_p, mv_p = plan_g.group_report(Rg)
         config2 = {'workload': '8-drone circular formation x 8192 replicas (65 536 coupled trajectories), CostCollision rows between all pairs '
                                '(BASELINE configs[2]); block Gauss-Seidel per scenario in one persistent launch (fit_groups_kernel)',
                    'tol': GTOL, 'max_sweeps': GSWEEPS,
@@ -924,7 +966,7 @@ def main():
                        'solver': 'MINPACK lmder path on the normal equations + second-order finish (d2d_fit_opts.mode = D2D_LM_MODE_MINPACK, the library default)'
                                  if a.mode == 'minpack' else 'D2D_LM_MODE_FAST',
                        'kernel': plan.kernel,
-                       'handout': 'longest-first by the iteration counts of the previous solve of the same batch (warmup)' if a.order_hint else 'index order (no foreknowledge)',
+                       'handout': 'longest-first by the iteration counts of the previous solve of the same batch (warmup)' if a.order_hint else HANDOUT_TXT[a.handout if a.mode == 'minpack' else 'index'],
                        'parallelism': f'trajectory-sharded x{world}'},
             'converged_frac': headline['converged_frac'], 'stalled_frac': headline['stalled_frac'], 'mean_iters': headline['mean_iters'],
             'evals_per_fit': headline['evals_per_fit'],          # Gauss-Newton units (200 rows); second-order evaluations count 1.5

@@ -71,6 +71,12 @@ struct d2d_comm {
 
 extern "C" {
 
+int d2d_comm_available(void) {
+  // local only: can this process load RCCL and resolve every symbol the exchange uses?  (ncclCommInitRank blocks until all
+  // ranks have joined, so every rank must know BEFORE d2d_comm_create that every other rank will get there)
+  return load_rccl();
+}
+
 int d2d_comm_unique_id(void *id_out) {
   D2D_REQUIRE(id_out != nullptr, "d2d_comm_unique_id: id_out is NULL");
   if (int rc = load_rccl()) return rc;

@@ -19,6 +19,7 @@
 #include "fit_phases.h"
 #include "fit_seg.h"
 #include "fit_plan.h"
+#include "fit_handout_prior.h"
 
 // wavefronts (= trajectories) per workgroup, fewer when K is large.  The launch bounds set the VGPR cap:
 // 16 waves -> 128 VGPRs (fit_eval_kernel needs ~85), 12 waves -> 168 (fit_step_kernel: ~135)
@@ -1746,6 +1747,32 @@ fit_order_kernel(int B, const int32_t *__restrict__ iters, int32_t *__restrict__
   }
 }
 
+// Predicted hand-out (include/d2d.h d2d_fit_plan_set_handout_prior): key[b] = the expected trial count of fit b from its scenario row
+// alone -- how far the end headings are from the legs of the 'tri' dog-leg the fit starts from, and the chord length -- quantised
+// for fit_order_kernel (1/8 trial per bin, offset 40: prior entries are a few tens at most).  One thread per fit.
+__global__ void __launch_bounds__(256)
+fit_handout_key_kernel(int B, double duration, const double *__restrict__ scen, const float *__restrict__ tab, int32_t *__restrict__ key) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const double *r = scen + (size_t)b * D2D_SCEN_STRIDE;
+  const double dx = r[D2D_SC_X1] - r[D2D_SC_X0], dy = r[D2D_SC_Y1] - r[D2D_SC_Y0];
+  const double d = sqrt(dx * dx + dy * dy), D = r[D2D_SC_VREF] * duration;
+  const double h = 0.5 * sqrt(fmax(D * D - d * d, 0.0));
+  const double gl = r[D2D_SC_GOLEFT] > 0.0 ? 1.0 : (r[D2D_SC_GOLEFT] < 0.0 ? -1.0 : 0.0);
+  const double beta = atan2(dy, dx), a = atan2(gl * h, 0.5 * d);
+  const double TWO_PI = 6.283185307179586, PI = 3.141592653589793;
+  auto wrap = [&](double v) { v = fmod(v + PI, TWO_PI); if (v < 0.0) v += TWO_PI; return v; };      // [0, 2 pi): angle + pi
+  auto abin = [&](double v) { int i = (int)(wrap(v) * (D2D_HANDOUT_NB / TWO_PI)); return i < 0 ? 0 : (i >= D2D_HANDOUT_NB ? D2D_HANDOUT_NB - 1 : i); };
+  const int b0 = abin(r[D2D_SC_PSI0] - (beta + a)), b1 = abin(r[D2D_SC_PSI1] - (beta - a));
+  const double x = D > 0.0 ? d / D : 0.0;
+  int bx = (int)floor((x - D2D_HANDOUT_X_LO) * (D2D_HANDOUT_ND / (D2D_HANDOUT_X_HI - D2D_HANDOUT_X_LO)));
+  bx = bx < 0 ? 0 : (bx >= D2D_HANDOUT_ND ? D2D_HANDOUT_ND - 1 : bx);
+  float k = tab[b0 * D2D_HANDOUT_ND + bx] + tab[(D2D_HANDOUT_NB + b1) * D2D_HANDOUT_ND + bx];
+  if (!(k == k)) k = 0.f;                                  // (a NaN end pose: the fit reports D2D_ST_NONFINITE itself)
+  int ki = (int)(8.f * (k + 40.f));
+  key[b] = ki < 0 ? 0 : (ki >= ORDER_BINS ? ORDER_BINS - 1 : ki);
+}
+
 // sampled x, y of every trajectory: pos [B][2][K]
 __global__ void __launch_bounds__(256)
 fit_pos_kernel(int B, FitGeom g, const double *__restrict__ G64, const double *__restrict__ Gp64,
@@ -1929,13 +1956,14 @@ static FitGeom geom_of(const d2d_fit_plan *pl) { return FitGeom{pl->K, pl->nq, p
 static void free_scratch(d2d_fit_plan *pl) {
   void **ptrs[] = {(void **)&pl->d_g, (void **)&pl->d_H, (void **)&pl->d_cost, (void **)&pl->d_lm, (void **)&pl->d_flags,
                    (void **)&pl->d_prep, (void **)&pl->d_pos, (void **)&pl->d_qprev, (void **)&pl->d_pk, (void **)&pl->d_rows,
-                   (void **)&pl->d_order, (void **)&pl->d_ring};
+                   (void **)&pl->d_order, (void **)&pl->d_ring, (void **)&pl->d_hkey, (void **)&pl->d_order_pred};
   for (void **p : ptrs) {
     if (*p) (void)hipFree(*p);
     *p = nullptr;
   }
   pl->cap_B = 0; pl->ring_cap = 0;
   pl->order_B = 0; pl->gorder_R = 0; pl->gsweeps_R = 0;
+  pl->last_order = nullptr; pl->last_order_B = 0;
   pl->rows_B = 0;            // (the row records of d2d_fit_rows lived in the freed scratch)
 }
 
@@ -1963,6 +1991,8 @@ static int ensure_scratch(d2d_fit_plan *pl, int B) {
   }
   SCRATCH_ALLOC(d_rows, (size_t)B * 4 * (pl->K + 1) * 4 * sizeof(float))
   SCRATCH_ALLOC(d_order, (size_t)B * sizeof(int32_t))
+  SCRATCH_ALLOC(d_hkey, (size_t)B * sizeof(int32_t))
+  SCRATCH_ALLOC(d_order_pred, (size_t)B * sizeof(int32_t))
   {
     int cap = 64;
     while (cap < B) cap <<= 1;
@@ -2038,10 +2068,28 @@ static int launch_step(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, double *q, c
   return D2D_OK;
 }
 
-// the time slice of the fused kernel's hand-out: d2d_fit_opts.slice, or D2D_LM_SLICE (A/B switch of the development tools)
-static int lm_slice(const d2d_fit_opts &o) {
-  static const int slice_env = getenv("D2D_LM_SLICE") ? atoi(getenv("D2D_LM_SLICE")) : -1;
-  return slice_env >= 0 ? slice_env : o.slice;
+// the time slice of the fused kernel's hand-out
+static int lm_slice(const d2d_fit_opts &o) { return o.slice > 0 ? o.slice : 0; }
+
+// which persistent kernel a launch of this plan with these options runs: 0 fit_lm_kernel, 1 fit_lm_knot_kernel, 2 fit_lm_long_kernel
+static int solve_kernel_of(const d2d_fit_plan *pl, const d2d_fit_opts &o) {
+  if (!pl->use_lm) return 2;
+  return (pl->kn.wpb > 0 && o.mode == D2D_LM_MODE_MINPACK && lm_slice(o) <= 0) ? 1 : 0;
+}
+
+// the hand-out order of a launch over B trajectories: the caller's explicit hint, else the predicted order of this solve, else index order
+static const int32_t *handout_order(const d2d_fit_plan *pl, int B) {
+  if (pl->order_B == B) return pl->d_order;
+  if (pl->last_order == pl->d_order_pred && pl->last_order_B == B) return pl->d_order_pred;
+  return nullptr;
+}
+
+// D2D_HANDOUT_PREDICTED: keys from the scenario rows + counting sort -> d_order_pred (two small launches at the start of a solve)
+static int launch_handout(d2d_ctx *ctx, d2d_fit_plan *pl, int B, const double *scen) {
+  hipLaunchKernelGGL(fit_handout_key_kernel, dim3((B + 255) / 256), dim3(256), 0, ctx->stream, B, pl->duration, scen, pl->d_hprior, pl->d_hkey);
+  hipLaunchKernelGGL(fit_order_kernel, dim3(1), dim3(1024), 0, ctx->stream, B, pl->d_hkey, pl->d_order_pred);
+  D2D_LAUNCH_CHECK();
+  return D2D_OK;
 }
 
 static int launch_lm(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, double *q, const d2d_fit_opts &o, int iter_cap) {
@@ -2055,17 +2103,17 @@ static int launch_lm(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, double *q, con
   if (want_stamps) D2D_CHECK_HIP(hipMemsetAsync(stamps, 0, 13 * sizeof(unsigned long long), ctx->stream));
   const int blocks = B < pl->n_cu ? B : pl->n_cu;     // persistent: one workgroup per CU
   int32_t *queue = ctx->counter_dev + 8;
-  static const int prio_only = getenv("D2D_LM_PRIO_AT") ? atoi(getenv("D2D_LM_PRIO_AT")) : 48;     // (A/B switch; large = never)
+  const int prio_only = o.prio_at;
   d2d_fit_opts oo = o;
   oo.slice = lm_slice(o);
   if (oo.slice > 0) {                    // time-sliced hand-out: every launch starts from an empty ring and zeroed tickets
     D2D_CHECK_HIP(hipMemsetAsync(pl->d_ring, 0xff, (size_t)pl->ring_cap * sizeof(int32_t), ctx->stream));
     D2D_CHECK_HIP(hipMemsetAsync(queue + 2, 0, 3 * sizeof(int32_t), ctx->stream));
   }
-  const int32_t *order = (pl->order_B == B) ? pl->d_order : nullptr;
+  const int32_t *order = handout_order(pl, B);
   // the default solver of the headline shape runs in knot coordinates (fit_knot.hip); the time-sliced hand-out and the FAST loop
   // stay on fit_lm_kernel
-  if (pl->kn.wpb > 0 && oo.mode == D2D_LM_MODE_MINPACK && oo.slice <= 0) {
+  if (solve_kernel_of(pl, oo) == 1) {
     if (int rc = fit_knot_launch(ctx, const_cast<d2d_fit_plan *>(pl), B, q, oo, iter_cap, order, prio_only)) return rc;
     if (want_times) {
       D2D_CHECK_HIP(hipStreamSynchronize(ctx->stream));
@@ -2116,23 +2164,21 @@ static SegArgs seg_args_of(const d2d_fit_plan *pl, int NB) {
 static int launch_lm_long(d2d_ctx *ctx, const d2d_fit_plan *pl, int B, double *q, const d2d_fit_opts &o, int budget, GroupArgs ga = no_groups()) {
   const FitGeom gm = geom_of(pl);
   const int NB = (2 * pl->nq + 15) / 16;
-  // D2D_FIT_LONG_TABLES (A/B switch): 0 = both tables from global memory, 1 = fp64 block in the LDS and the fp32 planes from global
+  // d2d_fit_plan_opts.long_tables (A/B switch): 0 = both tables from global memory, 1 = fp64 block in the LDS and the fp32 planes from global
   // memory, 2 = both in the LDS.  Default: both if they fit beside >= 3 per-wave blocks (K <= 121 at nq = 24; measured at K = 121,
   // 4096 fits: 251 k fits/s from global memory with 8 waves per CU, 416 k with the fp64 block in the LDS and 6 waves, 542 k with
   // both tables and 3 waves; converting the MFMA operands from the fp64 block instead -- 6 waves -- gave 409 k), else the fp64 block alone
-  static const int force = getenv("D2D_FIT_LONG_TABLES") ? atoi(getenv("D2D_FIT_LONG_TABLES")) : -1;
+  const int force = (pl->long_tables >= 0 && pl->long_tables <= 2) ? pl->long_tables : -1;
   const int w2 = long_tables_waves(pl->K, pl->nq, 16 * NB, true), w1 = long_tables_waves(pl->K, pl->nq, 16 * NB, false);
   int mode = force >= 0 ? force : (w2 ? 2 : (w1 ? 1 : 0));
   if ((mode == 2 && !w2) || (mode == 1 && !w1) || mode > 2) mode = 0;
   const int wpb = mode == 2 ? w2 : (mode ? w1 : pl->wpb_lm);
   const LongLds L = mode ? long_lds_layout(16 * NB, wpb, pl->K, pl->nq, mode == 2) : long_lds_layout(16 * NB, wpb);
   const int blocks = B < pl->n_cu ? B : pl->n_cu;
-  static const bool no_queue = getenv("D2D_LM_STATIC") != nullptr;
-  int32_t *queue = no_queue ? nullptr : ctx->counter_dev + 8;
-  const int32_t *order = (pl->order_B == B && ga.pos == nullptr) ? pl->d_order : nullptr;
-  // the segment formulation (fit_seg.h) is the default; D2D_FIT_LONG_SEG=0 or a forced table placement selects the table kernels (A/B)
-  static const bool seg_off = getenv("D2D_FIT_LONG_SEG") && atoi(getenv("D2D_FIT_LONG_SEG")) == 0;
-  const bool seg = !seg_off && force < 0;
+  int32_t *queue = ctx->counter_dev + 8;
+  const int32_t *order = ga.pos == nullptr ? handout_order(pl, B) : nullptr;
+  // the segment formulation (fit_seg.h) is the default; d2d_fit_plan_opts.long_tables >= 0 selects the table kernels (A/B)
+  const bool seg = pl->long_tables < 0;
   SegArgs sa{};
   if (seg) {
     sa = seg_args_of(pl, NB);
@@ -2176,17 +2222,39 @@ static void allow_big_lds(KernelT k) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, FIT_LDS_BYTES);
 }
 
+static d2d_fit_opts opts_or_default(const d2d_fit_opts *opts) {
+  d2d_fit_opts o = {200, 8, 1e-14, 1e-9, 1e-11, D2D_LM_SO_LAMBDA, D2D_LM_MODE_MINPACK, D2D_LM_MP_FINISH, 1e-15, 1e-15, 1e-15, D2D_LM_SLICE, D2D_LM_MP_SLOW,
+                    D2D_HANDOUT_PREDICTED, D2D_LM_PRIO_AT, 1, D2D_GS_LS_SWEEP0, D2D_GS_LS_RATIO, D2D_GS_PRIO_AT, 0};
+  if (opts) o = *opts;
+  return o;
+}
+
 extern "C" {
 
 int d2d_fit_plan_create(d2d_ctx *ctx, int S, int K, double duration, const double *wref,
                         d2d_fit_plan **out) {
+  return d2d_fit_plan_create_ex(ctx, S, K, duration, wref, nullptr, out);
+}
+
+int d2d_fit_opts_default(d2d_fit_opts *o) {
+  D2D_REQUIRE(o != nullptr, "d2d_fit_opts_default: o is NULL");
+  *o = opts_or_default(nullptr);
+  return D2D_OK;
+}
+
+int d2d_fit_plan_create_ex(d2d_ctx *ctx, int S, int K, double duration, const double *wref, const d2d_fit_plan_opts *popts,
+                           d2d_fit_plan **out) {
   D2D_REQUIRE(ctx && wref && out, "d2d_fit_plan_create: null argument");
+  const int kreq = popts ? popts->kernel : D2D_FIT_KERNEL_AUTO, ltab = popts ? popts->long_tables : -1;
+  D2D_REQUIRE(kreq >= D2D_FIT_KERNEL_AUTO && kreq <= D2D_FIT_KERNEL_KNOT, "d2d_fit_plan_create_ex: kernel=%d is not a D2D_FIT_KERNEL_* value", kreq);
+  D2D_REQUIRE(ltab >= -1 && ltab <= 3, "d2d_fit_plan_create_ex: long_tables=%d not in -1..3", ltab);
   D2D_REQUIRE(S >= 1 && S <= D2D_FIT_MAX_S, "d2d_fit_plan_create: S=%d not in 1..%d", S, D2D_FIT_MAX_S);
   D2D_REQUIRE(K >= 8 * S / 3 + 2, "d2d_fit_plan_create: K=%d too small for S=%d", K, S);
   D2D_REQUIRE(duration > 0, "d2d_fit_plan_create: duration must be > 0");
   d2d_fit_plan *pl = new d2d_fit_plan();
   pl->device = ctx->device;
   pl->S = S; pl->K = K; pl->duration = duration;
+  pl->kernel_req = kreq; pl->long_tables = ltab;
   for (int i = 0; i < 3; ++i) pl->wref[i] = wref[i];
   if (int rc = fit_basis_build(pl)) { delete pl; return rc; }
   if (int rc = fit_basis_segments(pl)) { delete pl; return rc; }
@@ -2195,16 +2263,37 @@ int d2d_fit_plan_create(d2d_ctx *ctx, int S, int K, double duration, const doubl
   // the split-path kernels (public d2d_fit_eval, coupled groups) stage the whole basis block in LDS: K <~ 229 at S = 6
   pl->split_ok = pick_eval_layout(K, nq, &pl->g32_lds, &pl->wpb_eval, 0) &&
                  pick_step_layout(K, nq, 16 * ((2 * nq + 15) / 16), &pl->wpb_step);
-  pl->use_lm = (nq == 24) && pick_fused_layout(K, nq, 48, &pl->wpb_lm) && !getenv("D2D_FIT_SPLIT");
+  const bool want_split = kreq == D2D_FIT_KERNEL_SPLIT;
+  if (want_split && !pl->split_ok) {
+    d2d_set_error("d2d_fit_plan_create_ex: D2D_FIT_KERNEL_SPLIT: K=%d, S=%d does not fit the LDS image of the launch-pair kernels", K, S);
+    delete pl;
+    return D2D_EINVAL;
+  }
+  pl->use_lm = (nq == 24) && pick_fused_layout(K, nq, 48, &pl->wpb_lm) && !want_split;
+  if ((kreq == D2D_FIT_KERNEL_FUSED || kreq == D2D_FIT_KERNEL_KNOT) && !pl->use_lm) {
+    d2d_set_error("d2d_fit_plan_create_ex: the fused / knot kernels serve S = 6 with K <= 64 only (S=%d, K=%d)", S, K);
+    delete pl;
+    return D2D_EINVAL;
+  }
   // everything else -- long horizons, segment counts other than six -- runs on the chunked persistent kernel (the segment
-  // formulation needs no K-sized table and deals its lanes to any number of segments); D2D_FIT_LONG=1 forces it for S = 6,
-  // K <= 64 (tests do), D2D_FIT_SPLIT=1 selects the launch-pair path where its LDS image holds K
-  pl->use_long = !pl->use_lm && (!getenv("D2D_FIT_SPLIT") || !pl->split_ok);
-  if (getenv("D2D_FIT_LONG") && !getenv("D2D_FIT_SPLIT")) { pl->use_lm = false; pl->use_long = true; }
+  // formulation needs no K-sized table and deals its lanes to any number of segments); D2D_FIT_KERNEL_LONG forces it for S = 6,
+  // K <= 64 (tests do), D2D_FIT_KERNEL_SPLIT selects the launch-pair path where its LDS image holds K
+  pl->use_long = !pl->use_lm && !want_split;
+  if (kreq == D2D_FIT_KERNEL_LONG) { pl->use_lm = false; pl->use_long = true; }
   if (pl->use_long) pl->wpb_lm = FIT_LM_WPB_MAX;
-  // the headline shape (S = 6, K <= 64) runs the default solver in knot coordinates (fit_knot.hip); D2D_FIT_KNOT=0: in q
-  if (pl->use_lm)
-    if (int rc = fit_knot_plan_init(pl)) { delete pl; return rc; }
+  // the headline shape (S = 6, K <= 64) runs the default solver in knot coordinates (fit_knot.hip); D2D_FIT_KERNEL_FUSED: in q.
+  // A plan whose knot tables cannot be built (fit_basis_knots rejects the metric, an upload fails) keeps the fused q kernel --
+  // unless the caller asked for the knot kernel by name
+  if (pl->use_lm && kreq != D2D_FIT_KERNEL_FUSED) {
+    const int rc = fit_knot_plan_init(pl);
+    if (rc != D2D_OK) fit_knot_plan_free(pl);
+    if ((rc != D2D_OK || pl->kn.wpb == 0) && kreq == D2D_FIT_KERNEL_KNOT) {
+      if (rc == D2D_OK) d2d_set_error("d2d_fit_plan_create_ex: D2D_FIT_KERNEL_KNOT: the knot kernel's LDS layout does not hold K=%d", K);
+      delete pl;
+      return rc != D2D_OK ? rc : D2D_EINVAL;
+    }
+    if (rc != D2D_OK) fprintf(stderr, "[d2d] fit plan S=%d K=%d: knot tables not built (%s); the fused q kernel serves the default solver\n", S, K, d2d_last_error());
+  }
   if (!pl->split_ok && !pl->use_long) {
     d2d_set_error("d2d_fit_plan_create: K=%d, S=%d does not fit the 160 KiB LDS image of the basis block", K, S);
     delete pl;
@@ -2259,6 +2348,10 @@ int d2d_fit_plan_create(d2d_ctx *ctx, int S, int K, double duration, const doubl
     if (!rc) rc = upload(&pl->d_Zlp, pl->Zlp);
     if (!rc) rc = upload(&pl->d_sx, pl->sx);
   }
+  if (!rc) {
+    std::vector<float> prior(&kHandoutPrior[0][0][0], &kHandoutPrior[0][0][0] + 2 * D2D_HANDOUT_NB * D2D_HANDOUT_ND);
+    rc = upload(&pl->d_hprior, prior);
+  }
   if (rc) { d2d_fit_plan_destroy(pl); return rc; }
   // opt in to large dynamic LDS
   allow_big_lds(&fit_eval_kernel<1, 0, true>); allow_big_lds(&fit_eval_kernel<2, 0, true>); allow_big_lds(&fit_eval_kernel<3, 0, true>);
@@ -2289,7 +2382,7 @@ int d2d_fit_plan_destroy(d2d_fit_plan *pl) {
   if (!pl) return D2D_OK;
   hipSetDevice(pl->device);
   for (hipEvent_t e : pl->prof_ev) (void)hipEventDestroy(e);
-  void *ptrs[] = {pl->d_G, pl->d_GT, pl->d_Gp, pl->d_G32, pl->d_W32, pl->d_Z, pl->d_Zp, pl->d_Pinit, pl->d_Zl64, pl->d_Zl32, pl->d_Zlp, pl->d_sx};
+  void *ptrs[] = {pl->d_G, pl->d_GT, pl->d_Gp, pl->d_G32, pl->d_W32, pl->d_Z, pl->d_Zp, pl->d_Pinit, pl->d_Zl64, pl->d_Zl32, pl->d_Zlp, pl->d_sx, pl->d_hprior};
   for (void *p : ptrs)
     if (p) hipFree(p);
   free_scratch(pl);
@@ -2396,9 +2489,10 @@ int d2d_fit_jtj(d2d_ctx *ctx, d2d_fit_plan *pl, int B, float *H) {
     return D2D_ESTATE;
   }
   const int NB = (2 * pl->nq + 15) / 16;
-  // launch geometry (A/B knobs for tools/bench_jtj.py: D2D_JTJ_WPB wavefronts per workgroup, D2D_JTJ_WGS workgroups per CU)
-  static const int env_wpb = getenv("D2D_JTJ_WPB") ? atoi(getenv("D2D_JTJ_WPB")) : 0;
-  static const int env_wgs = getenv("D2D_JTJ_WGS") ? atoi(getenv("D2D_JTJ_WGS")) : 0;
+  // launch geometry (A/B knobs for tools/bench_jtj.py: D2D_JTJ_GEOM="wpb,wgs": wavefronts per workgroup, workgroups per CU)
+  static int env_wpb = 0, env_wgs = 0;
+  static const bool geom_read = [] { if (const char *g = getenv("D2D_JTJ_GEOM")) sscanf(g, "%d,%d", &env_wpb, &env_wgs); return true; }();
+  (void)geom_read;
   int wpb = (env_wpb >= 1 && env_wpb <= FIT_EVAL_WPB_MAX) ? env_wpb : FIT_EVAL_WPB_MAX;
   while (wpb > 1 && jtj_lds_layout(pl->K, pl->nq, wpb).total > FIT_LDS_BYTES) --wpb;
   const JtjLds L = jtj_lds_layout(pl->K, pl->nq, wpb);
@@ -2475,11 +2569,6 @@ int d2d_fit_profile_read(d2d_fit_plan *pl, double *out) {
   return D2D_OK;
 }
 
-static d2d_fit_opts opts_or_default(const d2d_fit_opts *opts) {
-  d2d_fit_opts o = {200, 8, 1e-14, 1e-9, 1e-11, D2D_LM_SO_LAMBDA, D2D_LM_MODE_MINPACK, D2D_LM_MP_FINISH, 1e-15, 1e-15, 1e-15, D2D_LM_SLICE, D2D_LM_MP_SLOW};
-  if (opts) o = *opts;
-  return o;
-}
 
 int d2d_fit_begin(d2d_ctx *ctx, d2d_fit_plan *pl, int B) {
   D2D_REQUIRE(ctx && pl, "d2d_fit_begin: null argument");
@@ -2494,6 +2583,8 @@ int d2d_fit_begin(d2d_ctx *ctx, d2d_fit_plan *pl, int B) {
   D2D_CHECK_HIP(hipMemsetAsync(pl->d_ring, 0xff, (size_t)pl->ring_cap * sizeof(int32_t), ctx->stream));
   pl->it_done = 0;
   pl->active_B = B;
+  pl->solve_q = nullptr; pl->solve_kernel = -1;
+  pl->last_order = nullptr; pl->last_order_B = 0;
   pl->prep_valid_for = nullptr;
   pl->rows_B = 0;              // (a solve rewrites d_prep and, on the launch-pair path, d_H)
   pl->last_slice = 0; pl->last_running = -1;
@@ -2513,6 +2604,28 @@ int d2d_fit_iterate(d2d_ctx *ctx, d2d_fit_plan *pl, int B, const double *scen, d
     pl->prep_valid_for = scen;
   }
   if ((pl->use_lm || pl->use_long) && pl->n_group <= 1) {
+    // the solve owns q and stays on the kernel that holds its state (include/d2d.h: d2d_fit_iterate)
+    const int sk = solve_kernel_of(pl, o);
+    if (pl->solve_kernel < 0) {
+      pl->solve_q = q; pl->solve_kernel = sk;
+      // hand-out of this solve: the caller's explicit hint, else (default) longest-first by the predicted trial counts when the batch
+      // exceeds the resident wavefronts (<= 8 per CU) -- below that every fit starts at once and the order is immaterial
+      pl->last_order = pl->order_B == B ? pl->d_order : nullptr;
+      if (pl->order_B != B && o.handout == D2D_HANDOUT_PREDICTED && o.mode == D2D_LM_MODE_MINPACK && B > 8 * pl->n_cu) {
+        if (int rc = launch_handout(ctx, pl, B, scen)) return rc;
+        pl->last_order = pl->d_order_pred;
+      }
+      pl->last_order_B = pl->last_order ? B : 0;
+    } else {
+      if (q != pl->solve_q) {
+        d2d_set_error("d2d_fit_iterate: q differs from the buffer this solve started on (between d2d_fit_begin and d2d_fit_finish the solve owns q)");
+        return D2D_EINVAL;
+      }
+      if (sk != pl->solve_kernel) {
+        d2d_set_error("d2d_fit_iterate: these options (mode / slice) would move the solve in progress to another kernel; finish it and begin again");
+        return D2D_ESTATE;
+      }
+    }
     int budget = o.max_iter - pl->it_done;
     if (budget > n_iters) budget = n_iters;
     // Time-sliced hand-out: a fit that a launch left in its ring keeps D2D_ST_RUNNING with its own iteration count below the
@@ -2581,6 +2694,10 @@ int d2d_fit_finish(d2d_ctx *ctx, d2d_fit_plan *pl, int B, const double *scen, co
                    double *cost, int32_t *iters, int32_t *status, double *stats) {
   D2D_REQUIRE(ctx && pl && scen && q, "d2d_fit_finish: null argument");
   if (pl->active_B != B) { d2d_set_error("d2d_fit_finish: call d2d_fit_begin(B=%d) first", B); return D2D_ESTATE; }
+  if (pl->solve_q != nullptr && q != pl->solve_q) {
+    d2d_set_error("d2d_fit_finish: q differs from the buffer the d2d_fit_iterate calls of this solve worked on");
+    return D2D_EINVAL;
+  }
   const dim3 g1((B + 255) / 256), b1(256);
   // converged trajectories carry a pending evaluation at the accepted point: refresh cost / J^T r
   if (pl->prep_valid_for != scen) {
@@ -2639,6 +2756,30 @@ int d2d_fit_plan_set_order(d2d_ctx *ctx, d2d_fit_plan *pl, int B, const int32_t 
   hipLaunchKernelGGL(fit_order_kernel, dim3(1), dim3(1024), 0, ctx->stream, B, iters, pl->d_order);
   D2D_LAUNCH_CHECK();
   pl->order_B = B; pl->gorder_R = 0; pl->gsweeps_R = 0;
+  return D2D_OK;
+}
+
+int d2d_fit_plan_set_handout_prior(d2d_ctx *ctx, d2d_fit_plan *pl, const float *table) {
+  D2D_REQUIRE(ctx && pl, "d2d_fit_plan_set_handout_prior: null argument");
+  const size_t n = (size_t)2 * D2D_HANDOUT_NB * D2D_HANDOUT_ND;
+  const float *src = table ? table : &kHandoutPrior[0][0][0];
+  for (size_t i = 0; i < n; ++i)
+    D2D_REQUIRE(src[i] == src[i] && fabsf(src[i]) <= 1e4f, "d2d_fit_plan_set_handout_prior: table[%zu] is not a finite trial count", i);
+  D2D_CHECK_HIP(hipSetDevice(pl->device));
+  // (synchronous with respect to the stream: an earlier solve may still be reading the table)
+  D2D_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+  D2D_CHECK_HIP(hipMemcpy(pl->d_hprior, src, n * sizeof(float), hipMemcpyHostToDevice));
+  return D2D_OK;
+}
+
+int d2d_fit_plan_get_order(d2d_ctx *ctx, d2d_fit_plan *pl, int B, int32_t *order) {
+  D2D_REQUIRE(ctx && pl && order, "d2d_fit_plan_get_order: null argument");
+  if (pl->last_order == nullptr || pl->last_order_B != B || B > pl->cap_B) {
+    d2d_set_error("d2d_fit_plan_get_order: the last solve launch of this plan was not handed out by an order over B=%d trajectories", B);
+    return D2D_ESTATE;
+  }
+  D2D_CHECK_HIP(hipMemcpyAsync(order, pl->last_order, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  D2D_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   return D2D_OK;
 }
 
@@ -2711,7 +2852,7 @@ int d2d_fit_solve_groups(d2d_ctx *ctx, d2d_fit_plan *pl, int R, const double *sc
   pl->gsweeps_R = 0;           // only the persistent-kernel path below leaves a report; the launch-pair paths overwrite d_lm
   // ---- one persistent launch: a wavefront per scenario runs the whole block Gauss-Seidel of its group (fit_groups_kernel)
   int wpb_g = 0;
-  if (pl->nq == 24 && !getenv("D2D_FIT_SPLIT") && pick_fused_layout(pl->K, pl->nq, 48, &wpb_g)) {
+  if (pl->nq == 24 && pl->kernel_req != D2D_FIT_KERNEL_SPLIT && pick_fused_layout(pl->K, pl->nq, 48, &wpb_g)) {
     const FusedLds L = fused_lds_layout(pl->K, pl->nq, 48, wpb_g);
     const FitGeom gm = geom_of(pl);
     int32_t *queue = ctx->counter_dev + 8;
@@ -2723,21 +2864,18 @@ int d2d_fit_solve_groups(d2d_ctx *ctx, d2d_fit_plan *pl, int R, const double *sc
     double *d_moved = pl->d_lm;                           // [R] scratch
     const int blocks = R < pl->n_cu ? R : pl->n_cu;
     // Line search on the joint cost along slow sweeps (fit_groups_kernel): on from sweep 8 for sweeps that move >= 0.8 x the one
-    // before; D2D_GROUPS_LS=0 switches it off (plain block Gauss-Seidel), D2D_GROUPS_LS_S0 / D2D_GROUPS_LS_R0 move the thresholds
-    // (development).  Its per-trajectory scratch (the unknowns before the sweep, the trial point) lives in d_H, unused on this path.
+    // before; d2d_fit_opts.gs_ls = 0 switches it off (plain block Gauss-Seidel), gs_ls_s0 / gs_ls_r0 move the thresholds.  Its per-trajectory scratch (the unknowns before the sweep, the trial point) lives in d_H, unused on this path.
     // Measured on configs[2] (tools/dev_groups_accel.py, 8192 scenarios at tol 1e-6): the slowest scenario 200+ -> 39 sweeps, 19
     // scenarios beyond 40 sweeps -> 0, 0.15 evaluations of F per scenario on average, the same fixed point as the plain sweeps
     // in every scenario (F within 1e-12).  (The Anderson extrapolation of the sweep map tried before -- mean 10.5 -> 8.6 sweeps
     // -- was attracted by repelling fixed points, saddles of F, and is gone: DESIGN.md 5.5b.)
-    const int ls_env = getenv("D2D_GROUPS_LS") ? atoi(getenv("D2D_GROUPS_LS")) : 1;
-    const int ls_s0_env = getenv("D2D_GROUPS_LS_S0") ? atoi(getenv("D2D_GROUPS_LS_S0")) : D2D_GS_LS_SWEEP0;
-    const double ls_r0_env = getenv("D2D_GROUPS_LS_R0") ? atof(getenv("D2D_GROUPS_LS_R0")) : D2D_GS_LS_RATIO;
-    const int ls_s0 = ls_env > 0 ? (ls_s0_env < 2 ? 2 : ls_s0_env) : 0;
+    const int ls_s0 = o.gs_ls > 0 ? (o.gs_ls_s0 < 2 ? 2 : o.gs_ls_s0) : 0;
+    const double ls_r0_env = o.gs_ls_r0;
     if (int rc = prof_begin(ctx, pl, 2)) return rc;
     hipLaunchKernelGGL((fit_groups_kernel<3, 24>), dim3(blocks), dim3(64 * wpb_g), L.total, ctx->stream, R, n_ac, pl->nds, gm, L, o,
                        max_sweeps, inner_iters, tol, pl->d_G, pl->d_pk, pl->d_G32, pl->d_W32, pl->d_prep, q, pl->d_pos, pl->d_cost,
                        pl->d_g, pl->d_flags, d_sweeps, d_moved, queue, gorder, reinterpret_cast<double *>(pl->d_H), ls_s0, ls_r0_env,
-                       getenv("D2D_GROUPS_PRIO_AT") ? atoi(getenv("D2D_GROUPS_PRIO_AT")) : D2D_GS_PRIO_AT);
+                       o.gs_prio_at);
     D2D_LAUNCH_CHECK();
     if (int rc = prof_end(ctx, pl)) return rc;
     if (cost) D2D_CHECK_HIP(hipMemcpyAsync(cost, pl->d_cost, (size_t)B * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
@@ -2775,7 +2913,7 @@ int d2d_fit_solve_groups(d2d_ctx *ctx, d2d_fit_plan *pl, int R, const double *sc
   // (plans of the long-horizon kernel -- more than 64 nodes -- run every visit as ONE launch of it: 1.6 .. 3 x faster than the
   // launch pairs at 71 .. 201 nodes, tools/dev_groups_long.py; D2D_GROUPS_PAIRS=1 keeps the launch pairs where their LDS image
   // holds K, tests compare the two)
-  const bool long_path = !pl->split_ok || (pl->use_long && getenv("D2D_GROUPS_PAIRS") == nullptr);
+  const bool long_path = !pl->split_ok || (pl->use_long && o.gs_pairs == 0);
   d2d_fit_opts o_long = o;
   o_long.mode = D2D_LM_MODE_FAST; o_long.so_lambda = 0.0; o_long.max_iter = inner_iters; o_long.slice = 0;
   const FitGeom gm = geom_of(pl);

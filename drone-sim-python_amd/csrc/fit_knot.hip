@@ -908,12 +908,12 @@ int upload(T **dst, const std::vector<T> &src) {
 
 }  // namespace
 
-// The headline shape -- S = 6 (seven knots, 48 free entries), K <= 64, default solver -- runs on the knot kernel; D2D_FIT_KNOT=0 at
-// plan creation keeps the q-coordinate kernel (fit_lm_kernel) for A/B runs and for the tests that compare the two.
+// The headline shape -- S = 6 (seven knots, 48 free entries), K <= 64, default solver -- runs on the knot kernel;
+// d2d_fit_plan_opts.kernel = D2D_FIT_KERNEL_FUSED at plan creation keeps the q-coordinate kernel (fit_lm_kernel) for A/B runs and
+// for the tests that compare the two (d2d_fit_plan_create_ex does not call this function then).
 int fit_knot_plan_init(d2d_fit_plan *pl) {
   pl->kn.wpb = 0;
   if (pl->S != 6 || pl->nq != 24 || pl->K > 64) return D2D_OK;
-  if (getenv("D2D_FIT_KNOT") && atoi(getenv("D2D_FIT_KNOT")) == 0) return D2D_OK;
   if (int rc = fit_basis_knots(pl)) return rc;
   for (int s2 = 0; s2 < pl->S; ++s2)
     if (pl->kn.k0[s2 + 1] - pl->kn.k0[s2] > KN_SEG_MAX) return D2D_OK;      // (cannot happen at K <= 64, S = 6)
@@ -958,6 +958,9 @@ int fit_knot_ensure(d2d_fit_plan *pl, int cap_B) {
   if (kn.wpb == 0) return D2D_OK;
   if (kn.d_u) { hipFree(kn.d_u); kn.d_u = nullptr; }
   D2D_CHECK_HIP(hipMalloc(&kn.d_u, (size_t)cap_B * 64 * sizeof(double)));
+  // (a fit is resumed from its row only after a launch of THIS kernel left it RUNNING -- d2d_fit_iterate keeps a solve on one
+  // kernel -- but no read of this buffer shall ever see uninitialised memory)
+  D2D_CHECK_HIP(hipMemset(kn.d_u, 0, (size_t)cap_B * 64 * sizeof(double)));
   return D2D_OK;
 }
 

@@ -67,6 +67,12 @@ struct d2d_fit_plan {
   int rows_B = 0;              // trajectories whose records d_rows holds
   int32_t *d_order = nullptr;  // [B] hand-out order of the persistent LM kernel (longest fits of the previous solve first)
   int order_B = 0;             // batch size the order was built for (0: none)
+  // predicted hand-out (d2d_fit_opts.handout = D2D_HANDOUT_PREDICTED): the prior table, the keys and the order of the current solve
+  float *d_hprior = nullptr;   // [2][D2D_HANDOUT_NB][D2D_HANDOUT_ND] (plan lifetime; built-in table or d2d_fit_plan_set_handout_prior)
+  int32_t *d_hkey = nullptr;   // [B] sort keys (scratch)
+  int32_t *d_order_pred = nullptr;   // [B] (scratch; d_order stays the caller's explicit hint)
+  const int32_t *last_order = nullptr;   // what the last solve launch handed out by (nullptr: index order) ...
+  int last_order_B = 0;              // ... over this many trajectories (d2d_fit_plan_get_order)
   int32_t *d_ring = nullptr;   // [ring_cap] ring of yielded fits of the persistent LM kernel (-1 = empty slot)
   int ring_cap = 0;            // power of two >= cap_B
   int gorder_R = 0, gsweeps_R = 0;   // coupled groups: d_order[0, R) holds a scenario order / d_order[R, 2R) the sweeps of the last solve
@@ -79,7 +85,10 @@ struct d2d_fit_plan {
   bool use_long = false;    // ... in fit_lm_long_kernel: K > 64, samples in chunks of 64, basis through L2
   bool split_ok = true;     // the split-path kernels' LDS image holds this K (d2d_fit_eval, coupled groups)
   int n_cu = 256;
+  int kernel_req = D2D_FIT_KERNEL_AUTO, long_tables = -1;   // d2d_fit_plan_opts
   int it_done = 0, active_B = 0;   // LM loop state between d2d_fit_begin / iterate / finish
+  const double *solve_q = nullptr; // the q buffer the solve in progress owns (first d2d_fit_iterate after d2d_fit_begin)
+  int solve_kernel = -1;           // ... and the persistent kernel that holds its state: 0 fit_lm_kernel, 1 fit_lm_knot_kernel, 2 long (-1: none yet)
   int last_slice = 0, last_running = -1;   // ... slice of the last d2d_fit_iterate (0: no time-sliced hand-out), its count of RUNNING fits (-1: not counted)
   d2d_fit_opts last_opts = {};     // ... and its options (d2d_fit_finish sweeps up what a sliced launch left in the ring)
   // optional per-launch timing (d2d_fit_profile)

@@ -1305,15 +1305,14 @@ int d2d_nlp_solve(d2d_ctx *ctx, int B, int N, double h, const double *scen, cons
   D2D_REQUIRE(B >= 1 && N >= 3 && h > 0, "d2d_nlp_solve: B >= 1, N >= 3, h > 0 required (B=%d N=%d h=%g)", B, N, h);
   d2d_nlp_opts o = {D2D_NLP_RHO0, D2D_NLP_MUB0, D2D_NLP_MUB_MIN, 1e-9, 1e-7, 60, 40, 0, 0, nullptr};
   if (opts) o = *opts;
-  if (getenv("D2D_NLP_SERIAL")) o.serial = atoi(getenv("D2D_NLP_SERIAL"));      // A/B switch
   D2D_REQUIRE(o.inner_max >= 1 && o.outer_max >= 1 && o.rho0 > 0 && o.mub0 > 0 && o.mub_min > 0, "d2d_nlp_solve: bad options");
   unsigned long long *stamps = nullptr;
   if (getenv("D2D_NLP_STAMPS")) D2D_CHECK_HIP(hipMalloc(reinterpret_cast<void **>(&stamps), 16 * sizeof(unsigned long long)));
-  // one wavefront per wave slot (D2D_NLP_SLOTS: development override of the slot count)
+  // one wavefront per wave slot (d2d_nlp_opts.slots > 0: the caller's count)
   static int n_cu = 0;
   if (n_cu == 0) { int dev = 0; (void)hipGetDevice(&dev); if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256; }
   int slots = n_cu * 4 * NLP_WAVES_PER_SIMD;
-  if (getenv("D2D_NLP_SLOTS")) slots = atoi(getenv("D2D_NLP_SLOTS"));
+  if (o.slots > 0) slots = o.slots;
   const int grid = B < slots ? B : (slots < 1 ? 1 : slots);
   int32_t *queue = ctx->counter_dev + 2;
   D2D_CHECK_HIP(hipMemsetAsync(queue, 0, sizeof(int32_t), ctx->stream));
@@ -1341,7 +1340,6 @@ int d2d_nlp_solve_groups(d2d_ctx *ctx, int R, int n_ac, int N, double h, const d
   D2D_REQUIRE(max_sweeps >= 1 && tol >= 0, "d2d_nlp_solve_groups: max_sweeps >= 1 and tol >= 0 required");
   d2d_nlp_opts o = {D2D_NLP_RHO0, D2D_NLP_MUB0, D2D_NLP_MUB_MIN, 1e-9, 1e-7, 60, 40, 0, 0, nullptr};
   if (opts) o = *opts;
-  if (getenv("D2D_NLP_SERIAL")) o.serial = atoi(getenv("D2D_NLP_SERIAL"));
   D2D_REQUIRE(o.inner_max >= 1 && o.outer_max >= 1 && o.rho0 > 0 && o.mub0 > 0 && o.mub_min > 0, "d2d_nlp_solve_groups: bad options");
   // scratch for the positions before a turn: the tail of aircraft 0's workspace is not free, so it lives behind the workspaces
   double *prev = work + (size_t)R * n_ac * WS_TOTAL * N;

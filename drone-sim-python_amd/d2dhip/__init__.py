@@ -52,7 +52,7 @@ class TrackParams(C.Structure):
 
 class NlpOpts(C.Structure):
     _fields_ = [('rho0', C.c_double), ('mub0', C.c_double), ('mub_min', C.c_double), ('feas_tol', C.c_double),
-                ('opt_tol', C.c_double), ('inner_max', C.c_int32), ('outer_max', C.c_int32), ('serial', C.c_int32), ('reserved', C.c_int32),
+                ('opt_tol', C.c_double), ('inner_max', C.c_int32), ('outer_max', C.c_int32), ('serial', C.c_int32), ('slots', C.c_int32),
                 ('bounds', C.c_void_p)]
 
 
@@ -60,7 +60,13 @@ class FitOpts(C.Structure):
     _fields_ = [('max_iter', C.c_int32), ('check_every', C.c_int32), ('ftol', C.c_double),
                 ('gtol', C.c_double), ('xtol', C.c_double), ('so_lambda', C.c_double),
                 ('mode', C.c_int32), ('mp_finish', C.c_int32), ('mp_ftol', C.c_double), ('mp_xtol', C.c_double),
-                ('mp_gtol', C.c_double), ('slice', C.c_int32), ('mp_slow', C.c_int32)]
+                ('mp_gtol', C.c_double), ('slice', C.c_int32), ('mp_slow', C.c_int32),
+                ('handout', C.c_int32), ('prio_at', C.c_int32), ('gs_ls', C.c_int32), ('gs_ls_s0', C.c_int32), ('gs_ls_r0', C.c_double),
+                ('gs_prio_at', C.c_int32), ('gs_pairs', C.c_int32)]
+
+
+class FitPlanOpts(C.Structure):
+    _fields_ = [('kernel', C.c_int32), ('long_tables', C.c_int32), ('reserved', C.c_int32 * 2)]
 
 
 SO_LAMBDA = 1e-4          # D2D_LM_SO_LAMBDA: damping below which the evaluations carry the second-order term (FAST mode)
@@ -69,12 +75,19 @@ MODE_MINPACK, MODE_FAST = 0, 1     # D2D_LM_MODE_*: MINPACK's lmder path (what s
 MP_FINISH = 3             # D2D_LM_MP_FINISH: calm lmder steps before the second-order finish (0 = pure lmder)
 MP_SLOW = 8               # D2D_LM_MP_SLOW: stagnating lmder trials (cost change <= 1e-4 of itself) in a row before the finish (0 = never)
 SLICE = 0                 # D2D_LM_SLICE: iterations a fit runs before it yields its wavefront to waiting fits (0 = never)
+HANDOUT_INDEX, HANDOUT_PREDICTED = 0, 1   # D2D_HANDOUT_*: hand-out order of a batch larger than the resident wavefronts
+PRIO_AT = 48              # D2D_LM_PRIO_AT
+GS_LS_SWEEP0, GS_LS_RATIO, GS_PRIO_AT = 8, 0.8, 40     # D2D_GS_LS_SWEEP0 / D2D_GS_LS_RATIO / D2D_GS_PRIO_AT
+KERNEL_AUTO, KERNEL_SPLIT, KERNEL_FUSED, KERNEL_LONG, KERNEL_KNOT = -1, 0, 1, 2, 3     # D2D_FIT_KERNEL_*
+KERNELS = {'auto': KERNEL_AUTO, 'split': KERNEL_SPLIT, 'fused': KERNEL_FUSED, 'long': KERNEL_LONG, 'knot': KERNEL_KNOT}
 
 
 def fit_opts(max_iter=200, check_every=8, ftol=1e-14, gtol=1e-9, xtol=1e-11, so_lambda=SO_LAMBDA, mode=MODE_MINPACK,
-             mp_finish=MP_FINISH, mp_tol=1e-15, slice=SLICE, mp_slow=MP_SLOW):
-    """d2d_fit_opts with the library's defaults (include/d2d.h)."""
-    return FitOpts(max_iter, check_every, ftol, gtol, xtol, so_lambda, mode, mp_finish, mp_tol, mp_tol, mp_tol, slice, mp_slow)
+             mp_finish=MP_FINISH, mp_tol=1e-15, slice=SLICE, mp_slow=MP_SLOW, handout=HANDOUT_PREDICTED, prio_at=PRIO_AT,
+             gs_ls=1, gs_ls_s0=GS_LS_SWEEP0, gs_ls_r0=GS_LS_RATIO, gs_prio_at=GS_PRIO_AT, gs_pairs=0):
+    """d2d_fit_opts with the library's defaults (include/d2d.h; tests/test_abi.py compares them with d2d_fit_opts_default)."""
+    return FitOpts(max_iter, check_every, ftol, gtol, xtol, so_lambda, mode, mp_finish, mp_tol, mp_tol, mp_tol, slice, mp_slow,
+                   handout, prio_at, gs_ls, gs_ls_s0, gs_ls_r0, gs_prio_at, gs_pairs)
 
 
 _P = C.c_void_p
@@ -84,6 +97,7 @@ _SIGS = {
     'd2d_ctx_create': (C.c_int, [C.c_int, _P, C.POINTER(_P)]),
     'd2d_ctx_destroy': (C.c_int, [_P]),
     'd2d_ctx_sync': (C.c_int, [_P]),
+    'd2d_comm_available': (C.c_int, []),
     'd2d_comm_unique_id': (C.c_int, [_P]),
     'd2d_comm_create': (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(_P)]),
     'd2d_comm_destroy': (C.c_int, [_P]),
@@ -105,6 +119,8 @@ _SIGS = {
     'd2d_nlp_solve': (C.c_int, [_P, C.c_int, C.c_int, C.c_double, _P, C.POINTER(NlpOpts)] + [_P] * 8),
     'd2d_nlp_solve_groups': (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_double, _P, C.POINTER(NlpOpts), C.c_int, C.c_double] + [_P] * 9),
     'd2d_fit_plan_create': (C.c_int, [_P, C.c_int, C.c_int, C.c_double, _P, C.POINTER(_P)]),
+    'd2d_fit_plan_create_ex': (C.c_int, [_P, C.c_int, C.c_int, C.c_double, _P, C.POINTER(FitPlanOpts), C.POINTER(_P)]),
+    'd2d_fit_opts_default': (C.c_int, [C.POINTER(FitOpts)]),
     'd2d_fit_plan_destroy': (C.c_int, [_P]),
     'd2d_fit_plan_get': (C.c_int, [_P] * 6),
     'd2d_fit_plan_kernel': (C.c_int, [_P]),
@@ -118,6 +134,8 @@ _SIGS = {
     'd2d_fit_iterate': (C.c_int, [_P, _P, C.c_int, _P, _P, C.POINTER(FitOpts), C.c_int, C.POINTER(C.c_int32)]),
     'd2d_fit_finish': (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P, _P, _P]),
     'd2d_fit_plan_set_order': (C.c_int, [_P, _P, C.c_int, _P]),
+    'd2d_fit_plan_set_handout_prior': (C.c_int, [_P, _P, _P]),
+    'd2d_fit_plan_get_order': (C.c_int, [_P, _P, C.c_int, _P]),
     'd2d_fit_plan_set_group_order': (C.c_int, [_P, _P, C.c_int, C.c_int]),
     'd2d_fit_group_report': (C.c_int, [_P, _P, C.c_int, _P, _P]),
     'd2d_fit_plan_set_groups': (C.c_int, [_P, C.c_int]),
@@ -221,6 +239,11 @@ class Context:
         _check(self.lib.d2d_ctx_sync(self.h))
 
     # -- multi-GPU convergence exchange through the C-ABI (RCCL, include/d2d.h d2d_comm_*) ------------
+    def comm_available(self):
+        """local, no communication: can this process load RCCL (d2d_comm_available)?  None when it can, else the reason."""
+        rc = self.lib.d2d_comm_available()
+        return None if rc == 0 else self.lib.d2d_last_error().decode()
+
     def comm_unique_id(self):
         """128 opaque bytes (ncclGetUniqueId): rank 0 creates them, the host hands them to the other ranks."""
         buf = C.create_string_buffer(128)
@@ -385,7 +408,7 @@ class Context:
         return out
 
     def nlp_solve(self, scen, W, h, partner=None, rho0=10.0, mub0=0.1, mub_min=1e-9, feas_tol=1e-9, opt_tol=1e-7, inner_max=NLP_INNER_MAX,
-                  outer_max=NLP_OUTER_MAX, want_mult=False, serial=0, bounds=None):
+                  outer_max=NLP_OUTER_MAX, want_mult=False, serial=0, bounds=None, slots=0):
         """Direct-collocation NLP in node variables (d2d_nlp_solve): scen dev [B][SCEN_STRIDE], W dev [B][5][N] in/out (initial
         guess -> solution), partner dev [B][2][N] or None, bounds dev [B][4] = (phi_lo, phi_hi, psi_lo, psi_hi) or None (d2d_nlp_opts.bounds).
         Returns dict(cost, feas, iters, status[, mult [B][3][N]]) of device tensors."""
@@ -397,7 +420,7 @@ class Context:
         iters = torch.empty(B, dtype=torch.int32, device=self.device); status = torch.empty(B, dtype=torch.int32, device=self.device)
         mult = self.zeros(B, 3, N) if want_mult else None
         assert bounds is None or (bounds.is_contiguous() and tuple(bounds.shape) == (B, 4) and bounds.dtype == _torch().float64)
-        o = NlpOpts(rho0, mub0, mub_min, feas_tol, opt_tol, inner_max, outer_max, serial, 0, None if bounds is None else bounds.data_ptr())
+        o = NlpOpts(rho0, mub0, mub_min, feas_tol, opt_tol, inner_max, outer_max, serial, int(slots), None if bounds is None else bounds.data_ptr())
         _check(self.lib.d2d_nlp_solve(self.h, B, N, float(h), _ptr(scen), C.byref(o), _ptr(W), _ptr(partner), _ptr(work), _ptr(mult),
                                       _ptr(cost), _ptr(feas), _ptr(iters), _ptr(status)))
         out = dict(cost=cost, feas=feas, iters=iters, status=status, work=work)
@@ -455,12 +478,15 @@ def default_context():
 class FitPlan:
     """Shared basis block + solver scratch for one (S, K, duration, wref)."""
 
-    def __init__(self, ctx, S, K, duration, wref):
+    def __init__(self, ctx, S, K, duration, wref, kernel='auto', long_tables=-1):
+        """kernel: 'auto' | 'knot' | 'fused' | 'long' | 'split' (d2d_fit_plan_opts.kernel: which kernel family serves d2d_fit_solve);
+        long_tables: d2d_fit_plan_opts.long_tables (-1 = the segment formulation)."""
         self.ctx, self.S, self.K, self.duration = ctx, S, K, float(duration)
         self.nq = 4 * S
         w = np.ascontiguousarray(wref, dtype=np.float64)
         h = _P()
-        _check(ctx.lib.d2d_fit_plan_create(ctx.h, S, K, self.duration, _hptr(w), C.byref(h)))
+        po = FitPlanOpts(KERNELS[kernel], int(long_tables), (C.c_int32 * 2)(0, 0))
+        _check(ctx.lib.d2d_fit_plan_create_ex(ctx.h, S, K, self.duration, _hptr(w), C.byref(po), C.byref(h)))
         self.h = h
 
     def close(self):
@@ -550,6 +576,26 @@ class FitPlan:
     def clear_order(self):
         _check(self.ctx.lib.d2d_fit_plan_set_order(self.ctx.h, self.h, 0, None))
 
+    def set_handout_prior(self, table=None):
+        """Install a hand-out prior (float32 [2][48][12] expected trial counts, d2dhip.handout.fit_prior) or, with None, the built-in one."""
+        t = None if table is None else np.ascontiguousarray(table, dtype=np.float32).reshape(2, 48, 12)
+        _check(self.ctx.lib.d2d_fit_plan_set_handout_prior(self.ctx.h, self.h, _hptr(t)))
+
+    def learn_handout_prior(self, scen, iters):
+        """Calibrate the prior on a finished solve of this workload: scen [B][SCEN_STRIDE], iters [B] (device or host)."""
+        from . import handout
+        sc = scen.cpu().numpy() if hasattr(scen, 'cpu') else np.asarray(scen)
+        it = iters.cpu().numpy() if hasattr(iters, 'cpu') else np.asarray(iters)
+        table = handout.fit_prior(sc, self.duration, it)
+        self.set_handout_prior(table)
+        return table
+
+    def last_order(self, B):
+        """The hand-out order the last solve launch used (int32 [B]); raises if it ran in index order."""
+        o = np.zeros(B, np.int32)
+        _check(self.ctx.lib.d2d_fit_plan_get_order(self.ctx.h, self.h, B, _hptr(o)))
+        return o
+
     def group_order_from_last(self, R, enable=True):
         """Scheduling hint for solve_groups over R scenarios: start the scenarios that swept longest in the LAST solve_groups
         of this plan first (enable=False clears it)."""
@@ -565,7 +611,7 @@ class FitPlan:
         _check(self.ctx.lib.d2d_fit_plan_set_groups(self.h, n_ac))
         self.n_group = n_ac
 
-    def solve_groups(self, scen, q, n_ac, max_sweeps=60, inner_iters=8, tol=1e-12, ftol=1e-14, gtol=1e-9, xtol=1e-11):
+    def solve_groups(self, scen, q, n_ac, max_sweeps=60, inner_iters=8, tol=1e-12, ftol=1e-14, gtol=1e-9, xtol=1e-11, **gs_kw):
         """Block Gauss-Seidel over the aircraft of every group (scen / q rows g*n_ac + i).  Returns the
         per-aircraft sub-problem costs (device), sweeps used and stats (numpy[4])."""
         if getattr(self, 'n_group', 1) != n_ac:
@@ -573,7 +619,7 @@ class FitPlan:
         B = scen.shape[0]
         assert B % n_ac == 0
         cost = self.ctx.empty(B)
-        o = fit_opts(inner_iters, 1, ftol, gtol, xtol, 0.0)
+        o = fit_opts(inner_iters, 1, ftol, gtol, xtol, 0.0, **gs_kw)      # gs_kw: gs_ls, gs_ls_s0, gs_ls_r0, gs_prio_at, gs_pairs
         sw = C.c_int32(0)
         stats = np.zeros(4)
         _check(self.ctx.lib.d2d_fit_solve_groups(self.ctx.h, self.h, B // n_ac, _ptr(scen), _ptr(q), C.byref(o), max_sweeps,

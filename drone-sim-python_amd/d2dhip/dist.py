@@ -45,13 +45,27 @@ class StatsReducer:
             self.run_dev = torch.zeros(1, dtype=torch.float64, device=device)
 
     def _make_comm(self, dist, ctx):
-        """Every step that can fail on ONE rank is followed by a collective agreement, so that all ranks end on the same
-        collective: rank 0 always takes part in the broadcast of the id (129 bytes: the id + an ok flag, zero when it could not
+        """Every step that can fail on ONE rank is preceded or followed by a collective agreement, so that all ranks end on the
+        same collective: a local preflight (can RCCL be loaded here?) is agreed before anything collective on RCCL's side starts; rank 0 always takes part in the broadcast of the id (129 bytes: the id + an ok flag, zero when it could not
         be created), and after d2d_comm_create every rank all-reduces (MIN) its own ok flag over torch.distributed -- if any rank
         failed, every rank closes its d2d_comm and the exchange stays on torch.distributed."""
         import torch
         rank, world = dist.get_rank(), dist.get_world_size()
         why = None
+        # Preflight: d2d_comm_create is itself a collective (ncclCommInitRank returns when ALL ranks have joined), so a rank that
+        # cannot get there -- librccl does not load on it -- would leave the others waiting inside it.  Every rank checks locally
+        # (d2d_comm_available: dlopen + symbols, no communication) and the flags are agreed over torch.distributed FIRST.
+        try:
+            miss = ctx.comm_available()
+        except Exception as e:           # noqa: BLE001
+            miss = repr(e)
+        ready = torch.tensor([0 if miss else 1], dtype=torch.int32, device=ctx.device)
+        dist.all_reduce(ready, op=dist.ReduceOp.MIN)
+        if int(ready.item()) != 1:
+            self.comm = None
+            self.collective = (f'torch.distributed ({dist.get_backend()}); d2d_comm not used: '
+                               + (f'RCCL not available on this rank: {miss}' if miss else 'RCCL not available on another rank'))[:300]
+            return
         msg = torch.zeros(129, dtype=torch.uint8, device=ctx.device)
         if rank == 0:
             try:

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define D2D_VERSION 107
+#define D2D_VERSION 108
 
 /* error codes */
 #define D2D_OK 0
@@ -52,6 +52,10 @@ int d2d_ctx_sync(d2d_ctx *ctx);   /* hipStreamSynchronize on the context's strea
  * one).  The reference has no counterpart (it is single-process Python); SURVEY.md 8b asks for the entry point so that a host
  * without torch.distributed can drive the sharded solve.  RCCL is loaded at run time (dlopen of librccl.so.1): the library has
  * no link-time dependency on it.
+ *   d2d_comm_available  local, no communication: D2D_OK when this process can load RCCL and resolve the symbols used below.
+ *                       d2d_comm_create is itself a collective (ncclCommInitRank returns when ALL ranks have joined): a host
+ *                       agrees on this flag over its own channel first and calls d2d_comm_create only if every rank reported
+ *                       D2D_OK -- a rank that cannot get there would leave the others waiting inside it;
  *   d2d_comm_unique_id  rank 0 creates the 128-byte id (ncclGetUniqueId) and hands it to the other ranks by whatever channel the
  *                       host has (a file, MPI, a TCP store);
  *   d2d_comm_create     every rank, same id: ncclCommInitRank on the context's device;
@@ -60,6 +64,7 @@ int d2d_ctx_sync(d2d_ctx *ctx);   /* hipStreamSynchronize on the context's strea
  *                       d2d_fit_finish reports in stats[0..2].  The caller synchronises the stream before reading them. */
 typedef struct d2d_comm d2d_comm;
 #define D2D_COMM_ID_BYTES 128
+int d2d_comm_available(void);
 int d2d_comm_unique_id(void *id_out);
 int d2d_comm_create(d2d_ctx *ctx, const void *id, int rank, int world, d2d_comm **out);
 int d2d_comm_destroy(d2d_comm *comm);
@@ -347,25 +352,60 @@ typedef struct {
                            every fit to its end in index order, 4 % later at 32 768 fits -- so the default is 0 = off     */
   int32_t mp_slow;      /* MINPACK mode: stagnating trials in a row before the second-order finish (default D2D_LM_MP_SLOW; 0 = never;
                            only with mp_finish > 0).  (Was `reserved`, always 0, up to version 106.)                          */
+  /* ---- version 108: what used to be process-wide environment switches (D2D_LM_PRIO_AT, D2D_GROUPS_LS*, D2D_GROUPS_PRIO_AT,
+   * D2D_GROUPS_PAIRS) is part of the call; d2d_fit_opts_default() fills every field with the defaults named here ---- */
+  int32_t handout;      /* order in which the persistent kernels hand the fits of a batch to their wavefronts when the batch is larger
+                           than the resident wavefronts (results never depend on it: the fits are independent):
+                           D2D_HANDOUT_PREDICTED (default) longest-first by a PREDICTED trial count -- a key computed on the device from
+                           each scenario row alone, inside the solve (d2d_fit_plan_set_handout_prior; nothing is known from earlier
+                           solves); D2D_HANDOUT_INDEX index order.  An explicit d2d_fit_plan_set_order hint overrides both.        */
+  int32_t prio_at;      /* a fit that has used this many trial points raises its wave's priority (s_setprio): the stragglers get the
+                           SIMD's issue slots ahead of their co-resident wave (default D2D_LM_PRIO_AT; large = never)               */
+  int32_t gs_ls;        /* d2d_fit_solve_groups: 1 (default) line search on the joint cost along slow sweeps, 0 plain block Gauss-Seidel */
+  int32_t gs_ls_s0;     /* ... from this sweep on (default D2D_GS_LS_SWEEP0; values < 2 are raised to 2)                             */
+  double gs_ls_r0;      /* ... after a sweep that moved >= this fraction of the move of the sweep before (default D2D_GS_LS_RATIO)   */
+  int32_t gs_prio_at;   /* a scenario still sweeping after this many sweeps raises its wave's priority (default D2D_GS_PRIO_AT)      */
+  int32_t gs_pairs;     /* d2d_fit_solve_groups on plans of the long-horizon kernel: 1 = every visit as launch pairs of the split
+                           kernels (where their LDS image holds K) instead of ONE launch of the long kernel (default 0)              */
 } d2d_fit_opts;
+enum { D2D_HANDOUT_INDEX = 0, D2D_HANDOUT_PREDICTED = 1 };
+#define D2D_LM_PRIO_AT 48        /* default of d2d_fit_opts.prio_at */
+/* *o = the library's defaults (what a NULL opts pointer means).  Fill it first, then change fields: a struct built by hand from an
+ * older header would leave the fields of later versions zero. */
+int d2d_fit_opts_default(d2d_fit_opts *o);
 
 /* Build the shared basis block on the host (fp64) and upload it.  wref[3] = weights of the
  * whitening metric sum_d wref[d] Phi_d^T Phi_d.  Synchronous. */
 int d2d_fit_plan_create(d2d_ctx *ctx, int S, int K, double duration, const double *wref,
                         d2d_fit_plan **out);
+/* The same with the kernel family chosen by the caller (version 108; before: D2D_FIT_KNOT / D2D_FIT_LONG / D2D_FIT_SPLIT /
+ * D2D_FIT_LONG_SEG / D2D_FIT_LONG_TABLES in the environment of the process).  popts = NULL: the defaults. */
+#define D2D_FIT_KERNEL_AUTO (-1)
+typedef struct {
+  int32_t kernel;        /* D2D_FIT_KERNEL_AUTO (default): knot for S = 6, K <= 64, long otherwise.  D2D_FIT_KERNEL_FUSED: the q-coordinate
+                            fused kernel for the default solver too (S = 6, K <= 64 only); D2D_FIT_KERNEL_LONG: the long-horizon kernel
+                            whatever K; D2D_FIT_KERNEL_SPLIT: the launch-pair path (K must fit its LDS image); D2D_FIT_KERNEL_KNOT: as AUTO
+                            but D2D_EINVAL when the shape has no knot kernel.  A request the shape cannot serve is D2D_EINVAL.          */
+  int32_t long_tables;   /* long-horizon kernel: -1 (default) the segment formulation of csrc/fit_seg.h; 0 / 1 / 2: the table kernels with
+                            both tables in global memory / the fp64 block in the LDS / both in the LDS; 3: the table kernels, placement
+                            chosen from the LDS footprint (development A/B: tools/bench_long.py, tools/dev_seg.py)                      */
+  int32_t reserved[2];   /* zero */
+} d2d_fit_plan_opts;
+int d2d_fit_plan_create_ex(d2d_ctx *ctx, int S, int K, double duration, const double *wref, const d2d_fit_plan_opts *popts,
+                           d2d_fit_plan **out);
 int d2d_fit_plan_destroy(d2d_fit_plan *plan);
 /* Which kernel d2d_fit_solve runs for this plan (uncoupled): the fused persistent LM kernel (S = 6, K <= 64, everything in
  * LDS), the long-horizon persistent kernel (K > 64: the segment formulation of csrc/fit_seg.h -- Legendre coefficients per segment
  * instead of basis tables, LDS footprint independent of K: any K, e.g. the reference's 101 .. 151-node scenarios and its 50 Hz
  * horizons of 351 .. 1501 nodes; since round 3 also every plan with S != 6: the kernel deals its lanes to any number of segments), or
- * the launch-pair path (D2D_FIT_SPLIT=1 in the environment).  d2d_fit_eval uses the launch-pair evaluation kernel
+ * the launch-pair path (d2d_fit_plan_opts.kernel = D2D_FIT_KERNEL_SPLIT).  d2d_fit_eval uses the launch-pair evaluation kernel
  * while the basis block fits the LDS (K <~ 229 at S = 6) and the segment formulation beyond; coupled groups run on the group
  * kernels up to that K and on the long-horizon kernel beyond; d2d_fit_rows / d2d_fit_jtj (the contraction-only pair of the
  * bench) keep the LDS limit (D2D_EINVAL beyond).
  * D2D_FIT_KERNEL_KNOT (round 5): the fused shape (S = 6, K <= 64) with the DEFAULT solver runs in knot coordinates -- the reference's
  * local parameterisation CompositeTraj([MinSnapPoly...]) (src/d2d/trajectory.py:166-208), J^T J block tridiagonal, one MFMA per sample
  * (csrc/fit_knot.hip, oracle/fit_knot.py); D2D_LM_MODE_FAST and the time-sliced hand-out of such a plan stay on the fused q kernel.
- * D2D_FIT_KNOT=0 in the environment at plan creation keeps the q kernel for the default solver too (then: D2D_FIT_KERNEL_FUSED). */
+ * d2d_fit_plan_opts.kernel = D2D_FIT_KERNEL_FUSED at plan creation keeps the q kernel for the default solver too. */
 enum { D2D_FIT_KERNEL_SPLIT = 0, D2D_FIT_KERNEL_FUSED = 1, D2D_FIT_KERNEL_LONG = 2, D2D_FIT_KERNEL_KNOT = 3 };
 int d2d_fit_plan_kernel(const d2d_fit_plan *plan);
 
@@ -411,7 +451,11 @@ int d2d_fit_solve(d2d_ctx *ctx, const d2d_fit_plan *plan, int B, const double *s
  * (the cross-GPU all-reduce of the statistics): begin resets the per-trajectory LM state;
  * iterate runs up to n_iters more damped solves (never beyond opts->max_iter in total) and,
  * if n_running != NULL, synchronises and returns how many trajectories are still running (once max_iter is
- * reached it returns 0 without synchronising); finish refreshes cost / J^T r and exports as d2d_fit_solve. */
+ * reached it returns 0 without synchronising); finish refreshes cost / J^T r and exports as d2d_fit_solve.
+ * Between begin and finish the solve owns q: every d2d_fit_iterate and the d2d_fit_finish of one solve take the SAME q buffer
+ * (another pointer is D2D_EINVAL -- the persistent kernels keep the state of the fits that are still running against it, the knot
+ * kernel in its own coordinates, so an edited or swapped buffer would be ignored) and options that select the same kernel (a change
+ * of mode or slice that would move the solve to another kernel mid-way is D2D_ESTATE). */
 int d2d_fit_begin(d2d_ctx *ctx, d2d_fit_plan *plan, int B);
 int d2d_fit_iterate(d2d_ctx *ctx, d2d_fit_plan *plan, int B, const double *scen, double *q,
                     const d2d_fit_opts *opts, int n_iters, int32_t *n_running);
@@ -423,6 +467,27 @@ int d2d_fit_finish(d2d_ctx *ctx, d2d_fit_plan *plan, int B, const double *scen, 
  * persistent LM kernel then hands the fits out longest-first, so the launch does not end on one long fit that was drawn late.
  * Results do not depend on it (the fits are independent).  iters = NULL clears the hint; a batch of another size ignores it. */
 int d2d_fit_plan_set_order(d2d_ctx *ctx, d2d_fit_plan *plan, int B, const int32_t *iters);
+/* The hand-out prior behind D2D_HANDOUT_PREDICTED: how many trial points a fit is EXPECTED to need, as a function of the scenario
+ * row alone.  What decides it on the SURVEY 8d workload is how far the two end headings are from the legs of the 'tri' dog-leg the
+ * fit starts from (src/d2d/opty_utils.py:171-187) -- near two critical misalignments the start point sits on the watershed between
+ * turning left and turning right, lmder stagnates there and the finish walks down a saddle -- and the chord length; the obstacles
+ * barely matter (tools/fit_handout_prior.py: rank correlation with the measured trial counts 0.6 on held-out scenarios).  Key of a fit:
+ *   table[0][bin(t0)][bin(x)] + table[1][bin(t1)][bin(x)],   x = |p1 - p0| / (vref * duration),
+ *   t0 = wrap(psi0 - (beta + a)), t1 = wrap(psi1 - (beta - a)),  beta = heading of the chord, a = go_left * atan(2 h / |p1 - p0|) the
+ *   angle of the dog-leg's legs against the chord (h = its apex height, sqrt(max(D^2 - d^2, 0)) / 2),
+ * angles in D2D_HANDOUT_NB bins over [-pi, pi), x in D2D_HANDOUT_ND bins over [D2D_HANDOUT_X_LO, D2D_HANDOUT_X_HI) (clamped).  The device
+ * computes the keys and a counting sort of them at the start of every solve whose batch exceeds the resident wavefronts (two small
+ * launches on the solve's stream, inside whatever the caller times).  table: HOST float [2][D2D_HANDOUT_NB][D2D_HANDOUT_ND], in trial
+ * points relative to any common offset; NULL restores the built-in table (csrc/fit_handout_prior.h: regressed on 196 608 synthetic
+ * scenarios of OTHER seeds than any bench or test batch).  A prior only schedules: results are bit-identical whatever it says. */
+#define D2D_HANDOUT_NB 48
+#define D2D_HANDOUT_ND 12
+#define D2D_HANDOUT_X_LO 0.4
+#define D2D_HANDOUT_X_HI 1.0
+int d2d_fit_plan_set_handout_prior(d2d_ctx *ctx, d2d_fit_plan *plan, const float *table);
+/* The hand-out order the LAST solve launch of this plan used over B trajectories: order HOST int32 [B] (position i took trajectory
+ * order[i]); D2D_ESTATE if that launch ran in index order or over another batch size.  Synchronous (tests, diagnostics). */
+int d2d_fit_plan_get_order(d2d_ctx *ctx, d2d_fit_plan *plan, int B, int32_t *order);
 /* The same hint for d2d_fit_solve_groups over R scenarios: from_last != 0 orders the next solves by the sweep counts the
  * LAST d2d_fit_solve_groups of this plan (same R) recorded, longest first; 0 clears it.  Results do not depend on it (the
  * scenarios are independent).  D2D_ESTATE if the plan holds no sweep counts for R scenarios. */
@@ -522,7 +587,8 @@ typedef struct {
   int32_t serial;    /* solver of the reduced block-tridiagonal system of a Newton step: 0 (default) block cyclic reduction -- log2 N
                         levels of independent 3x3 eliminations, one lane per node; 1 the twisted serial block recursion of round 2
                         (N/2 dependent block pivots).  Same step to rounding.                                   */
-  int32_t reserved;
+  int32_t slots;     /* resident wavefronts (= workspaces) of the persistent launch; 0 (default) = every wave slot of the device
+                        (version 108; before: D2D_NLP_SLOTS in the environment.  Was `reserved`, always 0.)                 */
   const double *bounds; /* dev [B][4] = (phi_lo, phi_hi, psi_lo, psi_hi) per problem, or NULL.  phi_lo < phi_hi replaces the symmetric
                            |phi| <= D2D_SC_PHIMAX of the scenario row (opty's bounds dict may hold any interval,
                            src/single_opt_planner.py:53); psi_lo < psi_hi adds a box on the heading of the free nodes (none

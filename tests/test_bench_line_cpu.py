@@ -16,7 +16,8 @@ def fake_record(pad):
             'config': {'workload': 'w' * pad, 'solver': 's' * pad, 'handout': 'h' * pad, 'parallelism': 'trajectory-sharded x1', 'max_iter': 150},
             'rank_kernel_ms_per_step_min_max': [3.3, 3.5]}
     line.update({f'hoisted_scalar_number_{i}': 0.123456789012345 for i in range(30)})
-    roof = {'bound': 'mfma', 'kernel': 'k' * pad, 'achieved': 18.0, 'peak': 157.3, 'unit': 'TFLOP/s', 'frac': 0.117, 'traffic': 1.0e7, 'traffic_source': {'file': 'f' * pad},
+    roof = {'bound': 'issue', 'priced_against': 'mfma', 'executed_mfma_flop_per_unit': 188000.0, 'frac_of_executed_flop': 0.061, 'mfma_busy_frac': 0.069,
+            'issue_slot_frac': 0.70, 'wave_slots_occupied': 1.4, 'pmc_source': 'profiles/r06/01_bench_issue.json', 'kernel': 'k' * pad, 'achieved': 18.0, 'peak': 157.3, 'unit': 'TFLOP/s', 'frac': 0.117, 'traffic': 1.0e7, 'traffic_source': {'file': 'f' * pad},
             'alg_flop_per_unit': 470400, 'units_per_launch_avg': 134347.5, 'avg_launch_us': 3440.0, 'launches': 20, 'note': 'n' * 10 * pad}
     cpu = {'value': 720.0, 'unit': 'trajectory-optimisations/s', 'cores': 16, 'kind': 'port', 'sample': 'x' * pad, 'host_cpu_count': 256,
            'oracle_lm': {'sample': 'y' * 10 * pad}}
@@ -32,7 +33,7 @@ def test_final_line_is_small_and_carries_the_contract():
         for k in CONTRACT:
             assert k in rec
         assert rec['value'] == 1.2e6 and rec['config']['parallelism'] == 'trajectory-sharded x1'
-        assert set(rec['roofline']) == set(bench.ROOF_KEYS) and rec['roofline']['frac'] == 0.117 and rec['roofline']['bound'] == 'mfma'
+        assert set(rec['roofline']) == set(bench.ROOF_KEYS) and rec['roofline']['frac'] == 0.117 and rec['roofline']['bound'] == 'issue' and rec['roofline']['mfma_busy_frac'] == 0.069
         assert set(rec['cpu_baseline']) == set(bench.CPU_KEYS) and rec['cpu_baseline']['cores'] == 16 and rec['cpu_baseline']['kind'] == 'port'
         assert rec['rank_kernel_ms_per_step_min_max'] == [3.3, 3.5]
         assert rec['detail'] == 'gpurun_out/bench_detail.json'

@@ -133,6 +133,10 @@ class _FakeCtx:
     def __init__(self, dist, rank, case, log):
         self.dist, self.rank, self.case, self.log = dist, rank, case, log
 
+    def comm_available(self):
+        # d2d_comm_available: local, no communication
+        return 'librccl.so.1: cannot open shared object file' if (self.case == 'rccl_missing_on_rank1' and self.rank == 1) else None
+
     def comm_unique_id(self):
         if self.case == 'uid_fails_on_rank0':
             raise OSError('librccl.so.1 cannot be loaded')
@@ -140,8 +144,11 @@ class _FakeCtx:
 
     def comm_create(self, uid, rank, world):
         assert uid == bytes(range(128))
+        assert self.case != 'rccl_missing_on_rank1', 'comm_create entered although a rank reported RCCL missing'
         if self.case == 'create_fails_on_rank1' and rank == 1:
             raise RuntimeError('ncclCommInitRank failed')
+        if self.case == 'all_fine':
+            self.dist.barrier()          # like ncclCommInitRank, the real one returns only when every rank has joined
         return _FakeComm(self.dist, rank, world, self.log)
 
 
@@ -150,7 +157,7 @@ def _agree_worker(rank, world, port, out):
     os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     res = {}
-    for case in ('uid_fails_on_rank0', 'create_fails_on_rank1', 'all_fine'):
+    for case in ('rccl_missing_on_rank1', 'uid_fails_on_rank0', 'create_fails_on_rank1', 'all_fine'):
         log = []
         red = StatsReducer(dist, 'cpu', _FakeCtx(dist, rank, case, log), force_comm=True)
         # the exchange after the decision must be the SAME collective on both ranks: it completes and agrees
@@ -169,7 +176,8 @@ def test_comm_fallback_is_decided_collectively():
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_agree_worker, args=(2, _free_port(), out), nprocs=2, join=True)
-    for case, uses in (('uid_fails_on_rank0', False), ('create_fails_on_rank1', False), ('all_fine', True)):
+    # a rank that cannot load RCCL at all must keep EVERY rank out of comm_create (itself a collective): agreed by a preflight
+    for case, uses in (('rccl_missing_on_rank1', False), ('uid_fails_on_rank0', False), ('create_fails_on_rank1', False), ('all_fine', True)):
         a, b = out[0][case], out[1][case]
         assert a['uses_comm'] == b['uses_comm'] == uses, (case, a['collective'], b['collective'])
         assert a['tot'] == b['tot'] == (3.0, 20.0, 7) and a['run'] == b['run'] == 1
@@ -192,5 +200,6 @@ def test_bench_self_spawns_its_ranks():
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
-    recs = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith('{')]
+    import re
+    recs = [json.loads(m) for m in re.findall(r'\{[^{}]*\}', r.stdout)]      # (two ranks share the pipe: their lines may run together)
     assert sorted(x['rank'] for x in recs) == [0, 1] and all(x['world'] == 2 and x['gpus'] == 2 for x in recs)

@@ -119,11 +119,7 @@ def test_obstacle_kind0_and_bank_max_rows(ctx, plan, obasis):
     for split in (False, True):
         p2 = plan
         if split:
-            os.environ['D2D_FIT_SPLIT'] = '1'
-            try:
-                p2 = d2dhip.FitPlan(ctx, S_, K, DUR, WREF)
-            finally:
-                del os.environ['D2D_FIT_SPLIT']
+            p2 = d2dhip.FitPlan(ctx, S_, K, DUR, WREF, kernel='split')
         q = ctx.dev(q0.copy())
         cst, iters, status, stats = p2.solve(dsc, q)
         qs, cst = q.cpu().numpy(), cst.cpu().numpy()
@@ -285,16 +281,14 @@ def test_solve_full_batch_properties(ctx, plan, obasis):
 
 
 def test_fused_and_split_paths_agree(ctx, plan, obasis, monkeypatch):
-    """d2d_fit_solve runs the persistent fit_lm_kernel; D2D_FIT_SPLIT=1 at plan creation selects the
-    eval/step launch pairs (same building blocks): same fixed points, same iteration counts."""
+    """d2d_fit_solve runs the persistent fit_lm_kernel; kernel='split' (d2d_fit_plan_opts.kernel = D2D_FIT_KERNEL_SPLIT) at plan
+    creation selects the eval/step launch pairs (same building blocks): same fixed points, same iteration counts."""
     import d2dhip
     B = 300
     sc = F.set_scale(F.synth_scenarios(B, seed=5), 0.1, K)
     dsc = ctx.dev(sc)
     qa = plan.init(dsc); ca, ia, sa, _ = plan.solve(dsc, qa, so_lambda=0.0, **FAST)     # Gauss-Newton on both paths
-    monkeypatch.setenv('D2D_FIT_SPLIT', '1')
-    plan2 = d2dhip.FitPlan(ctx, S_, K, DUR, WREF)
-    monkeypatch.delenv('D2D_FIT_SPLIT')
+    plan2 = d2dhip.FitPlan(ctx, S_, K, DUR, WREF, kernel='split')
     try:
         qb = plan2.init(dsc); cb, ib, sb, _ = plan2.solve(dsc, qb)
     finally:
@@ -380,9 +374,7 @@ def test_more_than_two_obstacles(ctx, plan, obasis, monkeypatch):
         assert np.array_equal(H[i], H[i].T)
     # solves: Gauss-Newton fused vs split; default (second-order switch) vs the oracle's LM
     qa = ctx.dev(q0.copy()); ca, ia, sa, _ = plan.solve(dsc, qa, so_lambda=0.0, **FAST)
-    monkeypatch.setenv('D2D_FIT_SPLIT', '1')
-    plan2 = d2dhip.FitPlan(ctx, S_, K, DUR, WREF)
-    monkeypatch.delenv('D2D_FIT_SPLIT')
+    plan2 = d2dhip.FitPlan(ctx, S_, K, DUR, WREF, kernel='split')
     try:
         qb = ctx.dev(q0.copy()); cb, ib, sb, _ = plan2.solve(dsc, qb)
     finally:

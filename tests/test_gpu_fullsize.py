@@ -237,18 +237,9 @@ def test_collocation_batch_16384_properties(ctx):
 
 @pytest.fixture(scope='module')
 def plan_q(ctx):
-    """the same plan with the default solver on the q-coordinate kernel (D2D_FIT_KNOT=0): the time-sliced hand-out lives there"""
-    import os
+    """the same plan with the default solver on the q-coordinate kernel (kernel='fused'): the time-sliced hand-out lives there"""
     import d2dhip
-    old = os.environ.get('D2D_FIT_KNOT')
-    os.environ['D2D_FIT_KNOT'] = '0'
-    try:
-        p = d2dhip.FitPlan(ctx, S_, K, DUR, WREF)
-    finally:
-        if old is None:
-            del os.environ['D2D_FIT_KNOT']
-        else:
-            os.environ['D2D_FIT_KNOT'] = old
+    p = d2dhip.FitPlan(ctx, S_, K, DUR, WREF, kernel='fused')
     yield p
     p.close()
 

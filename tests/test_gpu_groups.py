@@ -86,11 +86,9 @@ def test_line_search_on_slow_scenarios_vs_oracle(monkeypatch):
     sc = synth.circle_group_scenarios(n_ac, 8192, DUR, K, seed=1)[ids]
     dsc = ctx.dev(sc.reshape(len(ids) * n_ac, -1))
     try:
-        monkeypatch.setenv('D2D_GROUPS_LS', '0')
         q0 = plan.init(dsc)
-        plan.solve_groups(dsc, q0, n_ac, max_sweeps=200, inner_iters=8, tol=1e-6)
+        plan.solve_groups(dsc, q0, n_ac, max_sweeps=200, inner_iters=8, tol=1e-6, gs_ls=0)      # d2d_fit_opts.gs_ls = 0: plain sweeps
         sw_plain, _ = plan.group_report(len(ids))
-        monkeypatch.delenv('D2D_GROUPS_LS')
         q = plan.init(dsc)
         plan.solve_groups(dsc, q, n_ac, max_sweeps=200, inner_iters=8, tol=1e-6)
         sw_ls, mv_ls = plan.group_report(len(ids))
@@ -166,10 +164,8 @@ def test_long_horizon_groups_on_the_chunked_kernel(monkeypatch):
                 assert swa < 80 and sta[2] <= 1e-12, (swa, sta)
                 qh = qa.cpu().numpy().reshape(R, n_ac, -1)
                 if both:
-                    monkeypatch.setenv('D2D_GROUPS_PAIRS', '1')       # the launch pairs of round 1, where their LDS image holds K
-                    qb = plan.init(dsc)
-                    cb, swb, stb = plan.solve_groups(dsc, qb, n_ac, max_sweeps=80, inner_iters=8, tol=1e-12)
-                    monkeypatch.delenv('D2D_GROUPS_PAIRS')
+                    qb = plan.init(dsc)         # d2d_fit_opts.gs_pairs = 1: the launch pairs of round 1, where their LDS image holds K
+                    cb, swb, stb = plan.solve_groups(dsc, qb, n_ac, max_sweeps=80, inner_iters=8, tol=1e-12, gs_pairs=1)
                     assert np.abs(qa.cpu().numpy() - qb.cpu().numpy()).max() <= 1e-6 * np.abs(qb.cpu().numpy()).max()
                     np.testing.assert_allclose(ca.cpu().numpy(), cb.cpu().numpy(), rtol=1e-8)
                 r = 0

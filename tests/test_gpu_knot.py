@@ -28,15 +28,7 @@ def ctx():
 def _plan(ctx, knot):
     import bench
     import d2dhip
-    old = os.environ.get('D2D_FIT_KNOT')
-    os.environ['D2D_FIT_KNOT'] = '1' if knot else '0'
-    try:
-        return d2dhip.FitPlan(ctx, S_, K, *bench._plan_consts())
-    finally:
-        if old is None:
-            del os.environ['D2D_FIT_KNOT']
-        else:
-            os.environ['D2D_FIT_KNOT'] = old
+    return d2dhip.FitPlan(ctx, S_, K, *bench._plan_consts(), kernel='knot' if knot else 'fused')
 
 
 def test_knot_kernel_vs_oracle_and_q_kernel_and_golden(ctx):
@@ -134,18 +126,7 @@ def test_knot_kernel_other_sample_counts(ctx, K2):
     wref = synth.default_wref(0.1, K2)
     sc = synth.synth_scenarios(96, seed=5, obj_scale=0.1, K=K2, dist_range=(30. * dur / 4.9, 55. * dur / 4.9))
     dsc = ctx.dev(sc)
-    plans = []
-    for knot in ('1', '0'):
-        old = os.environ.get('D2D_FIT_KNOT')
-        os.environ['D2D_FIT_KNOT'] = knot
-        try:
-            plans.append(d2dhip.FitPlan(ctx, S_, K2, dur, wref))
-        finally:
-            if old is None:
-                del os.environ['D2D_FIT_KNOT']
-            else:
-                os.environ['D2D_FIT_KNOT'] = old
-    pk, pq = plans
+    pk, pq = d2dhip.FitPlan(ctx, S_, K2, dur, wref, kernel='knot'), d2dhip.FitPlan(ctx, S_, K2, dur, wref, kernel='fused')
     try:
         assert pk.kernel == 'knot' and pq.kernel == 'fused'
         q0 = pk.init(dsc)

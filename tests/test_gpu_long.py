@@ -21,22 +21,11 @@ def ctx():
     c.close()
 
 
-def _plan(ctx, K, hz=10.0, env=None):
+def _plan(ctx, K, hz=10.0, kernel='auto'):
     import d2dhip
     dur = (K - 1) / hz
     s = 0.1 / K
-    old = {}
-    for k, v in (env or {}).items():
-        old[k] = os.environ.get(k); os.environ[k] = v
-    try:
-        p = d2dhip.FitPlan(ctx, S_, K, dur, (0.02 ** 2, s * 5.0, s / F.G_ACC ** 2))
-    finally:
-        for k, v in old.items():
-            if v is None:
-                del os.environ[k]
-            else:
-                os.environ[k] = v
-    return p, dur
+    return d2dhip.FitPlan(ctx, S_, K, dur, (0.02 ** 2, s * 5.0, s / F.G_ACC ** 2), kernel=kernel), dur
 
 
 def _scen(B, K, dur, seed):
@@ -106,12 +95,12 @@ def test_long_kernel_vs_oracle_lm(ctx, K, mode):
 
 
 def test_long_kernel_equals_fused_kernel_at_K50(ctx):
-    """The same algorithm through both persistent kernels (D2D_FIT_LONG=1 forces the chunked one at K = 50): same minima,
+    """The same algorithm through both persistent kernels (kernel='long' forces the chunked one at K = 50): same minima,
     iteration counts within rounding-level differences of the two summation orders."""
     import d2dhip
     K = 50
-    pf, dur = _plan(ctx, K, env={'D2D_FIT_KNOT': '0'})            # (the two q-coordinate copies of lmder; the knot kernel: tests/test_gpu_knot.py)
-    pl, _ = _plan(ctx, K, env={'D2D_FIT_LONG': '1'})
+    pf, dur = _plan(ctx, K, kernel='fused')            # (the two q-coordinate copies of lmder; the knot kernel: tests/test_gpu_knot.py)
+    pl, _ = _plan(ctx, K, kernel='long')
     try:
         assert pf.kernel == 'fused' and pl.kernel == 'long'
         B = 300

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The contraction-only kernel (fit_jtj_kernel, d2d_fit_rows + d2d_fit_jtj) alone, HIP events.
-  python tools/bench_jtj.py [B ...]        env: D2D_JTJ_WPB, D2D_JTJ_WGS (launch geometry A/B)"""
+  python tools/bench_jtj.py [B ...]        env: D2D_JTJ_GEOM="wpb,wgs" (launch geometry A/B)"""
 import json
 import os
 import sys
@@ -32,8 +32,7 @@ def main():
         plan.profile(False)
         us = 1e3 * pr[6] / pr[7]
         tf = bench.ALG_FLOP_PER_EVAL * B / (us * 1e-6) / 1e12
-        print(json.dumps({'B': B, 'us': us, 'tflops': tf, 'frac': tf / bench.FP32_PEAK_TFLOPS, 'wpb': os.environ.get('D2D_JTJ_WPB'),
-                          'wgs': os.environ.get('D2D_JTJ_WGS')}), flush=True)
+        print(json.dumps({'B': B, 'us': us, 'tflops': tf, 'frac': tf / bench.FP32_PEAK_TFLOPS, 'geom': os.environ.get('D2D_JTJ_GEOM')}), flush=True)
 
 
 if __name__ == '__main__':

@@ -61,5 +61,34 @@ for k, cs in acc.items():
                   'note': 'rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 '
                           '(wave-instructions, mean over the launches of the pass); executed flop = (2 FMA + MUL + ADD) x 64'}
 json.dump(valu, open(prefix + '_valu.json', 'w'), indent=1)
+# what the SIMDs did during a launch of the fused solver kernels (bench.py pmc_issue -> the parsed roofline object): per-launch means of the
+# SQ_* passes.  SQ_BUSY_CYCLES counts per shader engine (32 on the chip): / 32 = cycles of the launch; x 1024 SIMDs = SIMD-cycles;
+# SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES are in quad-cycles per SIMD (MI355X_MICROARCH.md).  The evaluation units of the same launches come
+# from the bench line the MFMA pass printed (roofline.units_per_launch_avg).
+issue = {}
+units = None
+for tag in ('SQ_INSTS_VALU_MFMA_MOPS_F32', 'SQ_WAVE_CYCLES'):
+    try:
+        line = [l for l in open(os.path.join(src, f'pmc_{tag}.json')).read().splitlines() if l.startswith('{')][-1]
+        units = json.loads(line)['roofline']['units_per_launch_avg']
+        break
+    except (OSError, KeyError, IndexError, ValueError, TypeError):
+        continue
+for k, cs in acc.items():
+    name = next((n for n in ('fit_lm_knot_kernel', 'fit_lm_kernel') if n in k), None)
+    if name is None or 'SQ_BUSY_CYCLES' not in cs or 'SQ_INSTS_VALU_MFMA_MOPS_F32' not in cs:
+        continue
+    m = lambda c: sum(cs[c]) / len(cs[c]) if c in cs else 0.0        # noqa: E731
+    cycles = m('SQ_BUSY_CYCLES') / 32.0
+    simd_cycles = cycles * 1024.0
+    mfma = m('SQ_INSTS_VALU_MFMA_MOPS_F32') / 4.0
+    issue[name] = {'kernel': k[:80], 'launches': len(cs['SQ_BUSY_CYCLES']), 'cycles_per_launch': cycles, 'mfma_insts_per_launch': mfma,
+                   'units_per_launch': units, 'mfma_insts_per_unit': (mfma / units) if units else None,
+                   'mfma_busy_frac': m('SQ_VALU_MFMA_BUSY_CYCLES') / simd_cycles, 'issue_slot_frac': m('SQ_ACTIVE_INST_ANY') / (simd_cycles / 4.0),
+                   'wave_slots_occupied': m('SQ_WAVE_CYCLES') / (simd_cycles / 4.0),
+                   'valu_insts': m('SQ_INSTS_VALU'), 'lds_insts': m('SQ_INSTS_LDS'), 'salu_insts': m('SQ_INSTS_SALU'),
+                   'note': 'rocprofv3 --pmc passes of tools/profile_bench.sh, mean over the launches of a pass; cycles = SQ_BUSY_CYCLES / 32, SIMD-cycles = x 1024, '
+                           'MFMA instructions = SQ_INSTS_VALU_MFMA_MOPS_F32 / 4 (v_mfma_f32_16x16x4_f32 = 2048 flop), issue slots / wave slots in quad-cycles'}
+json.dump(issue, open(prefix + '_issue.json', 'w'), indent=1)
 print(open(prefix + '_pmc_summary.txt').read()[:3000])
 print(json.dumps(traffic, indent=1)[:2000])

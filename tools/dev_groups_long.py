@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Development: coupled groups at 65 .. 229 nodes -- the visits of the block Gauss-Seidel as launch pairs (default there) or as one
-launch of the persistent segment kernel each (the default beyond 64 nodes; D2D_GROUPS_PAIRS=1: the launch pairs).  python tools/dev_groups_long.py [K ...]"""
+launch of the persistent segment kernel each (the default beyond 64 nodes; PAIRS=1 in the tool's environment -> d2d_fit_opts.gs_pairs: the launch pairs).  python tools/dev_groups_long.py [K ...]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'drone-sim-python_amd'))
@@ -20,7 +20,7 @@ for K in [int(x) for x in sys.argv[1:]] or [71, 121, 201]:
         best = 1e9
         for rep in range(3):
             q = plan.init(dsc); torch.cuda.synchronize(); t0 = time.perf_counter()
-            c, sw, st = plan.solve_groups(dsc, q, n_ac, max_sweeps=80, inner_iters=8, tol=1e-9)
+            c, sw, st = plan.solve_groups(dsc, q, n_ac, max_sweeps=80, inner_iters=8, tol=1e-9, gs_pairs=int(os.environ.get('PAIRS', '0')))
             torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
-        print(f'K={K} R={R} pairs={os.environ.get("D2D_GROUPS_PAIRS", "0")}: {best * 1e3:8.2f} ms, {sw} sweeps, cost sum {c.sum().item():.8f}', flush=True)
+        print(f'K={K} R={R} pairs={os.environ.get("PAIRS", "0")}: {best * 1e3:8.2f} ms, {sw} sweeps, cost sum {c.sum().item():.8f}', flush=True)
     plan.set_groups(1); plan.close()

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Development: the bench batch (S = 6, K = 50) on the fused kernel and, with D2D_FIT_LONG=1, on the persistent segment kernel."""
+"""Development: the bench batch (S = 6, K = 50) on the fused kernel and, with KERNEL=long in the tool's environment (d2d_fit_plan_opts.kernel), on the persistent segment kernel."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'drone-sim-python_amd'))
@@ -8,7 +8,7 @@ from d2dhip import synth
 K = 50
 dur = synth.planner_timing(0, 4.9, 10)[2]
 ctx = d2dhip.Context(0)
-plan = d2dhip.FitPlan(ctx, 6, K, dur, synth.default_wref(0.1, K))
+plan = d2dhip.FitPlan(ctx, 6, K, dur, synth.default_wref(0.1, K), kernel=os.environ.get('KERNEL', 'auto'))
 for B in (4096, 32768):
     dsc = ctx.dev(synth.synth_scenarios(B, seed=20241008, obj_scale=0.1, K=K))
     q0 = plan.init(dsc)

@@ -16,11 +16,8 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 sc = bench.bench_scenarios(B)
 dsc = ctx.dev(sc)
 res = {}
-for name, env in (('knot', '1'), ('q', '0')):
-    if env is not None:
-        os.environ['D2D_FIT_KNOT'] = env
-    plan = d2dhip.FitPlan(ctx, 6, 50, dur, wref)
-    os.environ.pop('D2D_FIT_KNOT', None)
+for name, kern in (('knot', 'knot'), ('q', 'fused')):
+    plan = d2dhip.FitPlan(ctx, 6, 50, dur, wref, kernel=kern)
     q0 = plan.init(dsc)
     q = q0.clone()
     cost, iters, status, stats = plan.solve(dsc, q, max_iter=150)

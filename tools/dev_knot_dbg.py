@@ -14,8 +14,7 @@ B = 8
 sc = bench.bench_scenarios(B)
 dsc = ctx.dev(sc)
 os.environ['D2D_KNOT_DEBUG'] = '/tmp/knot_dbg.bin'
-os.environ['D2D_FIT_KNOT'] = '1'
-plan = d2dhip.FitPlan(ctx, 6, 50, dur, wref)
+plan = d2dhip.FitPlan(ctx, 6, 50, dur, wref, kernel='knot')
 q0 = plan.init(dsc)
 q = q0.clone()
 cost, iters, status, stats = plan.solve(dsc, q, max_iter=1)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Development: the segment formulation of the long-horizon kernel (fit_seg.h, default) against the table kernels
-(D2D_FIT_LONG_SEG=0, a second process: the switch is read once): same minima, fits/s by node count, both solvers.
+(LONG_TABLES=3 in the tool's environment -> d2d_fit_plan_opts.long_tables): same minima, fits/s by node count, both solvers.
   python tools/dev_seg.py out.npz [K ...]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -18,7 +18,7 @@ MAXIT = int(os.environ.get('MAXIT', '300'))
 for K in Ks:
     t1 = (K - 1) / 10.0
     dur = synth.planner_timing(0, t1, 10)[2]
-    plan = d2dhip.FitPlan(ctx, 6, K, dur, synth.default_wref(0.1, K))
+    plan = d2dhip.FitPlan(ctx, 6, K, dur, synth.default_wref(0.1, K), long_tables=int(os.environ.get('LONG_TABLES', '-1')))
     dsc = ctx.dev(synth.synth_scenarios(B, seed=20241008, obj_scale=0.1, K=K, dist_range=(100. * t1 / 12, 150. * t1 / 12)))
     q0 = plan.init(dsc)
     for name, kw in (('minpack', {}), ('fast', dict(mode=d2dhip.MODE_FAST))):
@@ -33,7 +33,7 @@ for K in Ks:
         torch.cuda.synchronize(); hinted = time.perf_counter() - t0
         plan.clear_order()
         st = status.cpu().numpy()
-        print(f'K={K} {name:8s} seg={os.environ.get("D2D_FIT_LONG_SEG", "1")}: {best * 1e3:8.2f} ms  {B / best / 1e3:7.1f} k fits/s (hinted {B / hinted / 1e3:7.1f} k)  '
+        print(f'K={K} {name:8s} long_tables={os.environ.get("LONG_TABLES", "-1")}: {best * 1e3:8.2f} ms  {B / best / 1e3:7.1f} k fits/s (hinted {B / hinted / 1e3:7.1f} k)  '
               f'mean iters {iters.float().mean().item():.1f} max {iters.max().item()} conv {(st == 1).mean():.4f} mean cost {cost.mean().item():.8f}', flush=True)
         res[f'cost_{K}_{name}'] = cost.cpu().numpy(); res[f'iters_{K}_{name}'] = iters.cpu().numpy(); res[f'q_{K}_{name}'] = q.cpu().numpy()
     plan.close()

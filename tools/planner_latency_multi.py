@@ -19,5 +19,5 @@ for name in sys.argv[1:] or ['exp_1', 'exp_2', 'exp_3', 'exp_5', 'gvf_trial_3ac'
             p.run()
         torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
     info = getattr(p, 'info', {})
-    print(f'{name}: {len(scen.p0s)} aircraft x {p.num_nodes} nodes: Planner.run {1e3 * min(ts):.2f} ms (best of 5), pairs={os.environ.get("D2D_GROUPS_PAIRS", "0")}, '
+    print(f'{name}: {len(scen.p0s)} aircraft x {p.num_nodes} nodes: Planner.run {1e3 * min(ts):.2f} ms (best of 5)", '
           f'sweeps {info.get("sweeps")}, cost {info.get("obj_val")}', flush=True)
