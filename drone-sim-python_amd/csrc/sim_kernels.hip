@@ -52,20 +52,52 @@ __global__ void __launch_bounds__(256) step_kernel(int n, const double *__restri
 
 // ------------------------------------------------------------------------------------
 // Circular formation: block = fpb formations of n_ac consecutive threads.
-// LDS: theta[256] | e[256] | ok[256 ints] | B[n_ac*(n_ac-1)] | zdes[n_ac-1]
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))      // (two waves per SIMD for 131 072 drones and more: DESIGN 5.6)
-gvf_run_kernel(d2d_gvf_params p, GlMesh mesh, int fpb, const double *__restrict__ X0,
-               const double *__restrict__ centres, const double *__restrict__ radius,
-               const double *__restrict__ Bz, const double *__restrict__ X0f,
-               double *__restrict__ X_hist, double *__restrict__ U_hist,
-               double *__restrict__ Rr_hist, double *__restrict__ eth_hist,
-               double *__restrict__ X_final, int32_t *__restrict__ stop_row, int32_t *__restrict__ conv_row) {
+// NAC = 0: any formation size -- the phase angles / errors / stop flags of a formation travel through the LDS
+//          (theta[256] | e[256] | ok[256 ints]) with two block barriers per step;
+// NAC = 1, 2, 4: the formation is (part of) a DPP quad of ONE wavefront (64-thread blocks): its members' values are fetched with
+//          v_mov_b32 quad_perm -- no LDS round trip, no barrier in the step (a 10 000-step loop is one dependent chain per drone and,
+//          at 65 536 drones, alone on its SIMD: every exposed latency is paid in full).  Same sums in the same order: bit-identical.
+// LDS (both): B[n_ac*(n_ac-1)] | zdes[n_ac-1] behind the three exchange arrays.
+template <int CTRL>
+__device__ __forceinline__ double quad_get(double v) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+// member K of the lane's own formation (NAC aircraft, quad-aligned): quad_perm [K,K,K,K] for four, [K,K,2+K,2+K] for two
+template <int NAC, int K>
+__device__ __forceinline__ double member_get(double v) {
+  if (NAC == 4) return quad_get<K * 0x55>(v);
+  if (NAC == 2) return quad_get<(K & 1) * 0x05 + (2 + (K & 1)) * 0x50>(v);
+  return v;
+}
+template <int NAC, int K>
+__device__ __forceinline__ int member_get_i(int v) {
+  if (NAC == 4) return __builtin_amdgcn_mov_dpp(v, K * 0x55, 0xf, 0xf, true);
+  if (NAC == 2) return __builtin_amdgcn_mov_dpp(v, (K & 1) * 0x05 + (2 + (K & 1)) * 0x50, 0xf, 0xf, true);
+  return v;
+}
+
+// VCONST (the launch puts one wave on a SIMD and that wave has 512 VGPRs): the tableau of the one-panel step (36 + 6 doubles in constant
+// memory) and its mesh row (15, kernel arguments) are copied into vector registers before the time loop.  Wave-uniform fp64 constants
+// live in scalar register pairs, of which there are ~50; what does not fit is fetched again in EVERY step (s_load: 19 per step, each
+// behind its own wait -- measured with SQ_WAIT_ANY: 30 % of the wave's cycles, a lone wave hides nothing) or re-made from literals
+// (s_mov_b32: a scalar instruction costs a lone wave the same issue slot as an fp64 FMA; 263 per step against 802 vector ones).
+template <int NAC, bool VCONST>
+__device__ __forceinline__ void
+gvf_run_body(const d2d_gvf_params &p, const GlMesh &mesh, int fpb, const double *__restrict__ X0,
+             const double *__restrict__ centres, const double *__restrict__ radius,
+             const double *__restrict__ Bz, const double *__restrict__ X0f,
+             double *__restrict__ X_hist, double *__restrict__ U_hist,
+             double *__restrict__ Rr_hist, double *__restrict__ eth_hist,
+             double *__restrict__ X_final, int32_t *__restrict__ stop_row, int32_t *__restrict__ conv_row) {
   extern __shared__ double lds[];
+  constexpr bool QUAD = NAC != 0;
   double *sh_theta = lds;
   double *sh_e = lds + 256;
   int *sh_ok = reinterpret_cast<int *>(lds + 512);
   double *sh_B = lds + 512 + 128;
-  const int n_ac = p.n_ac, nm = n_ac - 1;
+  const int n_ac = QUAD ? NAC : p.n_ac, nm = n_ac - 1;
   double *sh_z = sh_B + n_ac * nm;
   for (int i = threadIdx.x; i < n_ac * nm + nm; i += blockDim.x) sh_B[i] = Bz[i];
 
@@ -89,7 +121,30 @@ gvf_run_kernel(d2d_gvf_params p, GlMesh mesh, int fpb, const double *__restrict_
     }
   }
   __syncthreads();
+  double fast6[3 + 2 * D2D_GL_FAST_STAGES];
+#pragma unroll
+  for (int r = 0; r < 3 + 2 * D2D_GL_FAST_STAGES; ++r) fast6[r] = mesh.fast[r];
+  double ga6[D2D_GL_FAST_STAGES][D2D_GL_FAST_STAGES], gb6[D2D_GL_FAST_STAGES];
+#pragma unroll
+  for (int r = 0; r < D2D_GL_FAST_STAGES; ++r) {
+    gb6[r] = GL6_B[r];
+#pragma unroll
+    for (int c = 0; c < D2D_GL_FAST_STAGES; ++c) ga6[r][c] = GL6_A[r][c];
+  }
+  if (VCONST) {
+#pragma unroll
+    for (int r = 0; r < 3 + 2 * D2D_GL_FAST_STAGES; ++r) asm volatile("" : "+v"(fast6[r]));
+#pragma unroll
+    for (int r = 0; r < D2D_GL_FAST_STAGES; ++r) {
+      asm volatile("" : "+v"(gb6[r]));
+#pragma unroll
+      for (int c = 0; c < D2D_GL_FAST_STAGES; ++c) asm volatile("" : "+v"(ga6[r][c]));
+    }
+  }
   const int rs = p.rec_stride;
+  // history rows: i % rs and i / rs of this step and of the one before, kept by counting (a division by a run-time number is ~25
+  // scalar instructions, four of them per step)
+  int ph_prev = 0, row_prev = 0, ph = rs == 1 ? 0 : 1, row = rs == 1 ? 1 : 0;
   int my_stop = p.n_rows;      // formation-uniform
   bool prev_all_ok = false;    // result of the stop test at the end of the previous step
   int n_true = 0, first_true = -1;   // phase-error rule (use_stop == 2): steps on which it held so far, loop index i-1 of the first one
@@ -107,46 +162,75 @@ gvf_run_kernel(d2d_gvf_params p, GlMesh mesh, int fpb, const double *__restrict_
       // use_stop == 2: src/12_full_sim_case2.py:156-164 / 12_full_sim_case3.py:163-178 -- `break` at the END of the step on
       // which the rule fired, rows [:i+1] are kept, which is the same row count as a break at the top of the next step
       if (prev_all_ok && (p.use_stop == 2 || (i - 1) > 0) && my_stop == p.n_rows) my_stop = i;
-      // every formation of this block has stopped: nothing left to integrate
-      if (__syncthreads_and((!live || my_stop != p.n_rows) ? 1 : 0)) break;
+      // every formation of this block (QUAD: of this wavefront, which is the block) has stopped: nothing left to integrate
+      const int gone = (!live || my_stop != p.n_rows) ? 1 : 0;
+      if (QUAD ? __all(gone) : __syncthreads_and(gone)) break;
     }
     const bool run = live && (my_stop == p.n_rows);
     // DCFController.get, src/d2d/guidance.py:103-126
-    sh_theta[t] = atan2(s.y - cy, s.x - cx);
-    __syncthreads();
-    double e = 0.0;
-    if (small_form) {
-      double th[GVF_FA], bc[GVF_FA];
+    const double theta = atan2(s.y - cy, s.x - cx);
+    double e = 0.0, Ur = 0.0;
+    if (QUAD) {
+      // partners' angles and errors by DPP; the matrix entries from the LDS (read-only after the barrier above: requested before
+      // the atan2 result is needed)
+      double bc[GVF_FA], br[GVF_FA - 1];
       const int ac = a < nm ? a : 0;
 #pragma unroll
-      for (int k = 0; k < GVF_FA; ++k) { const int kk = k < n_ac ? k : 0; th[k] = sh_theta[base + kk]; bc[k] = sh_B[kk * nm + ac]; }
-      const double zd = sh_z[ac];
+      for (int k = 0; k < GVF_FA; ++k) bc[k] = k < NAC ? sh_B[k * nm + ac] : 0.0;
+#pragma unroll
+      for (int m = 0; m < GVF_FA - 1; ++m) br[m] = m < NAC - 1 ? sh_B[a * nm + m] : 0.0;
+      const double zd = NAC > 1 ? sh_z[ac] : 0.0;
+      double th[GVF_FA];
+      th[0] = member_get<NAC, 0>(theta); th[1] = member_get<NAC, 1>(theta); th[2] = member_get<NAC, 2>(theta); th[3] = member_get<NAC, 3>(theta);
       double z = 0.0;
 #pragma unroll
-      for (int k = 0; k < GVF_FA; ++k) z += (k < n_ac ? bc[k] : 0.0) * th[k];
+      for (int k = 0; k < GVF_FA; ++k)
+        if (k < NAC) z += bc[k] * th[k];
       if (a < nm) {
         e = z - zd;
         if (e > D2D_PI) e -= D2D_TWO_PI;
         if (e <= -D2D_PI) e += D2D_TWO_PI;
       }
-    } else if (a < nm) {
-      double z = 0.0;
-      for (int k = 0; k < n_ac; ++k) z += sh_B[k * nm + a] * sh_theta[base + k];
-      e = z - sh_z[a];
-      if (e > D2D_PI) e -= D2D_TWO_PI;
-      if (e <= -D2D_PI) e += D2D_TWO_PI;
-    }
-    sh_e[t] = e;
-    __syncthreads();
-    double Ur = 0.0;
-    if (small_form) {
-      double ev[GVF_FA - 1], br[GVF_FA - 1];
+      double ev[GVF_FA - 1];
+      ev[0] = member_get<NAC, 0>(e); ev[1] = member_get<NAC, 1>(e); ev[2] = member_get<NAC, 2>(e);
 #pragma unroll
-      for (int m = 0; m < GVF_FA - 1; ++m) { const int mm = m < nm ? m : 0; ev[m] = sh_e[base + mm]; br[m] = nm > 0 ? sh_B[a * nm + mm] : 0.0; }
-#pragma unroll
-      for (int m = 0; m < GVF_FA - 1; ++m) Ur += (m < nm ? br[m] : 0.0) * ev[m];
+      for (int m = 0; m < GVF_FA - 1; ++m)
+        if (m < NAC - 1) Ur += br[m] * ev[m];
     } else {
-      for (int m = 0; m < nm; ++m) Ur += sh_B[a * nm + m] * sh_e[base + m];
+      sh_theta[t] = theta;
+      __syncthreads();
+      if (small_form) {
+        double th[GVF_FA], bc[GVF_FA];
+        const int ac = a < nm ? a : 0;
+#pragma unroll
+        for (int k = 0; k < GVF_FA; ++k) { const int kk = k < n_ac ? k : 0; th[k] = sh_theta[base + kk]; bc[k] = sh_B[kk * nm + ac]; }
+        const double zd = sh_z[ac];
+        double z = 0.0;
+#pragma unroll
+        for (int k = 0; k < GVF_FA; ++k) z += (k < n_ac ? bc[k] : 0.0) * th[k];
+        if (a < nm) {
+          e = z - zd;
+          if (e > D2D_PI) e -= D2D_TWO_PI;
+          if (e <= -D2D_PI) e += D2D_TWO_PI;
+        }
+      } else if (a < nm) {
+        double z = 0.0;
+        for (int k = 0; k < n_ac; ++k) z += sh_B[k * nm + a] * sh_theta[base + k];
+        e = z - sh_z[a];
+        if (e > D2D_PI) e -= D2D_TWO_PI;
+        if (e <= -D2D_PI) e += D2D_TWO_PI;
+      }
+      sh_e[t] = e;
+      __syncthreads();
+      if (small_form) {
+        double ev[GVF_FA - 1], br[GVF_FA - 1];
+#pragma unroll
+        for (int m = 0; m < GVF_FA - 1; ++m) { const int mm = m < nm ? m : 0; ev[m] = sh_e[base + mm]; br[m] = nm > 0 ? sh_B[a * nm + mm] : 0.0; }
+#pragma unroll
+        for (int m = 0; m < GVF_FA - 1; ++m) Ur += (m < nm ? br[m] : 0.0) * ev[m];
+      } else {
+        for (int m = 0; m < nm; ++m) Ur += sh_B[a * nm + m] * sh_e[base + m];
+      }
     }
     Ur *= -p.kr;
     const double Rr = Ur + R;
@@ -156,42 +240,52 @@ gvf_run_kernel(d2d_gvf_params p, GlMesh mesh, int fpb, const double *__restrict_
     double tan_c;
     const double phi_c = gvf_bank_cmd(s, sin_psi, cos_psi, cx, cy, Rr, p.ke, p.kd, nullptr, nullptr, &tan_c);
     double sn_n = sin_psi, cs_n = cos_psi;
-    State5 sn = plant_step<true>(s, phi_c, p.v_c, p.wx, p.wy, mesh, sn_n, cs_n, tan_c);
+    State5 sn = plant_step<true>(s, phi_c, p.v_c, p.wx, p.wy, mesh, sn_n, cs_n, tan_c, &ga6, &gb6, fast6);
     if (run) {
-      if (U_hist && ((i - 1) % rs == 0)) {
-        const long r = (long)((i - 1) / rs) * 2 * N;
+      if (U_hist && ph_prev == 0) {
+        const long r = (long)row_prev * 2 * N;
         U_hist[r + d] = phi_c; U_hist[r + N + d] = p.v_c;
       }
-      if (i % rs == 0) {
-        const long row = i / rs;
+      if (ph == 0) {
         if (X_hist) {
-          const long r = row * 5 * N;
+          const long r = (long)row * 5 * N;
           X_hist[r + d] = sn.x; X_hist[r + N + d] = sn.y; X_hist[r + 2 * N + d] = sn.psi;
           X_hist[r + 3 * N + d] = sn.phi; X_hist[r + 4 * N + d] = sn.v;
         }
-        if (Rr_hist) Rr_hist[row * N + d] = Rr;
-        if (eth_hist && a < nm) eth_hist[row * (long)p.n_form * nm + (long)f * nm + a] = e * (180.0 / D2D_PI);
+        if (Rr_hist) Rr_hist[(long)row * N + d] = Rr;
+        if (eth_hist && a < nm) eth_hist[(long)row * p.n_form * nm + (long)f * nm + a] = e * (180.0 / D2D_PI);
       }
       s = sn;
       sin_psi = sn_n; cos_psi = cs_n;
     }
+    ph_prev = ph; row_prev = row;
+    if (++ph == rs) { ph = 0; ++row; }
     if (p.use_stop) {
       // :170-175 -- |X[0:3]-X0f[0:3]| <= tol for every aircraft of the formation
       bool ok = fabs(sn.x - fx) <= p.stop_tol[0] && fabs(sn.y - fy) <= p.stop_tol[1] &&
                 fabs(sn.psi - fpsi) <= p.stop_tol[2];
       // phase-error rule: every (signed) inter-vehicle phase error of this step, in degrees, <= stop_tol[0]
       if (p.use_stop == 2) ok = (a < nm) ? (e * (180.0 / D2D_PI) <= p.stop_tol[0]) : true;
-      sh_ok[t] = ok ? 1 : 0;
-      __syncthreads();
       bool all_ok = true;
-      if (small_form) {
+      if (QUAD) {
+        const int oki = ok ? 1 : 0;
         int oks[GVF_FA];
+        oks[0] = member_get_i<NAC, 0>(oki); oks[1] = member_get_i<NAC, 1>(oki); oks[2] = member_get_i<NAC, 2>(oki); oks[3] = member_get_i<NAC, 3>(oki);
 #pragma unroll
-        for (int k = 0; k < GVF_FA; ++k) oks[k] = sh_ok[base + (k < n_ac ? k : 0)];
-#pragma unroll
-        for (int k = 0; k < GVF_FA; ++k) all_ok = all_ok && (oks[k] != 0);
+        for (int k = 0; k < GVF_FA; ++k)
+          if (k < NAC) all_ok = all_ok && (oks[k] != 0);
       } else {
-        for (int k = 0; k < n_ac; ++k) all_ok = all_ok && (sh_ok[base + k] != 0);
+        sh_ok[t] = ok ? 1 : 0;
+        __syncthreads();
+        if (small_form) {
+          int oks[GVF_FA];
+#pragma unroll
+          for (int k = 0; k < GVF_FA; ++k) oks[k] = sh_ok[base + (k < n_ac ? k : 0)];
+#pragma unroll
+          for (int k = 0; k < GVF_FA; ++k) all_ok = all_ok && (oks[k] != 0);
+        } else {
+          for (int k = 0; k < n_ac; ++k) all_ok = all_ok && (sh_ok[base + k] != 0);
+        }
       }
       if (p.use_stop == 2) {
         // ... and the loop goes on for stop_hold more steps on which the rule holds (the time the planner needs, case 3)
@@ -214,6 +308,20 @@ gvf_run_kernel(d2d_gvf_params p, GlMesh mesh, int fpb, const double *__restrict_
     if (a == 0 && conv_row) conv_row[f] = first_true;
   }
 }
+
+#define GVF_ARGS d2d_gvf_params p, GlMesh mesh, int fpb, const double *__restrict__ X0, const double *__restrict__ centres,          \
+                 const double *__restrict__ radius, const double *__restrict__ Bz, const double *__restrict__ X0f,                  \
+                 double *__restrict__ X_hist, double *__restrict__ U_hist, double *__restrict__ Rr_hist, double *__restrict__ eth_hist, \
+                 double *__restrict__ X_final, int32_t *__restrict__ stop_row, int32_t *__restrict__ conv_row
+#define GVF_PASS p, mesh, fpb, X0, centres, radius, Bz, X0f, X_hist, U_hist, Rr_hist, eth_hist, X_final, stop_row, conv_row
+// any formation size (LDS exchange); two waves per SIMD for 131 072 drones and more
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) gvf_run_kernel(GVF_ARGS) { gvf_run_body<0, false>(GVF_PASS); }
+// quad-aligned formations (1, 2, 4 aircraft), one wavefront per block; ..._wide: the launch puts at most one wave on a SIMD
+// (<= 1024 blocks: BASELINE configs[4], 65 536 drones), which then has the whole register file -- no scratch
+template <int NAC>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) gvf_run_quad_kernel(GVF_ARGS) { gvf_run_body<NAC, false>(GVF_PASS); }
+template <int NAC>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) gvf_run_quad_wide_kernel(GVF_ARGS) { gvf_run_body<NAC, true>(GVF_PASS); }
 
 // ------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(64)
@@ -611,8 +719,22 @@ int d2d_sim_gvf_run(d2d_ctx *ctx, const d2d_gvf_params *p, const double *X0,
   const int blocks = (p->n_form + fpb - 1) / fpb;
   const size_t lds = (512 + 128 + nb + 8) * sizeof(double);
   const GlMesh mesh = make_mesh(p->dt, p->tau_phi, p->tau_v);
-  hipLaunchKernelGGL(gvf_run_kernel, dim3(blocks), dim3(threads), lds, ctx->stream, *p, mesh, fpb, X0, centres,
-                     radius, ctx->Bmat_dev, X0f, X_hist, U_hist, Rr_hist, eth_hist, X_final, stop_row, conv_row);
+#define GVF_LAUNCH(KERNEL)                                                                                             \
+  hipLaunchKernelGGL(KERNEL, dim3(blocks), dim3(threads), lds, ctx->stream, *p, mesh, fpb, X0, centres, radius, ctx->Bmat_dev, \
+                     X0f, X_hist, U_hist, Rr_hist, eth_hist, X_final, stop_row, conv_row)
+  if (n_ac == 1 || n_ac == 2 || n_ac == 4) {
+    // formations inside a DPP quad: no LDS exchange, no barrier in the step; a launch of at most one wave per SIMD gets the
+    // instantiation that may use the whole register file
+    int n_cu = 256;
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, ctx->device);
+    const bool wide = blocks <= 4 * n_cu;
+    if (n_ac == 4) { if (wide) GVF_LAUNCH(gvf_run_quad_wide_kernel<4>); else GVF_LAUNCH(gvf_run_quad_kernel<4>); }
+    else if (n_ac == 2) { if (wide) GVF_LAUNCH(gvf_run_quad_wide_kernel<2>); else GVF_LAUNCH(gvf_run_quad_kernel<2>); }
+    else { if (wide) GVF_LAUNCH(gvf_run_quad_wide_kernel<1>); else GVF_LAUNCH(gvf_run_quad_kernel<1>); }
+  } else {
+    GVF_LAUNCH(gvf_run_kernel);
+  }
+#undef GVF_LAUNCH
   D2D_LAUNCH_CHECK();
   return D2D_OK;
 }
