@@ -3,7 +3,8 @@ constants -- host-side input generation for benchmarks and batch planning (numpy
 no numerics of the hot path live here)."""
 import numpy as np
 
-from . import (SCEN_STRIDE, SC_X0, SC_Y0, SC_PSI0, SC_X1, SC_Y1, SC_PSI1, SC_VREF, SC_VSP, SC_KV, SC_KPHI,
+from . import (SC_WX, SC_WY, SC_BANKMAX, obs_col,
+               SCEN_STRIDE, SC_X0, SC_Y0, SC_PSI0, SC_X1, SC_Y1, SC_PSI1, SC_VREF, SC_VSP, SC_KV, SC_KPHI,
                SC_KOBS, SC_S, SC_WWP, SC_GOLEFT, SC_O0X, SC_O0Y, SC_O0R, SC_O1X, SC_O1Y, SC_O1R, SC_WBND,
                SC_PHIMAX, SC_VMIN, SC_VMAX, SC_KCOL, SC_RCOL, SC_SCOL, SC_PMASK, SC_XMIN, SC_XMAX, SC_YMIN, SC_YMAX)
 
@@ -48,6 +49,28 @@ def synth_scenarios(B, seed=20241008, rank=0, n_obs=2, wbnd=1.0, wwp=0.02, obj_s
         sc[:, ox], sc[:, oy] = c[:, 0], c[:, 1]
         sc[:, orr] = rad[:, i] if i < n_obs else 0.0
     sc[:, SC_S] = obj_scale / K
+    return sc
+
+
+VARIANTS = ('wind', 'bankmax', 'box3')
+
+
+def variant_scenarios(kind, B, seed=20241008, rank=0, obj_scale=0.1, K=50):
+    """The rarer rows of the cost catalogue on bench-style scenarios -- the branches of the sample evaluation the plain
+    bench batch never takes:  'wind'  a constant wind (1.0, -0.5) m/s (exp_0_2, src/d2d/optyplan_scenarios.py:44-53);
+    'bankmax'  CostBank(use_mean=False) (src/d2d/opty_utils.py:72-73);  'box3'  an x box of +-40 m around the start (x_constraint,
+    src/single_opt_planner.py:56) and a third obstacle of radius 6 at (+10, +10) from it (CostObstacles, :136-144)."""
+    sc = synth_scenarios(B, seed=seed, rank=rank, obj_scale=obj_scale, K=K)
+    if kind == 'wind':
+        sc[:, SC_WX], sc[:, SC_WY] = 1.0, -0.5
+    elif kind == 'bankmax':
+        sc[:, SC_BANKMAX] = 1.0
+    elif kind == 'box3':
+        sc[:, SC_XMIN], sc[:, SC_XMAX] = sc[:, SC_X0] - 40.0, sc[:, SC_X0] + 40.0
+        c = obs_col(2)
+        sc[:, c], sc[:, c + 1], sc[:, c + 2] = sc[:, SC_X0] + 10.0, sc[:, SC_Y0] + 10.0, 6.0
+    else:
+        raise ValueError(kind)
     return sc
 
 

@@ -400,6 +400,72 @@ def test_three_phase_chain_on_device():
     assert np.isfinite(out['phase3'][1]['X_final'].cpu().numpy()).all()
 
 
+def test_three_phase_chain_vs_the_oracle():
+    """The chain of src/11_full_sim_case1.py main() (:405-499) for one formation, ORACLE end to end -- oracle/sim.py formation_gvf_run
+    until the stop rule -> the oracle's solve of the trap_4 scenario from where the oracle's phase 1 ended -> oracle track_run on the
+    oracle's plan -> two passes of phase 3 -- against full_sim.full_sim_phases_batch, which hands every phase's result to the next ON
+    the device.  Tolerances are those of the per-phase tests or tighter (measured on an MI355X: phase 1's end state 1e-13, the plan's nodes 8e-8 m, phase 2 1e-7, the
+    two passes of phase 3 5e-8 / 4e-13: the tracking loop contracts what the plan hands over)."""
+    import full_sim as fs
+    import multi_opt_planner as mop
+    import d2d.opty_utils as d2ou
+    n_ac, r, v, w = 4, 60, 15, [0, 0]
+    c = np.array([[0, -20], [25, -20], [25, -100], [0, -100]], float)
+    X1_f = np.array(((0, 40, 0, 0, 12), (25, 40, 0, 0, 12), (25, -40, 0, 0, 12), (0, -40, 0, 0, 12)), float)
+    X2_f = np.array(((75, 40, 0, 0, 12), (100, 40, 0, 0, 12), (100, -40, 0, 0, 12), (75, -40, 0, 0, 12)), float)
+    t_opt = 6
+    T3 = 120
+    th = np.linspace(0, 2 * np.pi, T3)
+    time_3 = np.arange(T3) * 0.1
+    x3 = X2_f[None, :, 0] + 30 * np.sin(th)[:, None]; y3 = X2_f[None, :, 1] + 30 * (1 - np.cos(th))[:, None]
+    X0 = np.tile(fs.X1_START, (n_ac, 1))
+    # ---- the oracle's chain --------------------------------------------------------------------------------------------------
+    Xo1, Uo1, _, _, stop = S.formation_gvf_run(c, r, v, X0, 20000, 0.05, X0f=X1_f)
+    assert 2 < stop < 20000
+    Xo1_end = Xo1[stop - 1]
+    scen = mop.trap_4
+    scen.t1 = t_opt
+    N2, dt2, dur2 = d2ou.planner_timing(scen.t0, scen.t1, scen.hz)
+    rows, plan, coupled = mop.scenario_rows(scen, [tuple(x) for x in Xo1_end], X2_f[:, :3], N2, dur2, scen.obj_scale, scen.wind.w)
+    ob = F.FitBasis.from_arrays(plan.S, N2, dur2, *plan.basis())
+    if coupled:                     # (a cost with CostCollision: block Gauss-Seidel over the pair, as d2d_fit_solve_groups)
+        qo, co, swo = F.bgs_solve(ob, rows, sweeps=250, inner_iters=8, tol=1e-12, ls=True)
+    else:                           # trap_4 as the reference ships it: four independent fits, the library's default solver
+        from oracle import fit_knot as FK
+        kbo = FK.KnotBasis(ob) if plan.kernel == 'knot' else None
+        qo = np.array([(FK.solve_minpack_knot(kbo, rows[i], hess_dtype=np.float32, chol_dtype=np.float32) if kbo is not None else
+                        F.solve_minpack(ob, rows[i], hess_dtype=np.float32, chol_dtype=np.float32))[0] for i in range(n_ac)])
+    Yo = np.array([F.flat_outputs(ob, rows[i], qo[i]) for i in range(n_ac)])          # (n_ac, 3, 2, K)
+    x_ref_o, y_ref_o = Yo[:, 0, 0].T.copy(), Yo[:, 0, 1].T.copy()
+    time_2 = np.arange(N2) * dt2
+    Xo2, Uo2, *_ = S.track_run(time_2, x_ref_o, y_ref_o, Xo1_end)
+    Xo3a, Uo3a, *_ = S.track_run(time_3, x3, y3, Xo2[-1])
+    Xo3b, *_ = S.track_run(time_3, x3, y3, Xo3a[-1])
+    # ---- the device's chain ----------------------------------------------------------------------------------------------------
+    t_end = (stop - 1) * 0.05 + t_opt + 2 * time_3[-1] - 1e-6          # room for exactly two passes of phase 3
+    out = fs.full_sim_phases_batch(c[None], r, v, n_ac, X1_f, mop.trap_4, X2_f, t_opt, ref3=(time_3, x3, y3), t_sim_end=t_end,
+                                   X0=X0[None], record2=('X', 'U'), record3=('X', 'U'))
+    fs.d2dhip.default_context().sync()
+    assert int(out['phase1']['stop_row'].cpu().numpy()[0]) == stop
+    Xf1 = out['phase1']['X_final'].cpu().numpy().T
+    np.testing.assert_allclose(Xf1, Xo1_end, rtol=0, atol=1e-9)                      # (measured 1e-13; tests/test_gpu_sim.py: the closed GVF loop vs the oracle)
+    Xs = out['plan']['Xs'].cpu().numpy()                                              # [n_ac][5][K]
+    assert np.abs(Xs[:, 0].T - x_ref_o).max() <= 1e-5 and np.abs(Xs[:, 1].T - y_ref_o).max() <= 1e-5       # (measured 8e-8 m)
+    zg = plan.coeffs(out['plan']['scen'], out['plan']['q']).cpu().numpy().reshape(n_ac, -1)
+    zo = np.array([F.coefficients(ob, rows[i], qo[i]).reshape(-1) for i in range(n_ac)])
+    assert np.abs(zg - zo).max() <= 1e-6 * np.abs(zo).max()                          # (the plan vs the oracle: the north-star's 1e-6)
+    X2 = out['phase2']['X'].cpu().numpy().transpose(0, 2, 1); U2 = out['phase2']['U'].cpu().numpy().transpose(0, 2, 1)
+    np.testing.assert_allclose(X2, Xo2, rtol=0, atol=1e-5)                             # (measured 1e-7)
+    np.testing.assert_allclose(U2[:-1], Uo2[:-1], rtol=0, atol=1e-5)
+    assert len(out['phase3']) == 2
+    X3a = out['phase3'][0]['X'].cpu().numpy().transpose(0, 2, 1); X3b = out['phase3'][1]['X'].cpu().numpy().transpose(0, 2, 1)
+    np.testing.assert_allclose(X3a, Xo3a, rtol=0, atol=1e-5)                           # (measured 5e-8)
+    np.testing.assert_allclose(X3b, Xo3b, rtol=0, atol=1e-5)
+    print('chain vs oracle: phase 1 end %.1e, plan %.1e m, phase 2 %.1e, phase 3 %.1e / %.1e' % (
+        np.abs(Xf1 - Xo1_end).max(), max(np.abs(Xs[:, 0].T - x_ref_o).max(), np.abs(Xs[:, 1].T - y_ref_o).max()),
+        np.abs(X2 - Xo2).max(), np.abs(X3a - Xo3a).max(), np.abs(X3b - Xo3b).max()))
+
+
 def test_run_simulation_like_05_test_simulation():
     """full_sim.run_simulation (the legacy DFFF loop of src/05_test_simulation.py:21-34, time loop on the GPU) against the
     same loop driven call by call through the mirror's DFFFController.get and Aircraft.disc_dyn."""
