@@ -206,9 +206,9 @@ def cpu_baseline(batch, n_sample=1024, n_oracle=1024):
 LONG_HORIZONS = ((121, 12.0), (301, 30.0))       # (nodes, seconds) of the long_horizon record
 
 
-def _long_scenarios(B, K2, t2):
+def _long_scenarios(B, K2, t2, rank=0):
     from d2dhip import synth
-    return synth.synth_scenarios(B, seed=SEED, obj_scale=OBJ_SCALE, K=K2, dist_range=(100. * t2 / 12.0, 150. * t2 / 12.0))
+    return synth.synth_scenarios(B, seed=SEED, rank=rank, obj_scale=OBJ_SCALE, K=K2, dist_range=(100. * t2 / 12.0, 150. * t2 / 12.0))
 
 
 def cpu_long_horizon(n=512, B=4096):
@@ -354,15 +354,26 @@ def long_horizon_record(ctx, torch, d2dhip, B=4096, K=121, t1=12.0, more=LONG_HO
             r = plan.solve(dsc, q, max_iter=300)
             torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
         return best, r
-    best, (cost, iters, status, stats) = best_of(3)                     # index order: nothing known about the fits
+    best_index, (cost, iters, status, stats) = best_of(3)               # index order (a long-horizon plan has no built-in hand-out prior)
+    # the hand-out prior of this horizon, regressed on ONE solve of 8192 OTHER scenarios of the same family (seed rank 1000: none of
+    # them is in the timed batch) -- FitPlan.learn_handout_prior; the timed solves then predict each fit's length from its row alone
+    dcal = ctx.dev(_long_scenarios(8192, K, t1, rank=1000))
+    qcal = plan.init(dcal)
+    _, it_cal, _, _ = plan.solve(dcal, qcal, max_iter=300)
+    plan.learn_handout_prior(dcal, it_cal)
+    del dcal, qcal
+    best, (cost_p, iters_p, status_p, _) = best_of(3)
+    assert torch.equal(cost_p, cost) and torch.equal(iters_p, iters)    # (the hand-out only schedules)
     plan.order_from_iters(iters)
     hinted, _ = best_of(2)
     plan.clear_order()
     st = status.cpu().numpy()
     rec = {'metric': f'trajectory-optimisations/sec (6-seg poly, {K} nodes)', 'value': B / best, 'unit': 'trajectory-optimisations/s',
            'workload': f'{B} independent fits, {K} nodes over {t1:g} s, end poses {100. * t1 / 12.0:g}-{150. * t1 / 12.0:g} m apart' + (' (the horizon of optyplan_scenarios.exp_14)' if K == 121 else ''),
-           'kernel': plan.kernel, 'solver': 'library default (MINPACK lmder path + second-order finish)', 'handout': 'index order',
-           'ms_per_step': 1e3 * best, 'value_with_order_hint': B / hinted, 'converged_frac': float((st == 1).mean()),
+           'kernel': plan.kernel, 'solver': 'library default (MINPACK lmder path + second-order finish)',
+           'handout': 'longest-first by the trial count predicted from each scenario row (d2d_fit_opts.handout = D2D_HANDOUT_PREDICTED) with a prior regressed on one '
+                      'solve of 8192 OTHER scenarios of this horizon (d2d_fit_plan_set_handout_prior / FitPlan.learn_handout_prior; untimed calibration)',
+           'ms_per_step': 1e3 * best, 'value_index_order': B / best_index, 'value_with_order_hint': B / hinted, 'converged_frac': float((st == 1).mean()),
            'mean_iters': float(iters.float().mean().item()), 'max_iters': int(iters.max().item()), 'evals_per_fit': float(stats[3]) / B}
     plan.close()
     if cpu_long and K in cpu_long:                  # the same scenarios through the CPU arbiter (scipy on the oracle's residuals), same start
@@ -379,7 +390,7 @@ def long_horizon_record(ctx, torch, d2dhip, B=4096, K=121, t1=12.0, more=LONG_HO
         rec['horizons'] = []
         for (K2, t2) in more:
             r2 = long_horizon_record(ctx, torch, d2dhip, B=B, K=K2, t1=t2, more=(), cpu_long=cpu_long, large_B=0)
-            h = {k: r2[k] for k in ('metric', 'value', 'workload', 'ms_per_step', 'value_with_order_hint', 'converged_frac',
+            h = {k: r2[k] for k in ('metric', 'value', 'workload', 'ms_per_step', 'value_index_order', 'value_with_order_hint', 'converged_frac',
                                     'mean_iters', 'max_iters', 'parity_vs_scipy') if k in r2}
             if large_B:
                 # the throughput regime: 4096 fits of 23 trials on average and 84 at most keep the machine a quarter full

@@ -2355,6 +2355,10 @@ int d2d_fit_plan_create_ex(d2d_ctx *ctx, int S, int K, double duration, const do
   if (!rc) {
     std::vector<float> prior(&kHandoutPrior[0][0][0], &kHandoutPrior[0][0][0] + 2 * D2D_HANDOUT_NB * D2D_HANDOUT_ND);
     rc = upload(&pl->d_hprior, prior);
+    // (regressed on the fused shape's default solver: it knows nothing about other horizons -- measured rank correlation with the
+    // trial counts of the 121- and 301-node bench families: -0.13 / 0.06 -- so plans of the long-horizon kernel hand out in index order
+    // until the caller installs a prior of their own, d2d_fit_plan_set_handout_prior)
+    pl->has_prior = pl->use_lm;
   }
   if (rc) { d2d_fit_plan_destroy(pl); return rc; }
   // opt in to large dynamic LDS
@@ -2615,7 +2619,7 @@ int d2d_fit_iterate(d2d_ctx *ctx, d2d_fit_plan *pl, int B, const double *scen, d
       // hand-out of this solve: the caller's explicit hint, else (default) longest-first by the predicted trial counts when the batch
       // exceeds the resident wavefronts (<= 8 per CU) -- below that every fit starts at once and the order is immaterial
       pl->last_order = pl->order_B == B ? pl->d_order : nullptr;
-      if (pl->order_B != B && o.handout == D2D_HANDOUT_PREDICTED && o.mode == D2D_LM_MODE_MINPACK && B > 8 * pl->n_cu) {
+      if (pl->order_B != B && pl->has_prior && o.handout == D2D_HANDOUT_PREDICTED && o.mode == D2D_LM_MODE_MINPACK && B > 8 * pl->n_cu) {
         if (int rc = launch_handout(ctx, pl, B, scen)) return rc;
         pl->last_order = pl->d_order_pred;
       }
@@ -2773,6 +2777,7 @@ int d2d_fit_plan_set_handout_prior(d2d_ctx *ctx, d2d_fit_plan *pl, const float *
   // (synchronous with respect to the stream: an earlier solve may still be reading the table)
   D2D_CHECK_HIP(hipStreamSynchronize(ctx->stream));
   D2D_CHECK_HIP(hipMemcpy(pl->d_hprior, src, n * sizeof(float), hipMemcpyHostToDevice));
+  pl->has_prior = table != nullptr || pl->use_lm;
   return D2D_OK;
 }
 

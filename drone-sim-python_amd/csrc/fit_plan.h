@@ -69,6 +69,7 @@ struct d2d_fit_plan {
   int order_B = 0;             // batch size the order was built for (0: none)
   // predicted hand-out (d2d_fit_opts.handout = D2D_HANDOUT_PREDICTED): the prior table, the keys and the order of the current solve
   float *d_hprior = nullptr;   // [2][D2D_HANDOUT_NB][D2D_HANDOUT_ND] (plan lifetime; built-in table or d2d_fit_plan_set_handout_prior)
+  bool has_prior = false;      // the table says something about THIS plan's fits: the built-in one for the shape it was regressed on (S = 6, K <= 64), a caller's for any
   int32_t *d_hkey = nullptr;   // [B] sort keys (scratch)
   int32_t *d_order_pred = nullptr;   // [B] (scratch; d_order stays the caller's explicit hint)
   const int32_t *last_order = nullptr;   // what the last solve launch handed out by (nullptr: index order) ...

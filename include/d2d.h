@@ -479,7 +479,11 @@ int d2d_fit_plan_set_order(d2d_ctx *ctx, d2d_fit_plan *plan, int B, const int32_
  * computes the keys and a counting sort of them at the start of every solve whose batch exceeds the resident wavefronts (two small
  * launches on the solve's stream, inside whatever the caller times).  table: HOST float [2][D2D_HANDOUT_NB][D2D_HANDOUT_ND], in trial
  * points relative to any common offset; NULL restores the built-in table (csrc/fit_handout_prior.h: regressed on 196 608 synthetic
- * scenarios of OTHER seeds than any bench or test batch).  A prior only schedules: results are bit-identical whatever it says. */
+ * scenarios of OTHER seeds than any bench or test batch).  The built-in table was regressed on the fused shape (S = 6, K <= 64, default
+ * solver) and says nothing about other horizons (rank correlation with the trial counts of 121- / 301-node fits: -0.13 / 0.06): plans of
+ * the long-horizon kernel hand out in index order until the caller installs a table regressed on solves of their own workload (one
+ * solve of a few thousand scenarios is enough: d2dhip/handout.py fit_prior, FitPlan.learn_handout_prior).  A prior only schedules:
+ * results are bit-identical whatever it says. */
 #define D2D_HANDOUT_NB 48
 #define D2D_HANDOUT_ND 12
 #define D2D_HANDOUT_X_LO 0.4
