@@ -35,6 +35,8 @@ traffic = {}
 for k, cs in acc.items():
     if 'FETCH_SIZE' in cs and 'WRITE_SIZE' in cs:
         name = next((n for n in ('fit_lm_knot_kernel', 'fit_lm_kernel', 'fit_jtj_kernel', 'gvf_run_kernel', 'track_run_kernel', 'nlp_solve_kernel') if n in k), None)
+        if name is None and 'gvf_run_quad' in k:
+            name = 'gvf_run_kernel'         # (round 6: the DPP-quad instantiations of the same loop; one of them serves a launch)
         if name is None:
             continue
         fetch_kib = sum(cs['FETCH_SIZE']) / len(cs['FETCH_SIZE'])
@@ -51,6 +53,8 @@ json.dump(traffic, open(prefix + '_traffic.json', 'w'), indent=1)
 valu = {}
 for k, cs in acc.items():
     name = next((n for n in ('gvf_run_kernel', 'track_run_kernel', 'nlp_solve_kernel', 'nlp_groups_kernel') if n in k), None)
+    if name is None and 'gvf_run_quad_wide' in k:
+        name = 'gvf_run_kernel'             # (the one-wave-per-SIMD instantiation: BASELINE configs[4])
     if name is None or 'SQ_INSTS_VALU_FMA_F64' not in cs:
         continue
     m = lambda c: sum(cs[c]) / len(cs[c]) if c in cs else 0.0        # noqa: E731
