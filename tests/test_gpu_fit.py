@@ -259,7 +259,19 @@ def test_solve_full_batch_properties(ctx, plan, obasis):
     assert np.abs(g1.cpu().numpy()[ok]).max() < 1e-5
     # (the default solver evaluates the polynomial through the knot data and a Hermite table, d2d_fit_eval through the dense basis:
     # two summation orders of the same flat outputs)
-    np.testing.assert_allclose(c1.cpu().numpy(), cost.cpu().numpy(), rtol=2e-11)
+    np.testing.assert_allclose(c1.cpu().numpy(), cost.cpu().numpy(), rtol=2e-11 if plan.kernel == 'knot' else 1e-12)
+    # ... and the q-coordinate kernel, whose solver and d2d_fit_eval share the dense basis, is still held to the bar of rounds 1-4
+    # (the tolerance was loosened for the knot kernel only)
+    import d2dhip
+    pq = d2dhip.FitPlan(ctx, S_, K, DUR, WREF, kernel='fused')
+    try:
+        dq = dsc[:1024].contiguous()
+        qq = pq.init(dq)
+        cq, _, sq, _ = pq.solve(dq, qq)
+        c1q, _, _ = pq.eval(dq, qq, want_H=False)
+        np.testing.assert_allclose(c1q.cpu().numpy(), cq.cpu().numpy(), rtol=1e-12)
+    finally:
+        pq.close()
     q2 = q.clone()
     cost2, *_ = plan.solve(dsc, q2, max_iter=20)
     assert (np.abs((q2 - q).cpu().numpy()).max(1)[ok] < 1e-5).all()
