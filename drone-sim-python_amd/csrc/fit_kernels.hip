@@ -1739,9 +1739,23 @@ fit_order_kernel(int B, const int32_t *__restrict__ iters, int32_t *__restrict__
     atomicAdd(&hist[ORDER_BINS - 1 - k], 1);          // bin 0 = the longest fits
   }
   __syncthreads();
-  if (threadIdx.x == 0) {                             // exclusive prefix sum (2048 adds: negligible beside a solve)
-    int run = 0;
-    for (int i = 0; i < ORDER_BINS; ++i) { const int h = hist[i]; hist[i] = run; run += h; }
+  {
+    // exclusive prefix sum of the bins: thread t owns bins 2t, 2t + 1; Hillis-Steele scan of the 1024 pair sums in the LDS (ten
+    // steps; the serial loop of one thread this replaces was 20 us of a 2.4 ms solve since the predicted hand-out sorts EVERY solve)
+    __shared__ int part[2][1024];
+    const int t = threadIdx.x;
+    const int h0 = hist[2 * t], h1 = hist[2 * t + 1];
+    int cur = 0;
+    part[0][t] = h0 + h1;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+      const int v = part[cur][t] + (t >= d ? part[cur][t - d] : 0);
+      part[cur ^ 1][t] = v;
+      cur ^= 1;
+      __syncthreads();
+    }
+    const int excl = part[cur][t] - (h0 + h1);
+    hist[2 * t] = excl; hist[2 * t + 1] = excl + h0;
   }
   __syncthreads();
   for (int b = threadIdx.x; b < B; b += blockDim.x) {
