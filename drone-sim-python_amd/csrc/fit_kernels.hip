@@ -2934,7 +2934,7 @@ int d2d_fit_solve_groups(d2d_ctx *ctx, d2d_fit_plan *pl, int R, const double *sc
   }
   // ---- launch-pair path (other plan shapes): every scenario sweeps until the slowest one has settled
   // (plans of the long-horizon kernel -- more than 64 nodes -- run every visit as ONE launch of it: 1.6 .. 3 x faster than the
-  // launch pairs at 71 .. 201 nodes, tools/dev_groups_long.py; D2D_GROUPS_PAIRS=1 keeps the launch pairs where their LDS image
+  // launch pairs at 71 .. 201 nodes, tools/dev_groups_long.py; d2d_fit_opts.gs_pairs = 1 keeps the launch pairs where their LDS image
   // holds K, tests compare the two)
   const bool long_path = !pl->split_ok || (pl->use_long && o.gs_pairs == 0);
   d2d_fit_opts o_long = o;
