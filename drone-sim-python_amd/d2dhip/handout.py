@@ -40,12 +40,26 @@ def key(sc, duration, table):
     return k, ki
 
 
-def fit_prior(sc, duration, iters, sweeps=12):
+def fit_prior(sc, duration, iters, sweeps=12, quantile=None, tail=None, min_count=20):
     """Additive model iters ~ mean + A[bin(t0), bin(x)] + B[bin(t1), bin(x)] by backfitting (a cell without data is neutral: 0).
-    Returns table float32 [2][NB][ND] with the mean folded into A, so that the key is an expected trial count."""
+    Returns table float32 [2][NB][ND] with the mean folded into A, so that the key is an expected trial count.
+    quantile = q in (0, 1): instead, A and B hold the q-quantile of the counts of their cell (a RISK-aware key: what ends a launch is
+    a long fit that starts late, so a cell with a heavy tail goes first whatever its mean); tail = T: 100 x the fraction of the cell's
+    fits with >= T trials.  Cells with fewer than min_count samples take the value of all samples."""
     n = np.asarray(iters, dtype=np.float64)
     b0, b1, bx = bins(sc, duration)
     c0, c1 = b0 * ND + bx, b1 * ND + bx
+    if quantile is not None or tail is not None:
+        stat = (lambda v: np.percentile(v, 100.0 * quantile)) if quantile is not None else (lambda v: 100.0 * np.mean(v >= tail))
+        out = np.empty((2, NB * ND))
+        for t, c in enumerate((c0, c1)):
+            order = np.argsort(c, kind='stable'); cs = c[order]; ns = n[order]
+            edges = np.searchsorted(cs, np.arange(NB * ND + 1))
+            glob = stat(n)
+            for cell in range(NB * ND):
+                lo, hi = edges[cell], edges[cell + 1]
+                out[t, cell] = stat(ns[lo:hi]) if hi - lo >= min_count else glob
+        return (0.5 * out).reshape(2, NB, ND).astype(np.float32)      # (halved: the key is the sum of two such entries)
     mu = n.mean()
     A = np.zeros(NB * ND); Bt = np.zeros(NB * ND)
     n0 = np.bincount(c0, minlength=NB * ND); n1 = np.bincount(c1, minlength=NB * ND)
