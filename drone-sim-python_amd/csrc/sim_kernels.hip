@@ -141,6 +141,25 @@ gvf_run_body(const d2d_gvf_params &p, const GlMesh &mesh, int fpb, const double 
       for (int c = 0; c < D2D_GL_FAST_STAGES; ++c) asm volatile("" : "+v"(ga6[r][c]));
     }
   }
+  // the lane's entries of the incidence matrix and its desired phase (QUAD: read once; VCONST: kept in vector registers -- re-read
+  // from the LDS every step they were two exposed round trips of the step's dependent chain)
+  constexpr int GVF_FA = 4;
+  double bc_q[GVF_FA] = {0, 0, 0, 0}, br_q[GVF_FA - 1] = {0, 0, 0}, zd_q = 0.0;
+  if (QUAD) {
+    const int ac = a < nm ? a : 0;
+#pragma unroll
+    for (int k = 0; k < GVF_FA; ++k) bc_q[k] = (k < NAC && NAC > 1) ? sh_B[k * nm + ac] : 0.0;
+#pragma unroll
+    for (int m = 0; m < GVF_FA - 1; ++m) br_q[m] = m < NAC - 1 ? sh_B[a * nm + m] : 0.0;
+    zd_q = NAC > 1 ? sh_z[ac] : 0.0;
+    if (VCONST) {
+#pragma unroll
+      for (int k = 0; k < GVF_FA; ++k) asm volatile("" : "+v"(bc_q[k]));
+#pragma unroll
+      for (int m = 0; m < GVF_FA - 1; ++m) asm volatile("" : "+v"(br_q[m]));
+      asm volatile("" : "+v"(zd_q));
+    }
+  }
   const int rs = p.rec_stride;
   // history rows: i % rs and i / rs of this step and of the one before, kept by counting (a division by a run-time number is ~25
   // scalar instructions, four of them per step)
@@ -154,7 +173,6 @@ gvf_run_body(const d2d_gvf_params &p, const GlMesh &mesh, int fpb, const double 
   // of its fma (the trip count is a run-time number): seven in a row per step at four aircraft, a tenth of a step that is one
   // dependent chain from end to end.  The sums keep their order (terms beyond n_ac add 0 * x): bit-identical.  (Held in registers
   // across the steps instead, the matrix entries put the kernel at one wave per SIMD.)
-  constexpr int GVF_FA = 4;
   const bool small_form = n_ac <= GVF_FA;
   for (int i = 1; i < p.n_rows; ++i) {
     // src/11_full_sim_case1.py:140 -- `if np.all(stop)==1 and t>0: break` at the top of step i
@@ -173,13 +191,9 @@ gvf_run_body(const d2d_gvf_params &p, const GlMesh &mesh, int fpb, const double 
     if (QUAD) {
       // partners' angles and errors by DPP; the matrix entries from the LDS (read-only after the barrier above: requested before
       // the atan2 result is needed)
-      double bc[GVF_FA], br[GVF_FA - 1];
-      const int ac = a < nm ? a : 0;
-#pragma unroll
-      for (int k = 0; k < GVF_FA; ++k) bc[k] = k < NAC ? sh_B[k * nm + ac] : 0.0;
-#pragma unroll
-      for (int m = 0; m < GVF_FA - 1; ++m) br[m] = m < NAC - 1 ? sh_B[a * nm + m] : 0.0;
-      const double zd = NAC > 1 ? sh_z[ac] : 0.0;
+      const double (&bc)[GVF_FA] = bc_q;
+      const double (&br)[GVF_FA - 1] = br_q;
+      const double zd = zd_q;
       double th[GVF_FA];
       th[0] = member_get<NAC, 0>(theta); th[1] = member_get<NAC, 1>(theta); th[2] = member_get<NAC, 2>(theta); th[3] = member_get<NAC, 3>(theta);
       double z = 0.0;
