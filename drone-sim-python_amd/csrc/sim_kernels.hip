@@ -137,8 +137,10 @@ gvf_run_body(const d2d_gvf_params &p, const GlMesh &mesh, int fpb, const double 
 #pragma unroll
     for (int r = 0; r < D2D_GL_FAST_STAGES; ++r) {
       asm volatile("" : "+v"(gb6[r]));
+      if (r < D2D_GL_FAST_STAGES / 2) {                   // (gl_panel reads the upper half of the symmetric tableau only)
 #pragma unroll
-      for (int c = 0; c < D2D_GL_FAST_STAGES; ++c) asm volatile("" : "+v"(ga6[r][c]));
+        for (int c = 0; c < D2D_GL_FAST_STAGES; ++c) asm volatile("" : "+v"(ga6[r][c]));
+      }
     }
   }
   // the lane's entries of the incidence matrix and its desired phase (QUAD: read once; VCONST: kept in vector registers -- re-read
