@@ -97,6 +97,28 @@ def test_lqr_vs_scipy_care():
         np.testing.assert_allclose(K[i], np.linalg.solve(R, Bm[i].T @ Pr), rtol=1e-7, atol=1e-8 * np.abs(Pr).max())
 
 
+def test_lqr_when_the_inverse_must_exchange_rows():
+    """The small-matrix inverse exchanges rows only where a diagonal entry is below 1e-3 of its column (a wave-uniform branch,
+    sim_device.h inverse): systems with A[0][0] equal to the Cayley shift (A - gamma I starts with a ZERO pivot) on every third
+    lane of the wavefront, ordinary ones on the others -- both kinds must come out right in the same launch."""
+    import scipy.linalg
+    import d2dhip
+    ctx = d2dhip.default_context()
+    rng = np.random.default_rng(11)
+    n = 96
+    A = rng.normal(0, 1.0, (n, 5, 5)); Bm = rng.normal(0, 1.0, (n, 5, 2))
+    A[::3, 0, 0] = 3.0                      # D2D_CARE_GAMMA
+    A[1::6, 1, 1] = 3.0; A[1::6, 0, 1] = 0.0; A[1::6, 1, 0] = 0.0      # a zero pivot in the SECOND column after the first elimination
+    Q = np.diag([1.0, 2.0, 0.5, 0.1, 0.3]); R = np.array([[2.0, 0.3], [0.3, 1.0]])
+    K, P = ctx.lqr(ctx.dev(np.ascontiguousarray(A.reshape(n, 25).T)), ctx.dev(np.ascontiguousarray(Bm.reshape(n, 10).T)), Q, R)
+    K = K.cpu().numpy().T.reshape(n, 2, 5); P = P.cpu().numpy().T.reshape(n, 5, 5)
+    assert np.isfinite(P).all()
+    for i in range(n):
+        Pr = scipy.linalg.solve_continuous_are(A[i], Bm[i], Q, R)
+        np.testing.assert_allclose(P[i], Pr, rtol=1e-8, atol=1e-8 * np.abs(Pr).max())
+        np.testing.assert_allclose(K[i], np.linalg.solve(R, Bm[i].T @ Pr), rtol=1e-7, atol=1e-8 * np.abs(Pr).max())
+
+
 def test_dcf_circle_gvf_helpers(gold):
     import d2d.guidance as ddg
     g = gold('guidance')
