@@ -306,6 +306,18 @@ def nlp_record(ctx, torch, cpu, B=4096):
            'infeasible_frac': float((st == 4).mean()),     # D2D_ST_STALLED: perturbed end poses that no v <= 15 path joins in 12 s (the oracle agrees)
            'mean_newton_steps': float(it.mean()),
            'max_newton_steps': int(it.max()), 'hbm_traffic_per_launch': pmc_traffic('nlp_solve_kernel')[0], 'cpu_baseline': cpu}
+    # d2d_nlp_opts.order: the same problems handed out longest first by the step counts of the solve above (a re-solve of a problem set
+    # knows them; the launch holds two problems per resident wavefront, so its end is the worst pair).  Results must not move.
+    order = torch.from_numpy(np.argsort(-it, kind='stable').astype(np.int32)).to(ctx.device)
+    hint = 1e30
+    for rep in range(2):
+        W2 = ctx.dev(np.ascontiguousarray(W0))
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        out2 = ctx.nlp_solve(dsc, W2, h, order=order)
+        torch.cuda.synchronize(); hint = min(hint, time.perf_counter() - t0)
+    assert torch.equal(out2['iters'], out['iters']) and torch.equal(out2['cost'], out['cost']) and torch.equal(W2, W), 'the hand-out order changed a result'
+    rec['value_order_hint'] = B / hint
+    rec['order_hint'] = "d2d_nlp_opts.order = argsort of the previous solve's Newton-step counts, descending; results bit-identical (checked)"
     # algorithmic HBM bytes per node and Newton step of the round-3 algorithm (every value a phase needs read once, every
     # value it produces written once, neighbours from the cache): merit 13 doubles read x ~1.3 calls, assembly 18 read + 40 written
     # (x ~1.1 with the retries), cyclic reduction 21 read + 6 written (the reduced records live in the LDS), recovery 40 read + 5

@@ -1208,7 +1208,15 @@ nlp_solve_kernel(int B, int N, double h, d2d_nlp_opts o, const double *__restric
   const int lane = threadIdx.x;
   extern __shared__ __attribute__((aligned(16))) double nlp_lds[];
   double *wsb = work + (size_t)blockIdx.x * WS_TOTAL * N;
-  for (int b = blockIdx.x; b < B;) {
+  const int32_t *__restrict__ order = o.order;
+  for (int t = blockIdx.x; t < B;) {
+    const int b = order ? __builtin_amdgcn_readfirstlane(order[t]) : t;
+    if ((unsigned)b >= (unsigned)B) {        // (an entry that is no problem index is skipped, not dereferenced)
+      int tn = 0;
+      if (lane == 0) tn = (int)gridDim.x + atomicAdd(queue, 1);
+      t = __builtin_amdgcn_readfirstlane(tn);
+      continue;
+    }
     NlpOut out;
     nlp_solve_one(N, h, o, scen + (size_t)b * D2D_SCEN_STRIDE, partner ? partner + (size_t)b * 2 * N : nullptr, W + (size_t)b * NLP_NV * N,
                   wsb, mult ? mult + (size_t)b * 3 * N : nullptr, lane, out, b == 0 ? stamps : nullptr, nlp_lds,
@@ -1220,9 +1228,9 @@ nlp_solve_kernel(int B, int N, double h, d2d_nlp_opts o, const double *__restric
       if (status_out) status_out[b] = out.status;
     }
     nlp_phase_sync();                        // (the next problem's first stores to the workspace follow this one's last loads)
-    int t = 0;
-    if (lane == 0) t = (int)gridDim.x + atomicAdd(queue, 1);
-    b = __builtin_amdgcn_readfirstlane(t);
+    int tn = 0;
+    if (lane == 0) tn = (int)gridDim.x + atomicAdd(queue, 1);
+    t = __builtin_amdgcn_readfirstlane(tn);
   }
 }
 
@@ -1303,7 +1311,7 @@ int d2d_nlp_solve(d2d_ctx *ctx, int B, int N, double h, const double *scen, cons
                   const double *partner, double *work, double *mult, double *cost, double *feas, int32_t *iters, int32_t *status) {
   D2D_REQUIRE(ctx && scen && W && work && cost && feas, "d2d_nlp_solve: null argument");
   D2D_REQUIRE(B >= 1 && N >= 3 && h > 0, "d2d_nlp_solve: B >= 1, N >= 3, h > 0 required (B=%d N=%d h=%g)", B, N, h);
-  d2d_nlp_opts o = {D2D_NLP_RHO0, D2D_NLP_MUB0, D2D_NLP_MUB_MIN, 1e-9, 1e-7, 60, 40, 0, 0, nullptr};
+  d2d_nlp_opts o = {D2D_NLP_RHO0, D2D_NLP_MUB0, D2D_NLP_MUB_MIN, 1e-9, 1e-7, 60, 40, 0, 0, nullptr, nullptr};
   if (opts) o = *opts;
   D2D_REQUIRE(o.inner_max >= 1 && o.outer_max >= 1 && o.rho0 > 0 && o.mub0 > 0 && o.mub_min > 0, "d2d_nlp_solve: bad options");
   unsigned long long *stamps = nullptr;
@@ -1338,7 +1346,7 @@ int d2d_nlp_solve_groups(d2d_ctx *ctx, int R, int n_ac, int N, double h, const d
   D2D_REQUIRE(ctx && scen && W && work && cost && feas, "d2d_nlp_solve_groups: null argument");
   D2D_REQUIRE(R >= 1 && n_ac >= 1 && n_ac <= 8 && N >= 3 && h > 0, "d2d_nlp_solve_groups: R >= 1, 1 <= n_ac <= 8, N >= 3, h > 0 required (R=%d n_ac=%d N=%d h=%g)", R, n_ac, N, h);
   D2D_REQUIRE(max_sweeps >= 1 && tol >= 0, "d2d_nlp_solve_groups: max_sweeps >= 1 and tol >= 0 required");
-  d2d_nlp_opts o = {D2D_NLP_RHO0, D2D_NLP_MUB0, D2D_NLP_MUB_MIN, 1e-9, 1e-7, 60, 40, 0, 0, nullptr};
+  d2d_nlp_opts o = {D2D_NLP_RHO0, D2D_NLP_MUB0, D2D_NLP_MUB_MIN, 1e-9, 1e-7, 60, 40, 0, 0, nullptr, nullptr};
   if (opts) o = *opts;
   D2D_REQUIRE(o.inner_max >= 1 && o.outer_max >= 1 && o.rho0 > 0 && o.mub0 > 0 && o.mub_min > 0, "d2d_nlp_solve_groups: bad options");
   // scratch for the positions before a turn: the tail of aircraft 0's workspace is not free, so it lives behind the workspaces

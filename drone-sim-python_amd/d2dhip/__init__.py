@@ -53,7 +53,7 @@ class TrackParams(C.Structure):
 class NlpOpts(C.Structure):
     _fields_ = [('rho0', C.c_double), ('mub0', C.c_double), ('mub_min', C.c_double), ('feas_tol', C.c_double),
                 ('opt_tol', C.c_double), ('inner_max', C.c_int32), ('outer_max', C.c_int32), ('serial', C.c_int32), ('slots', C.c_int32),
-                ('bounds', C.c_void_p)]
+                ('bounds', C.c_void_p), ('order', C.c_void_p)]
 
 
 class FitOpts(C.Structure):
@@ -408,9 +408,10 @@ class Context:
         return out
 
     def nlp_solve(self, scen, W, h, partner=None, rho0=10.0, mub0=0.1, mub_min=1e-9, feas_tol=1e-9, opt_tol=1e-7, inner_max=NLP_INNER_MAX,
-                  outer_max=NLP_OUTER_MAX, want_mult=False, serial=0, bounds=None, slots=0):
+                  outer_max=NLP_OUTER_MAX, want_mult=False, serial=0, bounds=None, slots=0, order=None):
         """Direct-collocation NLP in node variables (d2d_nlp_solve): scen dev [B][SCEN_STRIDE], W dev [B][5][N] in/out (initial
-        guess -> solution), partner dev [B][2][N] or None, bounds dev [B][4] = (phi_lo, phi_hi, psi_lo, psi_hi) or None (d2d_nlp_opts.bounds).
+        guess -> solution), partner dev [B][2][N] or None, bounds dev [B][4] = (phi_lo, phi_hi, psi_lo, psi_hi) or None (d2d_nlp_opts.bounds),
+        order dev int32 [B]: the hand-out order of the persistent launch (a permutation; d2d_nlp_opts.order) or None.
         Returns dict(cost, feas, iters, status[, mult [B][3][N]]) of device tensors."""
         torch = _torch()
         B, _, N = W.shape
@@ -420,7 +421,9 @@ class Context:
         iters = torch.empty(B, dtype=torch.int32, device=self.device); status = torch.empty(B, dtype=torch.int32, device=self.device)
         mult = self.zeros(B, 3, N) if want_mult else None
         assert bounds is None or (bounds.is_contiguous() and tuple(bounds.shape) == (B, 4) and bounds.dtype == _torch().float64)
-        o = NlpOpts(rho0, mub0, mub_min, feas_tol, opt_tol, inner_max, outer_max, serial, int(slots), None if bounds is None else bounds.data_ptr())
+        assert order is None or (order.is_contiguous() and tuple(order.shape) == (B,) and order.dtype == torch.int32)
+        o = NlpOpts(rho0, mub0, mub_min, feas_tol, opt_tol, inner_max, outer_max, serial, int(slots), None if bounds is None else bounds.data_ptr(),
+                    None if order is None else order.data_ptr())
         _check(self.lib.d2d_nlp_solve(self.h, B, N, float(h), _ptr(scen), C.byref(o), _ptr(W), _ptr(partner), _ptr(work), _ptr(mult),
                                       _ptr(cost), _ptr(feas), _ptr(iters), _ptr(status)))
         out = dict(cost=cost, feas=feas, iters=iters, status=status, work=work)
@@ -442,7 +445,7 @@ class Context:
         iters = torch.empty(B, dtype=torch.int32, device=self.device); status = torch.empty(B, dtype=torch.int32, device=self.device)
         sweeps = torch.empty(R, dtype=torch.int32, device=self.device)
         assert bounds is None or (bounds.is_contiguous() and tuple(bounds.shape) == (B, 4) and bounds.dtype == _torch().float64)
-        o = NlpOpts(rho0, mub0, mub_min, feas_tol, opt_tol, inner_max, outer_max, serial, 0, None if bounds is None else bounds.data_ptr())
+        o = NlpOpts(rho0, mub0, mub_min, feas_tol, opt_tol, inner_max, outer_max, serial, 0, None if bounds is None else bounds.data_ptr(), None)
         _check(self.lib.d2d_nlp_solve_groups(self.h, R, n_ac, N, float(h), _ptr(scen), C.byref(o), int(max_sweeps), float(tol), _ptr(W), _ptr(work),
                                              None, _ptr(cost), _ptr(feas), _ptr(iters), _ptr(status), _ptr(sweeps), _ptr(moved)))
         return dict(cost=cost, feas=feas, iters=iters, status=status, sweeps=sweeps, moved=moved, work=work)

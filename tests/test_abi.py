@@ -39,7 +39,7 @@ def test_struct_layouts_match_header():
     # + mode, mp_finish, mp_ftol/xtol/gtol, slice, mp_slow; version 108: handout, prio_at, gs_ls, gs_ls_s0, gs_ls_r0, gs_prio_at, gs_pairs
     assert ctypes.sizeof(d2dhip.FitOpts) == 2 * 4 + 4 * 8 + 2 * 4 + 3 * 8 + 2 * 4 + 4 * 4 + 8 + 2 * 4
     assert ctypes.sizeof(d2dhip.FitPlanOpts) == 4 * 4
-    assert ctypes.sizeof(d2dhip.NlpOpts) == 5 * 8 + 4 * 4 + 8
+    assert ctypes.sizeof(d2dhip.NlpOpts) == 5 * 8 + 4 * 4 + 8 + 8
     assert d2dhip.SCEN_STRIDE == 80 and d2dhip.MAX_OBS == 16
     # defaults that the binding and the oracle repeat from the header
     hdr = open(os.path.join(ROOT, 'include', 'd2d.h')).read()

@@ -523,3 +523,33 @@ def test_persistent_handout_is_independent_of_the_batch(ctx):
         assert (small['iters'].cpu().numpy() == it[sl]).all()
         np.testing.assert_array_equal(small['cost'].cpu().numpy(), co[sl])
         np.testing.assert_array_equal(Ws.cpu().numpy(), Wb[sl])
+
+
+def test_handout_order_only_schedules(ctx):
+    """d2d_nlp_opts.order (ABI 109): the persistent launch hands the problems out in the caller's order -- here longest first by the
+    step counts of a first solve, and a reversed order -- and every status, step count, cost and node value stays bit-identical.  An
+    entry that is no problem index is skipped, not dereferenced: the problems it should have named keep their initial guess."""
+    import torch
+    from d2dhip import synth
+    B = 2304                                        # more than the 2048 wave slots of an MI355X: the order decides who shares a slot
+    rows, W0, h = synth.nlp_problems(B, seed=5)
+    dsc = ctx.dev(rows)
+    W = ctx.dev(np.ascontiguousarray(W0))
+    ref = ctx.nlp_solve(dsc, W, h)
+    ctx.sync()
+    it = ref['iters'].cpu().numpy()
+    for perm in (np.argsort(-it, kind='stable'), np.arange(B)[::-1].copy()):
+        order = torch.from_numpy(perm.astype(np.int32)).to(ctx.device)
+        W2 = ctx.dev(np.ascontiguousarray(W0))
+        got = ctx.nlp_solve(dsc, W2, h, order=order)
+        ctx.sync()
+        for k in ('status', 'iters', 'cost', 'feas'):
+            assert torch.equal(got[k], ref[k]), k
+        assert torch.equal(W2, W)
+    bad = np.arange(64, dtype=np.int32); bad[5] = 64; bad[9] = -1
+    W3 = ctx.dev(np.ascontiguousarray(W0[:64]))
+    got = ctx.nlp_solve(ctx.dev(np.ascontiguousarray(rows[:64])), W3, h, order=torch.from_numpy(bad).to(ctx.device))
+    ctx.sync()
+    keep = np.ones(64, bool); keep[[5, 9]] = False
+    assert torch.equal(W3[torch.from_numpy(keep).to(ctx.device)], W[:64][torch.from_numpy(keep).to(ctx.device)])
+    np.testing.assert_array_equal(W3[[5, 9]].cpu().numpy(), W0[[5, 9]])
