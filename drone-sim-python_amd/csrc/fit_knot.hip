@@ -96,11 +96,6 @@ __device__ __forceinline__ int kn_entry_of(int i) { return i < 4 ? (i < 2 ? 2 + 
 __device__ __forceinline__ int kn_entry_all(int l) {
   return l < 48 ? kn_entry_of(l) : (l < 56 ? (l < 52 ? 0 : 48) + ((l & 2) ? 4 : 0) + (l & 1) : 0);
 }
-__device__ __forceinline__ int kn_dense_of(int e) {          // -1: an end condition
-  if (e >= 8 && e < 48) return e - 4;
-  if ((e & 3) < 2) return -1;
-  return (e < 8 ? 0 : 44) + 2 * ((e >> 2) & 1) + (e & 3) - 2;
-}
 
 // ---- phase 1 (lane = sample): flat outputs from the 16 knot values of the sample's segment, rows, records -------------------------
 // wv: the wave's knot vector [7][KN_WV_KNOT] (knot j: x (4), y (4)); seg: this lane's segment.  Records: us [K][KN_US] = u_k as
@@ -404,7 +399,6 @@ fit_lm_knot_kernel(int B, KnotGeom kg, KnotLds L, d2d_fit_opts opts, int iter_ca
   __syncthreads();
   const double *Hb64 = reinterpret_cast<const double *>(lds + L.Hb64);
   const float *Wseg = reinterpret_cast<const float *>(lds + L.Wseg);
-  const float *Md32 = reinterpret_cast<const float *>(lds + L.Md32);
   const float *Mi32 = reinterpret_cast<const float *>(lds + L.Mi32);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   unsigned char *wl = lds + L.wave0 + wave * L.wave_stride;
